@@ -1,0 +1,151 @@
+"""Deterministic synthetic inputs for parity tests, smoke() and bench.py.
+
+Everything is generated from an integer hash (splitmix64 of the flat element
+index, salted by a per-tensor name hash), so the same arrays can be rebuilt on
+any machine without shipping them: the committed golden fixtures store only the
+*outputs* of the reference on these inputs.
+
+High-variance on purpose: at the reference's own initialisation
+(hash_init_scale=1e-3) the field is almost constant and a wrong hash index or a
+swapped corner would pass a 1e-3 check (hard part 1).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def _salt(name: str, seed: int) -> np.uint64:
+    return np.uint64((zlib.crc32(name.encode()) << 20) ^ (seed * 0x1000193))
+
+
+def uniform(name: str, shape: Tuple[int, ...], lo: float = -1.0, hi: float = 1.0, seed: int = 0) -> np.ndarray:
+    """U[lo,hi) float32 array; element i depends only on (name, seed, i)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        bits = splitmix64(idx * np.uint64(0x2545F4914F6CDD1D) + _salt(name, seed))
+    u = (bits >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))  # 24 random bits -> exact in fp32
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def synth_params(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, table_scale: float = 0.5,
+                 pose_scale: float = 1e-3) -> Dict[str, np.ndarray]:
+    """Weights for every tensor in `shapes` (reference state_dict names).
+
+    hash tables x table_scale, Linear weights x sqrt(6/fan_in), biases x 0.1, appearance embedding x 1,
+    pose_adjustment x pose_scale.
+    """
+    out = {}
+    for name, shape in shapes.items():
+        if name.endswith("hash_table"):
+            out[name] = uniform(name, shape, seed=seed) * np.float32(table_scale)
+        elif name.endswith("pose_adjustment"):
+            out[name] = uniform(name, shape, seed=seed) * np.float32(pose_scale)
+        elif name.endswith("embedding.weight"):
+            out[name] = uniform(name, shape, seed=seed)
+        elif name.endswith(".weight"):
+            out[name] = uniform(name, shape, seed=seed) * np.float32(np.sqrt(6.0 / shape[-1]))
+        elif name.endswith(".bias"):
+            out[name] = uniform(name, shape, seed=seed) * np.float32(0.1)
+        else:
+            raise KeyError(name)
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# 8-camera RGB+T scene (4 RGB 640x480 fx=600; 4 thermal 160x120 fx=150) on a circle, looking at the origin
+# ------------------------------------------------------------------------------------------
+
+
+def synth_cameras(num_rgb: int = 4, num_thermal: int = 4, radius: float = 0.8, height: float = 0.3) -> Dict[str, np.ndarray]:
+    C = num_rgb + num_thermal
+    c2w = np.zeros((C, 3, 4), dtype=np.float32)
+    for i in range(C):
+        ang = 2.0 * np.pi * i / C
+        pos = np.array([radius * np.cos(ang), radius * np.sin(ang), height], dtype=np.float64)
+        fwd = -pos / np.linalg.norm(pos)  # camera looks along -z (OpenGL)
+        up = np.array([0.0, 0.0, 1.0])
+        right = np.cross(fwd, up)
+        right /= np.linalg.norm(right)
+        true_up = np.cross(right, fwd)
+        c2w[i, :, 0] = right
+        c2w[i, :, 1] = true_up
+        c2w[i, :, 2] = -fwd
+        c2w[i, :, 3] = pos
+    is_thermal = np.array([0] * num_rgb + [1] * num_thermal, dtype=np.int64)
+    width = np.where(is_thermal == 1, 160, 640).astype(np.int64)
+    heightpx = np.where(is_thermal == 1, 120, 480).astype(np.int64)
+    f = np.where(is_thermal == 1, 150.0, 600.0).astype(np.float32)
+    dist = np.zeros((C, 6), dtype=np.float32)  # k1 k2 k3 k4 p1 p2
+    dist[:, 0] = np.where(is_thermal == 1, -0.08, 0.05)
+    dist[:, 1] = np.where(is_thermal == 1, 0.02, -0.01)
+    dist[:, 4] = 1e-3
+    dist[:, 5] = -5e-4
+    return {
+        "c2w": c2w, "fx": f, "fy": f.copy(), "cx": (width / 2).astype(np.float32), "cy": (heightpx / 2).astype(np.float32),
+        "width": width, "height": heightpx, "distortion": dist, "is_thermal": is_thermal,
+    }
+
+
+def synth_ray_indices(cams: Dict[str, np.ndarray], num_rays: int, seed: int = 42) -> np.ndarray:
+    """[N,3] int64 (camera,row,col): N/C rays per camera in camera order, as 2x2 patches whose 4 pixels are adjacent
+    (what PatchPixelSampler(patch_size=2) + collate_image_dataset_batch_list produce, data/pixel_samplers.py:296-312,421-438)."""
+    C = cams["c2w"].shape[0]
+    per_cam = num_rays // C
+    assert per_cam % 4 == 0 and per_cam * C == num_rays, "num_rays must be a multiple of 4*num_cameras"
+    out = np.zeros((num_rays, 3), dtype=np.int64)
+    k = 0
+    for c in range(C):
+        npatch = per_cam // 4
+        H, W = int(cams["height"][c]), int(cams["width"][c])
+        r = (uniform(f"patch_row_{c}", (npatch,), 0.0, 1.0, seed) * (H - 1)).astype(np.int64).clip(0, H - 2)
+        q = (uniform(f"patch_col_{c}", (npatch,), 0.0, 1.0, seed) * (W - 1)).astype(np.int64).clip(0, W - 2)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                sl = slice(k + dy * 2 + dx, k + 4 * npatch, 4)
+                out[sl, 0] = c
+                out[sl, 1] = r + dy
+                out[sl, 2] = q + dx
+        k += 4 * npatch
+    return out
+
+
+def synth_gt(ray_indices: np.ndarray, cams: Dict[str, np.ndarray], seed: int = 7) -> Tuple[np.ndarray, np.ndarray]:
+    """Ground-truth pixels [N,3] (thermal stored as grey x3) and is_thermal [N] float32."""
+    N = ray_indices.shape[0]
+    is_th = cams["is_thermal"][ray_indices[:, 0]].astype(np.float32)
+    rgb = uniform("gt_rgb", (N, 3), 0.0, 1.0, seed)
+    grey = uniform("gt_thermal", (N, 1), 0.0, 1.0, seed)
+    img = np.where(is_th[:, None] > 0, np.repeat(grey, 3, axis=1), rgb).astype(np.float32)
+    return img, is_th
+
+
+def synth_jitters(num_rays: int, seed: int = 3, tag: str = "") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """The three per-ray uniforms the training sampler draws (level-0 stratified, two PDF levels)."""
+    return tuple(uniform(f"jitter{tag}_{i}", (num_rays, 1), 0.0, 1.0, seed) for i in range(3))
+
+
+def synth_rays_simple(num_rays: int, seed: int = 11) -> Dict[str, np.ndarray]:
+    """Rays without a camera model (unit tests of the sampler/field kernels): origins on a 0.8 shell, aimed near the origin."""
+    o = uniform("ray_o", (num_rays, 3), -1.0, 1.0, seed)
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * np.float32(0.8)
+    tgt = uniform("ray_t", (num_rays, 3), -0.3, 0.3, seed)
+    d = tgt - o
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    cam = (splitmix64(np.arange(num_rays, dtype=np.uint64) + np.uint64(seed)) % np.uint64(8)).astype(np.int64)
+    return {"origins": o.astype(np.float32), "directions": d.astype(np.float32), "camera_indices": np.sort(cam)}

@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/thermal_nerfacto_oracle.py) to vectors produced by the reference itself
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import thermal_nerfacto_oracle as orc
+from helpers import golden_inputs, make_params, maxdiff, sample_indices, tiny_cfg, GOLDEN_RAYS, SEED
+from nerfstudio_thermal_amd import synth
+
+
+@pytest.fixture(scope="module")
+def units(golden_dir):
+    return np.load(os.path.join(golden_dir, "units.npz"))
+
+
+def test_level_resolutions(units):
+    assert np.array_equal(orc.level_resolutions(16, 16, 2048).numpy(), units["res_main"])
+    assert np.array_equal(orc.level_resolutions(5, 16, 128).numpy(), units["res_prop0"])
+    assert np.array_equal(orc.level_resolutions(5, 16, 256).numpy(), units["res_prop1"])
+    # SURVEY.md 2.3 [probe]: fp32 rounding makes the top level 2047
+    assert orc.level_resolutions(16, 16, 2048)[-1].item() == 2047.0
+
+
+def test_hash_encoding(units):
+    table = torch.from_numpy(synth.uniform("unit_table", (16 * 4096, 2), seed=SEED) * np.float32(0.5))
+    x = torch.from_numpy(synth.uniform("unit_x", (256, 3), 0.0, 1.0, seed=SEED))
+    x[0] = torch.tensor([0.0, 0.0, 0.0])
+    x[1] = torch.tensor([0.5, 0.25, 0.125])
+    x[2] = torch.tensor([1.0 - 2**-20, 0.0, 0.5])
+    enc = orc.hash_encode(x, table, orc.level_resolutions(16, 16, 2048), 12)
+    assert enc.shape == (256, 32)
+    assert np.array_equal(enc.numpy(), units["hash_enc"])  # same ops in the same order: bit-exact
+
+
+def test_sh_contract_expmap(units):
+    d = torch.from_numpy(synth.uniform("unit_d", (64, 3), -1.0, 1.0, seed=SEED))
+    d = d / d.norm(dim=-1, keepdim=True)
+    assert maxdiff(orc.sh16((d + 1.0) / 2.0), units["sh16"]) == 0.0
+    p = torch.from_numpy(synth.uniform("unit_p", (128, 3), -4.0, 4.0, seed=SEED))
+    p[0] = torch.tensor([1.0, 0.2, -0.3])
+    p[1] = torch.tensor([0.0, 0.0, 0.0])
+    assert maxdiff(orc.contract_linf(p), units["contract"]) == 0.0
+    tv = torch.from_numpy(synth.uniform("unit_pose", (8, 6), -0.2, 0.2, seed=SEED))
+    tv[0, 3:] = 0.0
+    tv[1, 3:] = torch.tensor([1e-3, -2e-3, 5e-4])
+    assert maxdiff(orc.exp_map_so3xr3(tv), units["exp_map"]) < 1e-7
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_samplers(units, train):
+    N = 16
+    tag = "train" if train else "eval"
+    j0, j1, _ = (torch.from_numpy(j) for j in synth.synth_jitters(N))
+    nears = torch.ones(N, 1) * (0.05 if train else 0.0)
+    fars = torch.ones(N, 1) * 1000.0
+    s0 = orc.spaced_bins(N, 256, j0 if train else None)
+    assert maxdiff(s0, units[f"spaced_s_{tag}"]) == 0.0
+    e0 = orc.s_to_euclidean(s0, nears, fars)
+    assert maxdiff(e0, units[f"spaced_e_{tag}"]) == 0.0
+    w = torch.from_numpy(synth.uniform("unit_w", (N, 256, 1), 0.0, 1.0, seed=SEED)) ** 8
+    w[3] = 0.0
+    s1 = orc.pdf_resample(s0, w, 96, j1 if train else None)
+    assert maxdiff(s1, units[f"pdf_s_{tag}"]) == 0.0
+    assert maxdiff(orc.s_to_euclidean(s1, nears, fars), units[f"pdf_e_{tag}"]) == 0.0
+    if not train:
+        dens = torch.from_numpy(synth.uniform("unit_dens", (N, 256, 1), 0.0, 40.0, seed=SEED))
+        smp = orc.Samples(s_bins=s0, e_bins=e0)
+        assert maxdiff(orc.get_weights(smp.deltas, dens), units["weights_from_density"]) == 0.0
+
+
+def test_raygen(golden_dir):
+    g = np.load(os.path.join(golden_dir, "raygen.npz"))
+    cams = synth.synth_cameras()
+    idx = torch.from_numpy(synth.synth_ray_indices(cams, GOLDEN_RAYS))
+    t = lambda k: torch.from_numpy(cams[k])  # noqa: E731
+    o, d, area, nrm = orc.generate_rays(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    assert maxdiff(o, g["origins"]) == 0.0
+    assert maxdiff(d, g["directions"]) < 1e-7
+    assert maxdiff(area, g["pixel_area"]) < 1e-10
+    assert maxdiff(nrm, g["directions_norm"]) < 1e-6
+    assert np.array_equal(idx[:, 0:1].numpy(), g["camera_indices"])
+
+
+EVAL_KEYS = ["rgb", "rgb_thermal", "accumulation", "depth", "expected_depth", "density", "prop_depth_0", "prop_depth_1"]
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_model_eval(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
+    cfg = tiny_cfg(mode)
+    params = make_params(cfg)
+    gi = golden_inputs(golden_dir)
+    with torch.no_grad():
+        out = orc.get_outputs(params, cfg, gi["origins"], gi["directions"], gi["camera_indices"], training=False)
+    keys = list(EVAL_KEYS)
+    if mode == "shared":
+        keys.append("rgbt")
+    else:
+        keys += [k + "_thermal" for k in EVAL_KEYS if k != "rgb_thermal"] + ["density2", "density2_thermal", "removal", "removal_thermal"]
+    for k in keys:
+        ref = g[f"eval/{k}"]
+        assert tuple(out[k].shape) == ref.shape, k
+        assert maxdiff(out[k], ref) <= 2e-6, (k, maxdiff(out[k], ref))
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_model_train_losses_grads_adam(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
+    cfg = tiny_cfg(mode)
+    params = make_params(cfg, requires_grad=True)
+    gi = golden_inputs(golden_dir)
+    out = orc.get_outputs(
+        params, cfg, gi["origins"], gi["directions"], gi["camera_indices"], training=True,
+        anneal=float(g["train/anneal"]), jitters=gi["jitters"], jitters_thermal=gi["jitters_thermal"],
+    )
+    sfx = ("", "_thermal") if mode == "separate" else ("",)
+    for s in sfx:
+        for i in range(3):
+            assert maxdiff(out[f"samples_list{s}"][i].s_bins, g[f"train/sbins{s}_{i}"]) <= 1e-6, (s, i)
+            assert maxdiff(out[f"samples_list{s}"][i].e_bins, g[f"train/ebins{s}_{i}"]) <= 1e-3 * 1e-2, (s, i)
+            assert maxdiff(out[f"weights_list{s}"][i][..., 0], g[f"train/weights{s}_{i}"]) <= 1e-6, (s, i)
+        for k in ("rgb", "accumulation", "depth", "expected_depth", "density"):
+            assert maxdiff(out[f"{k}{s}"], g[f"train/{k}{s}"]) <= 2e-6, (k, s)
+    losses = orc.loss_dict(params, cfg, out, gi["image"], gi["is_thermal"], training=True)
+    ref_keys = sorted(k[5:] for k in g.files if k.startswith("loss/") and k != "loss/total")
+    assert sorted(losses.keys()) == ref_keys
+    for k in ref_keys:
+        a, b = float(losses[k]), float(g[f"loss/{k}"])
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)) + 1e-12, (k, a, b)
+    total = sum(losses.values())
+    total.backward()
+    for k, p in params.items():
+        if f"grad_none/{k}" in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        gr = p.grad.reshape(-1)
+        ref_norm = float(g[f"grad_norm/{k}"])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * ref_norm + 1e-9, (k, float(gr.double().norm()), ref_norm)
+        ii = torch.from_numpy(g[f"grad_idx/{k}"])
+        ref = torch.from_numpy(g[f"grad_val/{k}"])
+        scale = max(float(ref.abs().max()), 1e-12)
+        assert maxdiff(gr[ii], ref) <= 2e-4 * scale, (k, maxdiff(gr[ii], ref), scale)
+    # one Adam step
+    for gname, (keys, lr) in orc.optimizer_groups(cfg).items():
+        for k in keys:
+            p = params[k]
+            if p.grad is None:
+                continue
+            with torch.no_grad():
+                m, v = torch.zeros_like(p), torch.zeros_like(p)
+                orc.adam_step(p, p.grad, m, v, step=1, lr=lr)
+    for k, p in params.items():
+        ii = torch.from_numpy(sample_indices(k, p.numel()))
+        ref = torch.from_numpy(g[f"adam_val/{k}"])
+        cur = p.detach().reshape(-1)[ii]
+        assert maxdiff(cur, ref) <= 1e-6, (k, maxdiff(cur, ref))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="live reference not present")
+def test_oracle_matches_live_reference_hash_encoding():
+    """Where the reference tree exists (build container) compare directly, on a fresh random case."""
+    import ref_import
+
+    ref_import.import_reference()
+    from nerfstudio.field_components.encodings import HashEncoding
+
+    enc = HashEncoding(num_levels=5, min_res=16, max_res=256, log2_hashmap_size=10, implementation="torch")
+    x = torch.rand(1000, 3)
+    with torch.no_grad():
+        ref = enc(x)
+        mine = orc.hash_encode(x, enc.hash_table, orc.level_resolutions(5, 16, 256), 10)
+    assert torch.equal(ref, mine)
