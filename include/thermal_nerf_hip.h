@@ -1,0 +1,181 @@
+/*
+ * thermal_nerf_hip.h -- C ABI of libthermal_nerf_hip.so (MI355X / gfx950).
+ *
+ * The reference (yvette256/nerfstudio-thermal) has no FFI of its own: its native arithmetic enters
+ * through the Python objects of tinycudann (tcnn.Encoding / tcnn.Network / tcnn.NetworkWithInputEncoding)
+ * and, on the CPU path that is this project's oracle, through ATen.  Each entry point below replaces one
+ * such seam; the reference location it stands in for is cited as (file:line), relative to
+ * /root/reference/nerfstudio/.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - plain C: device pointers + sizes + an opaque stream handle (a hipStream_t passed as void*; NULL = default stream).
+ *  - every function returns 0 on success or a negative TN_E* code; nothing throws, nothing allocates or frees
+ *    caller memory, nothing synchronises the device.  Work is enqueued on `stream`.
+ *  - all float tensors are fp32, contiguous, row-major; sample tensors are dense [N, S] per level
+ *    (N rays, S samples; "bins" tensors are [N, S+1]).
+ *  - operand-shape violations are rejected on the host (TN_EINVAL) before anything is launched.
+ */
+#ifndef THERMAL_NERF_HIP_H
+#define THERMAL_NERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TN_OK 0
+#define TN_EINVAL (-22)   /* bad argument / unsupported shape */
+#define TN_ELAUNCH (-5)   /* hipLaunch / runtime error (see tn_last_error) */
+#define TN_MAX_LEVELS 16
+#define TN_MAX_SAMPLES 256 /* samples per ray per level (one 64-lane wave x 4) */
+
+typedef void* tn_stream_t;
+
+/* Multiresolution hash grid as the reference's torch HashEncoding lays it out
+ * (field_components/encodings.py:343-347,377-379): table [num_levels * 2^log2_hashmap_size, 2]. */
+typedef struct TnGrid {
+  const float* table;
+  float* table_grad; /* may be NULL when no gradient is wanted */
+  int32_t num_levels;
+  int32_t log2_hashmap_size;
+  float res[TN_MAX_LEVELS]; /* floor(min_res * growth^l) as fp32, computed by the host exactly as the reference does */
+} TnGrid;
+
+/* HashMLPDensityField (fields/density_fields.py:34-118): 5 lvl x 2 feat -> Linear(10,16) ReLU Linear(16,1). */
+typedef struct TnPropNet {
+  TnGrid grid;
+  const float *w0, *b0, *w1, *b1; /* [16,10] [16] [1,16] [1] as nn.Linear stores them */
+  float *gw0, *gb0, *gw1, *gb1;   /* gradient accumulators, may be NULL */
+} TnPropNet;
+
+/* ThermalNerfactoField (fields/thermal_nerfacto_field.py:37-99 over fields/nerfacto_field.py:73-202):
+ * 16 lvl x 2 feat -> Linear(32,64) ReLU Linear(64,16); head Linear(63,64) ReLU Linear(64,64) ReLU Linear(64,C) sigmoid. */
+typedef struct TnField {
+  TnGrid grid;
+  const float *w0, *b0, *w1, *b1;             /* [64,32] [64] [16,64] [16] */
+  const float *hw0, *hb0, *hw1, *hb1, *hw2, *hb2; /* [64,63] [64] [64,64] [64] [C,64] [C] */
+  const float* emb;                            /* [num_images, 32] appearance embedding */
+  float *gw0, *gb0, *gw1, *gb1, *ghw0, *ghb0, *ghw1, *ghb1, *ghw2, *ghb2, *gemb; /* gradients, may be NULL */
+  int32_t num_channels; /* C: 4 (shared RGBT), 3 or 1 (separate) */
+  int32_t num_images;
+} TnField;
+
+const char* tn_last_error(void);
+int tn_version(void);
+/* bytes of device scratch tn_field_* need for `num_points` samples (packed weights + saved activations). */
+int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
+
+/* ---- a1  RayGenerator.forward -> Cameras._generate_rays_from_coords (model_components/ray_generators.py:40-55,
+ *          cameras/cameras.py:598-655,781-786,886-909; undistortion cameras/camera_utils.py:409-446).
+ * ray_indices [N,3] int64 (camera,row,col); c2w [C,3,4]; fx,fy,cx,cy [C]; distortion [C,6] (k1,k2,k3,k4,p1,p2) or NULL. */
+int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx,
+              const float* cy, const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions,
+              float* pixel_area, float* directions_norm, tn_stream_t stream);
+
+/* ---- a4  CameraOptimizer(SO3xR3).apply_to_raybundle (cameras/camera_optimizers.py:130-176, cameras/lie_groups.py:24-58).
+ * pose_adjustment [C,6]; frozen [C] uint8 (1 = non-trainable camera -> identity); camera_indices [N] int64. */
+int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+                      const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
+                      tn_stream_t stream);
+/* backward: d_origins/d_directions [N,3] -> accumulates into grad_pose [C,6]. */
+int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                      const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                      tn_stream_t stream);
+
+/* ---- a6  UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (model_components/ray_samplers.py:78-128,225-248).
+ * lin_bins [S+1] = torch.linspace(0,1,S+1) supplied by the host; jitter [N] or NULL (eval). Outputs s_bins,e_bins [N,S+1]. */
+int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
+                   float* s_bins, float* e_bins, tn_stream_t stream);
+
+/* ---- a8/a9/a10  Field.density_fn -> HashMLPDensityField.get_density (fields/base_field.py:48-68, fields/density_fields.py:95-118,
+ *          field_components/encodings.py:401-461, field_components/mlp.py:159-178, field_components/activations.py:28-41).
+ * positions = origins + directions * (e_bins[s]+e_bins[s+1])/2 (cameras/rays.py:49-58). density [N,S]. */
+int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
+                        int32_t S, float* density, tn_stream_t stream);
+/* backward of the above: d_density [N,S] -> table/MLP gradients (accumulated) and, if non-NULL, d_origins/d_directions [N,3] (accumulated).
+ * workspace: tn_prop_workspace_bytes(N*S) bytes of device scratch (operands of the MLP weight-gradient GEMMs). */
+int64_t tn_prop_workspace_bytes(int64_t num_points);
+int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
+                        const float* d_density, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
+                        tn_stream_t stream);
+
+/* ---- a11 RaySamples.get_weights (cameras/rays.py:128-150) and, optionally, DepthRenderer("median") of the same level
+ *          (model_components/renderers.py:547-557; used for prop_depth_i, models/nerfacto.py:351-352). median_depth may be NULL. */
+int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
+                   tn_stream_t stream);
+int tn_weights_bwd(const float* e_bins, const float* density, const float* weights, const float* d_weights, int64_t N, int32_t S,
+                   float* d_density, tn_stream_t stream);
+
+/* ---- a7  PDFSampler.generate_ray_samples incl. the anneal pow of ProposalNetworkSampler (model_components/ray_samplers.py:276-372,602).
+ * u_lin [S+1] = torch.linspace(0, 1-1/(S+1), S+1) supplied by the host (eval adds 1/(2(S+1)), train adds jitter/(S+1)). */
+int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
+                    const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S, float* s_bins, float* e_bins,
+                    tn_stream_t stream);
+
+/* ---- a12/a13/a14  Field.forward = NerfactoField.get_density + get_outputs with ThermalNerfactoField.mlp_head
+ *          (fields/base_field.py:114-133, fields/nerfacto_field.py:205-229,272-348, fields/thermal_nerfacto_field.py:91-99).
+ * camera_indices [N] int64; training!=0 uses emb[camera], else mean(emb) (use_average_appearance_embedding=True).
+ * Outputs: density [N,S], rgb [N,S,C], optional density_before_activation [N,S] (may be NULL).
+ * workspace: device scratch of tn_field_workspace_bytes(N*S, training) bytes; when training!=0 it keeps the activations
+ * tn_field_bwd consumes, so the same pointer must be passed to both. */
+int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t stream);
+int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                 int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
+                 tn_stream_t stream);
+/* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated). */
+int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                 const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins,
+                 float* d_directions, tn_stream_t stream);
+/* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458). */
+int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                         void* workspace, float* density, tn_stream_t stream);
+
+/* ---- a15/a16  RGBRenderer / RGBTRenderer (background "last_sample"), AccumulationRenderer, DepthRenderer median+expected
+ *          (model_components/renderers.py:118-133,238-245,292-307,418-425,509,547-576).
+ * rgb [N,S,C]; outputs comp [N,C], accumulation [N], depth_median [N], depth_expected [N] (unclipped) and
+ * steps_minmax [2] (running min/max of the sample midpoints as ordered uint32 bit patterns; initialise with tn_minmax_init,
+ * then call tn_clip_depth to apply the batch-global clip of renderers.py:574). */
+int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream);
+int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
+                     float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* steps_minmax,
+                     tn_stream_t stream);
+int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N, tn_stream_t stream);
+/* backward (train mode): d_comp [N,C] -> d_rgb [N,S,C] (written) and d_weights [N,S] (accumulated). */
+int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
+                     float* d_weights, tn_stream_t stream);
+
+/* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
+ * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
+int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
+                       tn_stream_t stream);
+int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
+                       const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
+                       tn_stream_t stream);
+
+/* ---- a19  ThermalNerfactoModel.get_loss_dict pixel terms (models/thermal_nerfacto.py:284-354, model_components/losses.py:602-651,
+ *          utils/rgbt_utils.py:6-32): rgb MSE, thermal MSE x thermal_mult, 2x2-patch TV, cross-channel gradient loss.
+ * pred_rgb [N,3], pred_thermal [N,1] (for shared mode both are views of one [N,4] buffer: pass strides in floats),
+ * image [N,3], is_thermal [N] float.  losses_out[0..3] += {rgb, thermal, tv_pixel, cross_channel}; losses_out must have room for 8 floats
+ * (entry 4 is scratch: the number of RGB rays); d_pred_* accumulated. */
+int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
+                    const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
+                    float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
+/* density L1 cross loss with the reference's detach asymmetry (models/thermal_nerfacto.py:328-344): loss += a*mean|x-y| with
+ * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
+int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
+               tn_stream_t stream);
+/* camera regulariser (cameras/camera_optimizers.py:189-195). */
+int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans_pen, float rot_pen, float scale, float* loss_out,
+                  float* grad_pose, tn_stream_t stream);
+
+/* ---- N1  torch.optim.Adam(lr, eps) as engine/optimizers.py:73-210 builds it, fused over a flat fp32 arena.
+ * step is 1-based. */
+int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
+                 double beta1, double beta2, double eps, tn_stream_t stream);
+int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THERMAL_NERF_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libthermal_nerf_hip.so (the C ABI declared in include/thermal_nerf_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing the first op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libthermal_nerf_hip.so")
+TN_MAX_LEVELS = 16
+TN_MAX_SAMPLES = 256
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f = C.c_float
+_d = C.c_double
+
+
+class TnGrid(C.Structure):
+    _fields_ = [
+        ("table", _p),
+        ("table_grad", _p),
+        ("num_levels", _i32),
+        ("log2_hashmap_size", _i32),
+        ("res", _f * TN_MAX_LEVELS),
+    ]
+
+
+class TnPropNet(C.Structure):
+    _fields_ = [("grid", TnGrid)] + [(n, _p) for n in ("w0", "b0", "w1", "b1", "gw0", "gb0", "gw1", "gb1")]
+
+
+_FIELD_PTRS = ("w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb",
+               "gw0", "gb0", "gw1", "gb1", "ghw0", "ghb0", "ghw1", "ghb1", "ghw2", "ghb2", "gemb")
+
+
+class TnField(C.Structure):
+    _fields_ = [("grid", TnGrid)] + [(n, _p) for n in _FIELD_PTRS] + [("num_channels", _i32), ("num_images", _i32)]
+
+
+# name -> (restype, argtypes); must list every symbol include/thermal_nerf_hip.h declares
+SIGNATURES = {
+    "tn_last_error": (C.c_char_p, []),
+    "tn_version": (C.c_int, []),
+    "tn_field_workspace_bytes": (_i64, [_i64, _i32]),
+    "tn_prop_workspace_bytes": (_i64, [_i64]),
+    "tn_raygen": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
+    "tn_pose_apply_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_pose_apply_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "tn_spaced_bins": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_prop_density_fwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _i64, _i32, _p, _p]),
+    "tn_prop_density_bwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "tn_weights_fwd": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_weights_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "tn_pdf_resample": (C.c_int, [_p, _p, _i32, _f, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_field_pack_weights": (C.c_int, [C.POINTER(TnField), _p, _p]),
+    "tn_field_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "tn_field_bwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_minmax_init": (C.c_int, [_p, _p]),
+    "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "tn_clip_depth": (C.c_int, [_p, _p, _i64, _p]),
+    "tn_composite_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
+    "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
+    "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
+    "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),
+    "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
+    "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the HIP library; raise loudly when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the thermal-nerfacto hot path."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().tn_last_error()
+        raise RuntimeError(f"libthermal_nerf_hip {what} failed (code {rc}): {msg.decode() if msg else ''}")

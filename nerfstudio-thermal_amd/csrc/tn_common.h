@@ -1,0 +1,262 @@
+// Shared host/device helpers for libthermal_nerf_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/thermal_nerf_hip.h"
+
+#define TN_WAVE 64
+
+// ---------------------------------------------------------------- host side
+void tn_set_error(const char* fmt, ...);
+#define TN_REQUIRE(cond, ...)        \
+  do {                               \
+    if (!(cond)) {                   \
+      tn_set_error(__VA_ARGS__);     \
+      return TN_EINVAL;              \
+    }                                \
+  } while (0)
+#define TN_CHECK_LAUNCH(name)                                         \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) {                                          \
+      tn_set_error("%s: %s", name, hipGetErrorString(e__));           \
+      return TN_ELAUNCH;                                              \
+    }                                                                 \
+  } while (0)
+
+static inline hipStream_t tn_s(tn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+__host__ __device__ static inline int64_t tn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// POD copy of TnGrid that is passed to kernels by value
+struct GridK {
+  const float2* table;
+  float2* grad;
+  int L;
+  uint32_t mask;    // 2^log2T - 1
+  uint32_t tsize;   // 2^log2T
+  float res[TN_MAX_LEVELS];
+};
+static inline GridK make_gridk(const TnGrid& g) {
+  GridK k;
+  k.table = reinterpret_cast<const float2*>(g.table);
+  k.grad = reinterpret_cast<float2*>(g.table_grad);
+  k.L = g.num_levels;
+  k.tsize = 1u << g.log2_hashmap_size;
+  k.mask = k.tsize - 1u;
+  for (int i = 0; i < TN_MAX_LEVELS; ++i) k.res[i] = g.res[i];
+  return k;
+}
+
+// ---------------------------------------------------------------- device side
+#define TN_PRIME_Y 2654435761u
+#define TN_PRIME_Z 805459861u
+
+// torch.nan_to_num defaults: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+__device__ __forceinline__ float tn_nan_to_num(float x) {
+  if (x != x) return 0.0f;
+  if (x > 3.4028234663852886e38f) return 3.4028234663852886e38f;
+  if (x < -3.4028234663852886e38f) return -3.4028234663852886e38f;
+  return x;
+}
+
+// UniformLinDispPiecewiseSampler spacing function and inverse (model_components/ray_samplers.py:244-245)
+__device__ __forceinline__ float tn_spacing(float x) { return x < 1.0f ? x / 2.0f : 1.0f - 1.0f / (2.0f * x); }
+__device__ __forceinline__ float tn_spacing_inv(float x) { return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x); }
+// spacing_to_euclidean_fn (model_components/ray_samplers.py:113-118): s_inv(x*s_far + (1-x)*s_near)
+__device__ __forceinline__ float tn_s_to_euclid(float x, float s_near, float s_far) {
+  return tn_spacing_inv(x * s_far + (1.0f - x) * s_near);
+}
+
+// Frustums.get_positions + SceneContraction(L_inf) + (x+2)/4 + selector (cameras/rays.py:49-58,
+// field_components/spatial_distortions.py:66-69, fields/density_fields.py:96-103).
+// Returns the selector; p = masked unit-cube position; if jac != nullptr also d(p_unmasked)/d(world) facts for backward.
+struct Contracted {
+  float px, py, pz;  // masked [0,1]^3 position
+  bool sel;
+  // backward facts
+  float wx, wy, wz;  // world position
+  float mag;         // L_inf norm
+  int amax;          // arg max |component|
+};
+__device__ __forceinline__ Contracted tn_contract(float ox, float oy, float oz, float dx, float dy, float dz, float start, float end) {
+  Contracted c;
+  // origins + directions * (starts + ends) / 2   (evaluated left to right as torch does)
+  float se = start + end;
+  c.wx = ox + (dx * se) / 2.0f;
+  c.wy = oy + (dy * se) / 2.0f;
+  c.wz = oz + (dz * se) / 2.0f;
+  float ax = fabsf(c.wx), ay = fabsf(c.wy), az = fabsf(c.wz);
+  float mag = fmaxf(fmaxf(ax, ay), az);
+  c.mag = mag;
+  c.amax = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+  float x = c.wx, y = c.wy, z = c.wz;
+  if (!(mag < 1.0f)) {
+    float k = 2.0f - (1.0f / mag);
+    x = k * (x / mag);
+    y = k * (y / mag);
+    z = k * (z / mag);
+  }
+  x = (x + 2.0f) / 4.0f;
+  y = (y + 2.0f) / 4.0f;
+  z = (z + 2.0f) / 4.0f;
+  c.sel = (x > 0.0f) && (x < 1.0f) && (y > 0.0f) && (y < 1.0f) && (z > 0.0f) && (z < 1.0f);
+  float m = c.sel ? 1.0f : 0.0f;
+  c.px = x * m;
+  c.py = y * m;
+  c.pz = z * m;
+  return c;
+}
+
+// Backward of tn_contract: gradient wrt the masked unit-cube position -> gradient wrt the world position.
+__device__ __forceinline__ void tn_contract_bwd(const Contracted& c, float gx, float gy, float gz, float& wx, float& wy, float& wz) {
+  if (!c.sel) { wx = wy = wz = 0.0f; return; }
+  gx *= 0.25f; gy *= 0.25f; gz *= 0.25f;  // (x+2)/4
+  if (c.mag < 1.0f) { wx = gx; wy = gy; wz = gz; return; }
+  // y_i = (2 - 1/m) x_i / m = (2/m - 1/m^2) x_i,  m = |x_a|  (a = argmax)
+  // dy_i/dx_j = (2/m - 1/m^2) delta_ij + x_i * (-2/m^2 + 2/m^3) * sign(x_a) * delta_ja
+  float m = c.mag;
+  float s = 2.0f / m - 1.0f / (m * m);
+  float t = (-2.0f / (m * m) + 2.0f / (m * m * m));
+  float dot = gx * c.wx + gy * c.wy + gz * c.wz;
+  wx = s * gx; wy = s * gy; wz = s * gz;
+  float xa = c.amax == 0 ? c.wx : (c.amax == 1 ? c.wy : c.wz);
+  float extra = dot * t * (xa >= 0.0f ? 1.0f : -1.0f);
+  if (c.amax == 0) wx += extra; else if (c.amax == 1) wy += extra; else wz += extra;
+}
+
+// One level of the reference's torch hash encoding (field_components/encodings.py:420-461):
+// ceil/floor corners, every level hashed, x-then-y-then-z interpolation in this exact operation order.
+struct LevelCorners {
+  uint32_t idx[8];  // f0..f7 in the reference's naming
+  float ox, oy, oz;
+};
+__device__ __forceinline__ void tn_level_corners(float px, float py, float pz, float res, uint32_t mask, uint32_t level_off, LevelCorners& lc) {
+  float sx = px * res, sy = py * res, sz = pz * res;
+  float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+  uint32_t cx = (uint32_t)(int)ceilf(sx), cy = (uint32_t)(int)ceilf(sy), cz = (uint32_t)(int)ceilf(sz);
+  uint32_t fx = (uint32_t)(int)fxf, fy = (uint32_t)(int)fyf, fz = (uint32_t)(int)fzf;
+  lc.ox = sx - fxf; lc.oy = sy - fyf; lc.oz = sz - fzf;
+  uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
+  lc.idx[0] = ((cx ^ hcy ^ hcz) & mask) + level_off;  // (c,c,c)
+  lc.idx[1] = ((cx ^ hfy ^ hcz) & mask) + level_off;  // (c,f,c)
+  lc.idx[2] = ((fx ^ hfy ^ hcz) & mask) + level_off;  // (f,f,c)
+  lc.idx[3] = ((fx ^ hcy ^ hcz) & mask) + level_off;  // (f,c,c)
+  lc.idx[4] = ((cx ^ hcy ^ hfz) & mask) + level_off;  // (c,c,f)
+  lc.idx[5] = ((cx ^ hfy ^ hfz) & mask) + level_off;  // (c,f,f)
+  lc.idx[6] = ((fx ^ hfy ^ hfz) & mask) + level_off;  // (f,f,f)
+  lc.idx[7] = ((fx ^ hcy ^ hfz) & mask) + level_off;  // (f,c,f)
+}
+__device__ __forceinline__ float2 tn_level_interp(const float2 f[8], float ox, float oy, float oz) {
+  float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+  float2 r;
+#define TN_LERP3(C)                                      \
+  {                                                      \
+    float f03 = f[0].C * ox + f[3].C * ux;               \
+    float f12 = f[1].C * ox + f[2].C * ux;               \
+    float f56 = f[5].C * ox + f[6].C * ux;               \
+    float f47 = f[4].C * ox + f[7].C * ux;               \
+    float f0312 = f03 * oy + f12 * uy;                   \
+    float f4756 = f47 * oy + f56 * uy;                   \
+    r.C = f0312 * oz + f4756 * uz;                       \
+  }
+  TN_LERP3(x)
+  TN_LERP3(y)
+#undef TN_LERP3
+  return r;
+}
+__device__ __forceinline__ float2 tn_encode_level(const float2* __restrict__ table, float px, float py, float pz, float res, uint32_t mask,
+                                                  uint32_t level_off) {
+  LevelCorners lc;
+  tn_level_corners(px, py, pz, res, mask, level_off, lc);
+  float2 f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
+  return tn_level_interp(f, lc.ox, lc.oy, lc.oz);
+}
+
+// Backward of one level: scatter-add g (gradient of the 2 features) into the table gradient with the trilinear weights,
+// and return d(enc . g)/d(p) (needs the corner values).  Weight of corner i is the product of its per-axis factors:
+// x: c -> ox, f -> 1-ox etc.
+__device__ __forceinline__ void tn_level_bwd(const float2* __restrict__ table, float2* __restrict__ grad, float px, float py, float pz, float res,
+                                             uint32_t mask, uint32_t level_off, float gx, float gy, bool want_dpos, float& dpx, float& dpy,
+                                             float& dpz) {
+  LevelCorners lc;
+  tn_level_corners(px, py, pz, res, mask, level_off, lc);
+  float ox = lc.ox, oy = lc.oy, oz = lc.oz, ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+  // corner i: (x is c?, y is c?, z is c?)   f0 ccc, f1 cfc, f2 ffc, f3 fcc, f4 ccf, f5 cff, f6 fff, f7 fcf
+  const float wxs[8] = {ox, ox, ux, ux, ox, ox, ux, ux};
+  const float wys[8] = {oy, uy, uy, oy, oy, uy, uy, oy};
+  const float wzs[8] = {oz, oz, oz, oz, uz, uz, uz, uz};
+  if (grad != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float w = wxs[i] * wys[i] * wzs[i];
+      if (w != 0.0f) {
+        float* dst = reinterpret_cast<float*>(grad + lc.idx[i]);
+        unsafeAtomicAdd(dst, w * gx);
+        unsafeAtomicAdd(dst + 1, w * gy);
+      }
+    }
+  }
+  if (want_dpos) {
+    float2 f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
+    // sign of d(weight)/d(offset): +1 for "c" factors (offset), -1 for "f" factors (1-offset)
+    const float sxs[8] = {1, 1, -1, -1, 1, 1, -1, -1};
+    const float sys[8] = {1, -1, -1, 1, 1, -1, -1, 1};
+    const float szs[8] = {1, 1, 1, 1, -1, -1, -1, -1};
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = f[i].x * gx + f[i].y * gy;
+      ax += v * sxs[i] * wys[i] * wzs[i];
+      ay += v * wxs[i] * sys[i] * wzs[i];
+      az += v * wxs[i] * wys[i] * szs[i];
+    }
+    dpx += ax * res; dpy += ay * res; dpz += az * res;
+  }
+}
+
+// ---------------------------------------------------------------- wave primitives (64 lanes)
+__device__ __forceinline__ int tn_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float tn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double tn_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float tn_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float tn_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// inclusive prefix sum across the wave (double: torch's CPU cumsum accumulates float inputs in double)
+__device__ __forceinline__ double tn_wave_incl_scan_d(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// inclusive suffix sum across the wave (float)
+__device__ __forceinline__ float tn_wave_incl_rscan(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_down(v, o, 64);
+    if (lane + o < 64) v += t;
+  }
+  return v;
+}

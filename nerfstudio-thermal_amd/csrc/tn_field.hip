@@ -1,0 +1,731 @@
+// Main radiance field (ThermalNerfactoField): 16-level hash grid + fused fp32-MFMA MLP chain.
+//   Field.forward = NerfactoField.get_density + get_outputs   (fields/base_field.py:114-133, fields/nerfacto_field.py:205-229,272-348,
+//                                                              fields/thermal_nerfacto_field.py:91-99)
+//
+// Kernel split (each stage tuned for what bounds it):
+//   k_field_encode     gather-bound : lane = (sample, half of the levels); contraction + selector + 8 levels x 8 corners
+//                                     -> enc[P][32], sel[P]                (many waves in flight, few registers)
+//   k_field_mlp_fwd    MFMA chain   : one wave = 32 samples; Linear(32,64) ReLU Linear(64,16) | head Linear(64 slots,64) ReLU
+//                                     Linear(64,64) ReLU Linear(64,C) sigmoid, every layer as v_mfma_f32_32x32x2_f32 on
+//                                     OUT^T = W . IN^T so that a layer's accumulator tile IS the next layer's B operand
+//                                     (no LDS round trip, no cross-lane traffic between layers).
+//   k_field_mlp_bwd    MFMA chain   : dIN^T = W^T . dOUT^T with the same trick; writes the pre-activation gradients
+//   k_wgrad            MFMA         : dW = dY^T X (K = samples), bias sums for free, contiguous 128-B atomic epilogue
+//   k_field_scatter    atomic-bound : trilinear scatter-add of d_enc into the table gradient (+ d position)
+//
+// Register layout used everywhere ("D-layout" of v_mfma_f32_32x32x2_f32): lane = (j = lane&31 -> sample in the tile,
+// h = lane>>5), accumulator register r in [0,16) holds feature row  R(r,h) = (r&3) + 8*(r>>2) + 4*h  of a 32-row tile.
+// Exact fp32: the MFMA is a k-ordered fmaf chain (no reduced precision), which the 1e-4 density tolerance needs.
+#include "tn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TILE 32
+#define FRAG 64  // floats per A fragment (one per lane)
+
+__host__ __device__ __forceinline__ constexpr int RROW(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- packed-weight layout inside the workspace (float offsets) -------------------------------------------------------
+// forward fragments  Af[layer][m][t][r][lane] = W[32m + (lane&31)][32t + R(r, lane>>5)]
+// backward fragments Ab[layer][t][m][r][lane] = W[32m + R(r, lane>>5)][32t + (lane&31)]      (output tile t = input features)
+// layers: 0 base0 (out 64, in 32)  1 base1 (out 16, in 64)  2 head0 (out 64, in 64 slots)  3 head1 (64,64)  4 head2 (out C, in 64)
+struct LayerGeom { int mo, ti; };  // output tiles, input tiles (of 32)
+__host__ __device__ __forceinline__ constexpr int layer_mo(int l) { return (l == 0 || l == 2 || l == 3) ? 2 : 1; }
+__host__ __device__ __forceinline__ constexpr int layer_ti(int l) { return l == 0 ? 1 : 2; }
+__host__ __device__ __forceinline__ constexpr int layer_frags(int l) { return layer_mo(l) * layer_ti(l) * 16; }
+__host__ __device__ __forceinline__ constexpr int fwd_off(int l) {
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += layer_frags(i) * FRAG;
+  return o;
+}
+#define PACK_FWD_FLOATS (fwd_off(5))                      // 14336
+#define PACK_BIAS_OFF PACK_FWD_FLOATS                     // biases: 5 layers x 64 floats (padded)
+#define PACK_BIAS_FLOATS (5 * 64)
+#define PACK_MEANEMB_OFF (PACK_BIAS_OFF + PACK_BIAS_FLOATS)  // 32 floats: mean appearance embedding
+#define PACK_FWD_TOTAL (PACK_MEANEMB_OFF + 32)               // what the forward kernel stages in LDS (14688 floats = 58,752 B)
+#define PACK_BWD_OFF 14720                                   // (PACK_FWD_TOTAL rounded up to 64)
+#define PACK_BWD_FLOATS PACK_FWD_FLOATS
+#define PACK_TOTAL_FLOATS (PACK_BWD_OFF + PACK_BWD_FLOATS)   // 29056 floats
+static_assert(PACK_FWD_TOTAL <= PACK_BWD_OFF, "pack layout");
+
+// slot space of the colour head's first layer: [0,16) SH, [16,32) base-MLP output rows 0..15 (row 0 = density logit, weight 0),
+// [32,64) appearance embedding.  nn.Linear column for a slot (or -1):
+__host__ __device__ __forceinline__ constexpr int slot_to_col(int s) { return s < 16 ? s : (s == 16 ? -1 : s - 1); }
+
+struct FieldK {
+  const float *w0, *b0, *w1, *b1, *hw0, *hb0, *hw1, *hb1, *hw2, *hb2, *emb;
+  int C, num_images;
+};
+
+__device__ __forceinline__ float weight_at(const FieldK& f, int layer, int o, int i) {
+  switch (layer) {
+    case 0: return (o < 64 && i < 32) ? f.w0[o * 32 + i] : 0.0f;
+    case 1: return (o < 16 && i < 64) ? f.w1[o * 64 + i] : 0.0f;
+    case 2: { int c = slot_to_col(i); return (o < 64 && i < 64 && c >= 0) ? f.hw0[o * 63 + c] : 0.0f; }
+    case 3: return (o < 64 && i < 64) ? f.hw1[o * 64 + i] : 0.0f;
+    default: return (o < f.C && i < 64) ? f.hw2[o * 64 + i] : 0.0f;
+  }
+}
+__device__ __forceinline__ float bias_at(const FieldK& f, int layer, int o) {
+  switch (layer) {
+    case 0: return o < 64 ? f.b0[o] : 0.0f;
+    case 1: return o < 16 ? f.b1[o] : 0.0f;
+    case 2: return o < 64 ? f.hb0[o] : 0.0f;
+    case 3: return o < 64 ? f.hb1[o] : 0.0f;
+    default: return o < f.C ? f.hb2[o] : 0.0f;
+  }
+}
+
+__global__ void k_field_pack(FieldK f, float* __restrict__ pack) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < PACK_FWD_FLOATS) {
+    int layer = 0;
+    while (layer < 4 && idx >= fwd_off(layer + 1)) ++layer;
+    int rel = idx - fwd_off(layer);
+    int lane = rel & 63, frag = rel >> 6;
+    int r = frag & 15, mt = frag >> 4;
+    int ti = layer_ti(layer);
+    // forward: frag order [m][t][r]
+    int m = mt / ti, t = mt % ti;
+    pack[idx] = weight_at(f, layer, 32 * m + (lane & 31), 32 * t + RROW(r, lane >> 5));
+    // backward: frag order [t][m][r] (same count)
+    int mo = layer_mo(layer);
+    int tb = mt / mo, mb = mt % mo;
+    pack[PACK_BWD_OFF + idx] = weight_at(f, layer, 32 * mb + RROW(r, lane >> 5), 32 * tb + (lane & 31));
+  } else if (idx < PACK_FWD_FLOATS + PACK_BIAS_FLOATS) {
+    int q = idx - PACK_FWD_FLOATS;
+    pack[idx] = bias_at(f, q >> 6, q & 63);
+  } else if (idx < PACK_FWD_TOTAL) {
+    int e = idx - PACK_MEANEMB_OFF;
+    // Embedding.mean(dim=0) (field_components/embedding.py:45-47)
+    float s = 0.0f;
+    for (int c = 0; c < f.num_images; ++c) s += f.emb[c * 32 + e];
+    pack[idx] = s / (float)f.num_images;
+  }
+}
+
+// ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
+struct FieldWs {
+  float* pack;     // PACK_TOTAL_FLOATS
+  float* enc;      // [P][32]
+  float* sel;      // [P]
+  // training only
+  float* h1;       // [P][64]  relu(base layer 0)
+  float* hin;      // [P][64]  head input in slot space: sh16 | base_out16 | emb32
+  float* hh1;      // [P][64]
+  float* hh2;      // [P][64]
+  float* y;        // [P][4]   sigmoid outputs (for the sigmoid derivative)
+  float* g3;       // [P][4]   d(head pre-sigmoid)
+  float* gy_hh2;   // [P][64]  pre-activation gradients
+  float* gy_hh1;   // [P][64]
+  float* g_hin;    // [P][64]  gradient wrt head input slots (emb part feeds the embedding gradient)
+  float* gy_bo;    // [P][16]
+  float* gy_h1;    // [P][64]
+  float* g_enc;    // [P][32]
+  int64_t bytes;
+};
+static inline FieldWs ws_layout(void* base, int64_t P, int training) {
+  FieldWs w;
+  char* p = reinterpret_cast<char*>(base);
+  int64_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += ((floats * 4 + 255) / 256) * 256;
+    return r;
+  };
+  w.pack = take(PACK_TOTAL_FLOATS);
+  w.enc = take(P * 32);
+  w.sel = take(P);
+  if (training) {
+    w.h1 = take(P * 64); w.hin = take(P * 64); w.hh1 = take(P * 64); w.hh2 = take(P * 64); w.y = take(P * 4);
+    w.g3 = take(P * 4); w.gy_hh2 = take(P * 64); w.gy_hh1 = take(P * 64); w.g_hin = take(P * 64);
+    w.gy_bo = take(P * 16); w.gy_h1 = take(P * 64); w.g_enc = take(P * 32);
+  } else {
+    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = nullptr;
+  }
+  w.bytes = off;
+  return w;
+}
+extern "C" int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training) {
+  if (num_points < 0) return TN_EINVAL;
+  return ws_layout(nullptr, num_points, training).bytes;
+}
+
+// ---- encode ------------------------------------------------------------------------------------------------------------
+// thread = (sample p, half h): levels {4q + 2h, 4q + 2h + 1 : q = 0..3}  <->  features 8g + 4h + {0..3}, g = 0..3
+__global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                      const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ enc,
+                                                      float* __restrict__ sel) {
+  int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    // lanes 0-31: h=0 of 32 consecutive samples, lanes 32-63: h=1 of the same samples (matches the MFMA tile layout)
+    int64_t tile = idx >> 6;
+    int lane = (int)(idx & 63);
+    int h = lane >> 5;
+    int64_t p = tile * 32 + (lane & 31);
+    if (p >= N * (int64_t)S) continue;
+    int64_t ray = p / S;
+    int s = (int)(p - ray * S);
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+    if (h == 0) sel[p] = c.sel ? 1.0f : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int l0 = 4 * q + 2 * h;
+      float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+      if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
+      if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
+      *reinterpret_cast<float4*>(enc + p * 32 + 8 * q + 4 * h) = make_float4(a.x, a.y, b.x, b.y);
+    }
+  }
+}
+
+// ---- SH degree 4 on (d+1)/2, un-remapped (utils/math.py:45-78; fields/base_field.py:136-142) -------------------------------
+__device__ __forceinline__ void sh16(float dx, float dy, float dz, float* c) {
+  float x = (dx + 1.0f) / 2.0f, y = (dy + 1.0f) / 2.0f, z = (dz + 1.0f) / 2.0f;
+  float xx = x * x, yy = y * y, zz = z * z;
+  c[0] = 0.28209479177387814f;
+  c[1] = 0.4886025119029199f * y;
+  c[2] = 0.4886025119029199f * z;
+  c[3] = 0.4886025119029199f * x;
+  c[4] = 1.0925484305920792f * x * y;
+  c[5] = 1.0925484305920792f * y * z;
+  c[6] = 0.9461746957575601f * zz - 0.31539156525251999f;
+  c[7] = 1.0925484305920792f * x * z;
+  c[8] = 0.5462742152960396f * (xx - yy);
+  c[9] = 0.5900435899266435f * y * (3.0f * xx - yy);
+  c[10] = 2.890611442640554f * x * y * z;
+  c[11] = 0.4570457994644658f * y * (5.0f * zz - 1.0f);
+  c[12] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+  c[13] = 0.4570457994644658f * x * (5.0f * zz - 1.0f);
+  c[14] = 1.445305721320277f * z * (xx - yy);
+  c[15] = 0.5900435899266435f * x * (xx - 3.0f * yy);
+}
+
+// ---- MFMA helpers ------------------------------------------------------------------------------------------------------
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ lds_bias, int layer, int m, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = lds_bias[layer * 64 + 32 * m + RROW(r, h)];
+  return v;
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+  return v;
+}
+// row-major [P][ld] <-> D-layout tile m: registers 4g..4g+3 <-> features 32m + 8g + 4h + {0..3}
+__device__ __forceinline__ void store_tile(float* __restrict__ base, int64_t p, int ld, int m, int h, const f32x16& v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(base + p * ld + 32 * m + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+__device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int64_t p, int ld, int m, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 t = *reinterpret_cast<const float4*>(base + p * ld + 32 * m + 8 * g + 4 * h);
+    v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+  }
+  return v;
+}
+
+// ---- forward MLP chain ----------------------------------------------------------------------------------------------------
+template <bool TRAIN>
+__global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ enc, const float* __restrict__ sel,
+                                                          const float* __restrict__ directions, const int64_t* __restrict__ cam_idx,
+                                                          const float* __restrict__ emb, int num_images, int use_cam_emb, int64_t P, int S, int C,
+                                                          float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ density_pre,
+                                                          float* __restrict__ h1s, float* __restrict__ hins, float* __restrict__ hh1s,
+                                                          float* __restrict__ hh2s, float* __restrict__ ys) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_FWD_TOTAL floats
+  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
+  __syncthreads();
+  const float* lbias = lds + PACK_BIAS_OFF;
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t ntiles = tn_cdiv(P, TILE);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+#define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t p = tile * TILE + j;
+    bool valid = p < P;
+    int64_t pc = valid ? p : P - 1;
+    int64_t ray = pc / S;
+    // ---------------- base MLP: Linear(32,64) ReLU Linear(64,16)
+    f32x16 in0 = load_tile(enc, pc, 32, 0, h);
+    f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a0 = MFMA(AF(0, 0, 0, r), in0[r], a0);
+      a1 = MFMA(AF(0, 1, 0, r), in0[r], a1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = relu16(a0); a1 = relu16(a1);
+    if (TRAIN && valid) { store_tile(h1s, p, 64, 0, h, a0); store_tile(h1s, p, 64, 1, h, a1); }
+    f32x16 bo = bias_tile(lbias, 1, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
+    __builtin_amdgcn_sched_barrier(0);
+    // rows 0..15 live in registers 0..7; row 0 (density logit) = lane half 0, register 0
+    if (valid && h == 0) {
+      float pre = bo[0];
+      float sl = sel[p];
+      density[p] = expf(pre) * sl;  // average_init_density (=1.0) * trunc_exp(pre) * selector
+      if (density_pre) density_pre[p] = pre;
+    }
+    // ---------------- head input in slot space: tile 0 = sh[R(r,h)] (r<8) | base_out rows (r>=8), tile 1 = embedding
+    float sh[16];
+    sh16(directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2], sh);
+    f32x16 hi0, hi1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      hi0[r] = h ? sh[RROW(r, 1)] : sh[RROW(r, 0)];
+      hi0[8 + r] = bo[r];
+    }
+    {
+      const float* eb;
+      if (use_cam_emb) {
+        int64_t cam = cam_idx[ray];
+        if (cam < 0 || cam >= num_images) cam = 0;
+        eb = emb + cam * 32;
+      } else {
+        eb = lds + PACK_MEANEMB_OFF;  // ones * embedding.mean(0)  (fields/nerfacto_field.py:292-295)
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hi1[4 * g + q] = eb[8 * g + 4 * h + q];
+    }
+    if (TRAIN && valid) { store_tile(hins, p, 64, 0, h, hi0); store_tile(hins, p, 64, 1, h, hi1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- head layer 0
+    f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 0, r), hi0[r], c0); c1 = MFMA(AF(2, 1, 0, r), hi0[r], c1); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = relu16(c0); c1 = relu16(c1);
+    if (TRAIN && valid) { store_tile(hh1s, p, 64, 0, h, c0); store_tile(hh1s, p, 64, 1, h, c1); }
+    // ---------------- head layer 1
+    f32x16 d0 = bias_tile(lbias, 3, 0, h), d1 = bias_tile(lbias, 3, 1, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 0, r), c0[r], d0); d1 = MFMA(AF(3, 1, 0, r), c0[r], d1); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
+    __builtin_amdgcn_sched_barrier(0);
+    d0 = relu16(d0); d1 = relu16(d1);
+    if (TRAIN && valid) { store_tile(hh2s, p, 64, 0, h, d0); store_tile(hh2s, p, 64, 1, h, d1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- head layer 2 + sigmoid
+    f32x16 e = bias_tile(lbias, 4, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e = MFMA(AF(4, 0, 0, r), d0[r], e);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e = MFMA(AF(4, 0, 1, r), d1[r], e);
+    if (valid && h == 0) {
+      float y[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) { y[c] = 1.0f / (1.0f + expf(-e[c])); rgb[p * C + c] = y[c]; }
+      if (TRAIN) *reinterpret_cast<float4*>(ys + p * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+  }
+#undef AF
+}
+
+// density only (no head): cross-evaluated density2 / density2_thermal
+__global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __restrict__ pack, const float* __restrict__ enc,
+                                                               const float* __restrict__ sel, int64_t P, float* __restrict__ density) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
+  __syncthreads();
+  const float* lbias = lds + PACK_BIAS_OFF;
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t ntiles = tn_cdiv(P, TILE);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+#define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t p = tile * TILE + j;
+    bool valid = p < P;
+    int64_t pc = valid ? p : P - 1;
+    f32x16 in0 = load_tile(enc, pc, 32, 0, h);
+    f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0 = MFMA(AF(0, 0, 0, r), in0[r], a0); a1 = MFMA(AF(0, 1, 0, r), in0[r], a1); }
+    a0 = relu16(a0); a1 = relu16(a1);
+    f32x16 bo = bias_tile(lbias, 1, 0, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
+    if (valid && h == 0) density[p] = expf(bo[0]) * sel[p];
+  }
+#undef AF
+}
+
+// ---- backward MLP chain ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
+                                                          const float* __restrict__ d_rgb, const float* __restrict__ d_density, int64_t P, int C,
+                                                          const float* __restrict__ h1s, const float* __restrict__ hins,
+                                                          const float* __restrict__ hh1s, const float* __restrict__ hh2s, float* __restrict__ g3s,
+                                                          float* __restrict__ gy_hh2, float* __restrict__ gy_hh1, float* __restrict__ g_hin,
+                                                          float* __restrict__ gy_bo, float* __restrict__ gy_h1, float* __restrict__ g_enc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_BWD_FLOATS
+  const float* src = pack + PACK_BWD_OFF;
+  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t ntiles = tn_cdiv(P, TILE);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // Ab[layer][t][m][r][lane]: output tile t (input features), k from output-feature tile m
+#define AB(layer, t, m, r) lds[fwd_off(layer) + ((((t) * layer_mo(layer) + (m)) * 16 + (r)) << 6) + lane]
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    int64_t p = tile * TILE + j;
+    bool valid = p < P;
+    int64_t pc = valid ? p : P - 1;
+    // ---- sigmoid backward: g3_c = d_rgb_c * y (1-y) ; rows 0..3 live in half 0, registers 0..3
+    float g3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) { float y = ys[p * 4 + c]; g3[c] = d_rgb[p * C + c] * y * (1.0f - y); }
+      *reinterpret_cast<float4*>(g3s + p * 4) = make_float4(g3[0], g3[1], g3[2], g3[3]);
+    }
+    // ---- d hh2 = hw2^T . g3   (k-steps r=0..3 carry rows R(r,h): 0..3 for h=0, 4..7 (zero padding) for h=1)
+    f32x16 dd0 = zero16, dd1 = zero16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dd0 = MFMA(AB(4, 0, 0, r), g3[r], dd0); dd1 = MFMA(AB(4, 1, 0, r), g3[r], dd1); }
+    {
+      f32x16 s0 = load_tile(hh2s, pc, 64, 0, h), s1 = load_tile(hh2s, pc, 64, 1, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dd0[r] = s0[r] > 0.0f ? dd0[r] : 0.0f; dd1[r] = s1[r] > 0.0f ? dd1[r] : 0.0f; }
+    }
+    if (valid) { store_tile(gy_hh2, p, 64, 0, h, dd0); store_tile(gy_hh2, p, 64, 1, h, dd1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d hh1 = hw1^T . d hh2
+    f32x16 dc0 = zero16, dc1 = zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
+    {
+      f32x16 s0 = load_tile(hh1s, pc, 64, 0, h), s1 = load_tile(hh1s, pc, 64, 1, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dc0[r] = s0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = s1[r] > 0.0f ? dc1[r] : 0.0f; }
+    }
+    if (valid) { store_tile(gy_hh1, p, 64, 0, h, dc0); store_tile(gy_hh1, p, 64, 1, h, dc1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d head-input slots = Wslot^T . d hh1
+    f32x16 di0 = zero16, di1 = zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
+    if (valid) { store_tile(g_hin, p, 64, 0, h, di0); store_tile(g_hin, p, 64, 1, h, di1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d base_out rows: slots 16..31 = registers 8..15 of tile 0; row 0 (half 0, reg 0) takes the trunc_exp gradient instead
+    float dbo[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dbo[r] = di0[8 + r];
+    {
+      float pre = hins[pc * 64 + 16];  // slot 16 = density logit
+      float g = d_density[pc] * expf(fminf(fmaxf(pre, -15.0f), 15.0f)) * sel[pc];
+      if (h == 0) dbo[0] = valid ? g : 0.0f;
+    }
+    if (valid) {
+      *reinterpret_cast<float4*>(gy_bo + p * 16 + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
+      *reinterpret_cast<float4*>(gy_bo + p * 16 + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
+    f32x16 dh0 = zero16, dh1 = zero16;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
+    {
+      f32x16 s0 = load_tile(h1s, pc, 64, 0, h), s1 = load_tile(h1s, pc, 64, 1, h);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dh0[r] = s0[r] > 0.0f ? dh0[r] : 0.0f; dh1[r] = s1[r] > 0.0f ? dh1[r] : 0.0f; }
+    }
+    if (valid) { store_tile(gy_h1, p, 64, 0, h, dh0); store_tile(gy_h1, p, 64, 1, h, dh1); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d enc = w0^T . d h1
+    f32x16 de = zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 0, r), dh0[r], de);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 1, r), dh1[r], de);
+    if (valid) store_tile(g_enc, p, 32, 0, h, de);
+  }
+#undef AB
+}
+
+// ---- weight gradients: dW[o][i] += sum_p dY[p][o] X[p][i],  db[o] += sum_p dY[p][o] -----------------------------------------
+// One wave owns a contiguous range of samples; k-step = 2 samples: A lane = dY[p0 + (lane>>5)][32mo + (lane&31)],
+// B lane = X[p0 + (lane>>5)][32mi + (lane&31)].  Epilogue: register r of tile (mo,mi) is dW[32mo + R(r,h)][32mi + (lane&31)]
+// -> each atomic wave-instruction is two contiguous 128-B segments (the shape global float atomics run at full rate).
+// MODE 0: plain.  MODE 1: X columns are head slots (slot_to_col).  MODE 2: dY is the one-hot of the sample's camera (embedding rows).
+template <int MO, int MI, int MODE>
+__global__ void __launch_bounds__(256) k_wgrad(const float* __restrict__ dY, int ldy, int out_dim, const float* __restrict__ X, int ldx, int in_dim,
+                                               int x_col0, const int64_t* __restrict__ cam_idx, int out_base, int S, int64_t P,
+                                               float* __restrict__ dW, int ldw, float* __restrict__ db) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  int64_t per = tn_cdiv(tn_cdiv(P, 2), nwaves) * 2;  // samples per wave (even)
+  int64_t p_begin = wave * per, p_end = p_begin + per;
+  if (p_end > P) p_end = P;
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[MO][MI];
+  float bsum[MO];
+#pragma unroll
+  for (int a = 0; a < MO; ++a) {
+    bsum[a] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) acc[a][b] = zero16;
+  }
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += 2) {
+    int64_t p = p0 + h;
+    bool ok = p < p_end;
+    float av[MO], bv[MI];
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+      int o = 32 * a + j;
+      if (MODE == 2) {
+        int64_t cam = ok ? cam_idx[p / S] : -1;
+        av[a] = (o < out_dim && cam == (int64_t)(out_base + o)) ? 1.0f : 0.0f;
+      } else {
+        av[a] = (ok && o < out_dim) ? dY[p * ldy + o] : 0.0f;
+      }
+      bsum[a] += av[a];
+    }
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      int i = 32 * b + j;
+      bv[b] = (ok && i < in_dim) ? X[p * ldx + x_col0 + i] : 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < MO; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = MFMA(av[a], bv[b], acc[a][b]);
+  }
+  if (p_begin >= p_end) return;
+#pragma unroll
+  for (int a = 0; a < MO; ++a) {
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      int i = 32 * b + j;
+      int col = (MODE == 1) ? slot_to_col(i) : i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int o = 32 * a + RROW(r, h);
+        float v = acc[a][b][r];
+        if (o < out_dim && i < in_dim && col >= 0 && v != 0.0f) atomicAdd(dW + (int64_t)o * ldw + col, v);
+      }
+    }
+    if (db != nullptr) {
+      float s = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+      int o = 32 * a + j;
+      if (h == 0 && o < out_dim && s != 0.0f) atomicAdd(db + o, s);
+    }
+  }
+}
+
+// generic launcher (also used by the proposal networks): out_dim, in_dim <= 64
+int tn_wgrad_launch(const float* dY, int ldy, int out_dim, const float* X, int ldx, int in_dim, int64_t P, float* dW, int ldw, float* db,
+                    hipStream_t stream) {
+  TN_REQUIRE(dY && X && dW && out_dim >= 1 && out_dim <= 64 && in_dim >= 1 && in_dim <= 64 && P >= 0, "tn_wgrad_launch: bad argument");
+  if (P == 0) return TN_OK;
+  const dim3 wg(256), wb(256);
+  const int64_t* nocam = nullptr;
+  int mo = out_dim > 32 ? 2 : 1, mi = in_dim > 32 ? 2 : 1;
+  if (mo == 1 && mi == 1) hipLaunchKernelGGL((k_wgrad<1, 1, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
+  else if (mo == 1 && mi == 2) hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
+  else if (mo == 2 && mi == 1) hipLaunchKernelGGL((k_wgrad<2, 1, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
+  else hipLaunchKernelGGL((k_wgrad<2, 2, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
+  TN_CHECK_LAUNCH("tn_wgrad_launch");
+  return TN_OK;
+}
+
+// ---- table scatter (+ d position) ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_field_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                       const float* __restrict__ e_bins, const float* __restrict__ g_enc, int64_t N, int S,
+                                                       float* __restrict__ d_origins, float* __restrict__ d_directions) {
+  const bool want_dpos = d_origins != nullptr;
+  int64_t P = N * (int64_t)S;
+  int64_t total = tn_cdiv(P, 32) * 64;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t tile = idx >> 6;
+    int lane = (int)(idx & 63);
+    int h = lane >> 5;
+    int64_t p = tile * 32 + (lane & 31);
+    if (p >= P) continue;
+    int64_t ray = p / S;
+    int s = (int)(p - ray * S);
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    float st = eb[0], en = eb[1];
+    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 ge = *reinterpret_cast<const float4*>(g_enc + p * 32 + 8 * q + 4 * h);
+      int l0 = 4 * q + 2 * h;
+      if (l0 < g.L && (ge.x != 0.0f || ge.y != 0.0f))
+        tn_level_bwd(g.table, g.grad, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize, ge.x, ge.y, want_dpos, dpx, dpy, dpz);
+      if (l0 + 1 < g.L && (ge.z != 0.0f || ge.w != 0.0f))
+        tn_level_bwd(g.table, g.grad, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize, ge.z, ge.w, want_dpos, dpx, dpy, dpz);
+    }
+    if (want_dpos) {
+      float wx, wy, wz;
+      tn_contract_bwd(c, dpx, dpy, dpz, wx, wy, wz);
+      float tm = (st + en) / 2.0f;
+      if (wx != 0.0f || wy != 0.0f || wz != 0.0f) {
+        atomicAdd(d_origins + ray * 3 + 0, wx); atomicAdd(d_origins + ray * 3 + 1, wy); atomicAdd(d_origins + ray * 3 + 2, wz);
+        atomicAdd(d_directions + ray * 3 + 0, wx * tm); atomicAdd(d_directions + ray * 3 + 1, wy * tm); atomicAdd(d_directions + ray * 3 + 2, wz * tm);
+      }
+    }
+  }
+}
+
+// ---- host entry points -----------------------------------------------------------------------------------------------------
+static int check_field(const TnField* f, const char* who, bool need_grad) {
+  TN_REQUIRE(f != nullptr, "%s: null field", who);
+  TN_REQUIRE(f->grid.table && f->w0 && f->b0 && f->w1 && f->b1 && f->hw0 && f->hb0 && f->hw1 && f->hb1 && f->hw2 && f->hb2 && f->emb,
+             "%s: null parameter pointer", who);
+  TN_REQUIRE(f->grid.num_levels >= 1 && f->grid.num_levels <= TN_MAX_LEVELS, "%s: num_levels %d out of range", who, f->grid.num_levels);
+  TN_REQUIRE(f->grid.log2_hashmap_size >= 1 && f->grid.log2_hashmap_size <= 24, "%s: bad log2_hashmap_size", who);
+  TN_REQUIRE(f->num_channels >= 1 && f->num_channels <= 4, "%s: num_channels %d unsupported", who, f->num_channels);
+  TN_REQUIRE(f->num_images >= 1, "%s: num_images must be >= 1", who);
+  if (need_grad)
+    TN_REQUIRE(f->grid.table_grad && f->gw0 && f->gb0 && f->gw1 && f->gb1 && f->ghw0 && f->ghb0 && f->ghw1 && f->ghb1 && f->ghw2 && f->ghb2 && f->gemb,
+               "%s: null gradient pointer", who);
+  return TN_OK;
+}
+static FieldK make_fieldk(const TnField* f) {
+  FieldK k{f->w0, f->b0, f->w1, f->b1, f->hw0, f->hb0, f->hw1, f->hb1, f->hw2, f->hb2, f->emb, f->num_channels, f->num_images};
+  return k;
+}
+static int mlp_grid(int64_t P) {
+  int64_t tiles = tn_cdiv(P, TILE);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tiles, 4), 512));
+}
+
+extern "C" int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t stream) {
+  int rc = check_field(field, "tn_field_pack_weights", false);
+  if (rc) return rc;
+  TN_REQUIRE(workspace != nullptr, "tn_field_pack_weights: null workspace");
+  FieldWs ws = ws_layout(workspace, 0, 0);
+  hipLaunchKernelGGL(k_field_pack, dim3((unsigned)tn_cdiv(PACK_FWD_TOTAL, 256)), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack);
+  TN_CHECK_LAUNCH("tn_field_pack_weights");
+  return TN_OK;
+}
+
+static int launch_encode(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                         const FieldWs& ws, tn_stream_t stream) {
+  int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
+  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 256 * 32);
+  hipLaunchKernelGGL(k_field_encode, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel);
+  TN_CHECK_LAUNCH("tn_field_fwd(encode)");
+  return TN_OK;
+}
+
+extern "C" int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                            int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
+                            tn_stream_t stream) {
+  int rc = check_field(field, "tn_field_fwd", false);
+  if (rc) return rc;
+  TN_REQUIRE(origins && directions && camera_indices && e_bins && workspace && density && rgb, "tn_field_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_fwd: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  int64_t P = N * (int64_t)S;
+  FieldWs ws = ws_layout(workspace, P, training);
+  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
+  if (rc) return rc;
+  size_t shmem = PACK_FWD_TOTAL * sizeof(float);
+  int grid = mlp_grid(P);
+  if (training) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_mlp_fwd<true>, dim3(grid), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, directions, camera_indices, field->emb,
+                       field->num_images, 1, P, S, field->num_channels, density, rgb, density_pre, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_mlp_fwd<false>, dim3(grid), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, directions, camera_indices,
+                       field->emb, field->num_images, 0, P, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr, nullptr);
+  }
+  TN_CHECK_LAUNCH("tn_field_fwd(mlp)");
+  return TN_OK;
+}
+
+extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                                    void* workspace, float* density, tn_stream_t stream) {
+  int rc = check_field(field, "tn_field_density_fwd", false);
+  if (rc) return rc;
+  TN_REQUIRE(origins && directions && e_bins && workspace && density, "tn_field_density_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_density_fwd: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  int64_t P = N * (int64_t)S;
+  FieldWs ws = ws_layout(workspace, P, 0);
+  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
+  if (rc) return rc;
+  size_t shmem = PACK_FWD_TOTAL * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(k_field_density_only, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density);
+  TN_CHECK_LAUNCH("tn_field_density_fwd");
+  return TN_OK;
+}
+
+extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                            const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
+                            tn_stream_t stream) {
+  int rc = check_field(field, "tn_field_bwd", true);
+  if (rc) return rc;
+  TN_REQUIRE(origins && directions && camera_indices && e_bins && d_density && d_rgb && workspace, "tn_field_bwd: null pointer");
+  TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  int64_t P = N * (int64_t)S;
+  FieldWs ws = ws_layout(workspace, P, 1);
+  hipStream_t st = tn_s(stream);
+  const int C = field->num_channels;
+  size_t shmem = PACK_BWD_FLOATS * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
+                     ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
+  TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
+  // weight gradients: 256 blocks x 4 waves, each wave a contiguous slab of samples
+  const dim3 wg(256), wb(256);
+  const int64_t* ci = camera_indices;
+  hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, st, ws.g3, 4, C, ws.hh2, 64, 64, 0, ci, 0, S, P, field->ghw2, 64, field->ghb2);
+  hipLaunchKernelGGL((k_wgrad<2, 2, 0>), wg, wb, 0, st, ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, ci, 0, S, P, field->ghw1, 64, field->ghb1);
+  hipLaunchKernelGGL((k_wgrad<2, 2, 1>), wg, wb, 0, st, ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, ci, 0, S, P, field->ghw0, 63, field->ghb0);
+  hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, st, ws.gy_bo, 16, 16, ws.h1, 64, 64, 0, ci, 0, S, P, field->gw1, 64, field->gb1);
+  hipLaunchKernelGGL((k_wgrad<2, 1, 0>), wg, wb, 0, st, ws.gy_h1, 64, 64, ws.enc, 32, 32, 0, ci, 0, S, P, field->gw0, 32, field->gb0);
+  // appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(head input slot 32+e)
+  for (int base = 0; base < field->num_images; base += 32) {
+    int od = std::min(32, field->num_images - base);
+    hipLaunchKernelGGL((k_wgrad<1, 1, 2>), wg, wb, 0, st, nullptr, 0, od, ws.g_hin, 64, 32, 32, ci, base, S, P, field->gemb + (int64_t)base * 32, 32,
+                       nullptr);
+  }
+  TN_CHECK_LAUNCH("tn_field_bwd(wgrad)");
+  int64_t total = tn_cdiv(P, 32) * 64;
+  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 256 * 32);
+  hipLaunchKernelGGL(k_field_scatter, dim3(grid), dim3(256), 0, st, make_gridk(field->grid), origins, directions, e_bins, ws.g_enc, N, S, d_origins,
+                     d_directions);
+  TN_CHECK_LAUNCH("tn_field_bwd(scatter)");
+  return TN_OK;
+}

@@ -1,0 +1,450 @@
+// Ray generation, camera-pose correction, pixel-space losses, Adam, error plumbing.
+#include "tn_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void tn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tn_last_error(void) { return g_err; }
+extern "C" int tn_version(void) { return 100; }
+
+extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
+  TN_REQUIRE(ptr != nullptr && bytes >= 0, "tn_fill_zero: bad argument");
+  if (bytes == 0) return TN_OK;
+  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, tn_s(stream));
+  if (e != hipSuccess) { tn_set_error("tn_fill_zero: %s", hipGetErrorString(e)); return TN_ELAUNCH; }
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ray generation
+// Cameras._generate_rays_from_coords for PERSPECTIVE cameras with OPENCV distortion
+// (cameras/cameras.py:598-655,781-786,886-909; cameras/camera_utils.py:343-446,286-298).
+__device__ __forceinline__ void undistort(float xd, float yd, const float* __restrict__ k, float& xo, float& yo) {
+  const float k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3], p1 = k[4], p2 = k[5];
+  float x = xd, y = yd;
+  for (int it = 0; it < 10; ++it) {
+    float r = x * x + y * y;
+    float d = 1.0f + r * (k1 + r * (k2 + r * (k3 + r * k4)));
+    float fx = d * x + 2.0f * p1 * x * y + p2 * (r + 2.0f * x * x) - xd;
+    float fy = d * y + 2.0f * p2 * x * y + p1 * (r + 2.0f * y * y) - yd;
+    float d_r = k1 + r * (2.0f * k2 + r * (3.0f * k3 + r * 4.0f * k4));
+    float d_x = 2.0f * x * d_r;
+    float d_y = 2.0f * y * d_r;
+    float fx_x = d + d_x * x + 2.0f * p1 * y + 6.0f * p2 * x;
+    float fx_y = d_y * x + 2.0f * p1 * x + 2.0f * p2 * y;
+    float fy_x = d_x * y + 2.0f * p2 * y + 2.0f * p1 * x;
+    float fy_y = d + d_y * y + 2.0f * p2 * x + 6.0f * p1 * y;
+    float den = fy_x * fx_y - fx_x * fy_y;
+    float xn = fx * fy_y - fy * fx_y;
+    float yn = fy * fx_x - fx * fy_x;
+    bool ok = fabsf(den) > 1e-3f;
+    x = x + (ok ? xn / den : 0.0f);
+    y = y + (ok ? yn / den : 0.0f);
+  }
+  xo = x; yo = y;
+}
+
+__global__ void k_raygen(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w, const float* __restrict__ fx,
+                         const float* __restrict__ fy, const float* __restrict__ cx, const float* __restrict__ cy,
+                         const float* __restrict__ distortion, int any_distortion, int num_cameras, int64_t N, float* __restrict__ origins,
+                         float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ directions_norm) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cam = ray_indices[i * 3];
+    if (cam < 0 || cam >= num_cameras) cam = 0;  // host validates; keep the access in bounds regardless
+    float y = (float)ray_indices[i * 3 + 1] + 0.5f;  // get_image_coords(pixel_offset=0.5)
+    float x = (float)ray_indices[i * 3 + 2] + 0.5f;
+    float fxc = fx[cam], fyc = fy[cam], cxc = cx[cam], cyc = cy[cam];
+    // coord, coord_x_offset, coord_y_offset
+    float u[3] = {(x - cxc) / fxc, (x - cxc + 1.0f) / fxc, (x - cxc) / fxc};
+    float v[3] = {(y - cyc) / fyc, (y - cyc) / fyc, (y - cyc + 1.0f) / fyc};
+    const float* R = c2w + cam * 12;
+    float dir[3][3];
+    float nrm0 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float a = u[q], b = v[q];
+      if (any_distortion) undistort(a, b, distortion + cam * 6, a, b);
+      b = -b;  // OpenCV -> OpenGL
+      float dz = -1.0f;
+      // sum(d[None,:] * R, dim=-1): row r of R dotted with d
+      float w0 = a * R[0] + b * R[1] + dz * R[2];
+      float w1 = a * R[4] + b * R[5] + dz * R[6];
+      float w2 = a * R[8] + b * R[9] + dz * R[10];
+      float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+      n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
+      dir[q][0] = w0 / n; dir[q][1] = w1 / n; dir[q][2] = w2 / n;
+      if (q == 0) nrm0 = n;
+    }
+    float ddx = 0.0f, ddy = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = dir[0][c] - dir[1][c], b = dir[0][c] - dir[2][c];
+      ddx += a * a; ddy += b * b;
+    }
+    origins[i * 3 + 0] = R[3]; origins[i * 3 + 1] = R[7]; origins[i * 3 + 2] = R[11];
+    directions[i * 3 + 0] = dir[0][0]; directions[i * 3 + 1] = dir[0][1]; directions[i * 3 + 2] = dir[0][2];
+    pixel_area[i] = sqrtf(ddx) * sqrtf(ddy);
+    if (directions_norm) directions_norm[i] = nrm0;
+  }
+}
+
+extern "C" int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy,
+                         const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions, float* pixel_area,
+                         float* directions_norm, tn_stream_t stream) {
+  TN_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area, "tn_raygen: null pointer");
+  TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_raygen: bad N=%lld num_cameras=%d", (long long)N, num_cameras);
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_raygen, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 2048)), dim3(256), 0, tn_s(stream), ray_indices, c2w, fx, fy, cx,
+                     cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, N, origins, directions, pixel_area, directions_norm);
+  TN_CHECK_LAUNCH("tn_raygen");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pose correction
+struct Pose {
+  float R[9];
+  float t[3];
+};
+// exp_map_SO3xR3 (cameras/lie_groups.py:24-58)
+__device__ __forceinline__ Pose pose_exp(const float* __restrict__ p) {
+  Pose o;
+  float v0 = p[3], v1 = p[4], v2 = p[5];
+  float n = v0 * v0 + v1 * v1 + v2 * v2;
+  float ang = sqrtf(fmaxf(n, 1e-4f));
+  float inv = 1.0f / ang;
+  float f1 = inv * sinf(ang);
+  float f2 = inv * inv * (1.0f - cosf(ang));
+  float K[9] = {0.f, -v2, v1, v2, 0.f, -v0, -v1, v0, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+      o.R[i * 3 + j] = f1 * K[i * 3 + j] + f2 * kk + (i == j ? 1.0f : 0.0f);
+    }
+  o.t[0] = p[0]; o.t[1] = p[1]; o.t[2] = p[2];
+  return o;
+}
+
+__global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                           const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C, float* __restrict__ o_out,
+                           float* __restrict__ d_out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cam = cam_idx[i];
+    if (cam < 0 || cam >= C) cam = 0;
+    float ox = o_in[i * 3], oy = o_in[i * 3 + 1], oz = o_in[i * 3 + 2];
+    float dx = d_in[i * 3], dy = d_in[i * 3 + 1], dz = d_in[i * 3 + 2];
+    if (frozen != nullptr && frozen[cam]) {
+      // identity transform: origins + 0, bmm(I, d)
+      o_out[i * 3] = ox + 0.0f; o_out[i * 3 + 1] = oy + 0.0f; o_out[i * 3 + 2] = oz + 0.0f;
+      d_out[i * 3] = dx; d_out[i * 3 + 1] = dy; d_out[i * 3 + 2] = dz;
+      continue;
+    }
+    Pose p = pose_exp(pose + cam * 6);
+    o_out[i * 3] = ox + p.t[0]; o_out[i * 3 + 1] = oy + p.t[1]; o_out[i * 3 + 2] = oz + p.t[2];
+    d_out[i * 3 + 0] = p.R[0] * dx + p.R[1] * dy + p.R[2] * dz;
+    d_out[i * 3 + 1] = p.R[3] * dx + p.R[4] * dy + p.R[5] * dz;
+    d_out[i * 3 + 2] = p.R[6] * dx + p.R[7] * dy + p.R[8] * dz;
+  }
+}
+
+extern "C" int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+                                 const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
+                                 tn_stream_t stream) {
+  TN_REQUIRE(pose_adjustment && camera_indices && origins_in && directions_in && origins_out && directions_out, "tn_pose_apply_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_pose_apply_fwd: bad N=%lld C=%d", (long long)N, num_cameras);
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_pose_fwd, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 2048)), dim3(256), 0, tn_s(stream), pose_adjustment, frozen,
+                     camera_indices, origins_in, directions_in, N, num_cameras, origins_out, directions_out);
+  TN_CHECK_LAUNCH("tn_pose_apply_fwd");
+  return TN_OK;
+}
+
+// backward:  R = I + f1 K + f2 K^2, K = skew(v), K^2 = v v^T - |v|^2 I, theta = sqrt(clamp(|v|^2, 1e-4))
+//   G = g_d (outer) d_in ;  dL/dt = g_o
+//   dL/dv_m = f1 * skewpart(G)_m + f2 * ((G + G^T) v - 2 v tr G)_m + (<G,K> f1' + <G,K^2> f2') * dtheta/dn * 2 v_m
+__global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                           const float* __restrict__ d_in, const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N, int C,
+                           float* __restrict__ grad_pose) {
+  int lane = tn_lane();
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t iters = tn_cdiv(N, stride);
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool live = i < N;
+    int64_t ii = live ? i : N - 1;
+    int64_t cam = cam_idx[ii];
+    if (cam < 0 || cam >= C) cam = 0;
+    float out[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live && !(frozen != nullptr && frozen[cam])) {
+      const float* p = pose + cam * 6;
+      float v[3] = {p[3], p[4], p[5]};
+      float n = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      float th = sqrtf(fmaxf(n, 1e-4f));
+      float sn = sinf(th), cs = cosf(th);
+      float f1 = sn / th, f2 = (1.0f - cs) / (th * th);
+      float df1 = (th * cs - sn) / (th * th);
+      float df2 = (th * sn - 2.0f * (1.0f - cs)) / (th * th * th);
+      float dth_dn = (n >= 1e-4f) ? 0.5f / th : 0.0f;
+      float gd[3] = {g_d[ii * 3], g_d[ii * 3 + 1], g_d[ii * 3 + 2]};
+      float dd[3] = {d_in[ii * 3], d_in[ii * 3 + 1], d_in[ii * 3 + 2]};
+      float G[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) G[a * 3 + b] = gd[a] * dd[b];
+      float K[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
+      float GK = 0.f, GK2 = 0.f, tr = G[0] + G[4] + G[8];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          GK += G[a * 3 + b] * K[a * 3 + b];
+          GK2 += G[a * 3 + b] * (v[a] * v[b] - (a == b ? n : 0.0f));
+        }
+      float sk[3] = {G[2 * 3 + 1] - G[1 * 3 + 2], G[0 * 3 + 2] - G[2 * 3 + 0], G[1 * 3 + 0] - G[0 * 3 + 1]};
+      float common = (GK * df1 + GK2 * df2) * dth_dn * 2.0f;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        float Gv = G[m * 3] * v[0] + G[m * 3 + 1] * v[1] + G[m * 3 + 2] * v[2];
+        float Gtv = G[m] * v[0] + G[3 + m] * v[1] + G[6 + m] * v[2];
+        out[3 + m] = f1 * sk[m] + f2 * (Gv + Gtv - 2.0f * v[m] * tr) + common * v[m];
+        out[m] = g_o[ii * 3 + m];
+      }
+    }
+    int64_t c0 = __shfl(cam, 0, 64);
+    if (__all(cam == c0)) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        float r = tn_wave_sum(out[q]);
+        if (lane == 0 && r != 0.0f) atomicAdd(grad_pose + cam * 6 + q, r);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+        if (out[q] != 0.0f) atomicAdd(grad_pose + cam * 6 + q, out[q]);
+    }
+  }
+}
+
+extern "C" int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                                 const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                                 tn_stream_t stream) {
+  TN_REQUIRE(pose_adjustment && camera_indices && directions_in && d_origins && d_directions && grad_pose, "tn_pose_apply_bwd: null pointer");
+  TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_pose_apply_bwd: bad N=%lld C=%d", (long long)N, num_cameras);
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_pose_bwd, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024)), dim3(256), 0, tn_s(stream), pose_adjustment, frozen,
+                     camera_indices, directions_in, d_origins, d_directions, N, num_cameras, grad_pose);
+  TN_CHECK_LAUNCH("tn_pose_apply_bwd");
+  return TN_OK;
+}
+
+// camera_opt_regularizer = (mean_c |t_c| * trans_pen + mean_c |r_c| * rot_pen) * scale   (cameras/camera_optimizers.py:189-195)
+__global__ void k_camera_reg(const float* __restrict__ pose, int C, float trans_pen, float rot_pen, float scale, float* __restrict__ loss_out,
+                             float* __restrict__ grad_pose) {
+  float acc = 0.0f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* p = pose + c * 6;
+    float nt = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    float nr = sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5]);
+    acc += (nt * trans_pen + nr * rot_pen) * scale / (float)C;
+    if (grad_pose != nullptr) {
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        // torch.norm backward: x / |x| (0 at the origin)
+        if (nt > 0.0f) grad_pose[c * 6 + m] += p[m] / nt * trans_pen * scale / (float)C;
+        if (nr > 0.0f) grad_pose[c * 6 + 3 + m] += p[3 + m] / nr * rot_pen * scale / (float)C;
+      }
+    }
+  }
+  acc = tn_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss_out, acc);
+}
+
+extern "C" int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans_pen, float rot_pen, float scale, float* loss_out,
+                             float* grad_pose, tn_stream_t stream) {
+  TN_REQUIRE(pose_adjustment && loss_out && num_cameras >= 1, "tn_camera_reg: bad argument");
+  hipLaunchKernelGGL(k_camera_reg, dim3(1), dim3(256), 0, tn_s(stream), pose_adjustment, num_cameras, trans_pen, rot_pen, scale, loss_out, grad_pose);
+  TN_CHECK_LAUNCH("tn_camera_reg");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pixel losses
+// losses_out[0..3] += {rgb_loss, thermal_loss, tv_pixel_loss, cross_channel_loss}; losses_out[4] (scratch) = number of RGB rays.
+__global__ void k_count_rgb(const float* __restrict__ is_thermal, int64_t N, float* __restrict__ out) {
+  float c = 0.0f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) c += (is_thermal[i] == 0.0f) ? 1.0f : 0.0f;
+  c = tn_wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(out, c);
+}
+
+__device__ __forceinline__ float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// one thread per 2x2 patch (4 consecutive rays; is_thermal is constant inside a patch: PatchPixelSampler(patch_size=2))
+__global__ void k_pixel_losses(const float* __restrict__ pred_rgb, int rs, const float* __restrict__ pred_th, int ts, const float* __restrict__ image,
+                               const float* __restrict__ is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult,
+                               float* __restrict__ losses, float* __restrict__ d_rgb, float* __restrict__ d_th) {
+  float l_rgb = 0.f, l_th = 0.f, l_tv = 0.f, l_cc = 0.f;
+  float n_rgb_rays = losses[4];
+  float n_patches = n_rgb_rays / 4.0f;
+  int64_t Q = N / 4;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
+    float pt[4], grey[4];
+    bool rgb_patch = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t i = q * 4 + k;
+      float th = is_thermal[i], nt = 1.0f - th;
+      if (th != 0.0f) rgb_patch = false;
+      float gsum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float img = image[i * 3 + c];
+        float gt = img * nt;  // rgb_to_rgbt_image
+        float a = gt * nt, b = pred_rgb[i * rs + c] * nt;
+        float df = a - b;
+        l_rgb += df * df;
+        if (d_rgb) d_rgb[i * rs + c] += -2.0f * df * nt / ((float)N * 3.0f);
+        gsum += gt;
+      }
+      grey[k] = gsum / 3.0f;
+      float p = pred_th[i * ts];
+      pt[k] = p;
+      float gt_t = image[i * 3] * th;
+      float a = gt_t * th, b = p * th;
+      float df = a - b;
+      l_th += df * df;
+      if (d_th) d_th[i * ts] += thermal_mult * (-2.0f * df * th) / (float)N;
+    }
+    if (rgb_patch && n_patches > 0.0f) {
+      // tv: |p0-p1| + |p0-p2| + |p1-p3| + |p2-p3| ; cross: |(p1-p0)-(g1-g0)| + |(p2-p0)-(g2-g0)| + |(p3-p1)-(g3-g1)| + |(p3-p2)-(g3-g2)|
+      const int A[4] = {1, 2, 3, 3}, B[4] = {0, 0, 1, 2};
+      float dp[4] = {0.f, 0.f, 0.f, 0.f};
+      float tvw = tv_mult * 0.25f / n_patches, ccw = cross_mult * 0.25f / n_patches;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float dpt = pt[A[e]] - pt[B[e]];
+        float dg = grey[A[e]] - grey[B[e]];
+        l_tv += fabsf(dpt);
+        l_cc += fabsf(dpt - dg);
+        float s = tvw * sgn(dpt) + ccw * sgn(dpt - dg);  // d|B-A| = d|A-B|
+        dp[A[e]] += s;
+        dp[B[e]] -= s;
+      }
+      if (d_th) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d_th[(q * 4 + k) * ts] += dp[k];
+      }
+    }
+  }
+  l_rgb = tn_wave_sum(l_rgb); l_th = tn_wave_sum(l_th); l_tv = tn_wave_sum(l_tv); l_cc = tn_wave_sum(l_cc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&losses[0], l_rgb / ((float)N * 3.0f));
+    atomicAdd(&losses[1], thermal_mult * l_th / (float)N);
+    if (n_patches > 0.0f) {
+      atomicAdd(&losses[2], tv_mult * 0.25f * l_tv / n_patches);
+      atomicAdd(&losses[3], cross_mult * 0.25f * l_cc / n_patches);
+    }
+  }
+}
+
+extern "C" int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
+                               const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
+                               float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
+  TN_REQUIRE(pred_rgb && pred_thermal && image && is_thermal && losses_out, "tn_pixel_losses: null pointer");
+  TN_REQUIRE(N >= 0 && N % 4 == 0, "tn_pixel_losses: N=%lld must be a multiple of 4 (2x2 patches)", (long long)N);
+  TN_REQUIRE(rgb_stride >= 3 && thermal_stride >= 1, "tn_pixel_losses: bad strides");
+  if (N == 0) return TN_OK;
+  hipError_t e = hipMemsetAsync(losses_out + 4, 0, sizeof(float), tn_s(stream));
+  if (e != hipSuccess) { tn_set_error("tn_pixel_losses: %s", hipGetErrorString(e)); return TN_ELAUNCH; }
+  hipLaunchKernelGGL(k_count_rgb, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 256)), dim3(256), 0, tn_s(stream), is_thermal, N, losses_out + 4);
+  hipLaunchKernelGGL(k_pixel_losses, dim3((unsigned)std::min<int64_t>(tn_cdiv(N / 4, 256), 256)), dim3(256), 0, tn_s(stream), pred_rgb, rgb_stride,
+                     pred_thermal, thermal_stride, image, is_thermal, N, thermal_mult, tv_mult, cross_mult, losses_out, d_pred_rgb, d_pred_thermal);
+  TN_CHECK_LAUNCH("tn_pixel_losses");
+  return TN_OK;
+}
+
+// loss += a * mean|x - y| is expressed by the caller through gx/gy: d_x += gx * sign(x-y)/count, d_y -= gy * sign(x-y)/count,
+// loss_out += (gx_is_loss_weight) ... see tn_l1_loss in the header: loss value uses (gx + gy) * mean|x-y|.
+__global__ void k_l1(const float* __restrict__ x, const float* __restrict__ y, int64_t n, float gx, float gy, float* __restrict__ loss,
+                     float* __restrict__ d_x, float* __restrict__ d_y) {
+  float acc = 0.0f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float df = x[i] - y[i];
+    acc += fabsf(df);
+    float s = sgn(df) / (float)n;
+    if (d_x) d_x[i] += gx * s;
+    if (d_y) d_y[i] -= gy * s;
+  }
+  acc = tn_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, (gx + gy) * acc / (float)n);
+}
+extern "C" int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
+                          tn_stream_t stream) {
+  TN_REQUIRE(x && y && loss_out && count >= 0, "tn_l1_loss: bad argument");
+  if (count == 0) return TN_OK;
+  hipLaunchKernelGGL(k_l1, dim3((unsigned)std::min<int64_t>(tn_cdiv(count, 256), 2048)), dim3(256), 0, tn_s(stream), x, y, count, gx, gy, loss_out,
+                     d_x, d_y);
+  TN_CHECK_LAUNCH("tn_l1_loss");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam single-tensor arithmetic (no amsgrad / weight decay):
+//   m = m*b1 + g*(1-b1) ; v = v*b2 + (1-b2)*g*g ; p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                       float* __restrict__ pt, const float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt, int tail, float b1,
+                       float b2, float omb1, float omb2, float neg_step, float bc2_sqrt, float eps) {
+#define ADAM1(P, G, M, V)                         \
+  {                                               \
+    float mm = M * b1 + G * omb1;                 \
+    float vv = V * b2 + (omb2 * G) * G;           \
+    float den = sqrtf(vv) / bc2_sqrt + eps;       \
+    P = P + neg_step * (mm / den);                \
+    M = mm;                                       \
+    V = vv;                                       \
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p[i], gg = g[i], mm4 = m[i], vv4 = v[i];
+    ADAM1(pp.x, gg.x, mm4.x, vv4.x)
+    ADAM1(pp.y, gg.y, mm4.y, vv4.y)
+    ADAM1(pp.z, gg.z, mm4.z, vv4.z)
+    ADAM1(pp.w, gg.w, mm4.w, vv4.w)
+    p[i] = pp; m[i] = mm4; v[i] = vv4;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
+    int i = threadIdx.x;
+    float pp = pt[i], gg = gt[i], mm = mt[i], vv = vt[i];
+    ADAM1(pp, gg, mm, vv)
+    pt[i] = pp; mt[i] = mm; vt[i] = vv;
+  }
+#undef ADAM1
+}
+
+extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
+                            double beta1, double beta2, double eps, tn_stream_t stream) {
+  TN_REQUIRE(params && grads && exp_avg && exp_avg_sq, "tn_adam_step: null pointer");
+  TN_REQUIRE(count >= 0 && step >= 1, "tn_adam_step: bad count=%lld step=%d", (long long)count, step);
+  TN_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
+             "tn_adam_step: arena pointers must be 16-byte aligned");
+  if (count == 0) return TN_OK;
+  double bc1 = 1.0 - pow(beta1, (double)step);
+  double bc2 = 1.0 - pow(beta2, (double)step);
+  float neg_step = (float)(-(lr / bc1));
+  float bc2_sqrt = (float)sqrt(bc2);
+  int64_t n4 = count / 4;
+  int tail = (int)(count - n4 * 4);
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(n4, 256), 256 * 16));
+  hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, tn_s(stream), (float4*)params, (const float4*)grads, (float4*)exp_avg, (float4*)exp_avg_sq, n4,
+                     params + n4 * 4, grads + n4 * 4, exp_avg + n4 * 4, exp_avg_sq + n4 * 4, tail, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                     (float)(1.0 - beta2), neg_step, bc2_sqrt, (float)eps);
+  TN_CHECK_LAUNCH("tn_adam_step");
+  return TN_OK;
+}

@@ -1,0 +1,610 @@
+// Per-ray kernels: one 64-lane wave owns one ray; a level's <=256 samples sit ITEMS-per-lane in registers and
+// the serial dependences of the reference (transmittance cumsum, CDF cumsum, searchsorted) become wave-wide scans.
+//   tn_spaced_bins   - SpacedSampler / UniformLinDispPiecewiseSampler   (model_components/ray_samplers.py:78-128,225-248)
+//   tn_weights_fwd/bwd - RaySamples.get_weights (+ median depth)        (cameras/rays.py:128-150; renderers.py:547-557)
+//   tn_pdf_resample  - PDFSampler (+ anneal pow)                         (model_components/ray_samplers.py:276-372,602)
+//   tn_composite_*   - RGB(T)Renderer / Accumulation / Depth renderers   (model_components/renderers.py:118-133,238-245,509,547-576)
+//   tn_distortion_loss / tn_interlevel_loss                              (model_components/losses.py:57-158)
+#include "tn_common.h"
+
+#define RAYS_PER_BLOCK 4
+#define BLOCK (RAYS_PER_BLOCK * TN_WAVE)
+
+// ------------------------------------------------------------------------------------------------ spaced bins
+__global__ void k_spaced_bins(const float* __restrict__ lin_bins, const float* __restrict__ jitter, const float* __restrict__ nears,
+                              const float* __restrict__ fars, int64_t N, int S, float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  int64_t total = N * (int64_t)(S + 1);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ray = i / (S + 1);
+    int j = (int)(i - ray * (S + 1));
+    float b = lin_bins[j];
+    if (jitter != nullptr) {
+      // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
+      float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
+      float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
+      b = lower + (upper - lower) * jitter[ray];
+    }
+    float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
+    s_bins[i] = b;
+    e_bins[i] = tn_s_to_euclid(b, s_near, s_far);
+  }
+}
+
+extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
+                              float* s_bins, float* e_bins, tn_stream_t stream) {
+  TN_REQUIRE(lin_bins && nears && fars && s_bins && e_bins, "tn_spaced_bins: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_spaced_bins: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  int64_t total = N * (S + 1);
+  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 4096);
+  hipLaunchKernelGGL(k_spaced_bins, dim3(grid), dim3(256), 0, tn_s(stream), lin_bins, jitter, nears, fars, N, S, s_bins, e_bins);
+  TN_CHECK_LAUNCH("tn_spaced_bins");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+// lane l owns samples [l*ITEMS, (l+1)*ITEMS) of its ray.
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__ e_bins, const float* __restrict__ density, int64_t N, int S,
+                                                       float* __restrict__ weights, float* __restrict__ median_depth) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;  // whole wave exits together
+  const float* eb = e_bins + ray * (S + 1);
+  const float* dn = density + ray * S;
+  float dd[ITEMS], mid[ITEMS];
+  double loc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    dd[k] = 0.0f; mid[k] = 0.0f;
+    if (i < S) {
+      float st = eb[i], en = eb[i + 1];
+      dd[k] = (en - st) * dn[i];
+      mid[k] = (st + en) / 2.0f;
+    }
+    loc += (double)dd[k];
+  }
+  double incl = tn_wave_incl_scan_d(loc, lane);
+  double run = incl - loc;  // exclusive prefix over earlier lanes (exact in double for these magnitudes up to rounding)
+  float w[ITEMS];
+  double wloc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    float trans = (float)run;  // cumsum of dd[:-1] in double, rounded to float per element (torch CPU cumsum)
+    float a = 1.0f - expf(-dd[k]);
+    float T = expf(-trans);
+    w[k] = tn_nan_to_num(a * T);
+    if (i < S) weights[ray * S + i] = w[k];
+    else w[k] = 0.0f;
+    run += (double)dd[k];
+    wloc += (double)w[k];
+  }
+  if (median_depth != nullptr) {
+    // cumsum(weights) (double accumulate -> float), first index with cum >= 0.5 (searchsorted left), clamp, gather midpoints
+    double wincl = tn_wave_incl_scan_d(wloc, lane);
+    double wrun = wincl - wloc;
+    int cnt = 0;  // number of samples with cum < 0.5
+    float best = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i = lane * ITEMS + k;
+      wrun += (double)w[k];
+      if (i < S && (float)wrun < 0.5f) cnt++;
+    }
+    int total = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    int idx = total < S - 1 ? total : S - 1;
+    // gather mid[idx] from its owner lane
+    int owner = idx / ITEMS, slot = idx - owner * ITEMS;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (k == slot) v = mid[k];
+    best = __shfl(v, owner, 64);
+    if (lane == 0) median_depth[ray] = best;
+  }
+}
+
+extern "C" int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
+                              tn_stream_t stream) {
+  TN_REQUIRE(e_bins && density && weights, "tn_weights_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_weights_fwd: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+  if (S <= 64) hipLaunchKernelGGL(k_weights_fwd<1>, grid, block, 0, tn_s(stream), e_bins, density, N, S, weights, median_depth);
+  else if (S <= 128) hipLaunchKernelGGL(k_weights_fwd<2>, grid, block, 0, tn_s(stream), e_bins, density, N, S, weights, median_depth);
+  else hipLaunchKernelGGL(k_weights_fwd<4>, grid, block, 0, tn_s(stream), e_bins, density, N, S, weights, median_depth);
+  TN_CHECK_LAUNCH("tn_weights_fwd");
+  return TN_OK;
+}
+
+// backward: w_i = (1-exp(-dd_i)) * exp(-sum_{k<i} dd_k)
+//   d dd_i = dw_i * exp(-dd_i) * T_i  -  sum_{k>i} dw_k * w_k ;   d density_i = d dd_i * delta_i
+// (nan_to_num passes the gradient where the raw weight is finite, which is every finite-input case.)
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_weights_bwd(const float* __restrict__ e_bins, const float* __restrict__ density,
+                                                       const float* __restrict__ weights, const float* __restrict__ d_weights, int64_t N, int S,
+                                                       float* __restrict__ d_density) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const float* eb = e_bins + ray * (S + 1);
+  float dd[ITEMS], delta[ITEMS], gw[ITEMS], wk[ITEMS];
+  double loc = 0.0;
+  float sloc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    dd[k] = delta[k] = gw[k] = wk[k] = 0.0f;
+    if (i < S) {
+      delta[k] = eb[i + 1] - eb[i];
+      dd[k] = delta[k] * density[ray * S + i];
+      gw[k] = d_weights[ray * S + i];
+      wk[k] = weights[ray * S + i];
+    }
+    loc += (double)dd[k];
+    sloc += gw[k] * wk[k];
+  }
+  double incl = tn_wave_incl_scan_d(loc, lane);
+  double run = incl - loc;
+  float sincl = tn_wave_incl_rscan(sloc, lane);
+  float suffix = sincl - sloc;  // sum over later lanes
+  // inside the lane: walk backwards for the suffix part
+  float T[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) { T[k] = expf(-(float)run); run += (double)dd[k]; }
+#pragma unroll
+  for (int k = ITEMS - 1; k >= 0; --k) {
+    int i = lane * ITEMS + k;
+    float g = gw[k] * expf(-dd[k]) * T[k] - suffix;
+    if (i < S) d_density[ray * S + i] = g * delta[k];
+    suffix += gw[k] * wk[k];
+  }
+}
+
+extern "C" int tn_weights_bwd(const float* e_bins, const float* density, const float* weights, const float* d_weights, int64_t N, int32_t S,
+                              float* d_density, tn_stream_t stream) {
+  TN_REQUIRE(e_bins && density && weights && d_weights && d_density, "tn_weights_bwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_weights_bwd: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+  if (S <= 64) hipLaunchKernelGGL(k_weights_bwd<1>, grid, block, 0, tn_s(stream), e_bins, density, weights, d_weights, N, S, d_density);
+  else if (S <= 128) hipLaunchKernelGGL(k_weights_bwd<2>, grid, block, 0, tn_s(stream), e_bins, density, weights, d_weights, N, S, d_density);
+  else hipLaunchKernelGGL(k_weights_bwd<4>, grid, block, 0, tn_s(stream), e_bins, density, weights, d_weights, N, S, d_density);
+  TN_CHECK_LAUNCH("tn_weights_bwd");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PDF resample
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict__ s_bins_prev, const float* __restrict__ weights_prev, int Sp,
+                                                        float anneal, const float* __restrict__ u_lin, const float* __restrict__ jitter,
+                                                        const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
+                                                        float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  __shared__ float sh_cdf[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  __shared__ float sh_bins[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+  if (ray >= N) return;  // no block-level barrier below: waves are independent
+  float* cdf = sh_cdf[wv];
+  float* pb = sh_bins[wv];
+  const float* wp = weights_prev + ray * Sp;
+  const float* bp = s_bins_prev + ray * (Sp + 1);
+  float w[ITEMS];
+  double loc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    w[k] = 0.0f;
+    if (i < Sp) {
+      float x = wp[i];
+      if (anneal != 1.0f) x = powf(x, anneal);  // torch.pow(weights, anneal); pow(x,1) is the identity
+      w[k] = x + 0.01f;                        // histogram_padding
+    }
+    loc += (double)w[k];
+  }
+  for (int i = lane; i <= Sp; i += 64) pb[i] = bp[i];
+  float w_sum = (float)tn_wave_sum_d(loc);
+  float padding = fmaxf(1e-5f - w_sum, 0.0f);
+  float pad_each = padding / (float)Sp;
+  w_sum = w_sum + padding;
+  double ploc = 0.0;
+  float pdf[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    pdf[k] = (i < Sp) ? (w[k] + pad_each) / w_sum : 0.0f;
+    ploc += (double)pdf[k];
+  }
+  double incl = tn_wave_incl_scan_d(ploc, lane);
+  double run = incl - ploc;
+  if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    run += (double)pdf[k];
+    if (i < Sp) cdf[i + 1] = fminf(1.0f, (float)run);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
+  int nb = S + 1;
+  for (int j = lane; j < nb; j += 64) {
+    float u;
+    if (jitter != nullptr) u = u_lin[j] + jitter[ray] / (float)nb;
+    else u = u_lin[j] + (float)(1.0 / (2.0 * (double)nb));
+    // searchsorted(cdf, u, side="right"): number of cdf entries <= u
+    int lo = 0, hi = Sp + 1;
+    while (lo < hi) {
+      int m = (lo + hi) >> 1;
+      if (cdf[m] <= u) lo = m + 1; else hi = m;
+    }
+    int below = lo - 1; below = below < 0 ? 0 : (below > Sp ? Sp : below);
+    int above = lo > Sp ? Sp : lo;
+    float c0 = cdf[below], c1 = cdf[above], b0 = pb[below], b1 = pb[above];
+    float t = (u - c0) / (c1 - c0);
+    t = tn_nan_to_num(t);
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    float b = b0 + t * (b1 - b0);
+    s_bins[ray * nb + j] = b;
+    e_bins[ray * nb + j] = tn_s_to_euclid(b, s_near, s_far);
+  }
+}
+
+extern "C" int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
+                               const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S, float* s_bins,
+                               float* e_bins, tn_stream_t stream) {
+  TN_REQUIRE(s_bins_prev && weights_prev && u_lin && nears && fars && s_bins && e_bins, "tn_pdf_resample: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES && S_prev >= 1 && S_prev <= TN_MAX_SAMPLES, "tn_pdf_resample: bad N=%lld S=%d S_prev=%d",
+             (long long)N, S, S_prev);
+  if (N == 0) return TN_OK;
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+#define LAUNCH_PDF(I)                                                                                                                \
+  hipLaunchKernelGGL(k_pdf_resample<I>, grid, block, 0, tn_s(stream), s_bins_prev, weights_prev, S_prev, anneal, u_lin, jitter, nears, \
+                     fars, N, S, s_bins, e_bins)
+  if (S_prev <= 64) LAUNCH_PDF(1);
+  else if (S_prev <= 128) LAUNCH_PDF(2);
+  else LAUNCH_PDF(4);
+#undef LAUNCH_PDF
+  TN_CHECK_LAUNCH("tn_pdf_resample");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ composite
+__device__ __forceinline__ uint32_t f2ord(float f) { return __float_as_uint(f); }  // midpoints are >= 0: bit pattern is order-preserving
+
+__global__ void k_minmax_init(uint32_t* mm) {
+  mm[0] = 0x7f800000u;  // +inf
+  mm[1] = 0u;           // 0
+}
+extern "C" int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream) {
+  TN_REQUIRE(steps_minmax, "tn_minmax_init: null pointer");
+  hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, tn_s(stream), steps_minmax);
+  TN_CHECK_LAUNCH("tn_minmax_init");
+  return TN_OK;
+}
+
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict__ rgb, const float* __restrict__ weights,
+                                                         const float* __restrict__ e_bins, int64_t N, int S, int training,
+                                                         float* __restrict__ comp, float* __restrict__ accumulation,
+                                                         float* __restrict__ depth_median, float* __restrict__ depth_expected,
+                                                         uint32_t* __restrict__ steps_minmax) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const float* eb = e_bins + ray * (S + 1);
+  float acc_c[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc_c[c] = 0.0f;
+  float wsum = 0.0f, wmid = 0.0f, mn = INFINITY, mx = 0.0f;
+  float w[ITEMS], mid[ITEMS];
+  double wloc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    w[k] = 0.0f; mid[k] = 0.0f;
+    if (i < S) {
+      w[k] = weights[ray * S + i];
+      mid[k] = (eb[i] + eb[i + 1]) / 2.0f;
+      mn = fminf(mn, mid[k]); mx = fmaxf(mx, mid[k]);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float v = rgb[(ray * S + i) * C + c];
+        if (!training) v = tn_nan_to_num(v);
+        acc_c[c] += w[k] * v;
+      }
+      wsum += w[k];
+      wmid += w[k] * mid[k];
+    }
+    wloc += (double)w[k];
+  }
+  wsum = tn_wave_sum(wsum);
+  wmid = tn_wave_sum(wmid);
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc_c[c] = tn_wave_sum(acc_c[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float last = rgb[(ray * S + (S - 1)) * C + c];
+      if (!training) last = tn_nan_to_num(last);
+      float v = acc_c[c] + last * (1.0f - wsum);
+      if (!training) v = fminf(fmaxf(v, 0.0f), 1.0f);
+      comp[ray * C + c] = v;
+    }
+    if (accumulation) accumulation[ray] = wsum;
+    if (depth_expected) depth_expected[ray] = wmid / (wsum + 1e-10f);
+  }
+  if (steps_minmax != nullptr) {
+    mn = tn_wave_min(mn); mx = tn_wave_max(mx);
+    if (lane == 0) { atomicMin(&steps_minmax[0], f2ord(mn)); atomicMax(&steps_minmax[1], f2ord(mx)); }
+  }
+  if (depth_median != nullptr) {
+    double wincl = tn_wave_incl_scan_d(wloc, lane);
+    double wrun = wincl - wloc;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i = lane * ITEMS + k;
+      wrun += (double)w[k];
+      if (i < S && (float)wrun < 0.5f) cnt++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    int idx = cnt < S - 1 ? cnt : S - 1;
+    int owner = idx / ITEMS, slot = idx - owner * ITEMS;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) if (k == slot) v = mid[k];
+    v = __shfl(v, owner, 64);
+    if (lane == 0) depth_median[ray] = v;
+  }
+}
+
+extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
+                                float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* steps_minmax,
+                                tn_stream_t stream) {
+  TN_REQUIRE(rgb && weights && e_bins && comp, "tn_composite_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_composite_fwd: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_composite_fwd: unsupported channel count %d", C);
+  if (N == 0) return TN_OK;
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+#define LAUNCH_COMP(I, CC)                                                                                                                \
+  hipLaunchKernelGGL((k_composite_fwd<I, CC>), grid, block, 0, tn_s(stream), rgb, weights, e_bins, N, S, training, comp, accumulation, \
+                     depth_median, depth_expected, steps_minmax)
+#define LAUNCH_COMP_C(I) \
+  do { if (C == 1) LAUNCH_COMP(I, 1); else if (C == 3) LAUNCH_COMP(I, 3); else LAUNCH_COMP(I, 4); } while (0)
+  if (S <= 64) LAUNCH_COMP_C(1);
+  else if (S <= 128) LAUNCH_COMP_C(2);
+  else LAUNCH_COMP_C(4);
+#undef LAUNCH_COMP_C
+#undef LAUNCH_COMP
+  TN_CHECK_LAUNCH("tn_composite_fwd");
+  return TN_OK;
+}
+
+__global__ void k_clip_depth(float* __restrict__ d, const uint32_t* __restrict__ mm, int64_t N) {
+  float lo = __uint_as_float(mm[0]), hi = __uint_as_float(mm[1]);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = d[i];
+    // torch.clip(x, lo, hi) == min(max(x, lo), hi); NaN propagates
+    if (v == v) v = fminf(fmaxf(v, lo), hi);
+    d[i] = v;
+  }
+}
+extern "C" int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N, tn_stream_t stream) {
+  TN_REQUIRE(depth_expected && steps_minmax && N >= 0, "tn_clip_depth: bad argument");
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_clip_depth, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024)), dim3(256), 0, tn_s(stream), depth_expected,
+                     steps_minmax, N);
+  TN_CHECK_LAUNCH("tn_clip_depth");
+  return TN_OK;
+}
+
+// comp_c = sum_s w_s rgb_sc + rgb_{S-1,c} (1 - sum_s w_s)
+//   d rgb_sc = w_s g_c  (+ (1 - sum w) g_c for s = S-1) ;  d w_s = sum_c g_c (rgb_sc - rgb_{S-1,c})
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_composite_bwd(const float* __restrict__ rgb, const float* __restrict__ weights,
+                                                         const float* __restrict__ d_comp, int64_t N, int S, float* __restrict__ d_rgb,
+                                                         float* __restrict__ d_weights) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  float g[C], last[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { g[c] = d_comp[ray * C + c]; last[c] = rgb[(ray * S + (S - 1)) * C + c]; }
+  float wsum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    if (i < S) wsum += weights[ray * S + i];
+  }
+  wsum = tn_wave_sum(wsum);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    if (i < S) {
+      float w = weights[ray * S + i];
+      float dw = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float v = rgb[(ray * S + i) * C + c];
+        dw += g[c] * (v - last[c]);
+        float dr = w * g[c];
+        if (i == S - 1) dr += (1.0f - wsum) * g[c];
+        d_rgb[(ray * S + i) * C + c] = dr;
+      }
+      d_weights[ray * S + i] += dw;
+    }
+  }
+}
+
+extern "C" int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
+                                float* d_weights, tn_stream_t stream) {
+  TN_REQUIRE(rgb && weights && d_comp && d_rgb && d_weights, "tn_composite_bwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_composite_bwd: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_composite_bwd: unsupported channel count %d", C);
+  if (N == 0) return TN_OK;
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+#define LAUNCH_CB(I, CC) hipLaunchKernelGGL((k_composite_bwd<I, CC>), grid, block, 0, tn_s(stream), rgb, weights, d_comp, N, S, d_rgb, d_weights)
+#define LAUNCH_CB_C(I) \
+  do { if (C == 1) LAUNCH_CB(I, 1); else if (C == 3) LAUNCH_CB(I, 3); else LAUNCH_CB(I, 4); } while (0)
+  if (S <= 64) LAUNCH_CB_C(1);
+  else if (S <= 128) LAUNCH_CB_C(2);
+  else LAUNCH_CB_C(4);
+#undef LAUNCH_CB_C
+#undef LAUNCH_CB
+  TN_CHECK_LAUNCH("tn_composite_bwd");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ distortion loss
+// per ray: L = sum_ij w_i w_j |m_i - m_j| + (1/3) sum_i w_i^2 (t_{i+1}-t_i),  m = bin centres in s-space
+//   dL/dw_i = 2 sum_j w_j |m_i - m_j| + (2/3) w_i (t_{i+1}-t_i)      (s-space bins carry no gradient)
+// loss_out += mult * mean_over_rays(L)
+__global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S,
+                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_weights) {
+  __shared__ float sh_w[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+  __shared__ float sh_m[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+  if (ray >= N) return;
+  const float* t = s_bins + ray * (S + 1);
+  for (int i = lane; i < S; i += 64) {
+    sh_w[wv][i] = weights[ray * S + i];
+    sh_m[wv][i] = (t[i + 1] + t[i]) / 2.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  float total = 0.0f;
+  float scale = mult / (float)N;
+  for (int i = lane; i < S; i += 64) {
+    float wi = sh_w[wv][i], mi = sh_m[wv][i];
+    float inner = 0.0f;
+    for (int j = 0; j < S; ++j) inner += sh_w[wv][j] * fabsf(mi - sh_m[wv][j]);
+    float width = t[i + 1] - t[i];
+    total += wi * inner + wi * wi * width / 3.0f;
+    if (d_weights != nullptr) d_weights[ray * S + i] += scale * (2.0f * inner + 2.0f * wi * width / 3.0f);
+  }
+  total = tn_wave_sum(total);
+  if (lane == 0) atomicAdd(loss_out, total * scale);
+}
+
+extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
+                                  tn_stream_t stream) {
+  TN_REQUIRE(s_bins && weights && loss_out, "tn_distortion_loss: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_distortion_loss: bad N=%lld S=%d", (long long)N, S);
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_distortion, dim3((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), dim3(BLOCK), 0, tn_s(stream), s_bins, weights, N, S, mult,
+                     loss_out, d_weights);
+  TN_CHECK_LAUNCH("tn_distortion_loss");
+  return TN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ interlevel loss
+// c,w: fine level (S_f bins+1 / weights, detached);  cp,wp: proposal level.
+//   w_outer_i = cy[hi_i + 1] - cy[lo_i],  cy = [0, cumsum(wp)],
+//   lo_i = clamp(searchsorted_right(cp[:-1], c_i) - 1, 0, Sp-1), hi_i = clamp(searchsorted_right(cp[1:], c_{i+1}), 0, Sp-1)
+//   loss = mean_{rays, i} clip(w_i - w_outer_i, 0)^2 / (w_i + 1e-7)
+//   d wp_k = sum_i [lo_i <= k <= hi_i] * ( -2 clip(w_i - w_outer_i,0) / (w_i + eps) ) / (N*S_f)
+__global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
+                                                      const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N,
+                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
+  __shared__ float sh_cp[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  __shared__ float sh_cy[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  __shared__ float sh_diff[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 2];  // difference array for the range-add of the gradient
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+  if (ray >= N) return;
+  const float* cp = p_bins + ray * (Sp + 1);
+  const float* c = c_bins + ray * (Sf + 1);
+  // cumsum of wp (torch CPU: double accumulate, float per element); lane owns ITEMS=4 contiguous entries max (Sp<=256)
+  const int ITEMS = 4;
+  float v[ITEMS];
+  double loc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    v[k] = (i < Sp) ? w_prop[ray * Sp + i] : 0.0f;
+    loc += (double)v[k];
+  }
+  double incl = tn_wave_incl_scan_d(loc, lane);
+  double run = incl - loc;
+  if (lane == 0) sh_cy[wv][0] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    run += (double)v[k];
+    if (i < Sp) sh_cy[wv][i + 1] = (float)run;
+  }
+  for (int i = lane; i <= Sp; i += 64) sh_cp[wv][i] = cp[i];
+  for (int i = lane; i <= Sp + 1; i += 64) sh_diff[wv][i] = 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  float total = 0.0f;
+  float scale = mult / ((float)N * (float)Sf);
+  for (int i = lane; i < Sf; i += 64) {
+    float t0 = c[i], t1 = c[i + 1];
+    // searchsorted right over cp[0..Sp-1] (starts) for t0
+    int lo = 0, hi = Sp;
+    while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m] <= t0) lo = m + 1; else hi = m; }
+    int ilo = lo - 1; ilo = ilo < 0 ? 0 : (ilo > Sp - 1 ? Sp - 1 : ilo);
+    // searchsorted right over cp[1..Sp] (ends) for t1
+    lo = 0; hi = Sp;
+    while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m + 1] <= t1) lo = m + 1; else hi = m; }
+    int ihi = lo > Sp - 1 ? Sp - 1 : lo;
+    float w_outer = sh_cy[wv][ihi + 1] - sh_cy[wv][ilo];
+    float w = w_fine[ray * Sf + i];
+    float d = w - w_outer;
+    if (d < 0.0f) d = 0.0f;
+    total += d * d / (w + 1.0e-7f);
+    if (d_w_prop != nullptr && d > 0.0f) {  // d w_outer/d wp_k = [k < ihi+1] - [k < ilo]: a signed range-add
+      float g = -2.0f * d / (w + 1.0e-7f) * scale;
+      atomicAdd(&sh_diff[wv][ilo], g);
+      atomicAdd(&sh_diff[wv][ihi + 1], -g);
+    }
+  }
+  total = tn_wave_sum(total);
+  if (lane == 0) atomicAdd(loss_out, total * scale);
+  if (d_w_prop != nullptr) {
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // prefix sum of the difference array
+    float dv[ITEMS];
+    float dloc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i = lane * ITEMS + k;
+      dv[k] = (i < Sp) ? sh_diff[wv][i] : 0.0f;
+      dloc += dv[k];
+    }
+    float dincl = dloc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(dincl, o, 64); if (lane >= o) dincl += t; }
+    float drun = dincl - dloc;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i = lane * ITEMS + k;
+      drun += dv[k];
+      if (i < Sp) d_w_prop[ray * Sp + i] += drun;
+    }
+  }
+}
+
+extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
+                                  const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
+                                  tn_stream_t stream) {
+  TN_REQUIRE(s_bins_fine && weights_fine && s_bins_prop && weights_prop && loss_out, "tn_interlevel_loss: null pointer");
+  TN_REQUIRE(N >= 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES && S_prop >= 1 && S_prop <= TN_MAX_SAMPLES,
+             "tn_interlevel_loss: bad N=%lld S_fine=%d S_prop=%d", (long long)N, S_fine, S_prop);
+  if (N == 0) return TN_OK;
+  hipLaunchKernelGGL(k_interlevel, dim3((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), dim3(BLOCK), 0, tn_s(stream), s_bins_fine, weights_fine, S_fine,
+                     s_bins_prop, weights_prop, S_prop, N, mult, loss_out, d_weights_prop);
+  TN_CHECK_LAUNCH("tn_interlevel_loss");
+  return TN_OK;
+}

@@ -1,0 +1,417 @@
+"""Tensor-level wrappers over the C ABI: torch CUDA tensors in, torch CUDA tensors out.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all arithmetic runs in
+libthermal_nerf_hip.so.  Every function validates device / dtype / contiguity / shape on the host before a
+kernel is launched (a wrong shape must never reach a hand-written kernel).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import TnField, TnGrid, TnPropNet, check
+
+TN_MAX_SAMPLES = _lib.TN_MAX_SAMPLES
+
+
+def level_resolutions(num_levels: int, min_res: int, max_res: int) -> List[float]:
+    """floor(min_res * growth**level) exactly as the reference evaluates it (field_components/encodings.py:343-345):
+    numpy-float64 growth, torch int64 arange -> float32 pow; the default main grid tops out at 2047."""
+    levels = torch.arange(num_levels)
+    growth = np.exp((np.log(max_res) - np.log(min_res)) / (num_levels - 1)) if num_levels > 1 else 1
+    return torch.floor(min_res * growth**levels).to(torch.float32).tolist()
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: Optional[Tensor], name: str, shape: Optional[Tuple[int, ...]] = None, optional: bool = False):
+    if t is None:
+        if optional:
+            return None
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA(HIP) tensor: the thermal-nerfacto path has no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous float32, got {t.dtype} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _i64(t: Tensor, name: str, shape: Tuple[int, ...]):
+    if not t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must be a contiguous CUDA int64 tensor of shape {shape}, got {t.dtype} {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _grid_struct(table: Tensor, grad: Optional[Tensor], num_levels: int, log2_hashmap_size: int, res: Sequence[float]) -> TnGrid:
+    T = 2**log2_hashmap_size
+    g = TnGrid()
+    g.table = _f32(table, "hash_table", (num_levels * T, 2))
+    g.table_grad = _f32(grad, "hash_table.grad", (num_levels * T, 2), optional=True)
+    g.num_levels = num_levels
+    g.log2_hashmap_size = log2_hashmap_size
+    if len(res) != num_levels or num_levels > _lib.TN_MAX_LEVELS:
+        raise ValueError("bad level resolutions")
+    for i in range(_lib.TN_MAX_LEVELS):
+        g.res[i] = float(res[i]) if i < num_levels else 0.0
+    return g
+
+
+@dataclass
+class PropNetParams:
+    """HashMLPDensityField parameters (fields/density_fields.py:34-118); tensors are views of the caller's storage."""
+
+    table: Tensor
+    w0: Tensor
+    b0: Tensor
+    w1: Tensor
+    b1: Tensor
+    num_levels: int
+    log2_hashmap_size: int
+    res: List[float]
+    grads: Optional[dict] = None  # same keys -> gradient tensors
+
+    def cstruct(self, need_grad: bool = False) -> TnPropNet:
+        g = self.grads or {}
+        if need_grad and not g:
+            raise ValueError("gradient buffers required")
+        s = TnPropNet()
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res)
+        H, F = 16, self.num_levels * 2
+        s.w0, s.b0 = _f32(self.w0, "w0", (H, F)), _f32(self.b0, "b0", (H,))
+        s.w1, s.b1 = _f32(self.w1, "w1", (1, H)), _f32(self.b1, "b1", (1,))
+        s.gw0, s.gb0 = _f32(g.get("w0"), "gw0", (H, F), True), _f32(g.get("b0"), "gb0", (H,), True)
+        s.gw1, s.gb1 = _f32(g.get("w1"), "gw1", (1, H), True), _f32(g.get("b1"), "gb1", (1,), True)
+        return s
+
+
+_FIELD_KEYS = ("w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb")
+
+
+@dataclass
+class FieldParams:
+    """ThermalNerfactoField parameters (fields/thermal_nerfacto_field.py:37-99)."""
+
+    table: Tensor
+    w0: Tensor
+    b0: Tensor
+    w1: Tensor
+    b1: Tensor
+    hw0: Tensor
+    hb0: Tensor
+    hw1: Tensor
+    hb1: Tensor
+    hw2: Tensor
+    hb2: Tensor
+    emb: Tensor
+    num_levels: int
+    log2_hashmap_size: int
+    res: List[float]
+    num_channels: int
+    grads: Optional[dict] = None
+    _ws: dict = field(default_factory=dict, repr=False)
+
+    def shapes(self):
+        C_, I = self.num_channels, self.emb.shape[0]
+        return {"w0": (64, 32), "b0": (64,), "w1": (16, 64), "b1": (16,), "hw0": (64, 63), "hb0": (64,), "hw1": (64, 64),
+                "hb1": (64,), "hw2": (C_, 64), "hb2": (C_,), "emb": (I, 32)}
+
+    def cstruct(self, need_grad: bool = False) -> TnField:
+        if self.num_levels * 2 != 32:
+            raise ValueError("the fused main-field kernels are built for 16 levels x 2 features")
+        g = self.grads or {}
+        if need_grad and not g:
+            raise ValueError("gradient buffers required")
+        s = TnField()
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res)
+        for k, shp in self.shapes().items():
+            setattr(s, k, _f32(getattr(self, k), k, shp))
+            setattr(s, "g" + k, _f32(g.get(k), "g" + k, shp, optional=True))
+        s.num_channels = self.num_channels
+        s.num_images = self.emb.shape[0]
+        return s
+
+    def workspace(self, num_points: int, training: bool) -> Tensor:
+        """Device scratch for tn_field_* (packed weights + saved activations), grown on demand and reused."""
+        need = int(_lib.load().tn_field_workspace_bytes(num_points, 1 if training else 0))
+        key = "ws"
+        cur = self._ws.get(key)
+        if cur is None or cur.numel() < need or cur.device != self.table.device:
+            cur = torch.empty(need, dtype=torch.uint8, device=self.table.device)
+            self._ws[key] = cur
+        return cur
+
+
+# ------------------------------------------------------------------------------------------------ a1 / a4
+def raygen(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, distortion: Optional[Tensor]):
+    N, Cn = ray_indices.shape[0], c2w.shape[0]
+    dev = ray_indices.device
+    o = torch.empty((N, 3), device=dev)
+    d = torch.empty((N, 3), device=dev)
+    area = torch.empty((N, 1), device=dev)
+    nrm = torch.empty((N, 1), device=dev)
+    check(_lib.load().tn_raygen(_i64(ray_indices, "ray_indices", (N, 3)), _f32(c2w, "c2w", (Cn, 3, 4)), _f32(fx, "fx", (Cn,)),
+                                _f32(fy, "fy", (Cn,)), _f32(cx, "cx", (Cn,)), _f32(cy, "cy", (Cn,)),
+                                _f32(distortion, "distortion", (Cn, 6), optional=True), Cn, N, _f32(o, "o"), _f32(d, "d"), _f32(area, "a"),
+                                _f32(nrm, "n"), _stream()), "tn_raygen")
+    return o, d, area, nrm
+
+
+def _u8(t: Optional[Tensor], n: int):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.uint8 or tuple(t.shape) != (n,):
+        raise ValueError("frozen mask must be CUDA uint8 [num_cameras]")
+    return C.c_void_p(t.data_ptr())
+
+
+def pose_apply_fwd(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, origins: Tensor, directions: Tensor):
+    N, Cn = origins.shape[0], pose.shape[0]
+    o, d = torch.empty_like(origins), torch.empty_like(directions)
+    check(_lib.load().tn_pose_apply_fwd(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)), _f32(origins, "origins", (N, 3)),
+                                        _f32(directions, "directions", (N, 3)), N, Cn, _f32(o, "o"), _f32(d, "d"), _stream()), "tn_pose_apply_fwd")
+    return o, d
+
+
+def pose_apply_bwd(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, directions_in: Tensor, d_o: Tensor, d_d: Tensor, grad_pose: Tensor):
+    N, Cn = directions_in.shape[0], pose.shape[0]
+    check(_lib.load().tn_pose_apply_bwd(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)),
+                                        _f32(directions_in, "directions", (N, 3)), _f32(d_o, "d_origins", (N, 3)), _f32(d_d, "d_directions", (N, 3)),
+                                        N, Cn, _f32(grad_pose, "grad_pose", (Cn, 6)), _stream()), "tn_pose_apply_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ samplers
+_TABLES: dict = {}
+
+
+def _lin_table(kind: str, S: int, device) -> Tensor:
+    """torch.linspace tables the reference builds on the host (ray_samplers.py:100,319): computed by torch itself, uploaded once."""
+    key = (kind, S, str(device))
+    t = _TABLES.get(key)
+    if t is None:
+        if kind == "spaced":
+            t = torch.linspace(0.0, 1.0, S + 1)
+        else:
+            nb = S + 1
+            t = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)
+        t = t.to(device)
+        _TABLES[key] = t
+    return t
+
+
+def _ray_scalar(t: Optional[Tensor], name: str, N: int, optional=False):
+    if t is None and optional:
+        return None
+    if t.dim() == 2:
+        t = t.reshape(-1)
+    return _f32(t, name, (N,))
+
+
+def spaced_bins(nears: Tensor, fars: Tensor, S: int, jitter: Optional[Tensor] = None):
+    N = nears.shape[0]
+    s = torch.empty((N, S + 1), device=nears.device)
+    e = torch.empty((N, S + 1), device=nears.device)
+    check(_lib.load().tn_spaced_bins(_f32(_lin_table("spaced", S, nears.device), "lin"), _ray_scalar(jitter, "jitter", N, True), _ray_scalar(nears, "nears", N),
+                                     _ray_scalar(fars, "fars", N), N, S, _f32(s, "s"), _f32(e, "e"), _stream()), "tn_spaced_bins")
+    return s, e
+
+
+def pdf_resample(s_bins_prev: Tensor, weights_prev: Tensor, S: int, anneal: float, nears: Tensor, fars: Tensor, jitter: Optional[Tensor] = None):
+    N, Sp = weights_prev.shape[0], weights_prev.shape[1]
+    s = torch.empty((N, S + 1), device=nears.device)
+    e = torch.empty((N, S + 1), device=nears.device)
+    check(_lib.load().tn_pdf_resample(_f32(s_bins_prev, "s_bins_prev", (N, Sp + 1)), _f32(weights_prev, "weights_prev", (N, Sp)), Sp, float(anneal),
+                                      _f32(_lin_table("pdf", S, nears.device), "u"), _ray_scalar(jitter, "jitter", N, True), _ray_scalar(nears, "nears", N),
+                                      _ray_scalar(fars, "fars", N), N, S, _f32(s, "s"), _f32(e, "e"), _stream()), "tn_pdf_resample")
+    return s, e
+
+
+def weights_fwd(e_bins: Tensor, density: Tensor, want_median: bool = False):
+    N, S = density.shape
+    w = torch.empty((N, S), device=density.device)
+    med = torch.empty((N, 1), device=density.device) if want_median else None
+    check(_lib.load().tn_weights_fwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), N, S, _f32(w, "w"),
+                                     _f32(med, "median", optional=True), _stream()), "tn_weights_fwd")
+    return w, med
+
+
+def weights_bwd(e_bins: Tensor, density: Tensor, weights: Tensor, d_weights: Tensor) -> Tensor:
+    N, S = density.shape
+    dd = torch.empty((N, S), device=density.device)
+    check(_lib.load().tn_weights_bwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), _f32(weights, "weights", (N, S)),
+                                     _f32(d_weights, "d_weights", (N, S)), N, S, _f32(dd, "dd"), _stream()), "tn_weights_bwd")
+    return dd
+
+
+# ------------------------------------------------------------------------------------------------ proposal nets
+def prop_density_fwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_bins: Tensor) -> Tensor:
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    out = torch.empty((N, S), device=origins.device)
+    s = net.cstruct()
+    check(_lib.load().tn_prop_density_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                          _f32(e_bins, "e_bins", (N, S + 1)), N, S, _f32(out, "density"), _stream()), "tn_prop_density_fwd")
+    return out
+
+
+_PROP_WS: dict = {}
+
+
+def prop_density_bwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_bins: Tensor, d_density: Tensor,
+                     d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    need = int(_lib.load().tn_prop_workspace_bytes(N * S))
+    ws = _PROP_WS.get(str(origins.device))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
+        _PROP_WS[str(origins.device)] = ws
+    s = net.cstruct(need_grad=True)
+    check(_lib.load().tn_prop_density_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                          _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), N, S, C.c_void_p(ws.data_ptr()),
+                                          _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True), _stream()),
+          "tn_prop_density_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ main field
+def field_pack(fld: FieldParams, num_points: int, training: bool) -> Tensor:
+    ws = fld.workspace(num_points, training)
+    s = fld.cstruct()
+    check(_lib.load().tn_field_pack_weights(C.byref(s), C.c_void_p(ws.data_ptr()), _stream()), "tn_field_pack_weights")
+    return ws
+
+
+def field_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, training: bool, want_pre: bool = False,
+              repack: bool = True):
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    ws = field_pack(fld, N * S, training) if repack else fld.workspace(N * S, training)
+    dens = torch.empty((N, S), device=origins.device)
+    rgb = torch.empty((N, S, fld.num_channels), device=origins.device)
+    pre = torch.empty((N, S), device=origins.device) if want_pre else None
+    s = fld.cstruct()
+    check(_lib.load().tn_field_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
+                                   _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()), _f32(dens, "density"),
+                                   _f32(rgb, "rgb"), _f32(pre, "pre", optional=True), _stream()), "tn_field_fwd")
+    return dens, rgb, pre
+
+
+def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_bins: Tensor, repack: bool = True) -> Tensor:
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    # uses its own scratch so that a training workspace (saved activations) is not clobbered
+    key = "ws_density"
+    need = int(_lib.load().tn_field_workspace_bytes(N * S, 0))
+    ws = fld._ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
+        fld._ws[key] = ws
+    s = fld.cstruct()
+    if repack:
+        check(_lib.load().tn_field_pack_weights(C.byref(s), C.c_void_p(ws.data_ptr()), _stream()), "tn_field_pack_weights")
+    dens = torch.empty((N, S), device=origins.device)
+    check(_lib.load().tn_field_density_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                           _f32(e_bins, "e_bins", (N, S + 1)), N, S, C.c_void_p(ws.data_ptr()), _f32(dens, "density"), _stream()),
+          "tn_field_density_fwd")
+    return dens
+
+
+def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, d_density: Tensor, d_rgb: Tensor,
+              d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    ws = fld.workspace(N * S, True)
+    s = fld.cstruct(need_grad=True)
+    check(_lib.load().tn_field_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
+                                   _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)),
+                                   N, S, C.c_void_p(ws.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True),
+                                   _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ renderers
+def composite_fwd(rgb: Tensor, weights: Tensor, e_bins: Tensor, training: bool, want_depth: bool = True):
+    """-> comp [N,C], accumulation [N,1], depth_median [N,1], depth_expected [N,1] (clipped to the batch-global midpoint range)."""
+    N, S, Cc = rgb.shape
+    dev = rgb.device
+    comp = torch.empty((N, Cc), device=dev)
+    acc = torch.empty((N, 1), device=dev)
+    med = torch.empty((N, 1), device=dev) if want_depth else None
+    exp = torch.empty((N, 1), device=dev) if want_depth else None
+    mm = torch.empty(2, dtype=torch.int32, device=dev) if want_depth else None
+    lib = _lib.load()
+    if want_depth:
+        check(lib.tn_minmax_init(C.c_void_p(mm.data_ptr()), _stream()), "tn_minmax_init")
+    check(lib.tn_composite_fwd(_f32(rgb, "rgb", (N, S, Cc)), _f32(weights, "weights", (N, S)), _f32(e_bins, "e_bins", (N, S + 1)), N, S, Cc,
+                               1 if training else 0, _f32(comp, "comp"), _f32(acc, "acc"), _f32(med, "med", optional=True), _f32(exp, "exp", optional=True),
+                               C.c_void_p(mm.data_ptr()) if want_depth else None, _stream()), "tn_composite_fwd")
+    if want_depth:
+        check(lib.tn_clip_depth(_f32(exp, "exp"), C.c_void_p(mm.data_ptr()), N, _stream()), "tn_clip_depth")
+    return comp, acc, med, exp
+
+
+def composite_bwd(rgb: Tensor, weights: Tensor, d_comp: Tensor, d_weights: Tensor) -> Tensor:
+    N, S, Cc = rgb.shape
+    d_rgb = torch.empty_like(rgb)
+    check(_lib.load().tn_composite_bwd(_f32(rgb, "rgb", (N, S, Cc)), _f32(weights, "weights", (N, S)), _f32(d_comp, "d_comp", (N, Cc)), N, S, Cc,
+                                       _f32(d_rgb, "d_rgb"), _f32(d_weights, "d_weights", (N, S)), _stream()), "tn_composite_bwd")
+    return d_rgb
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def distortion_loss(s_bins: Tensor, weights: Tensor, mult: float, loss_out: Tensor, d_weights: Optional[Tensor]) -> None:
+    N, S = weights.shape
+    check(_lib.load().tn_distortion_loss(_f32(s_bins, "s_bins", (N, S + 1)), _f32(weights, "weights", (N, S)), N, S, float(mult), _f32(loss_out, "loss"),
+                                         _f32(d_weights, "d_weights", (N, S), True), _stream()), "tn_distortion_loss")
+
+
+def interlevel_loss(s_fine: Tensor, w_fine: Tensor, s_prop: Tensor, w_prop: Tensor, mult: float, loss_out: Tensor, d_w_prop: Optional[Tensor]) -> None:
+    N, Sf = w_fine.shape
+    Sp = w_prop.shape[1]
+    check(_lib.load().tn_interlevel_loss(_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, _f32(s_prop, "s_prop", (N, Sp + 1)),
+                                         _f32(w_prop, "w_prop", (N, Sp)), Sp, N, float(mult), _f32(loss_out, "loss"), _f32(d_w_prop, "d_w_prop", (N, Sp), True),
+                                         _stream()), "tn_interlevel_loss")
+
+
+def pixel_losses(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
+                 losses_out: Tensor, d_pred_rgb: Optional[Tensor], d_pred_thermal: Optional[Tensor]) -> None:
+    """pred_rgb [N,3] / pred_thermal [N,1] may be strided views of one [N,4] buffer (shared mode)."""
+    N = pred_rgb.shape[0]
+    if pred_rgb.dtype != torch.float32 or pred_thermal.dtype != torch.float32 or not pred_rgb.is_cuda:
+        raise ValueError("predictions must be CUDA float32")
+    if pred_rgb.stride(1) != 1 or pred_thermal.stride(1) != 1 or pred_rgb.shape != (N, 3) or pred_thermal.shape != (N, 1):
+        raise ValueError("bad prediction views")
+    if losses_out.numel() < 8:
+        raise ValueError("losses_out needs 8 floats")
+    for g, p in ((d_pred_rgb, pred_rgb), (d_pred_thermal, pred_thermal)):
+        if g is not None and (g.stride() != p.stride() or g.shape != p.shape or g.dtype != torch.float32):
+            raise ValueError("gradient views must mirror the prediction views")
+    check(_lib.load().tn_pixel_losses(C.c_void_p(pred_rgb.data_ptr()), pred_rgb.stride(0), C.c_void_p(pred_thermal.data_ptr()), pred_thermal.stride(0),
+                                      _f32(image, "image", (N, 3)), _f32(is_thermal, "is_thermal", (N,)), N, float(thermal_mult), float(tv_mult),
+                                      float(cross_mult), _f32(losses_out, "losses"), C.c_void_p(d_pred_rgb.data_ptr()) if d_pred_rgb is not None else None,
+                                      C.c_void_p(d_pred_thermal.data_ptr()) if d_pred_thermal is not None else None, _stream()), "tn_pixel_losses")
+
+
+def l1_loss(x: Tensor, y: Tensor, gx: float, gy: float, loss_out: Tensor, d_x: Optional[Tensor], d_y: Optional[Tensor]) -> None:
+    n = x.numel()
+    check(_lib.load().tn_l1_loss(_f32(x, "x"), _f32(y, "y", tuple(x.shape)), n, float(gx), float(gy), _f32(loss_out, "loss"),
+                                 _f32(d_x, "d_x", tuple(x.shape), True), _f32(d_y, "d_y", tuple(x.shape), True), _stream()), "tn_l1_loss")
+
+
+def camera_reg(pose: Tensor, trans_pen: float, rot_pen: float, scale: float, loss_out: Tensor, grad_pose: Optional[Tensor]) -> None:
+    Cn = pose.shape[0]
+    check(_lib.load().tn_camera_reg(_f32(pose, "pose", (Cn, 6)), Cn, float(trans_pen), float(rot_pen), float(scale), _f32(loss_out, "loss"),
+                                    _f32(grad_pose, "grad_pose", (Cn, 6), True), _stream()), "tn_camera_reg")
+
+
+def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+              eps: float = 1e-15) -> None:
+    n = params.numel()
+    for t in (grads, exp_avg, exp_avg_sq):
+        if t.numel() != n:
+            raise ValueError("Adam arenas must have equal length")
+    check(_lib.load().tn_adam_step(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n, int(step),
+                                   float(lr), float(beta1), float(beta2), float(eps), _stream()), "tn_adam_step")

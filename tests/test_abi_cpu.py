@@ -1,0 +1,60 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports exactly what the header declares."""
+import os
+import re
+
+import pytest
+
+import nerfstudio_thermal_amd  # noqa: F401
+from nerfstudio_thermal_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "thermal_nerf_hip.h")).read()
+    return set(re.findall(r"\b(tn_[a-z0-9_]+)\s*\(", hdr))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == set(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.tn_version() >= 100
+
+
+def test_host_side_argument_validation_without_gpu(lib):
+    # shape/pointer validation happens before any launch, so it can be exercised without a device
+    assert lib.tn_spaced_bins(None, None, None, None, 4, 16, None, None, None) == -22
+    assert b"null pointer" in lib.tn_last_error()
+    assert lib.tn_field_workspace_bytes(-1, 0) == -22
+    assert lib.tn_field_workspace_bytes(4096 * 48, 1) > lib.tn_field_workspace_bytes(4096 * 48, 0) > 0
+    assert lib.tn_prop_workspace_bytes(1024) >= 1024 * 49 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    from nerfstudio_thermal_amd import ops
+
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        ops.spaced_bins(torch.zeros(4, 1), torch.ones(4, 1), 16)
+
+
+def test_level_resolutions_match_reference_probe():
+    from nerfstudio_thermal_amd import ops
+
+    assert ops.level_resolutions(16, 16, 2048) == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047]
+    assert ops.level_resolutions(5, 16, 128) == [16, 26, 45, 76, 128]
+    assert ops.level_resolutions(5, 16, 256) == [16, 32, 64, 128, 256]

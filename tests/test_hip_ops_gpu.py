@@ -1,0 +1,361 @@
+"""GPU parity tests, op by op: every C-ABI entry point against the CPU oracle on identical seeded inputs.
+
+Tolerances (BASELINE.json north_star): RGB/thermal 1e-3 abs, density 1e-4 abs.  The per-op checks here are tighter wherever the
+arithmetic allows (most ops agree to a few fp32 ulps); discontinuous ops (searchsorted in the PDF sampler, median depth) report
+an outlier fraction instead of a max-abs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import thermal_nerfacto_oracle as orc
+from helpers import make_params, tiny_cfg, SEED
+from nerfstudio_thermal_amd import ops, synth
+from nerfstudio_thermal_amd.arena import ParamArena
+from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+from nerfstudio_thermal_amd.netparams import field_params, prop_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def pkg_cfg(ocfg: orc.OracleConfig) -> ThermalNerfactoModelConfig:
+    c = ThermalNerfactoModelConfig(density_mode=ocfg.density_mode, log2_hashmap_size=ocfg.log2_hashmap_size)
+    for a in c.proposal_net_args_list:
+        a["log2_hashmap_size"] = ocfg.prop_log2_hashmap_size
+    return c
+
+
+def setup_pair(mode="shared", **kw):
+    ocfg = tiny_cfg(mode, **kw)
+    params = make_params(ocfg)
+    cfg = pkg_cfg(ocfg)
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    return ocfg, params, cfg, arena
+
+
+def rays(n, seed=11):
+    r = synth.synth_rays_simple(n, seed)
+    return {k: torch.from_numpy(v) for k, v in r.items()}
+
+
+def g(x):
+    return x.to(DEV).contiguous()
+
+
+def md(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
+
+
+def outlier_fraction(a, b, tol):
+    d = (a.detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs()
+    return float((d > tol).double().mean())
+
+
+# ------------------------------------------------------------------------------------------------ a1 / a4
+def test_raygen_matches_oracle():
+    cams = synth.synth_cameras()
+    idx = torch.from_numpy(synth.synth_ray_indices(cams, 256))
+    t = lambda k: torch.from_numpy(cams[k])  # noqa: E731
+    ro, rd, ra, rn = orc.generate_rays(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    o, d, a, n = ops.raygen(g(idx), g(t("c2w")), g(t("fx")), g(t("fy")), g(t("cx")), g(t("cy")), g(t("distortion")))
+    assert md(o, ro) == 0.0
+    assert md(d, rd) < 2e-6
+    assert md(a, ra) < 1e-9
+    assert md(n, rn) < 1e-5
+    # no distortion
+    ro, rd, ra, rn = orc.generate_rays(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), None)
+    o, d, a, n = ops.raygen(g(idx), g(t("c2w")), g(t("fx")), g(t("fy")), g(t("cx")), g(t("cy")), None)
+    assert md(d, rd) < 1e-6
+
+
+def test_pose_apply_fwd_bwd():
+    N, C = 512, 8
+    r = rays(N)
+    pose = torch.from_numpy(synth.uniform("pose_t", (C, 6), -0.2, 0.2, 5))
+    pose[1, 3:] = 0.0
+    pose[2, 3:] = torch.tensor([1e-3, -2e-3, 5e-4])
+    pose.requires_grad_(True)
+    frozen = torch.tensor([0, 0, 0, 0, 1, 1, 1, 1], dtype=torch.bool)
+    ro, rd = orc.apply_pose_adjustment(pose, frozen, r["camera_indices"], r["origins"], r["directions"])
+    go = torch.from_numpy(synth.uniform("go", (N, 3), seed=5))
+    gd = torch.from_numpy(synth.uniform("gd", (N, 3), seed=5))
+    ((ro * go).sum() + (rd * gd).sum()).backward()
+    o, d = ops.pose_apply_fwd(g(pose.detach()), g(frozen.to(torch.uint8)), g(r["camera_indices"]), g(r["origins"]), g(r["directions"]))
+    assert md(o, ro) < 1e-6 and md(d, rd) < 1e-6
+    gp = torch.zeros((C, 6), device=DEV)
+    ops.pose_apply_bwd(g(pose.detach()), g(frozen.to(torch.uint8)), g(r["camera_indices"]), g(r["directions"]), g(go), g(gd), gp)
+    assert md(gp, pose.grad) < 2e-4 * float(pose.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ samplers / weights
+@pytest.mark.parametrize("train", [False, True])
+def test_spaced_pdf_weights_chain(train):
+    N = 300  # not a multiple of the 4 rays per workgroup
+    j0, j1, j2 = (torch.from_numpy(j) for j in synth.synth_jitters(N))
+    nears = torch.ones(N, 1) * (0.05 if train else 0.0)
+    fars = torch.ones(N, 1) * 1000.0
+    s0 = orc.spaced_bins(N, 256, j0 if train else None)
+    e0 = orc.s_to_euclidean(s0, nears, fars)
+    hs0, he0 = ops.spaced_bins(g(nears), g(fars), 256, g(j0) if train else None)
+    assert md(hs0, s0) == 0.0
+    assert md(he0, e0) <= 1e-6 * float(e0.max())
+    dens = torch.from_numpy(synth.uniform("dens0", (N, 256, 1), 0.0, 60.0, SEED)) ** 2 / 60.0
+    dens[5] = 0.0  # empty ray -> PDF padding guard
+    smp = orc.Samples(s_bins=s0, e_bins=e0)
+    w0 = orc.get_weights(smp.deltas, dens)
+    hw0, med0 = ops.weights_fwd(g(e0), g(dens[..., 0]), want_median=True)
+    assert md(hw0, w0[..., 0]) < 2e-6
+    ref_med = orc.depth_median(w0, smp)
+    assert outlier_fraction(med0, ref_med, 1e-6) <= 0.01
+    for anneal in (1.0, 0.37):
+        s1 = orc.pdf_resample(s0, torch.pow(w0, anneal), 96, j1 if train else None)
+        hs1, he1 = ops.pdf_resample(g(s0), g(w0[..., 0]), 96, anneal, g(nears), g(fars), g(j1) if train else None)
+        assert outlier_fraction(hs1, s1, 2e-6) <= 0.005, anneal
+        e1 = orc.s_to_euclidean(s1, nears, fars)
+        assert outlier_fraction(he1 / e1.to(DEV), torch.ones_like(e1), 1e-4) <= 0.005
+    # second resample 96 -> 48 (ITEMS=2 path)
+    smp1 = orc.Samples(s_bins=s1, e_bins=e1)
+    dens1 = torch.from_numpy(synth.uniform("dens1", (N, 96, 1), 0.0, 30.0, SEED))
+    w1 = orc.get_weights(smp1.deltas, dens1)
+    hw1, _ = ops.weights_fwd(g(e1), g(dens1[..., 0]))
+    assert md(hw1, w1[..., 0]) < 2e-6
+    s2 = orc.pdf_resample(s1, w1, 48, j2 if train else None)
+    hs2, _ = ops.pdf_resample(g(s1), g(w1[..., 0]), 48, 1.0, g(nears), g(fars), g(j2) if train else None)
+    assert outlier_fraction(hs2, s2, 2e-6) <= 0.005
+
+
+@pytest.mark.parametrize("S", [48, 96, 256, 7])
+def test_weights_bwd(S):
+    N = 130
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s = orc.spaced_bins(N, S, None)
+    e = orc.s_to_euclidean(s, nears, fars)
+    dens = (torch.from_numpy(synth.uniform(f"wd{S}", (N, S, 1), 0.0, 8.0, SEED))).requires_grad_(True)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    w = orc.get_weights(smp.deltas, dens)
+    gw = torch.from_numpy(synth.uniform(f"gw{S}", (N, S, 1), seed=SEED))
+    (w * gw).sum().backward()
+    hw, _ = ops.weights_fwd(g(e), g(dens.detach()[..., 0]))
+    dd = ops.weights_bwd(g(e), g(dens.detach()[..., 0]), hw, g(gw[..., 0]))
+    assert md(dd, dens.grad[..., 0]) <= 1e-5 * max(1.0, float(dens.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ proposal nets
+def sample_level(N, S, nears, fars):
+    s = orc.spaced_bins(N, S, None)
+    return s, orc.s_to_euclidean(s, nears, fars)
+
+
+@pytest.mark.parametrize("lvl,S", [(0, 256), (1, 96)])
+def test_prop_density_fwd_bwd(lvl, S):
+    ocfg, params, cfg, arena = setup_pair()
+    N = 128
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = r["origins"].clone().requires_grad_(True)
+    d = r["directions"].clone().requires_grad_(True)
+    dens = orc.prop_density(p, "proposal_networks", lvl, ocfg, smp.positions(o, d))
+    net = prop_params(arena, "proposal_networks", lvl, cfg, with_grads=True)
+    hd = ops.prop_density_fwd(net, g(r["origins"]), g(r["directions"]), g(e))
+    assert md(hd, dens[..., 0]) <= 1e-4, md(hd, dens[..., 0])
+    assert md(hd / dens[..., 0].detach().to(DEV).clamp_min(1e-6), torch.ones(N, S)) <= 2e-5
+    gd = torch.from_numpy(synth.uniform(f"gdens{lvl}", (N, S, 1), seed=SEED))
+    (dens * gd).sum().backward()
+    arena.zero_grad()
+    d_o = torch.zeros((N, 3), device=DEV)
+    d_d = torch.zeros((N, 3), device=DEV)
+    ops.prop_density_bwd(net, g(r["origins"]), g(r["directions"]), g(e), g(gd[..., 0]), d_o, d_d)
+    k = orc.prop_keys("proposal_networks", lvl)
+    for short in ("table", "w0", "b0", "w1", "b1"):
+        ref = p[k[short]].grad
+        got = arena.grad_view(k[short])
+        scale = float(ref.abs().max())
+        assert md(got, ref) <= 2e-4 * scale, (short, md(got, ref), scale)
+    assert md(d_o, o.grad) <= 2e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 2e-4 * float(d.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ main field
+@pytest.mark.parametrize("mode,training", [("shared", False), ("shared", True), ("separate", True)])
+def test_field_fwd_bwd(mode, training):
+    ocfg, params, cfg, arena = setup_pair(mode)
+    N, S = 100, 48  # 4800 points: not a multiple of the 32-sample MFMA tile
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    prefix = "field_thermal" if mode == "separate" else "field"
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = r["origins"].clone().requires_grad_(True)
+    d = r["directions"].clone().requires_grad_(True)
+    dens, geo, pre, enc = orc.field_density(p, prefix, ocfg, smp.positions(o, d))
+    rgb = orc.field_color(p, prefix, ocfg, d.detach(), geo, r["camera_indices"], training)
+    fld = field_params(arena, prefix, cfg, with_grads=True)
+    hd, hrgb, hpre = ops.field_fwd(fld, g(r["origins"]), g(r["directions"]), g(r["camera_indices"]), g(e), training, want_pre=True)
+    assert md(hpre, pre[..., 0]) <= 2e-5, md(hpre, pre[..., 0])
+    assert md(hd, dens[..., 0]) <= 1e-4, md(hd, dens[..., 0])
+    assert md(hrgb, rgb) <= 1e-4, md(hrgb, rgb)
+    hd2 = ops.field_density_fwd(fld, g(r["origins"]), g(r["directions"]), g(e))
+    assert md(hd2, hd) == 0.0
+    if not training:
+        return
+    C = fld.num_channels
+    gd = torch.from_numpy(synth.uniform("gfd", (N, S, 1), seed=SEED))
+    gc = torch.from_numpy(synth.uniform("gfc", (N, S, C), seed=SEED))
+    ((dens * gd).sum() + (rgb * gc).sum()).backward()
+    arena.zero_grad()
+    d_o = torch.zeros((N, 3), device=DEV)
+    d_d = torch.zeros((N, 3), device=DEV)
+    ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(r["camera_indices"]), g(e), g(gd[..., 0]), g(gc), d_o, d_d)
+    k = orc.field_keys(prefix)
+    for short in ("table", "w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
+        ref = p[k[short]].grad
+        got = arena.grad_view(k[short])
+        scale = float(ref.abs().max())
+        assert md(got, ref) <= 3e-4 * scale, (short, md(got, ref), scale)
+    assert md(d_o, o.grad) <= 3e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
+
+
+def test_field_default_table_size_hash_parity():
+    """Full 2^19-entry tables / 2047-resolution top level: exercises the uint32 hash against the oracle's int64 one."""
+    ocfg = orc.OracleConfig(density_mode="shared")
+    shapes = {k: v for k, v in orc.param_shapes(ocfg).items() if k.startswith("field.")}
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=SEED).items()}
+    cfg = ThermalNerfactoModelConfig(density_mode="shared")
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    N, S = 64, 48
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    with torch.no_grad():
+        dens, geo, pre, _ = orc.field_density(params, "field", ocfg, smp.positions(r["origins"], r["directions"]))
+        rgb = orc.field_color(params, "field", ocfg, r["directions"], geo, r["camera_indices"], False)
+    fld = field_params(arena, "field", cfg)
+    hd, hrgb, hpre = ops.field_fwd(fld, g(r["origins"]), g(r["directions"]), g(r["camera_indices"]), g(e), False, want_pre=True)
+    assert md(hpre, pre[..., 0]) <= 2e-5
+    assert md(hd, dens[..., 0]) <= 1e-4
+    assert md(hrgb, rgb) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ renderers and losses
+@pytest.mark.parametrize("C,S,training", [(4, 48, False), (4, 48, True), (3, 48, True), (1, 96, False), (4, 256, True)])
+def test_composite_fwd_bwd(C, S, training):
+    N = 257
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    dens = torch.from_numpy(synth.uniform(f"cd{S}", (N, S, 1), 0.0, 6.0, SEED)) ** 2
+    w = orc.get_weights(smp.deltas, dens).requires_grad_(True)
+    rgb = torch.from_numpy(synth.uniform(f"crgb{C}{S}", (N, S, C), 0.0, 1.0, SEED))
+    if not training:
+        rgb[3, 5, 0] = float("nan")
+        rgb[4, 1, 0] = 3.0
+    rgb.requires_grad_(True)
+    comp = orc.composite_rgb(rgb, w, training)
+    hc, hacc, hmed, hexp = ops.composite_fwd(g(rgb.detach()), g(w.detach()[..., 0]), g(e), training)
+    assert md(hc, comp) <= 2e-6
+    assert md(hacc, orc.accumulation(w)) <= 2e-6
+    assert md(hexp, orc.depth_expected(w, smp)) <= 1e-5 * float(e.max())
+    assert outlier_fraction(hmed, orc.depth_median(w, smp), 1e-6) <= 0.01
+    if not training:
+        return
+    gc = torch.from_numpy(synth.uniform(f"gcomp{C}", (N, C), seed=SEED))
+    (comp * gc).sum().backward()
+    dw = torch.zeros((N, S), device=DEV)
+    drgb = ops.composite_bwd(g(rgb.detach()), g(w.detach()[..., 0]), g(gc), dw)
+    assert md(drgb, rgb.grad) <= 1e-6
+    assert md(dw, w.grad[..., 0]) <= 1e-5
+
+
+def test_proposal_losses():
+    N = 190
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    j0, j1, j2 = (torch.from_numpy(j) for j in synth.synth_jitters(N))
+    lv = []
+    s_prev, w_prev = None, None
+    for i, S in enumerate((256, 96, 48)):
+        s = orc.spaced_bins(N, S, j0) if i == 0 else orc.pdf_resample(s_prev, w_prev, S, (j1, j2)[i - 1])
+        e = orc.s_to_euclidean(s, nears, fars)
+        smp = orc.Samples(s_bins=s, e_bins=e)
+        dens = torch.from_numpy(synth.uniform(f"pl{i}", (N, S, 1), 0.0, 5.0, SEED)) ** 3
+        w = orc.get_weights(smp.deltas, dens).detach().requires_grad_(True)
+        lv.append((smp, w))
+        s_prev, w_prev = s, w.detach()
+    wl, sl = [w for _, w in lv], [s for s, _ in lv]
+    dist = orc.distortion_loss(wl, sl) * 0.002
+    inter = orc.interlevel_loss(wl, sl)
+    (dist + inter).backward()
+    loss = torch.zeros(8, device=DEV)
+    dw2 = torch.zeros((N, 48), device=DEV)
+    ops.distortion_loss(g(sl[2].s_bins), g(wl[2].detach()[..., 0]), 0.002, loss[0:1], dw2)
+    dw0 = torch.zeros((N, 256), device=DEV)
+    dw1 = torch.zeros((N, 96), device=DEV)
+    ops.interlevel_loss(g(sl[2].s_bins), g(wl[2].detach()[..., 0]), g(sl[0].s_bins), g(wl[0].detach()[..., 0]), 1.0, loss[1:2], dw0)
+    ops.interlevel_loss(g(sl[2].s_bins), g(wl[2].detach()[..., 0]), g(sl[1].s_bins), g(wl[1].detach()[..., 0]), 1.0, loss[1:2], dw1)
+    assert abs(float(loss[0]) - float(dist)) <= 1e-5 * float(dist)
+    assert abs(float(loss[1]) - float(inter)) <= 1e-4 * float(inter) + 1e-9
+    assert md(dw2, wl[2].grad[..., 0]) <= 1e-5 * float(wl[2].grad.abs().max())
+    assert md(dw0, wl[0].grad[..., 0]) <= 1e-4 * float(wl[0].grad.abs().max())
+    assert md(dw1, wl[1].grad[..., 0]) <= 1e-4 * float(wl[1].grad.abs().max())
+
+
+def test_pixel_losses_l1_camera_reg():
+    cams = synth.synth_cameras()
+    N = 512
+    idx = synth.synth_ray_indices(cams, N)
+    img, is_th = synth.synth_gt(idx, cams)
+    img, is_th = torch.from_numpy(img), torch.from_numpy(is_th)
+    pred = torch.from_numpy(synth.uniform("pred", (N, 4), 0.0, 1.0, SEED)).requires_grad_(True)
+    ocfg = tiny_cfg("shared")
+    pose = (torch.from_numpy(synth.uniform("pose_r", (8, 6), -0.01, 0.01, SEED))).requires_grad_(True)
+    out = {"rgb": pred[:, :3], "rgb_thermal": pred[:, 3:]}
+    ld = orc.loss_dict({"camera_optimizer.pose_adjustment": pose}, ocfg, out, img, is_th, training=False)
+    reg = orc.camera_opt_regularizer(pose, ocfg, 1.0)
+    (sum(ld.values()) + reg).backward()
+    hp = g(pred.detach())
+    dp = torch.zeros_like(hp)
+    losses = torch.zeros(8, device=DEV)
+    ops.pixel_losses(hp[:, :3], hp[:, 3:], g(img), g(is_th), 100.0, 1e-6, 1e-6, losses, dp[:, :3], dp[:, 3:])
+    for i, k in enumerate(("rgb_loss", "thermal_loss", "tv_pixel_loss", "cross_channel_loss")):
+        assert abs(float(losses[i]) - float(ld[k])) <= 2e-5 * abs(float(ld[k])) + 1e-12, k
+    assert md(dp, pred.grad) <= 1e-5 * float(pred.grad.abs().max())
+    lr = torch.zeros(1, device=DEV)
+    gp = torch.zeros((8, 6), device=DEV)
+    ops.camera_reg(g(pose.detach()), 1e-2, 1e-3, 1.0, lr, gp)
+    assert abs(float(lr) - float(reg)) <= 1e-6 * float(reg)
+    assert md(gp, pose.grad) <= 1e-6
+    # l1 with the reference's detach asymmetry: a*|x.detach()-y| + b*|x-y.detach()|
+    x = torch.from_numpy(synth.uniform("l1x", (1000,), 0.0, 3.0, SEED)).requires_grad_(True)
+    y = torch.from_numpy(synth.uniform("l1y", (1000,), 0.0, 3.0, SEED)).requires_grad_(True)
+    a, b = 5e-5, 5e-7
+    l1 = torch.nn.functional.l1_loss
+    ref = a * l1(x.detach(), y) + b * l1(x, y.detach())
+    ref.backward()
+    lo = torch.zeros(1, device=DEV)
+    dx, dy = torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    ops.l1_loss(g(x.detach()), g(y.detach()), b, a, lo, dx, dy)
+    assert abs(float(lo) - float(ref)) <= 1e-6 * float(ref)
+    assert md(dx, x.grad) <= 1e-12 and md(dy, y.grad) <= 1e-12
+
+
+def test_adam_matches_torch_optim():
+    n = 100003
+    p = torch.from_numpy(synth.uniform("ap", (n,), seed=SEED))
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-2, eps=1e-15)
+    hp, m, v = g(p), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        grad = torch.from_numpy(synth.uniform(f"ag{step}", (n,), seed=SEED)) * 1e-3
+        grad[::7] = 0.0
+        ref_p.grad = grad.clone()
+        opt.step()
+        ops.adam_step(hp, g(grad), m, v, step, 1e-2)
+        assert md(hp, ref_p) <= 2e-6, step
