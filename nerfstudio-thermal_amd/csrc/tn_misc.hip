@@ -404,12 +404,12 @@ __global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, flo
                        float b2, float omb1, float omb2, float neg_step, float bc2_sqrt, float eps) {
 #define ADAM1(P, G, M, V)                         \
   {                                               \
-    float mm = M * b1 + G * omb1;                 \
-    float vv = V * b2 + (omb2 * G) * G;           \
-    float den = sqrtf(vv) / bc2_sqrt + eps;       \
-    P = P + neg_step * (mm / den);                \
-    M = mm;                                       \
-    V = vv;                                       \
+    float m_new_ = M * b1 + G * omb1;             \
+    float v_new_ = V * b2 + (omb2 * G) * G;       \
+    float den_ = sqrtf(v_new_) / bc2_sqrt + eps;  \
+    P = P + neg_step * (m_new_ / den_);           \
+    M = m_new_;                                   \
+    V = v_new_;                                   \
   }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = p[i], gg = g[i], mm4 = m[i], vv4 = v[i];

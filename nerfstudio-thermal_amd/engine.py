@@ -1,0 +1,324 @@
+"""Orchestration of the hot path over the C ABI: the kernel sequence behind ThermalNerfactoModel.get_outputs
+(models/thermal_nerfacto.py:403-489 -> models/nerfacto.py:299-353 -> model_components/ray_samplers.py:577-618) and, for
+training, get_loss_dict + backward + Adam as one fused step with no autograd tape.
+
+Everything here is launch plumbing; the arithmetic lives in libthermal_nerf_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+from .arena import ParamArena
+from .config import ThermalNerfactoModelConfig
+from .netparams import field_params, prop_params
+
+
+@dataclass
+class Level:
+    """One sampling level of one branch: what RaySamples carries (cameras/rays.py:251-295) plus the level's density/weights."""
+
+    S: int
+    s_bins: Tensor  # [N,S+1] spacing_starts/ends
+    e_bins: Tensor  # [N,S+1] frustums.starts/ends
+    density: Optional[Tensor] = None  # [N,S]
+    weights: Optional[Tensor] = None  # [N,S]
+    median: Optional[Tensor] = None  # [N,1]
+
+
+@dataclass
+class Branch:
+    """Everything one spectrum branch (rgb / thermal) produces in a forward pass."""
+
+    origins: Tensor
+    directions: Tensor
+    origins_in: Tensor
+    directions_in: Tensor
+    levels: List[Level]
+    rgb_samples: Tensor  # [N,S,C] per-sample colours
+    comp: Tensor  # [N,C]
+    accumulation: Tensor
+    depth: Tensor
+    expected_depth: Tensor
+    prop_grad: bool
+
+
+def exp_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> float:
+    """ExponentialDecayScheduler without warm-up (engine/schedulers.py:109-141)."""
+    t = float(np.clip(step / max_steps, 0, 1))
+    return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
+
+
+# optimiser table of method_configs["thermal-nerfacto"] (configs/method_configs.py:274-307): group -> (lr, lr_final, max_steps)
+OPTIMIZERS = {
+    "proposal_networks": (1e-2, 1e-4, 200000),
+    "fields": (1e-2, 1e-4, 200000),
+    "proposal_networks_thermal": (1e-2, 1e-4, 200000),
+    "fields_thermal": (1e-2, 1e-4, 200000),
+    "camera_opt": (1e-3, 1e-4, 5000),
+    "camera_opt_thermal": (1e-3, 1e-4, 5000),
+}
+
+
+class RenderEngine:
+    def __init__(self, cfg: ThermalNerfactoModelConfig, arena: ParamArena, num_images: int, is_thermal_cam: List[int]):
+        cfg.validate_for_hip()
+        self.cfg, self.arena, self.num_images = cfg, arena, num_images
+        dev = arena.device
+        self.device = dev
+        self.separate = cfg.density_mode == "separate"
+        th = torch.tensor([1 if x != 0 else 0 for x in is_thermal_cam], dtype=torch.uint8)
+        # camera_optimizer: thermal cameras are non-trainable; camera_optimizer_thermal: RGB cameras are (models/thermal_nerfacto.py:132-144)
+        self.frozen_rgb = th.to(dev)
+        self.frozen_thermal = (1 - th).to(dev)
+        self.props = [prop_params(arena, "proposal_networks", i, cfg, with_grads=True) for i in range(2)]
+        self.field = field_params(arena, "field", cfg, with_grads=True)
+        self.props_thermal = [prop_params(arena, "proposal_networks_thermal", i, cfg, with_grads=True) for i in range(2)]
+        self.field_thermal = field_params(arena, "field_thermal", cfg, with_grads=True) if self.separate else None
+        self.pose = arena.view("camera_optimizer.pose_adjustment") if cfg.camera_optimizer.mode != "off" else None
+        self.pose_grad = arena.grad_view("camera_optimizer.pose_adjustment") if self.pose is not None else None
+        self.pose_thermal = arena.view("camera_optimizer_thermal.pose_adjustment") if cfg.camera_optimizer_thermal.mode != "off" else None
+        self.pose_thermal_grad = arena.grad_view("camera_optimizer_thermal.pose_adjustment") if self.pose_thermal is not None else None
+        self.counts = list(cfg.num_proposal_samples_per_ray) + [cfg.num_nerf_samples_per_ray]
+        # ProposalNetworkSampler state (model_components/ray_samplers.py:564-575)
+        self.anneal = 1.0
+        self.steps_since_update = 0
+        self.sampler_step = 0
+        self.adam_step_count = 0
+
+    # ---------------------------------------------------------------- sampler schedule
+    def update_schedule(self, step: int) -> float:
+        c = self.cfg
+        return float(np.clip(np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every))
+
+    def set_anneal_for_step(self, step: int) -> None:
+        """set_anneal callback (models/nerfacto.py:271-281)."""
+        c = self.cfg
+        if not c.use_proposal_weight_anneal:
+            return
+        frac = float(np.clip(step / c.proposal_weights_anneal_max_num_iters, 0, 1))
+        b = c.proposal_weights_anneal_slope
+        self.anneal = b * frac / ((b - 1) * frac + 1)
+
+    def step_cb(self, step: int) -> None:
+        self.sampler_step = step
+        self.steps_since_update += 1
+
+    # ---------------------------------------------------------------- forward of one branch
+    def render_branch(self, props, fld, pose, frozen, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
+                      training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main") -> Branch:
+        o_in, d_in = origins, directions
+        if training and pose is not None:
+            origins, directions = ops.pose_apply_fwd(pose, frozen, cam, origins, directions)
+        levels: List[Level] = []
+        for lvl, S in enumerate(self.counts):
+            jit = None if jitters is None else jitters[lvl]
+            if lvl == 0:
+                s, e = ops.spaced_bins(nears, fars, S, jit)
+            else:
+                prev = levels[-1]
+                s, e = ops.pdf_resample(prev.s_bins, prev.weights, S, anneal, nears, fars, jit)
+            L = Level(S=S, s_bins=s, e_bins=e)
+            if lvl < len(self.counts) - 1:
+                L.density = ops.prop_density_fwd(props[lvl], origins, directions, e)
+                L.weights, L.median = ops.weights_fwd(e, L.density, want_median=True)
+            levels.append(L)
+        last = levels[-1]
+        last.density, rgb, _ = ops.field_fwd(fld, origins, directions, cam, last.e_bins, training, tag=tag)
+        last.weights, _ = ops.weights_fwd(last.e_bins, last.density)
+        comp, acc, med, exp = ops.composite_fwd(rgb, last.weights, last.e_bins, training)
+        last.median = med
+        return Branch(origins=origins, directions=directions, origins_in=o_in, directions_in=d_in, levels=levels, rgb_samples=rgb, comp=comp,
+                      accumulation=acc, depth=med, expected_depth=exp, prop_grad=prop_grad)
+
+    def _nears_fars(self, N: int, training: bool):
+        near = self.cfg.near_plane if training else 0.0  # NearFarCollider resets the near plane at inference (scene_colliders.py:186-191)
+        return (torch.full((N,), near, device=self.device), torch.full((N,), self.cfg.far_plane, device=self.device))
+
+    @staticmethod
+    def _branch_outputs(b: Branch, sfx: str, training: bool) -> Dict[str, object]:
+        out = {
+            f"rgb{sfx}": b.comp,
+            f"accumulation{sfx}": b.accumulation,
+            f"depth{sfx}": b.depth,
+            f"expected_depth{sfx}": b.expected_depth,
+            f"density{sfx}": b.levels[-1].density.unsqueeze(-1),
+        }
+        for i in range(len(b.levels) - 1):
+            out[f"prop_depth_{i}{sfx}"] = b.levels[i].median
+        if training:
+            out[f"weights_list{sfx}"] = [L.weights.unsqueeze(-1) for L in b.levels]
+            out[f"ray_samples_list{sfx}"] = list(b.levels)
+        return out
+
+    def get_outputs(self, origins: Tensor, directions: Tensor, cam: Tensor, training: bool, jitters: Optional[List[Tensor]] = None,
+                    jitters_thermal: Optional[List[Tensor]] = None):
+        """ThermalNerfactoModel.get_outputs.  Returns (outputs dict with the reference's keys, branches for backward)."""
+        N = origins.shape[0]
+        nears, fars = self._nears_fars(N, training)
+        if training and jitters is None:
+            jitters = [torch.rand(N, device=self.device) for _ in range(3)]
+        updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
+        b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
+                               jitters, prop_grad=updated)
+        if training and updated:
+            self.steps_since_update = 0
+        out = self._branch_outputs(b, "", training)
+        branches = {"": b}
+        if not self.separate:
+            rgbt = out["rgb"]
+            out["rgbt"] = rgbt
+            out["rgb"] = rgbt[..., :3]
+            out["rgb_thermal"] = rgbt[..., 3:]
+            return out, branches
+        if training and jitters_thermal is None:
+            jitters_thermal = [torch.rand(N, device=self.device) for _ in range(3)]
+        # thermal sampler: never receives step_cb -> anneal stays 1.0 and always "updated" (models/thermal_nerfacto.py:222-250)
+        bt = self.render_branch(self.props_thermal, self.field_thermal, self.pose_thermal, self.frozen_thermal, origins, directions, cam, nears, fars,
+                                training, 1.0, jitters_thermal, prop_grad=True)
+        out.update(self._branch_outputs(bt, "_thermal", training))
+        branches["_thermal"] = bt
+        if self.cfg.density_loss_mult > 0 or not training:
+            if training:
+                d2, _, _ = ops.field_fwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, True, tag="cross")
+                d2t, _, _ = ops.field_fwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, True, tag="cross")
+            else:
+                d2 = ops.field_density_fwd(self.field, bt.origins, bt.directions, bt.levels[-1].e_bins)
+                d2t = ops.field_density_fwd(self.field_thermal, b.origins, b.directions, b.levels[-1].e_bins)
+            out["density2"], out["density2_thermal"] = d2.unsqueeze(-1), d2t.unsqueeze(-1)
+        if not training:
+            thr = self.cfg.removal_min_density_diff
+            last, last_t = b.levels[-1], bt.levels[-1]
+            # removal renders (models/thermal_nerfacto.py:460-487): tiny element-wise masks on [N,48] tensors stay in torch,
+            # the weights / compositing go through the kernels.  sigma/sigma is NaN where sigma == 0, as in the reference.
+            m = ((last.density / last.density - d2t / last.density).abs() < thr).to(torch.float32)
+            w, _ = ops.weights_fwd(last.e_bins, (last.density * m).contiguous())
+            out["removal"] = ops.composite_fwd(b.rgb_samples, w, last.e_bins, False, want_depth=False)[0]
+            m = ((last_t.density / last_t.density - d2 / last_t.density).abs() < thr).to(torch.float32)
+            # reference quirk: the thermal removal weights use the RGB branch's ray_samples (models/thermal_nerfacto.py:485)
+            w, _ = ops.weights_fwd(last.e_bins, (last_t.density * m).contiguous())
+            out["removal_thermal"] = ops.composite_fwd(bt.rgb_samples, w, last.e_bins, False, want_depth=False)[0]
+        return out, branches
+
+    # ---------------------------------------------------------------- losses + backward (no autograd tape)
+    def loss_and_backward(self, out: Dict[str, object], branches: Dict[str, Branch], cam: Tensor, image: Tensor, is_thermal: Tensor) -> Dict[str, Tensor]:
+        """get_metrics_dict['distortion'] + get_loss_dict (models/thermal_nerfacto.py:253-388) and the gradient of their sum with respect to
+        every parameter, accumulated into the arena's gradient buffer."""
+        c = self.cfg
+        N = image.shape[0]
+        dev = self.device
+        L = torch.zeros(16, device=dev)  # 0 rgb 1 thermal 2 tv 3 cross 4 (scratch) 8 interlevel 9 distortion 10 density 11 camreg 12 camreg_thermal
+        b = branches[""]
+        bt = branches.get("_thermal")
+        C = b.comp.shape[1]
+        # ---- pixel losses -> d comp
+        d_comp = torch.zeros_like(b.comp)
+        if self.separate:
+            d_comp_t = torch.zeros_like(bt.comp)
+            ops.pixel_losses(b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8], d_comp, d_comp_t)
+        else:
+            ops.pixel_losses(b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8],
+                             d_comp[:, :3], d_comp[:, 3:])
+        # ---- proposal losses.  NB (models/thermal_nerfacto.py:363-368): metrics_dict["distortion"] is the SUM over suffixes and is added once per
+        # suffix, so in separate mode each branch's distortion enters with 2x distortion_loss_mult.
+        nsfx = 2 if self.separate else 1
+        grads_w: Dict[str, List[Optional[Tensor]]] = {}
+        for sfx, br in branches.items():
+            lv = br.levels
+            dws: List[Optional[Tensor]] = [None, None, torch.zeros_like(lv[2].weights)]
+            ops.distortion_loss(lv[2].s_bins, lv[2].weights, c.distortion_loss_mult * nsfx, L[9:10], dws[2])
+            for i in range(2):
+                if br.prop_grad:
+                    dws[i] = torch.zeros_like(lv[i].weights)
+                ops.interlevel_loss(lv[2].s_bins, lv[2].weights, lv[i].s_bins, lv[i].weights, c.interlevel_loss_mult, L[8:9], dws[i])
+            grads_w[sfx] = dws
+        # ---- per-branch backward
+        d_dens_extra: Dict[str, Optional[Tensor]] = {"": None, "_thermal": None}
+        if self.separate and c.density_loss_mult > 0:
+            a, bb = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
+            d2, d2t = out["density2"].squeeze(-1), out["density2_thermal"].squeeze(-1)
+            dens, dens_t = b.levels[-1].density, bt.levels[-1].density
+            g_d2, g_dt = torch.zeros_like(d2), torch.zeros_like(dens_t)
+            g_d, g_d2t = torch.zeros_like(dens), torch.zeros_like(d2t)
+            # a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|   (:336-344)
+            ops.l1_loss(d2, dens_t, bb, a, L[10:11], g_d2, g_dt)
+            ops.l1_loss(dens, d2t, bb, a, L[10:11], g_d, g_d2t)
+            d_dens_extra[""], d_dens_extra["_thermal"] = g_d, g_dt
+        for sfx, br in branches.items():
+            fld = self.field_thermal if sfx else self.field
+            props = self.props_thermal if sfx else self.props
+            pose = self.pose_thermal if sfx else self.pose
+            pose_grad = self.pose_thermal_grad if sfx else self.pose_grad
+            frozen = self.frozen_thermal if sfx else self.frozen_rgb
+            lv = br.levels
+            want_pos = pose is not None
+            d_o = torch.zeros((N, 3), device=dev) if want_pos else None
+            d_d = torch.zeros((N, 3), device=dev) if want_pos else None
+            dws = grads_w[sfx]
+            dc = d_comp_t if sfx else d_comp
+            d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, dc, dws[2])
+            d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dws[2])
+            if d_dens_extra[sfx] is not None:
+                d_dens += d_dens_extra[sfx]
+            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            if br.prop_grad:
+                for i in range(2):
+                    dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
+                    ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+            br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
+        if self.separate and c.density_loss_mult > 0:
+            # density2 = field at the thermal branch's samples/rays; density2_thermal = field_thermal at the rgb branch's
+            zeros_rgb = torch.zeros((N, self.counts[-1], self.field.num_channels), device=dev)
+            zeros_t = torch.zeros((N, self.counts[-1], 1), device=dev)
+            ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, zeros_rgb, bt._d_o, bt._d_d, tag="cross")
+            ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, zeros_t, b._d_o, b._d_d, tag="cross")
+        for sfx, br in branches.items():
+            pose = self.pose_thermal if sfx else self.pose
+            if pose is None:
+                continue
+            pose_grad = self.pose_thermal_grad if sfx else self.pose_grad
+            frozen = self.frozen_thermal if sfx else self.frozen_rgb
+            co = c.camera_optimizer_thermal if sfx else c.camera_optimizer
+            ops.pose_apply_bwd(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad)
+            ops.camera_reg(pose, co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale, L[12:13] if sfx else L[11:12], pose_grad)
+        losses = {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
+                  "distortion_loss": L[9]}
+        if self.separate and c.density_loss_mult > 0:
+            losses["density_loss"] = L[10]
+        if self.pose is not None:
+            losses["camera_opt_regularizer"] = L[11]
+        if self.separate and self.pose_thermal is not None:
+            losses["camera_opt_regularizer_thermal"] = L[12]
+        return losses
+
+    # ---------------------------------------------------------------- optimiser
+    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True) -> None:
+        """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307)."""
+        self.adam_step_count += 1
+        a = self.arena
+        for gname in a.optimised_groups:
+            lo, hi = a.group_range[gname]
+            lr0, lr_final, max_steps = OPTIMIZERS[gname]
+            # LambdaLR: the lr used at optimiser step k (1-based) is the schedule evaluated at k-1
+            lr = exp_decay_lr(self.adam_step_count - 1, lr0, lr_final, max_steps) if scheduled else lr0
+            if lr_overrides and gname in lr_overrides:
+                lr = lr_overrides[gname]
+            ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.adam_step_count, lr, eps=1e-15)
+
+    def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
+                   jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True) -> Dict[str, Tensor]:
+        """Trainer.train_iteration (engine/trainer.py:455-499) for this model: callbacks, forward, losses, backward, (all-reduce), Adam."""
+        self.set_anneal_for_step(step)
+        self.arena.zero_grad()
+        out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
+        losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
+        if grad_hook is not None:
+            grad_hook(self.arena)  # data-parallel gradient all-reduce
+        self.optimizer_step(scheduled=scheduled)
+        self.step_cb(step)
+        return losses

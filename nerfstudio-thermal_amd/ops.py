@@ -140,10 +140,11 @@ class FieldParams:
         s.num_images = self.emb.shape[0]
         return s
 
-    def workspace(self, num_points: int, training: bool) -> Tensor:
-        """Device scratch for tn_field_* (packed weights + saved activations), grown on demand and reused."""
+    def workspace(self, num_points: int, training: bool, tag: str = "main") -> Tensor:
+        """Device scratch for tn_field_* (packed weights + saved activations), grown on demand and reused.
+        `tag` names independent evaluations whose saved activations must coexist (e.g. the cross-evaluated densities)."""
         need = int(_lib.load().tn_field_workspace_bytes(num_points, 1 if training else 0))
-        key = "ws"
+        key = "ws_" + tag
         cur = self._ws.get(key)
         if cur is None or cur.numel() < need or cur.device != self.table.device:
             cur = torch.empty(need, dtype=torch.uint8, device=self.table.device)
@@ -281,17 +282,17 @@ def prop_density_bwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_
 
 
 # ------------------------------------------------------------------------------------------------ main field
-def field_pack(fld: FieldParams, num_points: int, training: bool) -> Tensor:
-    ws = fld.workspace(num_points, training)
+def field_pack(fld: FieldParams, num_points: int, training: bool, tag: str = "main") -> Tensor:
+    ws = fld.workspace(num_points, training, tag)
     s = fld.cstruct()
     check(_lib.load().tn_field_pack_weights(C.byref(s), C.c_void_p(ws.data_ptr()), _stream()), "tn_field_pack_weights")
     return ws
 
 
 def field_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, training: bool, want_pre: bool = False,
-              repack: bool = True):
+              tag: str = "main"):
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
-    ws = field_pack(fld, N * S, training) if repack else fld.workspace(N * S, training)
+    ws = field_pack(fld, N * S, training, tag)
     dens = torch.empty((N, S), device=origins.device)
     rgb = torch.empty((N, S, fld.num_channels), device=origins.device)
     pre = torch.empty((N, S), device=origins.device) if want_pre else None
@@ -305,7 +306,7 @@ def field_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
 def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_bins: Tensor, repack: bool = True) -> Tensor:
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
     # uses its own scratch so that a training workspace (saved activations) is not clobbered
-    key = "ws_density"
+    key = "ws_density_only"
     need = int(_lib.load().tn_field_workspace_bytes(N * S, 0))
     ws = fld._ws.get(key)
     if ws is None or ws.numel() < need:
@@ -322,9 +323,9 @@ def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_b
 
 
 def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, d_density: Tensor, d_rgb: Tensor,
-              d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
+              d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, tag: str = "main") -> None:
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
-    ws = fld.workspace(N * S, True)
+    ws = fld.workspace(N * S, True, tag)
     s = fld.cstruct(need_grad=True)
     check(_lib.load().tn_field_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
                                    _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)),
