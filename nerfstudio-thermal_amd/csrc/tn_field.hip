@@ -561,18 +561,20 @@ int tn_wgrad_launch(const float* dY, int ldy, int out_dim, const float* X, int l
 }
 
 // ---- table scatter (+ d position) ---------------------------------------------------------------------------------------------
+// lane = sample (64 consecutive samples per wave), all levels in turn; runs of lanes in the same cell are reduced in registers
+// before the atomics (tn_level_bwd_wave).
 __global__ void __launch_bounds__(256) k_field_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                        const float* __restrict__ e_bins, const float* __restrict__ g_enc, int64_t N, int S,
                                                        float* __restrict__ d_origins, float* __restrict__ d_directions) {
   const bool want_dpos = d_origins != nullptr;
+  const int lane = tn_lane();
   int64_t P = N * (int64_t)S;
-  int64_t total = tn_cdiv(P, 32) * 64;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t tile = idx >> 6;
-    int lane = (int)(idx & 63);
-    int h = lane >> 5;
-    int64_t p = tile * 32 + (lane & 31);
-    if (p >= P) continue;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t iters = tn_cdiv(P, stride);
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t p = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    if (!live) p = P - 1;
     int64_t ray = p / S;
     int s = (int)(p - ray * S);
     const float* o = origins + ray * 3;
@@ -581,23 +583,20 @@ __global__ void __launch_bounds__(256) k_field_scatter(GridK g, const float* __r
     float st = eb[0], en = eb[1];
     Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 ge = *reinterpret_cast<const float4*>(g_enc + p * 32 + 8 * q + 4 * h);
-      int l0 = 4 * q + 2 * h;
-      if (l0 < g.L && (ge.x != 0.0f || ge.y != 0.0f))
-        tn_level_bwd(g.table, g.grad, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize, ge.x, ge.y, want_dpos, dpx, dpy, dpz);
-      if (l0 + 1 < g.L && (ge.z != 0.0f || ge.w != 0.0f))
-        tn_level_bwd(g.table, g.grad, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize, ge.z, ge.w, want_dpos, dpx, dpy, dpz);
+    for (int l2 = 0; l2 < TN_MAX_LEVELS / 2; ++l2) {
+      if (2 * l2 >= g.L) break;  // wave-uniform
+      float4 ge = *reinterpret_cast<const float4*>(g_enc + p * 32 + 4 * l2);
+      if (!live) ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      tn_level_bwd_wave(g.table, g.grad, c.px, c.py, c.pz, g.res[2 * l2], g.mask, (uint32_t)(2 * l2) * g.tsize, ge.x, ge.y, want_dpos, dpx, dpy, dpz, lane);
+      if (2 * l2 + 1 < g.L)
+        tn_level_bwd_wave(g.table, g.grad, c.px, c.py, c.pz, g.res[2 * l2 + 1], g.mask, (uint32_t)(2 * l2 + 1) * g.tsize, ge.z, ge.w, want_dpos, dpx, dpy,
+                          dpz, lane);
     }
     if (want_dpos) {
       float wx, wy, wz;
       tn_contract_bwd(c, dpx, dpy, dpz, wx, wy, wz);
-      float tm = (st + en) / 2.0f;
-      if (wx != 0.0f || wy != 0.0f || wz != 0.0f) {
-        atomicAdd(d_origins + ray * 3 + 0, wx); atomicAdd(d_origins + ray * 3 + 1, wy); atomicAdd(d_origins + ray * 3 + 2, wz);
-        atomicAdd(d_directions + ray * 3 + 0, wx * tm); atomicAdd(d_directions + ray * 3 + 1, wy * tm); atomicAdd(d_directions + ray * 3 + 2, wz * tm);
-      }
+      if (!live) { wx = wy = wz = 0.0f; }
+      tn_ray_grad_wave(ray, wx, wy, wz, (st + en) / 2.0f, d_origins, d_directions, lane);
     }
   }
 }
@@ -722,8 +721,7 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
                        nullptr);
   }
   TN_CHECK_LAUNCH("tn_field_bwd(wgrad)");
-  int64_t total = tn_cdiv(P, 32) * 64;
-  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 256 * 32);
+  int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
   hipLaunchKernelGGL(k_field_scatter, dim3(grid), dim3(256), 0, st, make_gridk(field->grid), origins, directions, e_bins, ws.g_enc, N, S, d_origins,
                      d_directions);
   TN_CHECK_LAUNCH("tn_field_bwd(scatter)");

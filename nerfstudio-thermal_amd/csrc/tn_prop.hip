@@ -77,7 +77,14 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
                                                   float* __restrict__ ws_h, float* __restrict__ d_origins, float* __restrict__ d_directions) {
   int64_t P = N * (int64_t)S;
   const bool want_dpos = d_origins != nullptr;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = tn_lane();
+  // uniform trip count: the wave-cooperative scatter below needs every lane of a wave in every iteration
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t iters = tn_cdiv(P, stride);
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool live = i < P;
+    if (!live) i = P - 1;
     int64_t ray = i / S;
     int s = (int)(i - ray * S);
     const float* o = origins + ray * 3;
@@ -102,7 +109,7 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
       a[j] = t;
       out = fmaf(net.w1[j], fmaxf(t, 0.0f), out);
     }
-    float d_out = c.sel ? d_density[i] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
+    float d_out = (c.sel && live) ? d_density[i] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
     float denc[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) denc[k] = 0.0f;
@@ -114,30 +121,27 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
 #pragma unroll
       for (int k = 0; k < PF; ++k) denc[k] = fmaf(da[j], net.w0[j * PF + k], denc[k]);
     }
+    if (live) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<float4*>(ws_da + i * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-      *reinterpret_cast<float4*>(ws_h + i * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4*>(ws_da + i * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+        *reinterpret_cast<float4*>(ws_h + i * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
+      }
+      *reinterpret_cast<float4*>(ws_enc + i * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
+      *reinterpret_cast<float4*>(ws_enc + i * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
+      *reinterpret_cast<float4*>(ws_enc + i * 16 + 8) = make_float4(enc[8], enc[9], 0.0f, 0.0f);
+      ws_dout[i] = d_out;
     }
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 8) = make_float4(enc[8], enc[9], 0.0f, 0.0f);
-    ws_dout[i] = d_out;
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-    if (d_out != 0.0f) {
 #pragma unroll
-      for (int l = 0; l < PL; ++l)
-        tn_level_bwd(net.g.table, net.g.grad, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize, denc[2 * l],
-                     denc[2 * l + 1], want_dpos, dpx, dpy, dpz);
-    }
+    for (int l = 0; l < PL; ++l)
+      tn_level_bwd_wave(net.g.table, net.g.grad, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize, denc[2 * l], denc[2 * l + 1],
+                        want_dpos, dpx, dpy, dpz, lane);
     if (want_dpos) {
       float wx, wy, wz;
       tn_contract_bwd(c, dpx, dpy, dpz, wx, wy, wz);
-      float tm = (st + en) / 2.0f;
-      if (wx != 0.0f || wy != 0.0f || wz != 0.0f) {
-        atomicAdd(d_origins + ray * 3 + 0, wx); atomicAdd(d_origins + ray * 3 + 1, wy); atomicAdd(d_origins + ray * 3 + 2, wz);
-        atomicAdd(d_directions + ray * 3 + 0, wx * tm); atomicAdd(d_directions + ray * 3 + 1, wy * tm); atomicAdd(d_directions + ray * 3 + 2, wz * tm);
-      }
+      if (!live) { wx = wy = wz = 0.0f; }
+      tn_ray_grad_wave(ray, wx, wy, wz, (st + en) / 2.0f, d_origins, d_directions, lane);
     }
   }
 }

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__
     loc += (double)dd[k];
   }
   double incl = tn_wave_incl_scan_d(loc, lane);
-  double run = incl - loc;  // exclusive prefix over earlier lanes (exact in double for these magnitudes up to rounding)
+  double run = tn_excl_from_incl_d(incl, lane);  // exclusive prefix over earlier lanes
   float w[ITEMS];
   double wloc = 0.0;
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__
   if (median_depth != nullptr) {
     // cumsum(weights) (double accumulate -> float), first index with cum >= 0.5 (searchsorted left), clamp, gather midpoints
     double wincl = tn_wave_incl_scan_d(wloc, lane);
-    double wrun = wincl - wloc;
+    double wrun = tn_excl_from_incl_d(wincl, lane);
     int cnt = 0;  // number of samples with cum < 0.5
     float best = 0.0f;
 #pragma unroll
@@ -148,9 +148,9 @@ __global__ void __launch_bounds__(BLOCK) k_weights_bwd(const float* __restrict__
     sloc += gw[k] * wk[k];
   }
   double incl = tn_wave_incl_scan_d(loc, lane);
-  double run = incl - loc;
+  double run = tn_excl_from_incl_d(incl, lane);
   float sincl = tn_wave_incl_rscan(sloc, lane);
-  float suffix = sincl - sloc;  // sum over later lanes
+  float suffix = tn_rexcl_from_incl(sincl, lane);  // sum over later lanes
   // inside the lane: walk backwards for the suffix part
   float T[ITEMS];
 #pragma unroll
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict_
     ploc += (double)pdf[k];
   }
   double incl = tn_wave_incl_scan_d(ploc, lane);
-  double run = incl - ploc;
+  double run = tn_excl_from_incl_d(incl, lane);
   if (lane == 0) cdf[0] = 0.0f;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
   }
   if (depth_median != nullptr) {
     double wincl = tn_wave_incl_scan_d(wloc, lane);
-    double wrun = wincl - wloc;
+    double wrun = tn_excl_from_incl_d(wincl, lane);
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -510,20 +510,24 @@ extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int
 //   w_outer_i = cy[hi_i + 1] - cy[lo_i],  cy = [0, cumsum(wp)],
 //   lo_i = clamp(searchsorted_right(cp[:-1], c_i) - 1, 0, Sp-1), hi_i = clamp(searchsorted_right(cp[1:], c_{i+1}), 0, Sp-1)
 //   loss = mean_{rays, i} clip(w_i - w_outer_i, 0)^2 / (w_i + 1e-7)
-//   d wp_k = sum_i [lo_i <= k <= hi_i] * ( -2 clip(w_i - w_outer_i,0) / (w_i + eps) ) / (N*S_f)
+//   d wp_k = sum_i ([lo_i <= k <= hi_i] - [hi_i < k < lo_i]) * g_i,   g_i = -2 clip(w_i - w_outer_i,0) / (w_i + eps) / (N*S_f)
+// The gradient is summed directly over the covering fine intervals (all g_i have one sign): no difference-array / prefix-sum, whose
+// cancellation residue (1e-16) would become full-size Adam steps on table entries whose true gradient is exactly 0.
 __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
                                                       const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N,
                                                       float mult, float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
   __shared__ float sh_cp[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
   __shared__ float sh_cy[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
-  __shared__ float sh_diff[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 2];  // difference array for the range-add of the gradient
+  __shared__ float sh_g[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+  __shared__ int sh_lo[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+  __shared__ int sh_hi[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
   int lane = tn_lane();
   int wv = threadIdx.x >> 6;
   int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
   if (ray >= N) return;
   const float* cp = p_bins + ray * (Sp + 1);
   const float* c = c_bins + ray * (Sf + 1);
-  // cumsum of wp (torch CPU: double accumulate, float per element); lane owns ITEMS=4 contiguous entries max (Sp<=256)
+  // cumsum of wp (torch CPU: double accumulate, float per element); lane owns 4 contiguous entries (Sp<=256)
   const int ITEMS = 4;
   float v[ITEMS];
   double loc = 0.0;
@@ -534,7 +538,7 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
     loc += (double)v[k];
   }
   double incl = tn_wave_incl_scan_d(loc, lane);
-  double run = incl - loc;
+  double run = tn_excl_from_incl_d(incl, lane);
   if (lane == 0) sh_cy[wv][0] = 0.0f;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -543,19 +547,16 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
     if (i < Sp) sh_cy[wv][i + 1] = (float)run;
   }
   for (int i = lane; i <= Sp; i += 64) sh_cp[wv][i] = cp[i];
-  for (int i = lane; i <= Sp + 1; i += 64) sh_diff[wv][i] = 0.0f;
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float total = 0.0f;
   float scale = mult / ((float)N * (float)Sf);
   for (int i = lane; i < Sf; i += 64) {
     float t0 = c[i], t1 = c[i + 1];
-    // searchsorted right over cp[0..Sp-1] (starts) for t0
-    int lo = 0, hi = Sp;
+    int lo = 0, hi = Sp;  // searchsorted right over the starts cp[0..Sp-1]
     while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m] <= t0) lo = m + 1; else hi = m; }
     int ilo = lo - 1; ilo = ilo < 0 ? 0 : (ilo > Sp - 1 ? Sp - 1 : ilo);
-    // searchsorted right over cp[1..Sp] (ends) for t1
-    lo = 0; hi = Sp;
+    lo = 0; hi = Sp;      // searchsorted right over the ends cp[1..Sp]
     while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m + 1] <= t1) lo = m + 1; else hi = m; }
     int ihi = lo > Sp - 1 ? Sp - 1 : lo;
     float w_outer = sh_cy[wv][ihi + 1] - sh_cy[wv][ilo];
@@ -563,35 +564,24 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
     float d = w - w_outer;
     if (d < 0.0f) d = 0.0f;
     total += d * d / (w + 1.0e-7f);
-    if (d_w_prop != nullptr && d > 0.0f) {  // d w_outer/d wp_k = [k < ihi+1] - [k < ilo]: a signed range-add
-      float g = -2.0f * d / (w + 1.0e-7f) * scale;
-      atomicAdd(&sh_diff[wv][ilo], g);
-      atomicAdd(&sh_diff[wv][ihi + 1], -g);
-    }
+    sh_g[wv][i] = -2.0f * d / (w + 1.0e-7f) * scale;
+    sh_lo[wv][i] = ilo;
+    sh_hi[wv][i] = ihi;
   }
   total = tn_wave_sum(total);
   if (lane == 0) atomicAdd(loss_out, total * scale);
   if (d_w_prop != nullptr) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    // prefix sum of the difference array
-    float dv[ITEMS];
-    float dloc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      int i = lane * ITEMS + k;
-      dv[k] = (i < Sp) ? sh_diff[wv][i] : 0.0f;
-      dloc += dv[k];
-    }
-    float dincl = dloc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(dincl, o, 64); if (lane >= o) dincl += t; }
-    float drun = dincl - dloc;
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-      int i = lane * ITEMS + k;
-      drun += dv[k];
-      if (i < Sp) d_w_prop[ray * Sp + i] += drun;
+    for (int k = lane; k < Sp; k += 64) {
+      float acc = 0.0f;
+      for (int i = 0; i < Sf; ++i) {
+        int a = sh_lo[wv][i], b = sh_hi[wv][i];
+        float gi = sh_g[wv][i];
+        if (a <= k && k <= b) acc += gi;
+        else if (b < k && k < a) acc -= gi;
+      }
+      d_w_prop[ray * Sp + k] += acc;
     }
   }
 }
