@@ -81,6 +81,11 @@ def load() -> C.CDLL:
     """Load (once) and return the HIP library; raise loudly when it is not built."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; /opt/rocm ships another with the SAME soname.  Whichever is loaded first serves the whole
+        # process, and a process that ends up with ROCm's runtime under torch's HSA loses the device ("no ROCm-capable device").  Importing
+        # torch first makes its runtime the one this library binds to, so kernels launched here and by torch share streams and memory.
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). "

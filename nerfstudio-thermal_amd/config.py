@@ -90,8 +90,10 @@ class ThermalNerfactoModelConfig:
 
     def setup(self, **kwargs):
         """InstantiateConfig.setup (configs/base_config.py:47-54)."""
-        assert self._target is not None
-        return self._target(self, **kwargs)
+        target = self._target
+        if target is None:
+            from .model import ThermalNerfactoModel as target  # noqa: N813
+        return target(self, **kwargs)
 
     # ------------------------------------------------------------------ what the HIP path supports
     def validate_for_hip(self) -> None:

@@ -1,0 +1,476 @@
+"""ThermalNerfactoModel for MI355X: the reference's Model API (models/base_model.py:57-263, models/nerfacto.py:136-447,
+models/thermal_nerfacto.py:67-564) over the HIP hot path.
+
+ * construction: `ThermalNerfactoModelConfig(...).setup(scene_box=, num_train_data=, metadata={"is_thermal": [...]}, device=)`
+ * state_dict keys / shapes are the reference's (checkpoints round-trip), including the aliased proposal hash tables and the
+   int64 buffers; every Parameter is a view into one flat arena (arena.py)
+ * forward(ray_bundle) / get_outputs / get_metrics_dict / get_loss_dict / get_param_groups / get_training_callbacks /
+   get_outputs_for_camera_ray_bundle keep their signatures; in train mode the outputs carry an autograd edge (one fused
+   torch.autograd.Function for the whole render), so `sum(loss_dict.values()).backward()` fills `param.grad` as the Trainer expects
+ * `train_iteration(ray_bundle, batch, step)` is the fast path: forward + every loss + backward + Adam in one fused sequence of
+   kernel launches with no autograd tape (what bench.py times)
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from dataclasses import dataclass
+from enum import Enum, auto
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .arena import ParamArena
+from .config import ThermalNerfactoModelConfig
+from .engine import Branch, RenderEngine
+from .model_components import (
+    AccumulationRenderer,
+    CameraOptimizer,
+    DepthRenderer,
+    HashMLPDensityField,
+    NearFarCollider,
+    ProposalNetworkSampler,
+    RGBRenderer,
+    RGBTRenderer,
+    ThermalNerfactoField,
+)
+from .rays import RayBundle, ray_samples_from_level
+
+
+class TrainingCallbackLocation(Enum):
+    """engine/callbacks.py:44-56."""
+
+    BEFORE_TRAIN_ITERATION = auto()
+    AFTER_TRAIN_ITERATION = auto()
+    AFTER_TRAIN = auto()
+
+
+@dataclass
+class TrainingCallback:
+    """engine/callbacks.py:59-115 (the subset the model registers)."""
+
+    where_to_run: List[TrainingCallbackLocation]
+    func: Callable
+    update_every_num_iters: Optional[int] = None
+
+    def run_callback_at_location(self, step: int, location: TrainingCallbackLocation) -> None:
+        if location in self.where_to_run and (self.update_every_num_iters is None or step % self.update_every_num_iters == 0):
+            self.func(step)
+
+
+@dataclass
+class SceneBox:
+    """data/scene_box.py:29-80 (the aabb buffer is all the path needs)."""
+
+    aabb: Tensor
+
+
+def _psnr(pred: Tensor, gt: Tensor) -> Tensor:
+    """PeakSignalNoiseRatio(data_range=1.0)."""
+    return -10.0 * torch.log10(torch.mean((pred - gt) ** 2))
+
+
+# loss pieces for the autograd-compatible path (small [N,S] element-wise torch ops on the device; the fused path uses the loss kernels)
+def _sdist(rs) -> Tensor:
+    return rs.s_bins
+
+
+def _outer(t0s, t0e, t1s, t1e, y1):
+    cy1 = torch.cat([torch.zeros_like(y1[..., :1]), torch.cumsum(y1, dim=-1)], dim=-1)
+    lo = torch.clamp(torch.searchsorted(t1s.contiguous(), t0s.contiguous(), side="right") - 1, 0, y1.shape[-1] - 1)
+    hi = torch.clamp(torch.searchsorted(t1e.contiguous(), t0e.contiguous(), side="right"), 0, y1.shape[-1] - 1)
+    return torch.take_along_dim(cy1[..., 1:], hi, dim=-1) - torch.take_along_dim(cy1[..., :-1], lo, dim=-1)
+
+
+def interlevel_loss(weights_list, ray_samples_list) -> Tensor:
+    """model_components/losses.py:117-135."""
+    c = _sdist(ray_samples_list[-1]).detach()
+    w = weights_list[-1][..., 0].detach()
+    total = 0.0
+    for rs, wp in zip(ray_samples_list[:-1], weights_list[:-1]):
+        cp = _sdist(rs)
+        w_outer = _outer(c[..., :-1], c[..., 1:], cp[..., :-1], cp[..., 1:], wp[..., 0])
+        total = total + torch.mean(torch.clip(w - w_outer, min=0) ** 2 / (w + 1.0e-7))
+    return total
+
+
+def distortion_loss(weights_list, ray_samples_list) -> Tensor:
+    """model_components/losses.py:139-158."""
+    t = _sdist(ray_samples_list[-1])
+    w = weights_list[-1][..., 0]
+    ut = (t[..., 1:] + t[..., :-1]) / 2
+    dut = torch.abs(ut[..., :, None] - ut[..., None, :])
+    inter = torch.sum(w * torch.sum(w[..., None, :] * dut, dim=-1), dim=-1)
+    intra = torch.sum(w**2 * (t[..., 1:] - t[..., :-1]), dim=-1) / 3
+    return torch.mean(inter + intra)
+
+
+def rgb_to_rgbt_image(image: Tensor, is_thermal: Tensor) -> Tensor:
+    """utils/rgbt_utils.py:6-32."""
+    rgbt = torch.zeros(image.shape[:-1] + (4,), device=image.device)
+    rgbt[..., :3] = image * (1 - is_thermal)[:, None]
+    rgbt[..., 3] = image[..., 0] * is_thermal
+    return rgbt
+
+
+def tv_pixel_loss(pred_thermal: Tensor, is_thermal: Tensor) -> Tensor:
+    """model_components/losses.py:602-620."""
+    p = pred_thermal[(1 - is_thermal).bool()].view(-1, 4)
+    return 0.25 * torch.mean((p[:, 0] - p[:, 1]).abs() + (p[:, 0] - p[:, 2]).abs() + (p[:, 1] - p[:, 3]).abs() + (p[:, 2] - p[:, 3]).abs())
+
+
+def cross_channel_loss(pred_thermal: Tensor, gt_rgb: Tensor, is_thermal: Tensor) -> Tensor:
+    """model_components/losses.py:623-651."""
+    keep = (1 - is_thermal).bool()
+
+    def grad(img):
+        q = img.view(-1, 4)
+        return torch.stack((q[:, 1] - q[:, 0], q[:, 2] - q[:, 0], q[:, 3] - q[:, 1], q[:, 3] - q[:, 2]))
+
+    diff = (grad(pred_thermal[keep]) - grad(gt_rgb[keep].mean(-1, keepdim=True))).abs()
+    return 0.25 * (diff[0] + diff[1] + diff[2] + diff[3]).mean()
+
+
+class _RenderFn(torch.autograd.Function):
+    """The whole train-mode render as ONE autograd node: forward = engine.get_outputs, backward = the backward kernel sequence.
+    Tensor outputs (per branch): comp [N,C], density [N,S2,1], weights of the 3 levels [N,S,1]; separate mode adds density2 / density2_thermal."""
+
+    @staticmethod
+    def forward(ctx, model, origins, directions, cam, jitters, jitters_thermal, *params):
+        eng: RenderEngine = model.engine
+        eng.arena.zero_grad()  # one backward per training forward (what Trainer.train_iteration does)
+        out, branches = eng.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
+        ctx.model, ctx.out, ctx.branches, ctx.cam = model, out, branches, cam
+        tensors = []
+        for sfx, br in branches.items():
+            tensors += [br.comp, out[f"density{sfx}"]] + out[f"weights_list{sfx}"]
+        if eng.separate and "density2" in out:
+            tensors += [out["density2"], out["density2_thermal"]]
+        model._last_out, model._last_branches = out, branches
+        return tuple(tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        model, out, branches, cam = ctx.model, ctx.out, ctx.branches, ctx.cam
+        eng: RenderEngine = model.engine
+        dev = eng.device
+        it = iter(grads)
+        N = cam.shape[0]
+        per = {}
+        for sfx, br in branches.items():
+            g_comp, g_dens = next(it), next(it)
+            g_w = [next(it) for _ in range(3)]
+            per[sfx] = (g_comp, g_dens, g_w)
+        g_d2 = g_d2t = None
+        if eng.separate and "density2" in out:
+            g_d2, g_d2t = next(it), next(it)
+        z = lambda ref: torch.zeros_like(ref)  # noqa: E731
+        d_od = {}
+        for sfx, br in branches.items():
+            g_comp, g_dens, g_w = per[sfx]
+            fld = eng.field_thermal if sfx else eng.field
+            props = eng.props_thermal if sfx else eng.props
+            pose = eng.pose_thermal if sfx else eng.pose
+            lv = br.levels
+            d_o = torch.zeros((N, 3), device=dev) if pose is not None else None
+            d_d = torch.zeros((N, 3), device=dev) if pose is not None else None
+            dw2 = (g_w[2][..., 0].contiguous().clone() if g_w[2] is not None else z(lv[2].weights))
+            d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, (g_comp.contiguous() if g_comp is not None else z(br.comp)), dw2)
+            d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dw2)
+            if g_dens is not None:
+                d_dens += g_dens[..., 0]
+            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            if br.prop_grad:
+                for i in range(2):
+                    if g_w[i] is None:
+                        continue
+                    dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, g_w[i][..., 0].contiguous())
+                    ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+            d_od[sfx] = (d_o, d_d)
+        if g_d2 is not None or g_d2t is not None:
+            b, bt = branches[""], branches["_thermal"]
+            S2 = eng.counts[-1]
+            if g_d2 is not None:
+                ops.field_bwd(eng.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2[..., 0].contiguous(),
+                              torch.zeros((N, S2, eng.field.num_channels), device=dev), *d_od["_thermal"], tag="cross")
+            if g_d2t is not None:
+                ops.field_bwd(eng.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t[..., 0].contiguous(),
+                              torch.zeros((N, S2, 1), device=dev), *d_od[""], tag="cross")
+        for sfx, br in branches.items():
+            pose = eng.pose_thermal if sfx else eng.pose
+            if pose is None:
+                continue
+            ops.pose_apply_bwd(pose, eng.frozen_thermal if sfx else eng.frozen_rgb, cam, br.directions_in, *d_od[sfx],
+                               eng.pose_thermal_grad if sfx else eng.pose_grad)
+        # hand the arena's gradient views to autograd as the parameters' gradients
+        pg = [model.arena.grad_view(n) for n in model._param_names]
+        return (None, None, None, None, None, None, *pg)
+
+
+class ThermalNerfactoModel(nn.Module):
+    config: ThermalNerfactoModelConfig
+
+    def __init__(self, config: ThermalNerfactoModelConfig, scene_box, num_train_data: int, **kwargs) -> None:
+        super().__init__()
+        config.validate_for_hip()
+        self.config = config
+        self.scene_box = scene_box
+        self.render_aabb = None
+        self.num_train_data = num_train_data
+        self.kwargs = kwargs
+        dev = kwargs.get("device", "cuda")
+        self._device = torch.device(dev)
+        if self._device.type != "cuda":
+            raise RuntimeError("ThermalNerfactoModel(implementation='hip') needs a HIP device: there is no CPU fallback on this path")
+        ops._lib.load()
+        self.collider = None
+        self.populate_modules()
+        self.callbacks = None
+        self.device_indicator_param = nn.Parameter(torch.empty(0, device=self._device))
+        self.step = 0
+
+    @property
+    def device(self):
+        return self.device_indicator_param.device
+
+    # ------------------------------------------------------------------------------------------------ construction
+    def populate_modules(self):
+        cfg = self.config
+        is_thermal = list(self.kwargs["metadata"]["is_thermal"])
+        self.arena = ParamArena(cfg, self.num_train_data, self._device)
+        self._init_parameters()
+        self.engine = RenderEngine(cfg, self.arena, self.num_train_data, is_thermal)
+        eng = self.engine
+        aabb = torch.as_tensor(self.scene_box.aabb, dtype=torch.float32).to(self._device)
+        self.output_suffixes = ("", "_thermal") if cfg.density_mode == "separate" else ("",)
+        self._params: Dict[str, nn.Parameter] = {n: nn.Parameter(self.arena.view(n)) for n in self.arena.names()}
+
+        def P(name):
+            return self._params[name]
+
+        def mk_field(prefix, fld):
+            names = {
+                "emb": "embedding_appearance.embedding.weight", "table": "mlp_base.model.0.hash_table",
+                "w0": "mlp_base.model.1.layers.0.weight", "b0": "mlp_base.model.1.layers.0.bias",
+                "w1": "mlp_base.model.1.layers.1.weight", "b1": "mlp_base.model.1.layers.1.bias",
+                "hw0": "mlp_head.layers.0.weight", "hb0": "mlp_head.layers.0.bias", "hw1": "mlp_head.layers.1.weight",
+                "hb1": "mlp_head.layers.1.bias", "hw2": "mlp_head.layers.2.weight", "hb2": "mlp_head.layers.2.bias",
+            }
+            return ThermalNerfactoField(aabb, fld, cfg.max_res, {k: P(f"{prefix}.{v}") for k, v in names.items()}, names,
+                                        cfg.use_average_appearance_embedding)
+
+        def mk_props(prefix, nets):
+            mods = nn.ModuleList()
+            for i, net in enumerate(nets):
+                a = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
+                ps = {"table": P(f"{prefix}.{i}.mlp_base.0.hash_table"), "w0": P(f"{prefix}.{i}.mlp_base.1.layers.0.weight"),
+                      "b0": P(f"{prefix}.{i}.mlp_base.1.layers.0.bias"), "w1": P(f"{prefix}.{i}.mlp_base.1.layers.1.weight"),
+                      "b1": P(f"{prefix}.{i}.mlp_base.1.layers.1.bias")}
+                mods.append(HashMLPDensityField(aabb, net, a["max_res"], ps))
+            return mods
+
+        self.field = mk_field("field", eng.field)
+        if cfg.density_mode == "separate":
+            self.field_thermal = mk_field("field_thermal", eng.field_thermal)
+        rgb_frozen = torch.tensor([i for i, x in enumerate(is_thermal) if x != 0], dtype=torch.long)
+        th_frozen = torch.tensor([i for i, x in enumerate(is_thermal) if x == 0], dtype=torch.long)
+        self.camera_optimizer = CameraOptimizer(cfg.camera_optimizer, self.num_train_data, self._device, rgb_frozen,
+                                                pose_param=self._params.get("camera_optimizer.pose_adjustment"))
+        self.camera_optimizer_thermal = CameraOptimizer(cfg.camera_optimizer_thermal, self.num_train_data, self._device, th_frozen,
+                                                        pose_param=self._params.get("camera_optimizer_thermal.pose_adjustment"), suffix="_thermal")
+        self.shared_camera_optimizer = CameraOptimizer(cfg.shared_camera_optimizer, self.num_train_data, self._device, rgb_frozen, suffix="_shared")
+        self.shared_camera_optimizer_thermal = CameraOptimizer(cfg.shared_camera_optimizer_thermal, self.num_train_data, self._device, th_frozen,
+                                                               suffix="_shared_thermal")
+        self.proposal_networks = mk_props("proposal_networks", eng.props)
+        self.density_fns = [n.density_fn for n in self.proposal_networks]
+        self.proposal_networks_thermal = mk_props("proposal_networks_thermal", eng.props_thermal)
+        self.density_fns_thermal = [n.density_fn for n in self.proposal_networks_thermal]
+
+        def update_schedule(step):
+            return np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every)
+
+        mk_sampler = lambda: ProposalNetworkSampler(  # noqa: E731
+            num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray, num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=cfg.num_proposal_iterations, single_jitter=cfg.use_single_jitter, update_sched=update_schedule)
+        self.proposal_sampler = mk_sampler()
+        self.proposal_sampler_thermal = mk_sampler()
+        self.collider = NearFarCollider(near_plane=cfg.near_plane, far_plane=cfg.far_plane)
+        self.renderer_rgb = RGBRenderer(background_color=cfg.background_color)
+        self.renderer_rgbt = RGBTRenderer(background_color=cfg.background_color)
+        self.renderer_thermal = RGBRenderer(background_color=cfg.background_color, num_channels=1)
+        self.renderer_accumulation = AccumulationRenderer()
+        self.renderer_depth = DepthRenderer(method="median")
+        self.renderer_expected_depth = DepthRenderer(method="expected")
+        self.rgb_loss = nn.MSELoss()
+        self.density_loss = nn.L1Loss()
+        self.psnr = _psnr
+        # parameters in arena order: what _RenderFn receives / returns gradients for
+        self._param_names = list(self.arena.names())
+
+    def _init_parameters(self) -> None:
+        """The reference's initialisers: hash tables U(-1,1)*1e-3 (field_components/encodings.py:377-379), nn.Linear default
+        (kaiming-uniform(a=sqrt(5)) = U(+-1/sqrt(fan_in)) for weight and bias), nn.Embedding N(0,1), pose_adjustment zeros."""
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int(self.kwargs.get("seed", 0)) if isinstance(self.kwargs.get("seed", 0), int) else 0)
+        a = self.arena
+        fan_in = {}
+        for name, (_, shape) in a.layout.items():
+            if name.endswith(".weight") and "embedding" not in name:
+                fan_in[name[: -len("weight")]] = shape[1]
+        for name, (_, shape) in a.layout.items():
+            if name.endswith("hash_table"):
+                t = (torch.rand(shape, generator=g) * 2 - 1) * 1e-3
+            elif name.endswith("embedding.weight"):
+                t = torch.randn(shape, generator=g)
+            elif name.endswith(".weight"):
+                b = 1.0 / np.sqrt(shape[1])
+                t = (torch.rand(shape, generator=g) * 2 - 1) * b
+            elif name.endswith(".bias"):
+                b = 1.0 / np.sqrt(fan_in[name[: -len("bias")]])
+                t = (torch.rand(shape, generator=g) * 2 - 1) * b
+            else:  # pose_adjustment
+                t = torch.zeros(shape)
+            a.view(name).copy_(t.to(a.device))
+
+    # ------------------------------------------------------------------------------------------------ trainer hooks
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """models/nerfacto.py:256-261 + models/thermal_nerfacto.py:390-401."""
+        a = self.arena
+        groups = {g: [self._params[k] for k in a.group_keys[g]] for g in a.optimised_groups}
+        return groups
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List[TrainingCallback]:
+        """models/nerfacto.py:263-297 (the thermal sampler's callbacks are only registered with use_proposal_thermal_weight_anneal)."""
+        cbs: List[TrainingCallback] = []
+        if self.config.use_proposal_weight_anneal:
+            def set_anneal(step):
+                self.step = step
+                self.engine.set_anneal_for_step(step)
+                self.proposal_sampler.set_anneal(self.engine.anneal)
+
+            def step_cb(step):
+                self.engine.step_cb(step)
+                self.proposal_sampler.step_cb(step)
+
+            cbs.append(TrainingCallback([TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], set_anneal, update_every_num_iters=1))
+            cbs.append(TrainingCallback([TrainingCallbackLocation.AFTER_TRAIN_ITERATION], step_cb, update_every_num_iters=1))
+        return cbs
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, ray_bundle: RayBundle) -> Dict[str, Any]:
+        """models/base_model.py:132-143 (the collider's near/far constants are applied inside the engine; the bundle still receives them)."""
+        if self.collider is not None:
+            ray_bundle = self.collider(ray_bundle)
+        return self.get_outputs(ray_bundle)
+
+    def get_outputs(self, ray_bundle: RayBundle, jitters=None, jitters_thermal=None) -> Dict[str, Any]:
+        """models/thermal_nerfacto.py:403-489."""
+        o = ray_bundle.origins.contiguous()
+        d = ray_bundle.directions.contiguous()
+        cam = ray_bundle.camera_indices.reshape(-1).contiguous()
+        eng = self.engine
+        grad_mode = self.training and torch.is_grad_enabled()
+        if not grad_mode:
+            out, branches = eng.get_outputs(o, d, cam, self.training, jitters, jitters_thermal)
+        else:
+            params = [self._params[n] for n in self._param_names]
+            flat = _RenderFn.apply(self, o, d, cam, jitters, jitters_thermal, *params)
+            out, branches = self._last_out, self._last_branches
+            it = iter(flat)
+            for sfx in branches:
+                out[f"rgb{sfx}"] = next(it)
+                out[f"density{sfx}"] = next(it)
+                out[f"weights_list{sfx}"] = [next(it) for _ in range(3)]
+            if eng.separate and "density2" in out:
+                out["density2"], out["density2_thermal"] = next(it), next(it)
+            if not eng.separate:
+                rgbt = out["rgb"]
+                out["rgbt"], out["rgb"], out["rgb_thermal"] = rgbt, rgbt[..., :3], rgbt[..., 3:]
+        if self.training:
+            nears, fars = eng._nears_fars(o.shape[0], True)
+            for sfx, br in branches.items():
+                bundle = RayBundle(origins=br.origins, directions=br.directions, pixel_area=ray_bundle.pixel_area, camera_indices=ray_bundle.camera_indices,
+                                   nears=nears[:, None], fars=fars[:, None])
+                out[f"ray_samples_list{sfx}"] = [ray_samples_from_level(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
+        return out
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
+        """models/thermal_nerfacto.py:253-282."""
+        m: Dict[str, Any] = {}
+        is_th = batch["is_thermal"].to(self.device).float()
+        gt = rgb_to_rgbt_image(batch["image"].to(self.device)[..., :3], is_th)
+        rgb_rays, th_rays = (1 - is_th).bool(), is_th.bool()
+        m["psnr_rgb"] = self.psnr(gt[..., :3][rgb_rays], outputs["rgb"][rgb_rays].detach())
+        m["psnr_thermal"] = self.psnr(gt[..., 3:][th_rays], outputs["rgb_thermal"][th_rays].detach())
+        if self.training:
+            m["distortion"] = 0
+            for s in self.output_suffixes:
+                m["distortion"] = m["distortion"] + distortion_loss(outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"])
+        self.camera_optimizer.get_metrics_dict(m)
+        if self.config.density_mode == "separate":
+            self.camera_optimizer_thermal.get_metrics_dict(m)
+        return m
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        """models/thermal_nerfacto.py:284-388."""
+        c = self.config
+        ld: Dict[str, Any] = {}
+        is_th = batch["is_thermal"].to(self.device).float()
+        pred = torch.cat((outputs["rgb"], outputs["rgb_thermal"]), dim=1)
+        gt = rgb_to_rgbt_image(batch["image"].to(self.device)[..., :3], is_th)
+        ld["rgb_loss"] = self.rgb_loss(gt[..., :3] * (1 - is_th)[:, None], pred[..., :3] * (1 - is_th)[:, None])
+        ld["thermal_loss"] = c.thermal_loss_mult * self.rgb_loss(gt[..., 3:] * is_th[:, None], pred[..., 3:] * is_th[:, None])
+        if c.density_mode == "separate" and c.density_loss_mult > 0:
+            a, b = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
+            ld["density_loss"] = (a * self.density_loss(outputs["density2"].detach(), outputs["density_thermal"])
+                                  + a * self.density_loss(outputs["density"].detach(), outputs["density2_thermal"])
+                                  + b * self.density_loss(outputs["density2"], outputs["density_thermal"].detach())
+                                  + b * self.density_loss(outputs["density"], outputs["density2_thermal"].detach()))
+        if c.tv_pixel_loss_mult > 0:
+            ld["tv_pixel_loss"] = c.tv_pixel_loss_mult * tv_pixel_loss(pred[..., 3:], is_th)
+        if c.cross_channel_loss_mult > 0:
+            ld["cross_channel_loss"] = c.cross_channel_loss_mult * cross_channel_loss(pred[..., 3:], gt[..., :3], is_th)
+        if self.training:
+            ld["interlevel_loss"] = 0
+            ld["distortion_loss"] = 0
+            assert metrics_dict is not None and "distortion" in metrics_dict
+            for s in self.output_suffixes:
+                ld["interlevel_loss"] = ld["interlevel_loss"] + c.interlevel_loss_mult * interlevel_loss(outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"])
+                ld["distortion_loss"] = ld["distortion_loss"] + c.distortion_loss_mult * metrics_dict["distortion"]
+            self.camera_optimizer.get_loss_dict(ld)
+            if c.density_mode == "separate":
+                self.camera_optimizer_thermal.get_loss_dict(ld)
+        return ld
+
+    # ------------------------------------------------------------------------------------------------ fused fast path
+    def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor], step: int, grad_hook=None, jitters=None, jitters_thermal=None):
+        """Trainer.train_iteration for this model without an autograd tape: callbacks + forward + losses + backward (+ all-reduce) + Adam."""
+        cam = ray_bundle.camera_indices.reshape(-1).contiguous()
+        return self.engine.train_step(ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous(), cam, batch["image"].to(self.device)[..., :3].contiguous(),
+                                      batch["is_thermal"].to(self.device).float().contiguous(), step, jitters, jitters_thermal, grad_hook)
+
+    # ------------------------------------------------------------------------------------------------ eval
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """models/base_model.py:177-205: chunks of eval_num_rays_per_chunk rays; outputs reshaped to (H, W, -1)."""
+        input_device = camera_ray_bundle.directions.device
+        h, w = camera_ray_bundle.origins.shape[:2]
+        n = len(camera_ray_bundle)
+        chunk = self.config.eval_num_rays_per_chunk
+        lists = defaultdict(list)
+        for i in range(0, n, chunk):
+            rb = camera_ray_bundle.get_row_major_sliced_ray_bundle(i, i + chunk).to(self.device)
+            for k, v in self.forward(rb).items():
+                if isinstance(v, Tensor):
+                    lists[k].append(v.to(input_device))
+        return {k: torch.cat(v).view(h, w, -1) for k, v in lists.items()}
+
+    def load_model(self, loaded_state: Dict[str, Any]) -> None:
+        state = {k.replace("module.", ""): v for k, v in loaded_state["model"].items()}
+        self.load_state_dict(state)
+
+    def update_to_step(self, step: int) -> None:
+        self.step = step
+

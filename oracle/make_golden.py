@@ -302,6 +302,11 @@ def golden_model(mode: str, rb_src):
         ii = sample_indices(k, p.numel())
         out[f"adam_val/{k}"] = tonp(p[torch.from_numpy(ii)])
     np.savez_compressed(os.path.join(GOLDEN, f"model_{mode}.npz"), **out)
+    # the checkpoint contract: every state_dict key of the reference model with its shape and dtype (default table sizes differ only in shape)
+    import json
+
+    with open(os.path.join(GOLDEN, f"state_dict_keys_{mode}.json"), "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}, f, indent=0, sort_keys=True)
     print(mode, {k: float(v) for k, v in losses.items()})
 
 

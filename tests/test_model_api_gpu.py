@@ -1,0 +1,159 @@
+"""The drop-in boundary, tier 2: ThermalNerfactoModel with the reference's Model API on the GPU.
+state_dict contract, forward/get_outputs keys and shapes, autograd-compatible training step, fused training step, chunked camera render."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_inputs, make_params, tiny_cfg
+from test_hip_ops_gpu import md, pkg_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build_model(mode):
+    from nerfstudio_thermal_amd.model import SceneBox
+
+    ocfg = tiny_cfg(mode)
+    cfg = pkg_cfg(ocfg)
+    model = cfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=ocfg.num_images,
+                      metadata={"is_thermal": list(ocfg.is_thermal_cam)}, device=DEV)
+    return ocfg, cfg, model
+
+
+def bundle(golden_dir):
+    from nerfstudio_thermal_amd.rays import RayBundle
+
+    gi = golden_inputs(golden_dir)
+    g = np.load(os.path.join(golden_dir, "raygen.npz"))
+    rb = RayBundle(origins=gi["origins"].to(DEV), directions=gi["directions"].to(DEV), pixel_area=torch.from_numpy(g["pixel_area"]).to(DEV),
+                   camera_indices=gi["camera_indices"][:, None].to(DEV))
+    return gi, rb
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_state_dict_contract_and_checkpoint_roundtrip(golden_dir, mode):
+    ocfg, cfg, model = build_model(mode)
+    ref = json.load(open(os.path.join(golden_dir, f"state_dict_keys_{mode}.json")))
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == sorted(ref.keys())
+    for k, (shape, dtype) in ref.items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == dtype, (k, sd[k].shape, shape, sd[k].dtype, dtype)
+    # aliased proposal tables stay aliased and every parameter aliases the flat arena
+    a = model.proposal_networks[0]
+    assert a.encoding.hash_table.data_ptr() == a.mlp_base._modules["0"].hash_table.data_ptr()
+    lo, hi = model.arena.params.data_ptr(), model.arena.params.data_ptr() + model.arena.params.numel() * 4
+    for n, p in model.named_parameters():
+        if n != "device_indicator_param":
+            assert lo <= p.data_ptr() < hi, n
+    # load a reference-style (DDP-prefixed) checkpoint in place: the arena must see the new values
+    params = make_params(ocfg)
+    state = {"module." + k: v for k, v in sd.items()}
+    for k, v in params.items():
+        state["module." + k] = v
+        alias = k.replace("mlp_base.0.hash_table", "encoding.hash_table")
+        if alias != k:
+            state["module." + alias] = v
+    model.load_model({"model": state})
+    for k, v in params.items():
+        assert md(model.arena.view(k), v) == 0.0, k
+    assert sorted(model.get_param_groups().keys()) == sorted(
+        ["proposal_networks", "fields", "camera_opt"] + (["proposal_networks_thermal", "fields_thermal", "camera_opt_thermal"] if mode == "separate" else []))
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_forward_eval_keys_shapes_values(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
+    ocfg, cfg, model = build_model(mode)
+    model.arena.load(make_params(ocfg))
+    gi, rb = bundle(golden_dir)
+    model.eval()
+    with torch.no_grad():
+        out = model(rb)
+    ref_keys = sorted(k[5:] for k in g.files if k.startswith("eval/"))
+    assert sorted(k for k, v in out.items() if isinstance(v, torch.Tensor)) == ref_keys
+    for k in ref_keys:
+        assert tuple(out[k].shape) == g[f"eval/{k}"].shape, k
+    assert md(out["rgb"], g["eval/rgb"]) <= 1e-3 and md(out["rgb_thermal"], g["eval/rgb_thermal"]) <= 1e-3
+    assert rb.nears is not None and float(rb.nears.max()) == 0.0 and float(rb.fars.min()) == 1000.0  # collider mutated the bundle (eval: near reset to 0)
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_autograd_training_step_matches_fused_step(golden_dir, mode):
+    """Trainer-style step (loss_dict -> backward -> param.grad) against the fused no-tape step on the same inputs."""
+    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
+    gi, rb = bundle(golden_dir)
+    jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+    batch = {"image": gi["image"].to(DEV), "is_thermal": gi["is_thermal"].to(DEV)}
+    # --- autograd path
+    ocfg, cfg, model = build_model(mode)
+    model.arena.load(make_params(ocfg))
+    model.train()
+    for cb in model.get_training_callbacks():
+        cb.run_callback_at_location(500, list(cb.where_to_run)[0]) if "BEFORE" in cb.where_to_run[0].name else None
+    assert abs(model.engine.anneal - float(g["train/anneal"])) < 1e-12
+    rb1 = model.collider(rb[...])
+    out = model.get_outputs(rb1, jit, jit_t)
+    metrics = model.get_metrics_dict(out, batch)
+    losses = model.get_loss_dict(out, batch, metrics)
+    ref_keys = sorted(k[5:] for k in g.files if k.startswith("loss/") and k != "loss/total")
+    assert sorted(losses.keys()) == ref_keys
+    for k in ref_keys:
+        a, b = float(losses[k]), float(g[f"loss/{k}"])
+        assert abs(a - b) <= 2e-4 * abs(b) + 1e-9, (k, a, b)
+    sum(losses.values()).backward()
+    grads_auto = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    # --- fused path on a fresh model
+    ocfg2, cfg2, model2 = build_model(mode)
+    model2.arena.load(make_params(ocfg2))
+    model2.train()
+    eng = model2.engine
+    eng.set_anneal_for_step(500)
+    eng.arena.zero_grad()
+    o, d, cam = rb.origins.contiguous(), rb.directions.contiguous(), rb.camera_indices.reshape(-1).contiguous()
+    out2, br2 = eng.get_outputs(o, d, cam, True, jit, jit_t)
+    eng.loss_and_backward(out2, br2, cam, batch["image"], batch["is_thermal"])
+    for name in model2.arena.names():
+        fused = model2.arena.grad_view(name)
+        key = name if name in grads_auto else name.replace("mlp_base.0.hash_table", "encoding.hash_table")
+        if float(fused.abs().max()) == 0.0:
+            assert key not in grads_auto or float(grads_auto[key].abs().max()) == 0.0, name
+            continue
+        scale = float(fused.abs().max())
+        assert md(grads_auto[key], fused) <= 1e-4 * scale, (name, md(grads_auto[key], fused), scale)
+
+
+def test_train_iteration_reduces_loss_and_camera_render_chunks():
+    from nerfstudio_thermal_amd import ops, synth
+    from nerfstudio_thermal_amd.rays import RayBundle
+
+    ocfg, cfg, model = build_model("shared")
+    cfg.eval_num_rays_per_chunk = 1000  # force several chunks
+    cams = synth.synth_cameras()
+    N = 1024
+    idx = torch.from_numpy(synth.synth_ray_indices(cams, N)).to(DEV)
+    t = lambda k: torch.from_numpy(cams[k]).to(DEV)  # noqa: E731
+    o, d, area, _ = ops.raygen(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    img, is_th = (torch.from_numpy(a).to(DEV) for a in synth.synth_gt(idx.cpu().numpy(), cams))
+    img = torch.where(is_th[:, None] > 0, torch.full_like(img, 0.7), torch.tensor([0.2, 0.5, 0.8], device=DEV).expand_as(img)).contiguous()
+    model.train()
+    first = last = None
+    for step in range(60):
+        rb = RayBundle(origins=o, directions=d, pixel_area=area, camera_indices=idx[:, 0:1].contiguous())
+        losses = model.train_iteration(rb, {"image": img, "is_thermal": is_th}, step)
+        tot = float(losses["rgb_loss"] + losses["thermal_loss"])
+        first = tot if first is None else first
+        last = tot
+    assert np.isfinite(last) and last < 0.25 * first, (first, last)
+    # full-"image" render: a 40 x 30 ray grid through the chunked eval path
+    model.eval()
+    H, W = 20, 40
+    rb = RayBundle(origins=o[: H * W].reshape(H, W, 3), directions=d[: H * W].reshape(H, W, 3), pixel_area=area[: H * W].reshape(H, W, 1),
+                   camera_indices=idx[: H * W, 0:1].reshape(H, W, 1).contiguous())
+    outs = model.get_outputs_for_camera_ray_bundle(rb)
+    assert outs["rgb"].shape == (H, W, 3) and outs["rgb_thermal"].shape == (H, W, 1) and outs["density"].shape == (H, W, 48)
+    assert bool(torch.isfinite(outs["rgb"]).all())
