@@ -1,0 +1,47 @@
+"""Method-plugin entry (SURVEY.md 8b tier 1): `thermal-nerfacto-hip` for nerfstudio's method registry
+(plugins/registry.py:34-79, plugins/types.py:23-33).  Use with
+    NERFSTUDIO_METHOD_CONFIGS="thermal-nerfacto-hip=nerfstudio_thermal_amd.plugin:thermal_nerfacto_hip"
+When nerfstudio itself is importable the full TrainerConfig of method_configs["thermal-nerfacto"] (configs/method_configs.py:255-310) is
+rebuilt with this package's model config; otherwise a plain description object carrying the same optimiser table is exposed."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict
+
+from .config import CameraOptimizerConfig, ThermalNerfactoModelConfig
+from .engine import OPTIMIZERS
+
+
+def model_config() -> ThermalNerfactoModelConfig:
+    return ThermalNerfactoModelConfig(eval_num_rays_per_chunk=1 << 15, camera_optimizer=CameraOptimizerConfig(mode="SO3xR3"))
+
+
+@dataclass
+class MethodDescription:
+    method_name: str = "thermal-nerfacto-hip"
+    description: str = "thermal-nerfacto (RGB+thermal NeRF) on the MI355X-native HIP hot path"
+    max_num_iterations: int = 30000
+    steps_per_eval_batch: int = 500
+    steps_per_save: int = 2000
+    train_num_rays_per_batch: int = 8192
+    eval_num_rays_per_batch: int = 8192
+    patch_size: int = 2
+    model: ThermalNerfactoModelConfig = field(default_factory=model_config)
+    optimizers: Dict[str, Any] = field(default_factory=lambda: {k: {"lr": v[0], "eps": 1e-15, "lr_final": v[1], "max_steps": v[2]} for k, v in OPTIMIZERS.items()})
+
+
+def _build():
+    try:  # inside a nerfstudio installation: a real MethodSpecification
+        from nerfstudio.configs.method_configs import method_configs
+        from nerfstudio.plugins.types import MethodSpecification
+        import copy
+
+        base = copy.deepcopy(method_configs["thermal-nerfacto"])
+        base.method_name = "thermal-nerfacto-hip"
+        base.pipeline.model = model_config()
+        return MethodSpecification(config=base, description=MethodDescription().description)
+    except Exception:
+        return MethodDescription()
+
+
+thermal_nerfacto_hip = _build()
