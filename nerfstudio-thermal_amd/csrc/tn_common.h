@@ -275,6 +275,20 @@ __device__ __forceinline__ float tn_wave_incl_rscan(float v, int lane) {
   return v;
 }
 
+// Work-item -> (ray, sample) in PATCH order: groups of 4 consecutive rays (a 2x2 pixel patch from PatchPixelSampler: neighbouring pixels,
+// near-identical rays) walked sample-major, so consecutive lanes are the same depth of neighbouring rays, then the next depth.  Runs of
+// lanes in one grid cell become ~3x longer than in ray-major order (scripts/analyze_scatter.py), which is what the run-length merging of the
+// scatter-add feeds on.  Any N is handled (the last group may hold fewer than 4 rays).
+__device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int64_t& ray, int& s) {
+  int64_t per = 4 * (int64_t)S;
+  int64_t g = i / per;
+  int w = (int)(i - g * per);
+  int64_t r0 = g * 4;
+  int nr = (N - r0) < 4 ? (int)(N - r0) : 4;
+  s = w / nr;
+  ray = r0 + (w - s * nr);
+}
+
 // ---------------------------------------------------------------- segmented (run-length) reductions across the wave
 // Consecutive lanes are consecutive samples along a ray, so on the coarse levels long runs of lanes fall into the SAME grid cell and
 // would add into the same 8 table entries.  A run is reduced in registers first and only its last lane issues the atomics: on the
@@ -348,17 +362,30 @@ __device__ __forceinline__ void tn_level_bwd_wave(const float2* __restrict__ tab
   }
 }
 
-// d origins / d directions of a ray: reduce over the lanes that belong to the same ray, one atomic burst per (wave, ray).
+// d origins / d directions of a ray.  In patch order lane l of a wave works on ray (l & 3) of its 4-ray group, so the wave reduces the
+// four interleaved classes with a stride-4 butterfly and lanes 0..3 issue the atomics.  Waves that straddle groups (only possible when
+// 4*S is not a multiple of 64) fall back to a run-length reduction over consecutive lanes.
 // EVERY lane must call this (dead lanes: w = 0 and any ray id).
 __device__ __forceinline__ void tn_ray_grad_wave(int64_t ray, float wx, float wy, float wz, float tmid, float* __restrict__ d_origins,
                                                  float* __restrict__ d_directions, int lane) {
+  float v[6] = {wx, wy, wz, wx * tmid, wy * tmid, wz * tmid};
   int r32 = (int)ray;
+  int lead = __shfl(r32, lane & 3, 64);
+  if (__all(r32 == lead)) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      float r = v[q];
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) r += __shfl_xor(r, o, 64);
+      if (lane < 4 && r != 0.0f) atomicAdd((q < 3 ? d_origins : d_directions) + ray * 3 + (q % 3), r);
+    }
+    return;
+  }
   int prev = __shfl_up(r32, 1, 64);
   bool head = (lane == 0) || (prev != r32);
   int start = tn_seg_start(head, lane);
   int next_head = __shfl_down((int)head, 1, 64);
   bool tail = (lane == 63) || (next_head != 0);
-  float v[6] = {wx, wy, wz, wx * tmid, wy * tmid, wz * tmid};
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
     float r = tn_seg_sum(v[q], start, lane);

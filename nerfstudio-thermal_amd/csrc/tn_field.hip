@@ -575,8 +575,10 @@ __global__ void __launch_bounds__(256) k_field_scatter(GridK g, const float* __r
     int64_t p = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool live = p < P;
     if (!live) p = P - 1;
-    int64_t ray = p / S;
-    int s = (int)(p - ray * S);
+    int64_t ray;
+    int s;
+    tn_patch_order(p, N, S, ray, s);
+    p = ray * S + s;  // row of this sample in the [P, .] activation / gradient tensors
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;

@@ -85,8 +85,9 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
     int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool live = i < P;
     if (!live) i = P - 1;
-    int64_t ray = i / S;
-    int s = (int)(i - ray * S);
+    int64_t ray;
+    int s;
+    tn_patch_order(i, N, S, ray, s);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
       a[j] = t;
       out = fmaf(net.w1[j], fmaxf(t, 0.0f), out);
     }
-    float d_out = (c.sel && live) ? d_density[i] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
+    float d_out = (c.sel && live) ? d_density[ray * S + s] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
     float denc[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) denc[k] = 0.0f;
