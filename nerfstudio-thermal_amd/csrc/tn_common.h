@@ -392,3 +392,8 @@ __device__ __forceinline__ void tn_ray_grad_wave(int64_t ray, float wx, float wy
     if (tail && r != 0.0f) atomicAdd((q < 3 ? d_origins : d_directions) + ray * 3 + (q % 3), r);
   }
 }
+
+// ---------------------------------------------------------------- the shared table-gradient scatter kernel (tn_scatter.hip)
+// g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
+int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
+                           int64_t N, int S, float* d_origins, float* d_directions, hipStream_t stream);

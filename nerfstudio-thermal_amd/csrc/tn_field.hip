@@ -560,49 +560,6 @@ int tn_wgrad_launch(const float* dY, int ldy, int out_dim, const float* X, int l
   return TN_OK;
 }
 
-// ---- table scatter (+ d position) ---------------------------------------------------------------------------------------------
-// lane = sample (64 consecutive samples per wave), all levels in turn; runs of lanes in the same cell are reduced in registers
-// before the atomics (tn_level_bwd_wave).
-__global__ void __launch_bounds__(256) k_field_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                       const float* __restrict__ e_bins, const float* __restrict__ g_enc, int64_t N, int S,
-                                                       float* __restrict__ d_origins, float* __restrict__ d_directions) {
-  const bool want_dpos = d_origins != nullptr;
-  const int lane = tn_lane();
-  int64_t P = N * (int64_t)S;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t iters = tn_cdiv(P, stride);
-  for (int64_t it = 0; it < iters; ++it) {
-    int64_t p = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const bool live = p < P;
-    if (!live) p = P - 1;
-    int64_t ray;
-    int s;
-    tn_patch_order(p, N, S, ray, s);
-    p = ray * S + s;  // row of this sample in the [P, .] activation / gradient tensors
-    const float* o = origins + ray * 3;
-    const float* d = directions + ray * 3;
-    const float* eb = e_bins + ray * (S + 1) + s;
-    float st = eb[0], en = eb[1];
-    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
-    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-    for (int l2 = 0; l2 < TN_MAX_LEVELS / 2; ++l2) {
-      if (2 * l2 >= g.L) break;  // wave-uniform
-      float4 ge = *reinterpret_cast<const float4*>(g_enc + p * 32 + 4 * l2);
-      if (!live) ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      tn_level_bwd_wave(g.table, g.grad, c.px, c.py, c.pz, g.res[2 * l2], g.mask, (uint32_t)(2 * l2) * g.tsize, ge.x, ge.y, want_dpos, dpx, dpy, dpz, lane);
-      if (2 * l2 + 1 < g.L)
-        tn_level_bwd_wave(g.table, g.grad, c.px, c.py, c.pz, g.res[2 * l2 + 1], g.mask, (uint32_t)(2 * l2 + 1) * g.tsize, ge.z, ge.w, want_dpos, dpx, dpy,
-                          dpz, lane);
-    }
-    if (want_dpos) {
-      float wx, wy, wz;
-      tn_contract_bwd(c, dpx, dpy, dpz, wx, wy, wz);
-      if (!live) { wx = wy = wz = 0.0f; }
-      tn_ray_grad_wave(ray, wx, wy, wz, (st + en) / 2.0f, d_origins, d_directions, lane);
-    }
-  }
-}
-
 // ---- host entry points -----------------------------------------------------------------------------------------------------
 static int check_field(const TnField* f, const char* who, bool need_grad) {
   TN_REQUIRE(f != nullptr, "%s: null field", who);
@@ -723,9 +680,7 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
                        nullptr);
   }
   TN_CHECK_LAUNCH("tn_field_bwd(wgrad)");
-  int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
-  hipLaunchKernelGGL(k_field_scatter, dim3(grid), dim3(256), 0, st, make_gridk(field->grid), origins, directions, e_bins, ws.g_enc, N, S, d_origins,
-                     d_directions);
-  TN_CHECK_LAUNCH("tn_field_bwd(scatter)");
+  rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, st);
+  if (rc) return rc;
   return TN_OK;
 }

@@ -66,33 +66,22 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// Recomputes the forward per point, then:  d_out = g * exp(clamp(out,-15,15)) * sel     (trunc_exp backward)
-//   d a_j = d_out*w1_j*[a_j>0] ;  d enc_k = sum_j d a_j w0_jk  -> scatter-add into the table gradient with the trilinear
-//   weights (float atomics);  d pos (optional) -> contraction Jacobian -> d origins += d, d directions += d * (start+end)/2.
-// The MLP-weight gradients are GEMMs with K = all points (dW0 = dA^T ENC, dW1 = dOUT^T H): the kernel writes the four operands
-// to the workspace and the shared fp32-MFMA weight-gradient kernel (tn_wgrad_launch) reduces them.
-__global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                  const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
-                                                  float* __restrict__ ws_da, float* __restrict__ ws_dout, float* __restrict__ ws_enc,
-                                                  float* __restrict__ ws_h, float* __restrict__ d_origins, float* __restrict__ d_directions) {
+// k_prop_bwd_mlp (1 lane = 1 sample): recompute the forward, then  d_out = g * exp(clamp(out,-15,15)) * sel  (trunc_exp backward),
+//   d a_j = d_out*w1_j*[a_j>0],  d enc_k = sum_j d a_j w0_jk.  It writes the operands of the two weight-gradient GEMMs
+//   (dW0 = dA^T ENC, dW1 = dOUT^T H; K = all points; reduced by the shared fp32-MFMA kernel tn_wgrad_launch) and d enc.
+// The table scatter-add (+ d position) is the shared request-coalescing kernel in tn_scatter.hip.
+__global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                      const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
+                                                      float* __restrict__ ws_da, float* __restrict__ ws_dout, float* __restrict__ ws_enc,
+                                                      float* __restrict__ ws_h, float* __restrict__ ws_denc) {
   int64_t P = N * (int64_t)S;
-  const bool want_dpos = d_origins != nullptr;
-  const int lane = tn_lane();
-  // uniform trip count: the wave-cooperative scatter below needs every lane of a wave in every iteration
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t iters = tn_cdiv(P, stride);
-  for (int64_t it = 0; it < iters; ++it) {
-    int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const bool live = i < P;
-    if (!live) i = P - 1;
-    int64_t ray;
-    int s;
-    tn_patch_order(i, N, S, ray, s);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t ray = i / S;
+    int s = (int)(i - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
-    float st = eb[0], en = eb[1];
-    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
     float enc[PF];
 #pragma unroll
     for (int l = 0; l < PL; ++l) {
@@ -110,7 +99,7 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
       a[j] = t;
       out = fmaf(net.w1[j], fmaxf(t, 0.0f), out);
     }
-    float d_out = (c.sel && live) ? d_density[ray * S + s] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
+    float d_out = c.sel ? d_density[i] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
     float denc[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) denc[k] = 0.0f;
@@ -122,34 +111,24 @@ __global__ void __launch_bounds__(256) k_prop_bwd(PropK net, const float* __rest
 #pragma unroll
       for (int k = 0; k < PF; ++k) denc[k] = fmaf(da[j], net.w0[j * PF + k], denc[k]);
     }
-    if (live) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float4*>(ws_da + i * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-        *reinterpret_cast<float4*>(ws_h + i * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
-      }
-      *reinterpret_cast<float4*>(ws_enc + i * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
-      *reinterpret_cast<float4*>(ws_enc + i * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
-      *reinterpret_cast<float4*>(ws_enc + i * 16 + 8) = make_float4(enc[8], enc[9], 0.0f, 0.0f);
-      ws_dout[i] = d_out;
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(ws_da + i * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+      *reinterpret_cast<float4*>(ws_h + i * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
     }
-    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-#pragma unroll
-    for (int l = 0; l < PL; ++l)
-      tn_level_bwd_wave(net.g.table, net.g.grad, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize, denc[2 * l], denc[2 * l + 1],
-                        want_dpos, dpx, dpy, dpz, lane);
-    if (want_dpos) {
-      float wx, wy, wz;
-      tn_contract_bwd(c, dpx, dpy, dpz, wx, wy, wz);
-      if (!live) { wx = wy = wz = 0.0f; }
-      tn_ray_grad_wave(ray, wx, wy, wz, (st + en) / 2.0f, d_origins, d_directions, lane);
-    }
+    *reinterpret_cast<float4*>(ws_enc + i * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
+    *reinterpret_cast<float4*>(ws_enc + i * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
+    *reinterpret_cast<float4*>(ws_enc + i * 16 + 8) = make_float4(enc[8], enc[9], 0.0f, 0.0f);
+    *reinterpret_cast<float4*>(ws_denc + i * 16 + 0) = make_float4(denc[0], denc[1], denc[2], denc[3]);
+    *reinterpret_cast<float4*>(ws_denc + i * 16 + 4) = make_float4(denc[4], denc[5], denc[6], denc[7]);
+    *reinterpret_cast<float4*>(ws_denc + i * 16 + 8) = make_float4(denc[8], denc[9], 0.0f, 0.0f);
+    ws_dout[i] = d_out;
   }
 }
 
 extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
   if (num_points < 0) return TN_EINVAL;
-  return num_points * (16 + 16 + 16 + 1) * (int64_t)sizeof(float) + 1024;
+  return num_points * (16 + 16 + 16 + 16 + 1) * (int64_t)sizeof(float) + 1024;
 }
 
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
@@ -167,11 +146,13 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, net->gw0, net->gb0, net->gw1, net->gb1};
   int64_t P = N * (int64_t)S;
   float* ws = reinterpret_cast<float*>(workspace);
-  float *ws_da = ws, *ws_h = ws + P * 16, *ws_enc = ws + P * 32, *ws_dout = ws + P * 48;
+  float *ws_da = ws, *ws_h = ws + P * 16, *ws_enc = ws + P * 32, *ws_denc = ws + P * 48, *ws_dout = ws + P * 64;
   int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
-  hipLaunchKernelGGL(k_prop_bwd, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, d_density, N, S, ws_da, ws_dout, ws_enc,
-                     ws_h, d_origins, d_directions);
+  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, d_density, N, S, ws_da, ws_dout, ws_enc,
+                     ws_h, ws_denc);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
+  int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions, tn_s(stream));
+  if (rcs) return rcs;
   int rc = tn_wgrad_launch(ws_da, 16, 16, ws_enc, 16, PF, P, net->gw0, PF, net->gb0, tn_s(stream));
   if (rc) return rc;
   return tn_wgrad_launch(ws_dout, 1, 1, ws_h, 16, 16, P, net->gw1, 16, net->gb1, tn_s(stream));

@@ -1,0 +1,142 @@
+// Trilinear scatter-add of d(encoding) into a hash table's gradient (+ d position), shared by the proposal grids and the main grid.
+//
+// Global float atomics on MI355X are bound by 64-byte REQUESTS (~21 G requests/s, scripts/microbench/atomic_shapes.hip): lanes of one
+// wave-instruction that fall into the same 64-B line cost one request.  The kernel is laid out for that:
+//   * 4 lanes per sample: lane q = (x-corner choice, feature) = [f.x, f.y, c.x, c.y].  The floor and ceil corners differ by 1 in x, and
+//     the reference's hash (x*1 ^ y*P1 ^ z*P2) & mask keeps x in the low bits, so 7 times out of 8 the two entries (2 x float2 = 16 B or
+//     within one 64-B line) are served by ONE request: a sample costs ~4.5 requests per level instead of 16.
+//   * work items in patch order (tn_patch_order) and run-length merging across consecutive samples of the wave: samples in the same
+//     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
+#include "tn_common.h"
+
+__device__ __forceinline__ int seg_start4(bool head, int lane) {
+  int s = head ? (lane >> 2) : 0;  // in sample units
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    int t = __shfl_up(s, o, 64);
+    if (lane >= o) s = s > t ? s : t;
+  }
+  return s;
+}
+__device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
+  int sl = lane >> 2;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    float t = __shfl_up(v, 4 * o, 64);
+    if (sl - o >= start) v += t;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                      const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
+                                                      float* __restrict__ d_origins, float* __restrict__ d_directions) {
+  const bool want_dpos = d_origins != nullptr;
+  const int lane = tn_lane();
+  const int q = lane & 3, xc = q >> 1, ft = q & 1;
+  const int64_t P = N * (int64_t)S;
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 2);
+  const int64_t iters = tn_cdiv(P, stride);
+  for (int64_t it = 0; it < iters; ++it) {
+    int64_t i = it * stride + (int64_t)blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2);
+    const bool live = i < P;
+    if (!live) i = P - 1;
+    int64_t ray;
+    int s;
+    tn_patch_order(i, N, S, ray, s);
+    const int64_t p = ray * S + s;
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    const float st = eb[0], en = eb[1];
+    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+    for (int l = 0; l < g.L; ++l) {  // wave-uniform trip count
+      float gv = live ? g_enc[p * ld + 2 * l + ft] : 0.0f;
+      const float res = g.res[l];
+      const uint32_t level_off = (uint32_t)l * g.tsize;
+      float sx = c.px * res, sy = c.py * res, sz = c.pz * res;
+      float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+      uint32_t fx = (uint32_t)(int)fxf, fy = (uint32_t)(int)fyf, fz = (uint32_t)(int)fzf;
+      uint32_t cx = (uint32_t)(int)ceilf(sx), cy = (uint32_t)(int)ceilf(sy), cz = (uint32_t)(int)ceilf(sz);
+      float ox = sx - fxf, oy = sy - fyf, oz = sz - fzf;
+      float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+      // run key over consecutive samples (lanes 4 apart): floor cell + which axes sit exactly on the lattice
+      uint32_t k1 = fx | (fy << 16);
+      uint32_t k2 = fz | ((ox == 0.0f) ? 1u << 16 : 0u) | ((oy == 0.0f) ? 1u << 17 : 0u) | ((oz == 0.0f) ? 1u << 18 : 0u);
+      uint32_t p1 = __shfl_up(k1, 4, 64), p2 = __shfl_up(k2, 4, 64);
+      bool head = (lane < 4) || (k1 != p1) || (k2 != p2);
+      int start = seg_start4(head, lane);
+      int next_head = __shfl_down((int)head, 4, 64);
+      bool tail = (lane >= 60) || (next_head != 0);
+      // this lane's x corner and its 4 (y,z) partners: (c,c) (f,c) (c,f) (f,f)
+      uint32_t xi = xc ? cx : fx;
+      float wxv = xc ? ox : ux;
+      uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
+      const uint32_t hy[4] = {hcy, hfy, hcy, hfy};
+      const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
+      const float wy[4] = {oy, uy, oy, uy};
+      const float wz[4] = {oz, oz, uz, uz};
+      float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t idx = ((xi ^ hy[k] ^ hz[k]) & g.mask) + level_off;
+        float w = wxv * wy[k] * wz[k];
+        float v = seg_sum4(w * gv, start, lane);
+        if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(g.grad + idx) + ft, v);
+        if (want_dpos) {
+          float2 t = g.table[idx];
+          float tv = ft ? t.y : t.x;
+          a += wy[k] * wz[k] * tv;
+          b += ((k & 1) ? -1.0f : 1.0f) * wz[k] * tv;
+          cc += wy[k] * ((k & 2) ? -1.0f : 1.0f) * tv;
+        }
+      }
+      if (want_dpos) {
+        dpx += (xc ? 1.0f : -1.0f) * a * gv * res;
+        dpy += wxv * b * gv * res;
+        dpz += wxv * cc * gv * res;
+      }
+    }
+    if (want_dpos) {
+      // sum the 4 lanes of the sample, then reduce the wave's 16 samples per ray
+      dpx += __shfl_xor(dpx, 1, 64); dpx += __shfl_xor(dpx, 2, 64);
+      dpy += __shfl_xor(dpy, 1, 64); dpy += __shfl_xor(dpy, 2, 64);
+      dpz += __shfl_xor(dpz, 1, 64); dpz += __shfl_xor(dpz, 2, 64);
+      float wx, wy_, wz_;
+      tn_contract_bwd(c, dpx, dpy, dpz, wx, wy_, wz_);
+      if (!live) { wx = wy_ = wz_ = 0.0f; }
+      float tm = (st + en) / 2.0f;
+      float v[6] = {wx, wy_, wz_, wx * tm, wy_ * tm, wz_ * tm};
+      // patch order: sample (lane>>2) of the wave belongs to ray class (lane>>2)&3 -> lanes 16 and 32 apart share a ray
+      int r32 = (int)ray;
+      int lead = __shfl(r32, lane & 15, 64);
+      if (__all(r32 == lead)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          float r = v[k];
+          r += __shfl_xor(r, 16, 64);
+          r += __shfl_xor(r, 32, 64);
+          if (lane < 16 && q == 0 && r != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), r);
+        }
+      } else if (q == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (v[k] != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), v[k]);
+      }
+    }
+  }
+}
+
+int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
+                           int64_t N, int S, float* d_origins, float* d_directions, hipStream_t stream) {
+  TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
+  TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
+  int64_t P = N * (int64_t)S;
+  if (P == 0) return TN_OK;
+  int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
+  hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim), dim3(256), 0, stream, make_gridk(grid), origins, directions, e_bins, g_enc, ld, N, S, d_origins,
+                     d_directions);
+  TN_CHECK_LAUNCH("tn_grid_scatter");
+  return TN_OK;
+}
