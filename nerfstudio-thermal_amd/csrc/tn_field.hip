@@ -479,12 +479,12 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restric
 // -> each atomic wave-instruction is two contiguous 128-B segments (the shape global float atomics run at full rate).
 // MODE 0: plain.  MODE 1: X columns are head slots (slot_to_col).  MODE 2: dY is the one-hot of the sample's camera (embedding rows).
 template <int MO, int MI, int MODE>
-__global__ void __launch_bounds__(256) k_wgrad(const float* __restrict__ dY, int ldy, int out_dim, const float* __restrict__ X, int ldx, int in_dim,
-                                               int x_col0, const int64_t* __restrict__ cam_idx, int out_base, int S, int64_t P,
-                                               float* __restrict__ dW, int ldw, float* __restrict__ db) {
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ dY, int ldy, int out_dim, const float* __restrict__ X, int ldx, int in_dim,
+                                           int x_col0, const int64_t* __restrict__ cam_idx, int out_base, int S, int64_t P,
+                                           float* __restrict__ dW, int ldw, float* __restrict__ db, int nblocks, float* __restrict__ red) {
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t nwaves = (int64_t)nblocks * (blockDim.x >> 6);
   int64_t per = tn_cdiv(tn_cdiv(P, 2), nwaves) * 2;  // samples per wave (even)
   int64_t p_begin = wave * per, p_end = p_begin + per;
   if (p_end > P) p_end = P;
@@ -497,67 +497,132 @@ __global__ void __launch_bounds__(256) k_wgrad(const float* __restrict__ dY, int
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = zero16;
   }
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += 2) {
-    int64_t p = p0 + h;
-    bool ok = p < p_end;
-    float av[MO], bv[MI];
+  // U k-steps per iteration: all loads of the iteration are issued before the first MFMA consumes one (the loop was latency-bound with
+  // one dependent load pair per k-step)
+  constexpr int U = 8;
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += 2 * U) {
+    float av[U][MO], bv[U][MI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t p = p0 + 2 * u + h;
+      bool ok = p < p_end;
+      // loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a "load or 0" select makes hipcc branch around
+      // every load and wait for each one separately (the loop ran at 1/6 of its speed that way)
+      int64_t pc = ok ? p : p_begin;
+#pragma unroll
+      for (int a = 0; a < MO; ++a) {
+        int o = 32 * a + j;
+        int oc = o < out_dim ? o : out_dim - 1;
+        if (MODE == 2) {
+          int64_t cam = cam_idx[pc / S];
+          av[u][a] = (ok && o < out_dim && cam == (int64_t)(out_base + o)) ? 1.0f : 0.0f;
+        } else {
+          // multiply by a 0/1 mask instead of selecting: a select lets hipcc sink the load back under a branch
+          av[u][a] = dY[pc * ldy + oc] * ((ok && o < out_dim) ? 1.0f : 0.0f);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        int i = 32 * b + j;
+        int ic = i < in_dim ? i : in_dim - 1;
+        bv[u][b] = X[pc * ldx + x_col0 + ic] * ((ok && i < in_dim) ? 1.0f : 0.0f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int a = 0; a < MO; ++a) {
+        bsum[a] += av[u][a];
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = MFMA(av[u][a], bv[u][b], acc[a][b]);
+      }
+    }
+  }
+  // Epilogue.  Same-line global atomics serialise at ~25 ns each (measured: 4096 waves adding into one 64-B line = 100 us), so the block's
+  // waves are first summed in LDS and then ONE coalesced burst per block goes out (16 consecutive floats per 64-B request).
+  for (int t = threadIdx.x; t < MO * MI * 1024 + MO * 32; t += blockDim.x) red[t] = 0.0f;
+  __syncthreads();
+  if (p_begin < p_end) {
 #pragma unroll
     for (int a = 0; a < MO; ++a) {
-      int o = 32 * a + j;
-      if (MODE == 2) {
-        int64_t cam = ok ? cam_idx[p / S] : -1;
-        av[a] = (o < out_dim && cam == (int64_t)(out_base + o)) ? 1.0f : 0.0f;
-      } else {
-        av[a] = (ok && o < out_dim) ? dY[p * ldy + o] : 0.0f;
-      }
-      bsum[a] += av[a];
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[a][b][r];
+          if (v != 0.0f) atomicAdd(&red[((a * 32 + RROW(r, h)) * MI + b) * 32 + j], v);
+        }
+      float sb = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+      if (h == 0 && sb != 0.0f) atomicAdd(&red[MO * MI * 1024 + 32 * a + j], sb);
     }
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-      int i = 32 * b + j;
-      bv[b] = (ok && i < in_dim) ? X[p * ldx + x_col0 + i] : 0.0f;
-    }
-#pragma unroll
-    for (int a = 0; a < MO; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b) acc[a][b] = MFMA(av[a], bv[b], acc[a][b]);
   }
-  if (p_begin >= p_end) return;
-#pragma unroll
-  for (int a = 0; a < MO; ++a) {
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-      int i = 32 * b + j;
-      int col = (MODE == 1) ? slot_to_col(i) : i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int o = 32 * a + RROW(r, h);
-        float v = acc[a][b][r];
-        if (o < out_dim && i < in_dim && col >= 0 && v != 0.0f) atomicAdd(dW + (int64_t)o * ldw + col, v);
-      }
-    }
-    if (db != nullptr) {
-      float s = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-      int o = 32 * a + j;
-      if (h == 0 && o < out_dim && s != 0.0f) atomicAdd(db + o, s);
+  __syncthreads();
+  for (int t = threadIdx.x; t < MO * MI * 1024; t += blockDim.x) {
+    int i = t % (32 * MI), o = t / (32 * MI);  // row-major over the padded [32*MO][32*MI] tile: consecutive threads = consecutive columns
+    float v = red[t];
+    int col = (MODE == 1) ? slot_to_col(i) : i;
+    if (o < out_dim && i < in_dim && col >= 0 && v != 0.0f) atomicAdd(dW + (int64_t)o * ldw + col, v);
+  }
+  if (db != nullptr) {
+    for (int t = threadIdx.x; t < MO * 32; t += blockDim.x) {
+      float v = red[MO * MI * 1024 + t];
+      if (t < out_dim && v != 0.0f) atomicAdd(db + t, v);
     }
   }
 }
 
-// generic launcher (also used by the proposal networks): out_dim, in_dim <= 64
-int tn_wgrad_launch(const float* dY, int ldy, int out_dim, const float* X, int ldx, int in_dim, int64_t P, float* dW, int ldw, float* db,
-                    hipStream_t stream) {
-  TN_REQUIRE(dY && X && dW && out_dim >= 1 && out_dim <= 64 && in_dim >= 1 && in_dim <= 64 && P >= 0, "tn_wgrad_launch: bad argument");
+// Several weight-gradient problems in ONE launch (blockIdx.y = problem): each problem alone is latency-bound at ~1 wave per SIMD, so the
+// five layers of the field (+ the embedding rows), or the two layers of a proposal net, overlap instead of queueing behind each other.
+struct WgradProb {
+  const float* dY; const float* X; float* dW; float* db; const int64_t* cam_idx;
+  int ldy, out_dim, ldx, in_dim, x_col0, out_base, ldw, mode, nblocks, S;
+};
+#define WGRAD_MAX_PROBS 8
+struct WgradBatch { WgradProb p[WGRAD_MAX_PROBS]; int64_t P; };
+
+__global__ void __launch_bounds__(256) k_wgrad_batch(WgradBatch bt) {
+  __shared__ float red[2 * 2 * 1024 + 64];
+  const WgradProb& q = bt.p[blockIdx.y];
+  if ((int)blockIdx.x >= q.nblocks) return;  // whole block leaves together
+  const int mo = q.out_dim > 32 ? 2 : 1, mi = q.in_dim > 32 ? 2 : 1;
+#define WG_CALL(MO_, MI_, MODE_) wgrad_body<MO_, MI_, MODE_>(q.dY, q.ldy, q.out_dim, q.X, q.ldx, q.in_dim, q.x_col0, q.cam_idx, q.out_base, q.S, bt.P, q.dW, q.ldw, q.db, q.nblocks, red)
+  if (q.mode == 2) WG_CALL(1, 1, 2);
+  else if (q.mode == 1) WG_CALL(2, 2, 1);
+  else if (mo == 1 && mi == 1) WG_CALL(1, 1, 0);
+  else if (mo == 1 && mi == 2) WG_CALL(1, 2, 0);
+  else if (mo == 2 && mi == 1) WG_CALL(2, 1, 0);
+  else WG_CALL(2, 2, 0);
+#undef WG_CALL
+}
+
+static WgradProb make_prob(const float* dY, int ldy, int out_dim, const float* X, int ldx, int in_dim, int x_col0, float* dW, int ldw, float* db,
+                           int mode = 0, const int64_t* cam = nullptr, int out_base = 0, int S = 1) {
+  WgradProb q;
+  q.dY = dY; q.X = X; q.dW = dW; q.db = db; q.cam_idx = cam;
+  q.ldy = ldy; q.out_dim = out_dim; q.ldx = ldx; q.in_dim = in_dim; q.x_col0 = x_col0; q.out_base = out_base; q.ldw = ldw; q.mode = mode; q.S = S;
+  int tiles = (out_dim > 32 ? 2 : 1) * (in_dim > 32 ? 2 : 1);
+  q.nblocks = tiles >= 4 ? 256 : (tiles == 2 ? 512 : 1024);  // small tiles: cheap epilogue, spread over more waves
+  return q;
+}
+static int launch_wgrad_batch(const WgradProb* probs, int n, int64_t P, hipStream_t stream) {
+  TN_REQUIRE(n >= 1 && n <= WGRAD_MAX_PROBS, "wgrad batch: bad problem count");
   if (P == 0) return TN_OK;
-  const dim3 wg(256), wb(256);
-  const int64_t* nocam = nullptr;
-  int mo = out_dim > 32 ? 2 : 1, mi = in_dim > 32 ? 2 : 1;
-  if (mo == 1 && mi == 1) hipLaunchKernelGGL((k_wgrad<1, 1, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
-  else if (mo == 1 && mi == 2) hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
-  else if (mo == 2 && mi == 1) hipLaunchKernelGGL((k_wgrad<2, 1, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
-  else hipLaunchKernelGGL((k_wgrad<2, 2, 0>), wg, wb, 0, stream, dY, ldy, out_dim, X, ldx, in_dim, 0, nocam, 0, 1, P, dW, ldw, db);
-  TN_CHECK_LAUNCH("tn_wgrad_launch");
+  WgradBatch bt;
+  bt.P = P;
+  int maxb = 0;
+  for (int i = 0; i < n; ++i) { bt.p[i] = probs[i]; maxb = std::max(maxb, probs[i].nblocks); }
+  for (int i = n; i < WGRAD_MAX_PROBS; ++i) { bt.p[i] = probs[0]; bt.p[i].nblocks = 0; }
+  hipLaunchKernelGGL(k_wgrad_batch, dim3(maxb, n), dim3(256), 0, stream, bt);
+  TN_CHECK_LAUNCH("k_wgrad_batch");
   return TN_OK;
+}
+
+// the two weight-gradient GEMMs of a proposal network (tn_prop.hip)
+int tn_wgrad_launch2(const float* dY0, int ldy0, int out0, const float* X0, int ldx0, int in0, float* dW0, int ldw0, float* db0, const float* dY1,
+                     int ldy1, int out1, const float* X1, int ldx1, int in1, float* dW1, int ldw1, float* db1, int64_t P, hipStream_t stream) {
+  TN_REQUIRE(dY0 && X0 && dW0 && dY1 && X1 && dW1 && out0 <= 64 && in0 <= 64 && out1 <= 64 && in1 <= 64 && P >= 0, "tn_wgrad_launch2: bad argument");
+  WgradProb pr[2] = {make_prob(dY0, ldy0, out0, X0, ldx0, in0, 0, dW0, ldw0, db0), make_prob(dY1, ldy1, out1, X1, ldx1, in1, 0, dW1, ldw1, db1)};
+  return launch_wgrad_batch(pr, 2, P, stream);
 }
 
 // ---- host entry points -----------------------------------------------------------------------------------------------------
@@ -665,21 +730,28 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
   hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
                      ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
   TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
-  // weight gradients: 256 blocks x 4 waves, each wave a contiguous slab of samples
-  const dim3 wg(256), wb(256);
-  const int64_t* ci = camera_indices;
-  hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, st, ws.g3, 4, C, ws.hh2, 64, 64, 0, ci, 0, S, P, field->ghw2, 64, field->ghb2);
-  hipLaunchKernelGGL((k_wgrad<2, 2, 0>), wg, wb, 0, st, ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, ci, 0, S, P, field->ghw1, 64, field->ghb1);
-  hipLaunchKernelGGL((k_wgrad<2, 2, 1>), wg, wb, 0, st, ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, ci, 0, S, P, field->ghw0, 63, field->ghb0);
-  hipLaunchKernelGGL((k_wgrad<1, 2, 0>), wg, wb, 0, st, ws.gy_bo, 16, 16, ws.h1, 64, 64, 0, ci, 0, S, P, field->gw1, 64, field->gb1);
-  hipLaunchKernelGGL((k_wgrad<2, 1, 0>), wg, wb, 0, st, ws.gy_h1, 64, 64, ws.enc, 32, 32, 0, ci, 0, S, P, field->gw0, 32, field->gb0);
-  // appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(head input slot 32+e)
-  for (int base = 0; base < field->num_images; base += 32) {
-    int od = std::min(32, field->num_images - base);
-    hipLaunchKernelGGL((k_wgrad<1, 1, 2>), wg, wb, 0, st, nullptr, 0, od, ws.g_hin, 64, 32, 32, ci, base, S, P, field->gemb + (int64_t)base * 32, 32,
-                       nullptr);
+  // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch
+  {
+    const int64_t* ci = camera_indices;
+    WgradProb pr[WGRAD_MAX_PROBS];
+    int n = 0;
+    pr[n++] = make_prob(ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, field->ghw1, 64, field->ghb1);
+    pr[n++] = make_prob(ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, field->ghw0, 63, field->ghb0, 1);
+    pr[n++] = make_prob(ws.g3, 4, C, ws.hh2, 64, 64, 0, field->ghw2, 64, field->ghb2);
+    pr[n++] = make_prob(ws.gy_bo, 16, 16, ws.h1, 64, 64, 0, field->gw1, 64, field->gb1);
+    pr[n++] = make_prob(ws.gy_h1, 64, 64, ws.enc, 32, 32, 0, field->gw0, 32, field->gb0);
+    // appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(head input slot 32+e); 32 cameras per problem
+    int base = 0;
+    for (; base < field->num_images && n < WGRAD_MAX_PROBS; base += 32)
+      pr[n++] = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
+    rc = launch_wgrad_batch(pr, n, P, st);
+    if (rc) return rc;
+    for (; base < field->num_images; base += 32) {  // > 96 cameras: the remaining embedding rows
+      WgradProb e = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
+      rc = launch_wgrad_batch(&e, 1, P, st);
+      if (rc) return rc;
+    }
   }
-  TN_CHECK_LAUNCH("tn_field_bwd(wgrad)");
   rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, st);
   if (rc) return rc;
   return TN_OK;

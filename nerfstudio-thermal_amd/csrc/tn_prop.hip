@@ -10,8 +10,8 @@
 #define PH 16    // hidden width
 #define PROP_NW (PH * PF + PH + PH + 1)  // 193 weights: w0[16][10], b0[16], w1[16], b1
 
-int tn_wgrad_launch(const float* dY, int ldy, int out_dim, const float* X, int ldx, int in_dim, int64_t P, float* dW, int ldw, float* db,
-                    hipStream_t stream);  // tn_field.hip
+int tn_wgrad_launch2(const float* dY0, int ldy0, int out0, const float* X0, int ldx0, int in0, float* dW0, int ldw0, float* db0, const float* dY1,
+                     int ldy1, int out1, const float* X1, int ldx1, int in1, float* dW1, int ldw1, float* db1, int64_t P, hipStream_t stream);  // tn_field.hip
 
 struct PropK {
   GridK g;
@@ -153,7 +153,5 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
   int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions, tn_s(stream));
   if (rcs) return rcs;
-  int rc = tn_wgrad_launch(ws_da, 16, 16, ws_enc, 16, PF, P, net->gw0, PF, net->gb0, tn_s(stream));
-  if (rc) return rc;
-  return tn_wgrad_launch(ws_dout, 1, 1, ws_h, 16, 16, P, net->gw1, 16, net->gb1, tn_s(stream));
+  return tn_wgrad_launch2(ws_da, 16, 16, ws_enc, 16, PF, net->gw0, PF, net->gb0, ws_dout, 1, 1, ws_h, 16, 16, net->gw1, 16, net->gb1, P, tn_s(stream));
 }

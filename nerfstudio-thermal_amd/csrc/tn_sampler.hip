@@ -340,7 +340,12 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
   }
   if (steps_minmax != nullptr) {
     mn = tn_wave_min(mn); mx = tn_wave_max(mx);
-    if (lane == 0) { atomicMin(&steps_minmax[0], f2ord(mn)); atomicMax(&steps_minmax[1], f2ord(mx)); }
+    if (lane == 0) {
+      // 4096 waves hammering two words serialise (~10 ns each): look first, update only when this wave improves the bound
+      uint32_t omn = f2ord(mn), omx = f2ord(mx);
+      if (omn < __hip_atomic_load(&steps_minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&steps_minmax[0], omn);
+      if (omx > __hip_atomic_load(&steps_minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&steps_minmax[1], omx);
+    }
   }
   if (depth_median != nullptr) {
     double wincl = tn_wave_incl_scan_d(wloc, lane);
@@ -573,15 +578,23 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
   if (d_w_prop != nullptr) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    for (int k = lane; k < Sp; k += 64) {
+    // most fine intervals have no excess (g_i == 0): walk only the others (wave-uniform bit masks, 64 intervals per word)
+    for (int k0 = 0; k0 < Sp; k0 += 64) {
+      int k = k0 + lane;
       float acc = 0.0f;
-      for (int i = 0; i < Sf; ++i) {
-        int a = sh_lo[wv][i], b = sh_hi[wv][i];
-        float gi = sh_g[wv][i];
-        if (a <= k && k <= b) acc += gi;
-        else if (b < k && k < a) acc -= gi;
+      for (int i0 = 0; i0 < Sf; i0 += 64) {
+        int ii = i0 + lane;
+        unsigned long long m = __ballot(ii < Sf && sh_g[wv][ii < Sf ? ii : 0] != 0.0f);
+        while (m) {
+          int i = i0 + __builtin_ctzll(m);
+          m &= m - 1;
+          int a = sh_lo[wv][i], b = sh_hi[wv][i];
+          float gi = sh_g[wv][i];
+          if (a <= k && k <= b) acc += gi;
+          else if (b < k && k < a) acc -= gi;
+        }
       }
-      d_w_prop[ray * Sp + k] += acc;
+      if (k < Sp && acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
     }
   }
 }
