@@ -528,6 +528,9 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ dY, int ldy
         bv[u][b] = X[pc * ldx + x_col0 + ic] * ((ok && i < in_dim) ? 1.0f : 0.0f);
       }
     }
+    // keep the whole batch of loads in flight: without the fence hipcc sinks each load next to the MFMA that consumes it (vmcnt(0..3)),
+    // which leaves ~2 loads outstanding per wave and makes the loop latency-bound
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll

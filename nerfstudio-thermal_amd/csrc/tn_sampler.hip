@@ -294,8 +294,11 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
                                                          float* __restrict__ depth_median, float* __restrict__ depth_expected,
                                                          uint32_t* __restrict__ steps_minmax) {
   int lane = tn_lane();
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-  if (ray >= N) return;
+  __shared__ float sh_mn[RAYS_PER_BLOCK], sh_mx[RAYS_PER_BLOCK];
+  float blk_mn = INFINITY, blk_mx = 0.0f;
+  // grid-stride over groups of RAYS_PER_BLOCK rays: same-address atomics serialise at ~15-25 ns each, so the batch-global min/max (and the
+  // loss sums of the kernels below) leave the block once, not once per ray
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
   const float* eb = e_bins + ray * (S + 1);
   float acc_c[C];
 #pragma unroll
@@ -339,13 +342,8 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
     if (depth_expected) depth_expected[ray] = wmid / (wsum + 1e-10f);
   }
   if (steps_minmax != nullptr) {
-    mn = tn_wave_min(mn); mx = tn_wave_max(mx);
-    if (lane == 0) {
-      // 4096 waves hammering two words serialise (~10 ns each): look first, update only when this wave improves the bound
-      uint32_t omn = f2ord(mn), omx = f2ord(mx);
-      if (omn < __hip_atomic_load(&steps_minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&steps_minmax[0], omn);
-      if (omx > __hip_atomic_load(&steps_minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&steps_minmax[1], omx);
-    }
+    blk_mn = fminf(blk_mn, tn_wave_min(mn));
+    blk_mx = fmaxf(blk_mx, tn_wave_max(mx));
   }
   if (depth_median != nullptr) {
     double wincl = tn_wave_incl_scan_d(wloc, lane);
@@ -367,6 +365,16 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
     v = __shfl(v, owner, 64);
     if (lane == 0) depth_median[ray] = v;
   }
+  }  // ray loop
+  if (steps_minmax != nullptr) {
+    if (lane == 0) { sh_mn[threadIdx.x >> 6] = blk_mn; sh_mx[threadIdx.x >> 6] = blk_mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = sh_mn[0], b = sh_mx[0];
+      for (int w = 1; w < RAYS_PER_BLOCK; ++w) { a = fminf(a, sh_mn[w]); b = fmaxf(b, sh_mx[w]); }
+      if (a != INFINITY) { atomicMin(&steps_minmax[0], f2ord(a)); atomicMax(&steps_minmax[1], f2ord(b)); }
+    }
+  }
 }
 
 extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
@@ -376,7 +384,7 @@ extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const fl
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_composite_fwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_composite_fwd: unsupported channel count %d", C);
   if (N == 0) return TN_OK;
-  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), block(BLOCK);
 #define LAUNCH_COMP(I, CC)                                                                                                                \
   hipLaunchKernelGGL((k_composite_fwd<I, CC>), grid, block, 0, tn_s(stream), rgb, weights, e_bins, N, S, training, comp, accumulation, \
                      depth_median, depth_expected, steps_minmax)
@@ -476,9 +484,12 @@ __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ 
   __shared__ float sh_m[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
   int lane = tn_lane();
   int wv = threadIdx.x >> 6;
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-  if (ray >= N) return;
+  __shared__ float sh_part[RAYS_PER_BLOCK];
+  float wave_total = 0.0f;
+  float scale = mult / (float)N;
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
   const float* t = s_bins + ray * (S + 1);
+  __builtin_amdgcn_wave_barrier();
   for (int i = lane; i < S; i += 64) {
     sh_w[wv][i] = weights[ray * S + i];
     sh_m[wv][i] = (t[i + 1] + t[i]) / 2.0f;
@@ -486,7 +497,6 @@ __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ 
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float total = 0.0f;
-  float scale = mult / (float)N;
   for (int i = lane; i < S; i += 64) {
     float wi = sh_w[wv][i], mi = sh_m[wv][i];
     float inner = 0.0f;
@@ -495,8 +505,16 @@ __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ 
     total += wi * inner + wi * wi * width / 3.0f;
     if (d_weights != nullptr) d_weights[ray * S + i] += scale * (2.0f * inner + 2.0f * wi * width / 3.0f);
   }
-  total = tn_wave_sum(total);
-  if (lane == 0) atomicAdd(loss_out, total * scale);
+  wave_total += tn_wave_sum(total);
+  __threadfence_block();
+  }  // ray loop
+  if (lane == 0) sh_part[wv] = wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f;
+    for (int w = 0; w < RAYS_PER_BLOCK; ++w) a += sh_part[w];
+    if (a != 0.0f) atomicAdd(loss_out, a * scale);
+  }
 }
 
 extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
@@ -504,7 +522,7 @@ extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int
   TN_REQUIRE(s_bins && weights && loss_out, "tn_distortion_loss: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_distortion_loss: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
-  hipLaunchKernelGGL(k_distortion, dim3((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), dim3(BLOCK), 0, tn_s(stream), s_bins, weights, N, S, mult,
+  hipLaunchKernelGGL(k_distortion, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), dim3(BLOCK), 0, tn_s(stream), s_bins, weights, N, S, mult,
                      loss_out, d_weights);
   TN_CHECK_LAUNCH("tn_distortion_loss");
   return TN_OK;
@@ -528,8 +546,12 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
   __shared__ int sh_hi[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
   int lane = tn_lane();
   int wv = threadIdx.x >> 6;
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-  if (ray >= N) return;
+  __shared__ float sh_part[RAYS_PER_BLOCK];
+  float wave_total = 0.0f;
+  float scale = mult / ((float)N * (float)Sf);
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
   const float* cp = p_bins + ray * (Sp + 1);
   const float* c = c_bins + ray * (Sf + 1);
   // cumsum of wp (torch CPU: double accumulate, float per element); lane owns 4 contiguous entries (Sp<=256)
@@ -555,7 +577,6 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float total = 0.0f;
-  float scale = mult / ((float)N * (float)Sf);
   for (int i = lane; i < Sf; i += 64) {
     float t0 = c[i], t1 = c[i + 1];
     int lo = 0, hi = Sp;  // searchsorted right over the starts cp[0..Sp-1]
@@ -573,8 +594,7 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
     sh_lo[wv][i] = ilo;
     sh_hi[wv][i] = ihi;
   }
-  total = tn_wave_sum(total);
-  if (lane == 0) atomicAdd(loss_out, total * scale);
+  wave_total += tn_wave_sum(total);
   if (d_w_prop != nullptr) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -597,6 +617,14 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
       if (k < Sp && acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
     }
   }
+  }  // ray loop
+  if (lane == 0) sh_part[wv] = wave_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f;
+    for (int w = 0; w < RAYS_PER_BLOCK; ++w) a += sh_part[w];
+    if (a != 0.0f) atomicAdd(loss_out, a * scale);
+  }
 }
 
 extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
@@ -606,7 +634,7 @@ extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights
   TN_REQUIRE(N >= 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES && S_prop >= 1 && S_prop <= TN_MAX_SAMPLES,
              "tn_interlevel_loss: bad N=%lld S_fine=%d S_prop=%d", (long long)N, S_fine, S_prop);
   if (N == 0) return TN_OK;
-  hipLaunchKernelGGL(k_interlevel, dim3((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), dim3(BLOCK), 0, tn_s(stream), s_bins_fine, weights_fine, S_fine,
+  hipLaunchKernelGGL(k_interlevel, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), dim3(BLOCK), 0, tn_s(stream), s_bins_fine, weights_fine, S_fine,
                      s_bins_prop, weights_prop, S_prop, N, mult, loss_out, d_weights_prop);
   TN_CHECK_LAUNCH("tn_interlevel_loss");
   return TN_OK;

@@ -44,3 +44,25 @@ for lvl, (name, L, minr, maxr) in enumerate([("prop0", 5, 16, 128), ("prop1", 5,
     print(name, "S", S, "overall reduction: run-merge %.2fx, patch-unique %.2fx, wave-unique %.2fx" % (tot_naive / tot_run, tot_naive / tot_patch, tot_naive / tot_wave_sorted))
     for r in per_level:
         print("   res %6.0f  run %.2fx  patch %.2fx  wave-unique %.2fx" % r)
+
+print("\n--- exact simulation of k_grid_scatter's merging (patch order, 16 samples per wave, run tails) ---")
+for lvl, (name, L, minr, maxr) in enumerate([("prop0", 5, 16, 128), ("prop1", 5, 16, 256), ("main", 16, 16, 2048)]):
+    smp = out["samples_list"][lvl]
+    pos = smp.positions(o, d)
+    p, sel = orc.unit_cube_positions(pos)
+    res = orc.level_resolutions(L, minr, maxr)
+    S = p.shape[1]
+    # patch order: groups of 4 rays, sample-major
+    pp = p.reshape(N // 4, 4, S, 3).permute(0, 2, 1, 3).reshape(-1, 3)
+    tot_req = 0
+    for l in range(L):
+        f = torch.floor(pp * res[l]).to(torch.int64)
+        key = (f[:, 0] * 4096 + f[:, 1]) * 4096 + f[:, 2]
+        kw = key.reshape(-1, 16)
+        tails = 1 + (kw[:, 1:] != kw[:, :-1]).sum(1)
+        ntails = int(tails.sum())
+        cross = float(((f[:, 0] % 8) == 7).float().mean())
+        req = ntails * 4 * (1 + cross)
+        tot_req += req
+        print(f"   {name} res {float(res[l]):6.0f}: samples/tail {len(key)/ntails:6.2f}  requests/sample {req/len(key):.2f}")
+    print(f"{name}: total requests for N={N}: {tot_req/1e6:.2f} M -> for 4096 rays {tot_req*4096/N/1e6:.2f} M = {tot_req*4096/N/21e9*1e6:.0f} us at 21 G req/s")
