@@ -72,9 +72,24 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
+# HBM-side traffic per launch from rocprofv3 PMC passes (profiles/r01_pmc_summary.md; N = 4096, shared mode): read bytes = TCC_EA0_RDREQ x 64 B
+# (the calibrated form for these 8-byte gathers; FETCH_SIZE under-reports wide streams 2x on gfx950), write bytes = WRITE_SIZE x 1024.
+PMC_TRAFFIC_BYTES = {
+    "k_grid_scatter(main grid)": 332.9e6 + 347.9e6,
+    "k_grid_scatter(prop0 grid)": 47.6e6 + 193.2e6,
+    "k_grid_scatter(prop1 grid)": 27.2e6 + 119.2e6,
+    "k_field_encode": 347.2e6 + 26.4e6,
+    "k_prop_fwd(level0)": 12.1e6 + 4.1e6,
+    "k_prop_fwd(level1)": 12.4e6 + 1.5e6,
+}
+ATOMIC_REQ_PEAK = 21.0e9  # 64-B atomic requests/s, measured by scripts/microbench/atomic_shapes.hip on MI355X
+PMC_ATOMIC_REQUESTS = {"k_grid_scatter(main grid)": 9.96e6, "k_grid_scatter(prop0 grid)": 5.46e6, "k_grid_scatter(prop1 grid)": 3.41e6}
+
+
 def kernel_roofline(eng, cam_t, idx):
-    """Live HIP-event timing (on the stream the kernels are launched on: torch's current stream) of the hash-gather kernels,
-    each launched alone.  Algorithmic bytes per launch = points x levels x 8 corners x 8 B."""
+    """Live HIP-event timing (torch.cuda.Event on torch's current stream = the stream every kernel of this library is launched on) of the
+    hash-grid gather / scatter kernels, each launched alone as a single-kernel C-ABI call.  Algorithmic bytes: gather =
+    points x levels x 8 corners x 8 B; scatter-add = read-modify-write = 2 x that."""
     from nerfstudio_thermal_amd import ops
 
     N = idx.shape[0]
@@ -84,18 +99,18 @@ def kernel_roofline(eng, cam_t, idx):
     b = br[""]
     lv = b.levels
     rows = []
-    # forward gathers
     for i in range(2):
         S = lv[i].S
         ms = time_ms(lambda i=i: ops.prop_density_fwd(eng.props[i], b.origins, b.directions, lv[i].e_bins))
         rows.append((f"k_prop_fwd(level{i})", ms, N * S * 5 * 8 * 8))
-    # backward scatter (read-modify-write = 2x) + gather for d(position)
-    gd = [torch.ones_like(lv[i].density) for i in range(2)]
     d_o, d_d = torch.zeros_like(o), torch.zeros_like(d)
-    for i in range(2):
-        S = lv[i].S
-        ms = time_ms(lambda i=i: ops.prop_density_bwd(eng.props[i], b.origins, b.directions, lv[i].e_bins, gd[i], d_o, d_d))
-        rows.append((f"tn_prop_density_bwd(level{i}) [k_prop_bwd + 2 k_wgrad]", ms, N * S * 5 * 8 * 8 * 3))
+    grids = [("prop0 grid", eng.props[0], lv[0]), ("prop1 grid", eng.props[1], lv[1]), ("main grid", eng.field, lv[2])]
+    for name, net, L in grids:
+        ld = 16 if net.num_levels == 5 else 32
+        g_enc = torch.randn((N * L.S, ld), device=o.device) * 1e-3
+        ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
+                                              L.e_bins, g_enc, d_o, d_d))
+        rows.append((f"k_grid_scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
     eng.arena.zero_grad()
     return rows
 
@@ -143,6 +158,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="shared", choices=["shared", "separate"], help="density_mode (default = BASELINE configs[1]; separate = configs[2])")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU per step (configs[2] uses 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=RAYS_PER_GPU)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -161,9 +178,10 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    cfg, arena, eng = build_engine(device)
+    cfg, arena, eng = build_engine(device, mode=args.mode)
+    rays = args.rays
     broadcast_params(arena)
-    cam_t, idx, img, is_th = make_batch(device, RAYS_PER_GPU, seed=rank_seed(42, rank))
+    cam_t, idx, img, is_th = make_batch(device, rays, seed=rank_seed(42, rank))
     hook = GradAllReducer(world) if world > 1 else None
 
     def barrier():
@@ -198,10 +216,15 @@ def main():
         name, ms, nbytes = max(rows, key=lambda r: r[1])
         achieved = nbytes / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms}
+                    "traffic": PMC_TRAFFIC_BYTES.get(name) if (rays == 4096 and args.mode == "shared") else None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                    "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows}}
+        if name in PMC_ATOMIC_REQUESTS:
+            # what actually bounds the scatter: 64-byte atomic requests at the memory side (microbenchmarked peak 21 G requests/s)
+            rate = PMC_ATOMIC_REQUESTS[name] / (ms * 1e-3)
+            roofline["atomic_requests"] = {"per_launch": PMC_ATOMIC_REQUESTS[name], "achieved_per_s": rate, "peak_per_s": ATOMIC_REQ_PEAK, "frac": rate / ATOMIC_REQ_PEAK}
         result = {
             "metric": "train rays/sec (4096-ray batch, 96 samples/ray)",
-            "value": world * RAYS_PER_GPU * args.steps / dt,
+            "value": world * rays * args.steps / dt,
             "unit": "rays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -212,12 +235,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "thermal-nerfacto density_mode=shared train step (raygen+fwd+losses+bwd+allreduce+Adam), 4096 rays/GPU, "
+            "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
                                    "256/96 proposal + 48 field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
-                       "rays_per_gpu": RAYS_PER_GPU, "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "rays_per_gpu": rays, "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "shared":
             torch.cuda.synchronize()
             cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
             result["cpu_baseline"] = cpu_baseline(args.cpu_rays, args.cpu_steps, cores)

@@ -30,7 +30,7 @@ __device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
 
 __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
-                                                      float* __restrict__ d_origins, float* __restrict__ d_directions) {
+                                                      float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups) {
   const bool want_dpos = d_origins != nullptr;
   const int lane = tn_lane();
   const int q = lane & 3, xc = q >> 1, ft = q & 1;
@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
     const float st = eb[0], en = eb[1];
     const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-    for (int l = 0; l < g.L; ++l) {  // wave-uniform trip count
+    // blockIdx.y = level group: levels l == group (mod level_groups).  Splitting the levels gives the dispatcher more, shorter work items
+    // (the 16-level main grid at 4096 rays is otherwise 1.5 waves of resident blocks: a 25% tail)
+    for (int l = blockIdx.y; l < g.L; l += level_groups) {  // wave-uniform trip count
       float gv = live ? g_enc[p * ld + 2 * l + ft] : 0.0f;
       const float res = g.res[l];
       const uint32_t level_off = (uint32_t)l * g.tsize;
@@ -135,8 +137,23 @@ int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
-  hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim), dim3(256), 0, stream, make_gridk(grid), origins, directions, e_bins, g_enc, ld, N, S, d_origins,
-                     d_directions);
+  // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups
+  int level_groups = 1;
+  if (grid.num_levels >= 8) {
+    double rounds = (double)grid_dim / 2048.0;
+    if (rounds < 4.0 && (rounds - floor(rounds)) > 0.0 && (rounds - floor(rounds)) < 0.75) level_groups = 2;
+  }
+  hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim, level_groups), dim3(256), 0, stream, make_gridk(grid), origins, directions, e_bins, g_enc, ld, N, S,
+                     d_origins, d_directions, level_groups);
   TN_CHECK_LAUNCH("tn_grid_scatter");
   return TN_OK;
+}
+
+extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
+                               int64_t N, int32_t S, float* d_origins, float* d_directions, tn_stream_t stream) {
+  TN_REQUIRE(grid != nullptr, "tn_hash_scatter: null grid");
+  TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_hash_scatter: d_origins and d_directions must both be given or both NULL");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_hash_scatter: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 24, "tn_hash_scatter: bad log2_hashmap_size");
+  return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, tn_s(stream));
 }

@@ -333,6 +333,17 @@ def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
                                    _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
 
 
+def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashmap_size: int, res, origins: Tensor, directions: Tensor, e_bins: Tensor,
+                 g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
+    """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] into table_grad."""
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    ld = g_enc.shape[1]
+    g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
+    check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),
+                                      _f32(g_enc, "g_enc", (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
+                                      _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_hash_scatter")
+
+
 # ------------------------------------------------------------------------------------------------ renderers
 def composite_fwd(rgb: Tensor, weights: Tensor, e_bins: Tensor, training: bool, want_depth: bool = True):
     """-> comp [N,C], accumulation [N,1], depth_median [N,1], depth_expected [N,1] (clipped to the batch-global midpoint range)."""

@@ -245,6 +245,52 @@ def test_field_default_table_size_hash_parity():
     assert md(hrgb, rgb) <= 1e-4
 
 
+def test_hash_scatter_matches_autograd_of_hash_encode():
+    """tn_hash_scatter alone: d table and d position of the reference hash encoding, for a 5-level and a 16-level grid, N not a multiple of 4."""
+    for L, log2T, maxr, S in ((5, 10, 256, 96), (16, 12, 2048, 48)):
+        N = 37
+        r = rays(N)
+        nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+        s, e = sample_level(N, S, nears, fars)
+        smp = orc.Samples(s_bins=s, e_bins=e)
+        table = (torch.from_numpy(synth.uniform(f"hs_table{L}", (L * 2**log2T, 2), seed=SEED)) * 0.5).requires_grad_(True)
+        o = r["origins"].clone().requires_grad_(True)
+        d = r["directions"].clone().requires_grad_(True)
+        res = orc.level_resolutions(L, 16, maxr)
+        p, sel = orc.unit_cube_positions(smp.positions(o, d))
+        enc = orc.hash_encode(p.view(-1, 3), table, res, log2T)
+        ld = 16 if L == 5 else 32
+        g_enc = torch.zeros((N * S, ld))
+        g_enc[:, : 2 * L] = torch.from_numpy(synth.uniform(f"hs_g{L}", (N * S, 2 * L), seed=SEED))
+        (enc * g_enc[:, : 2 * L]).sum().backward()
+        tg = torch.zeros((L * 2**log2T, 2), device=DEV)
+        d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
+        ops.hash_scatter(g(table.detach()), tg, L, log2T, res.tolist(), g(r["origins"]), g(r["directions"]), g(e), g(g_enc), d_o, d_d)
+        assert md(tg, table.grad) <= 2e-5 * float(table.grad.abs().max()), L
+        assert md(d_o, o.grad) <= 2e-4 * float(o.grad.abs().max()), L
+        assert md(d_d, d.grad) <= 2e-4 * float(d.grad.abs().max()), L
+
+
+def test_render_psnr_vs_oracle():
+    """'render PSNR vs ref' half of the BASELINE metric: eval-mode render of 512 rays, HIP vs oracle on identical rays."""
+    from nerfstudio_thermal_amd.engine import RenderEngine
+
+    ocfg, params, cfg, arena = setup_pair("shared")
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    cams = synth.synth_cameras()
+    idx = torch.from_numpy(synth.synth_ray_indices(cams, 512))
+    t = lambda k: torch.from_numpy(cams[k])  # noqa: E731
+    ro, rd, _, _ = orc.generate_rays(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    with torch.no_grad():
+        ref = orc.get_outputs(params, ocfg, ro, rd, idx[:, 0], training=False)
+    out, _ = eng.get_outputs(g(ro), g(rd), g(idx[:, 0]), training=False)
+    for key, refv in (("rgb", ref["rgb"]), ("rgb_thermal", ref["rgb_thermal"])):
+        mse = float(((out[key].cpu().double() - refv.double()) ** 2).mean())
+        psnr = 99.0 if mse == 0 else -10.0 * np.log10(mse)
+        assert psnr >= 80.0, (key, psnr)  # 1e-3 abs everywhere would be 60 dB; measured > 100 dB
+        assert md(out[key], refv) <= 1e-3
+
+
 # ------------------------------------------------------------------------------------------------ renderers and losses
 @pytest.mark.parametrize("C,S,training", [(4, 48, False), (4, 48, True), (3, 48, True), (1, 96, False), (4, 256, True)])
 def test_composite_fwd_bwd(C, S, training):
