@@ -163,8 +163,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=RAYS_PER_GPU)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(host cores, 32): more threads than that"
-                    " make the many small ATen ops of this path slower, measured on the 256-thread GPU-box host)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(host cores, 16): more threads make the"
+                    " many small ATen ops of this path slower; measured on the 256-thread GPU-box host at 1024 rays: 8 -> 2427, 16 -> 2286, 32 -> 1906, 64 -> 1025,"
+                    " 256 -> 24 rays/s)")
     ap.add_argument("--ops", action="store_true", help="print the per-kernel timing table to stderr")
     args = ap.parse_args()
 
@@ -242,7 +243,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "shared":
             torch.cuda.synchronize()
-            cores = args.cpu_threads or min(os.cpu_count() or 1, 32)
+            cores = args.cpu_threads or min(os.cpu_count() or 1, 16)
             result["cpu_baseline"] = cpu_baseline(args.cpu_rays, args.cpu_steps, cores)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))

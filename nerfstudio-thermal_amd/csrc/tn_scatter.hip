@@ -52,9 +52,57 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
     const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
     float dpx = 0.f, dpy = 0.f, dpz = 0.f;
     // blockIdx.y = level group: levels l == group (mod level_groups).  Splitting the levels gives the dispatcher more, shorter work items
-    // (the 16-level main grid at 4096 rays is otherwise 1.5 waves of resident blocks: a 25% tail)
-    for (int l = blockIdx.y; l < g.L; l += level_groups) {  // wave-uniform trip count
-      float gv = live ? g_enc[p * ld + 2 * l + ft] : 0.0f;
+    // (the 16-level main grid at 4096 rays is otherwise 1.5 waves of resident blocks: a 25% tail).
+    // Two passes over the levels: (1) every LOAD (the level's gradient and, for d position, the corner values), (2) every ATOMIC.  vmcnt
+    // retires in order, so a load issued behind an atomic waits for it (~3000 cycles when every CU is adding): keeping the loads first lets the
+    // wave fire all its atomics back to back.
+    float gvs[TN_MAX_LEVELS];
+#pragma unroll
+    for (int li = 0; li < TN_MAX_LEVELS; ++li) {
+      int l = blockIdx.y + li * level_groups;
+      gvs[li] = (live && l < g.L) ? g_enc[p * ld + 2 * l + ft] : 0.0f;
+    }
+    if (want_dpos) {
+#pragma unroll 1
+      for (int li = 0; li < TN_MAX_LEVELS; ++li) {
+        int l = blockIdx.y + li * level_groups;
+        if (l >= g.L) break;
+        float gv = gvs[li];
+        const float res = g.res[l];
+        const uint32_t level_off = (uint32_t)l * g.tsize;
+        float sx = c.px * res, sy = c.py * res, sz = c.pz * res;
+        float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+        uint32_t fx = (uint32_t)(int)fxf, fy = (uint32_t)(int)fyf, fz = (uint32_t)(int)fzf;
+        uint32_t cx = (uint32_t)(int)ceilf(sx), cy = (uint32_t)(int)ceilf(sy), cz = (uint32_t)(int)ceilf(sz);
+        float ox = sx - fxf, oy = sy - fyf, oz = sz - fzf;
+        float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+        uint32_t xi = xc ? cx : fx;
+        float wxv = xc ? ox : ux;
+        uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
+        const uint32_t hy[4] = {hcy, hfy, hcy, hfy};
+        const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
+        const float wy[4] = {oy, uy, oy, uy};
+        const float wz[4] = {oz, oz, uz, uz};
+        float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t idx = ((xi ^ hy[k] ^ hz[k]) & g.mask) + level_off;
+          float2 t = g.table[idx];
+          float tv = ft ? t.y : t.x;
+          a += wy[k] * wz[k] * tv;
+          b += ((k & 1) ? -1.0f : 1.0f) * wz[k] * tv;
+          cc += wy[k] * ((k & 2) ? -1.0f : 1.0f) * tv;
+        }
+        dpx += (xc ? 1.0f : -1.0f) * a * gv * res;
+        dpy += wxv * b * gv * res;
+        dpz += wxv * cc * gv * res;
+      }
+    }
+#pragma unroll 1
+    for (int li = 0; li < TN_MAX_LEVELS; ++li) {  // wave-uniform trip count
+      int l = blockIdx.y + li * level_groups;
+      if (l >= g.L) break;
+      float gv = gvs[li];
       const float res = g.res[l];
       const uint32_t level_off = (uint32_t)l * g.tsize;
       float sx = c.px * res, sy = c.py * res, sz = c.pz * res;
@@ -79,25 +127,12 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
       const float wy[4] = {oy, uy, oy, uy};
       const float wz[4] = {oz, oz, uz, uz};
-      float a = 0.f, b = 0.f, cc = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         uint32_t idx = ((xi ^ hy[k] ^ hz[k]) & g.mask) + level_off;
         float w = wxv * wy[k] * wz[k];
         float v = seg_sum4(w * gv, start, lane);
         if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(g.grad + idx) + ft, v);
-        if (want_dpos) {
-          float2 t = g.table[idx];
-          float tv = ft ? t.y : t.x;
-          a += wy[k] * wz[k] * tv;
-          b += ((k & 1) ? -1.0f : 1.0f) * wz[k] * tv;
-          cc += wy[k] * ((k & 2) ? -1.0f : 1.0f) * tv;
-        }
-      }
-      if (want_dpos) {
-        dpx += (xc ? 1.0f : -1.0f) * a * gv * res;
-        dpy += wxv * b * gv * res;
-        dpz += wxv * cc * gv * res;
       }
     }
     if (want_dpos) {

@@ -91,6 +91,11 @@ class RenderEngine:
         self.sampler_step = 0
         self.adam_step_count = 0
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ---------------------------------------------------------------- sampler schedule
     def update_schedule(self, step: int) -> float:
         c = self.cfg
@@ -265,11 +270,20 @@ class RenderEngine:
             d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dws[2])
             if d_dens_extra[sfx] is not None:
                 d_dens += d_dens_extra[sfx]
-            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            # The proposal networks' backward (its own tables, MLPs and scatter) is independent of the main field's: it runs on a side
+            # stream so that its non-atomic work hides under the main grid's atomic-bound scatter and both keep the atomic units busy.
+            side = None
             if br.prop_grad:
-                for i in range(2):
-                    dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
-                    ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+                side = self._side_stream()
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)  # dws[i], d_o, d_d are produced/zeroed on the main stream
+                with torch.cuda.stream(side):
+                    for i in range(2):
+                        dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
+                        ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
         if self.separate and c.density_loss_mult > 0:
             # density2 = field at the thermal branch's samples/rays; density2_thermal = field_thermal at the rgb branch's

@@ -66,3 +66,21 @@ for lvl, (name, L, minr, maxr) in enumerate([("prop0", 5, 16, 128), ("prop1", 5,
         tot_req += req
         print(f"   {name} res {float(res[l]):6.0f}: samples/tail {len(key)/ntails:6.2f}  requests/sample {req/len(key):.2f}")
     print(f"{name}: total requests for N={N}: {tot_req/1e6:.2f} M -> for 4096 rays {tot_req*4096/N/1e6:.2f} M = {tot_req*4096/N/21e9*1e6:.0f} us at 21 G req/s")
+
+print("\n--- window-size study (patch order, run tails within a window of W samples) ---")
+for lvl, (name, L, minr, maxr) in enumerate([("prop0", 5, 16, 128), ("prop1", 5, 16, 256), ("main", 16, 16, 2048)]):
+    smp = out["samples_list"][lvl]
+    p, sel = orc.unit_cube_positions(smp.positions(o, d))
+    res = orc.level_resolutions(L, minr, maxr)
+    S = p.shape[1]
+    pp = p.reshape(N // 4, 4, S, 3).permute(0, 2, 1, 3).reshape(-1, 3)
+    for W in (16, 64, 256, 4 * S):
+        tot = 0
+        for l in range(L):
+            f = torch.floor(pp * res[l]).to(torch.int64)
+            key = (f[:, 0] * 4096 + f[:, 1]) * 4096 + f[:, 2]
+            kw = key.reshape(-1, W)
+            ntails = int((1 + (kw[:, 1:] != kw[:, :-1]).sum(1)).sum())
+            cross = float(((f[:, 0] % 8) == 7).float().mean())
+            tot += ntails * 4 * (1 + cross)
+        print(f"{name}: window {W:5d}: {tot*4096/N/1e6:6.2f} M requests at 4096 rays -> {tot*4096/N/21e9*1e6:5.0f} us")
