@@ -673,6 +673,7 @@ static int launch_encode(const TnField* field, const float* origins, const float
 extern "C" int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                             int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
                             tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_fwd", false);
   if (rc) return rc;
   TN_REQUIRE(origins && directions && camera_indices && e_bins && workspace && density && rgb, "tn_field_fwd: null pointer");
@@ -699,6 +700,7 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
 
 extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                                     void* workspace, float* density, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_density_fwd", false);
   if (rc) return rc;
   TN_REQUIRE(origins && directions && e_bins && workspace && density, "tn_field_density_fwd: null pointer");
@@ -718,6 +720,7 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
 extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                             const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
                             tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_bwd", true);
   if (rc) return rc;
   TN_REQUIRE(origins && directions && camera_indices && e_bins && d_density && d_rgb && workspace, "tn_field_bwd: null pointer");

@@ -98,6 +98,7 @@ __global__ void k_raygen(const int64_t* __restrict__ ray_indices, const float* _
 extern "C" int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy,
                          const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions, float* pixel_area,
                          float* directions_norm, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area, "tn_raygen: null pointer");
   TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_raygen: bad N=%lld num_cameras=%d", (long long)N, num_cameras);
   if (N == 0) return TN_OK;
@@ -158,6 +159,7 @@ __global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __rest
 extern "C" int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
                                  const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
                                  tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(pose_adjustment && camera_indices && origins_in && directions_in && origins_out && directions_out, "tn_pose_apply_fwd: null pointer");
   TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_pose_apply_fwd: bad N=%lld C=%d", (long long)N, num_cameras);
   if (N == 0) return TN_OK;
@@ -237,6 +239,7 @@ __global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __rest
 extern "C" int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
                                  const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                                  tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(pose_adjustment && camera_indices && directions_in && d_origins && d_directions && grad_pose, "tn_pose_apply_bwd: null pointer");
   TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_pose_apply_bwd: bad N=%lld C=%d", (long long)N, num_cameras);
   if (N == 0) return TN_OK;
@@ -358,6 +361,7 @@ __global__ void k_pixel_losses(const float* __restrict__ pred_rgb, int rs, const
 extern "C" int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
                                const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
                                float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(pred_rgb && pred_thermal && image && is_thermal && losses_out, "tn_pixel_losses: null pointer");
   TN_REQUIRE(N >= 0 && N % 4 == 0, "tn_pixel_losses: N=%lld must be a multiple of 4 (2x2 patches)", (long long)N);
   TN_REQUIRE(rgb_stride >= 3 && thermal_stride >= 1, "tn_pixel_losses: bad strides");
@@ -388,6 +392,7 @@ __global__ void k_l1(const float* __restrict__ x, const float* __restrict__ y, i
 }
 extern "C" int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
                           tn_stream_t stream) {
+  if (count == 0) return TN_OK;
   TN_REQUIRE(x && y && loss_out && count >= 0, "tn_l1_loss: bad argument");
   if (count == 0) return TN_OK;
   hipLaunchKernelGGL(k_l1, dim3((unsigned)std::min<int64_t>(tn_cdiv(count, 256), 2048)), dim3(256), 0, tn_s(stream), x, y, count, gx, gy, loss_out,
@@ -430,6 +435,7 @@ __global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, flo
 
 extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
                             double beta1, double beta2, double eps, tn_stream_t stream) {
+  if (count == 0) return TN_OK;
   TN_REQUIRE(params && grads && exp_avg && exp_avg_sq, "tn_adam_step: null pointer");
   TN_REQUIRE(count >= 0 && step >= 1, "tn_adam_step: bad count=%lld step=%d", (long long)count, step);
   TN_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),

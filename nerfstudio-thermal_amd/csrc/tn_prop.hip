@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256) k_prop_fwd(PropK net, const float* __rest
 
 extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
                                    int32_t S, float* density, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(net && origins && directions && e_bins && density, "tn_prop_density_fwd: null pointer");
   TN_REQUIRE(net->grid.table && net->w0 && net->b0 && net->w1 && net->b1, "tn_prop_density_fwd: null parameter pointer");
   TN_REQUIRE(net->grid.num_levels == PL, "tn_prop_density_fwd: proposal grids are built for %d levels, got %d", PL, net->grid.num_levels);
@@ -134,6 +135,7 @@ extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
                                    const float* d_density, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
                                    tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(net && origins && directions && e_bins && d_density && workspace, "tn_prop_density_bwd: null pointer");
   TN_REQUIRE(net->grid.table && net->grid.table_grad && net->w0 && net->b0 && net->w1 && net->b1 && net->gw0 && net->gb0 && net->gw1 && net->gb1,
              "tn_prop_density_bwd: null parameter/gradient pointer");

@@ -32,6 +32,7 @@ __global__ void k_spaced_bins(const float* __restrict__ lin_bins, const float* _
 
 extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
                               float* s_bins, float* e_bins, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(lin_bins && nears && fars && s_bins && e_bins, "tn_spaced_bins: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_spaced_bins: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__
 
 extern "C" int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
                               tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(e_bins && density && weights, "tn_weights_fwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_weights_fwd: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
@@ -166,6 +168,7 @@ __global__ void __launch_bounds__(BLOCK) k_weights_bwd(const float* __restrict__
 
 extern "C" int tn_weights_bwd(const float* e_bins, const float* density, const float* weights, const float* d_weights, int64_t N, int32_t S,
                               float* d_density, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(e_bins && density && weights && d_weights && d_density, "tn_weights_bwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_weights_bwd: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
@@ -257,6 +260,7 @@ __global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict_
 extern "C" int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
                                const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S, float* s_bins,
                                float* e_bins, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(s_bins_prev && weights_prev && u_lin && nears && fars && s_bins && e_bins, "tn_pdf_resample: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES && S_prev >= 1 && S_prev <= TN_MAX_SAMPLES, "tn_pdf_resample: bad N=%lld S=%d S_prev=%d",
              (long long)N, S, S_prev);
@@ -380,6 +384,7 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
 extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
                                 float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* steps_minmax,
                                 tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(rgb && weights && e_bins && comp, "tn_composite_fwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_composite_fwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_composite_fwd: unsupported channel count %d", C);
@@ -409,6 +414,7 @@ __global__ void k_clip_depth(float* __restrict__ d, const uint32_t* __restrict__
   }
 }
 extern "C" int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(depth_expected && steps_minmax && N >= 0, "tn_clip_depth: bad argument");
   if (N == 0) return TN_OK;
   hipLaunchKernelGGL(k_clip_depth, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024)), dim3(256), 0, tn_s(stream), depth_expected,
@@ -457,6 +463,7 @@ __global__ void __launch_bounds__(BLOCK) k_composite_bwd(const float* __restrict
 
 extern "C" int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
                                 float* d_weights, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(rgb && weights && d_comp && d_rgb && d_weights, "tn_composite_bwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_composite_bwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_composite_bwd: unsupported channel count %d", C);
@@ -519,6 +526,7 @@ __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ 
 
 extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
                                   tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(s_bins && weights && loss_out, "tn_distortion_loss: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_distortion_loss: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
@@ -630,6 +638,7 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
 extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
                                   const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
                                   tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(s_bins_fine && weights_fine && s_bins_prop && weights_prop && loss_out, "tn_interlevel_loss: null pointer");
   TN_REQUIRE(N >= 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES && S_prop >= 1 && S_prop <= TN_MAX_SAMPLES,
              "tn_interlevel_loss: bad N=%lld S_fine=%d S_prop=%d", (long long)N, S_fine, S_prop);

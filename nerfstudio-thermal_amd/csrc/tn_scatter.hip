@@ -186,6 +186,7 @@ int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float
 
 extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
                                int64_t N, int32_t S, float* d_origins, float* d_directions, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(grid != nullptr, "tn_hash_scatter: null grid");
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_hash_scatter: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_hash_scatter: bad N=%lld S=%d", (long long)N, S);

@@ -405,3 +405,31 @@ def test_adam_matches_torch_optim():
         opt.step()
         ops.adam_step(hp, g(grad), m, v, step, 1e-2)
         assert md(hp, ref_p) <= 2e-6, step
+
+
+def test_empty_single_and_eval_chunk_sizes():
+    """Edge sizes: N = 0 (valid, touches nothing), N = 1, and the reference's eval chunk of 32768 rays (8.4 M proposal points)."""
+    from nerfstudio_thermal_amd.engine import RenderEngine
+
+    ocfg, params, cfg, arena = setup_pair("shared")
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    z3 = torch.zeros((0, 3), device=DEV)
+    s, e = ops.spaced_bins(torch.zeros(0, device=DEV), torch.zeros(0, device=DEV), 256)
+    assert s.shape == (0, 257)
+    d = ops.prop_density_fwd(eng.props[0], z3, z3, e)
+    assert d.shape == (0, 256)
+    w, _ = ops.weights_fwd(e, d)
+    assert w.shape == (0, 256)
+    r1 = rays(1)
+    out1, _ = eng.get_outputs(g(r1["origins"]), g(r1["directions"]), g(r1["camera_indices"]), training=False)
+    with torch.no_grad():
+        ref1 = orc.get_outputs(params, ocfg, r1["origins"], r1["directions"], r1["camera_indices"], training=False)
+    assert md(out1["rgb"], ref1["rgb"]) <= 1e-3
+    N = 32768
+    r = rays(N)
+    out, br = eng.get_outputs(g(r["origins"]), g(r["directions"]), g(r["camera_indices"]), training=False)
+    assert out["rgbt"].shape == (N, 4) and bool(torch.isfinite(out["rgbt"]).all())
+    sub = slice(1000, 1064)
+    with torch.no_grad():
+        ref = orc.get_outputs(params, ocfg, r["origins"][sub], r["directions"][sub], r["camera_indices"][sub], training=False)
+    assert md(out["rgbt"][sub], torch.cat([ref["rgb"], ref["rgb_thermal"]], -1)) <= 1e-3
