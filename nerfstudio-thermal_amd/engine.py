@@ -311,18 +311,28 @@ class RenderEngine:
         return losses
 
     # ---------------------------------------------------------------- optimiser
-    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True) -> None:
-        """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307)."""
+    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=()) -> None:
+        """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307).
+
+        torch.optim.Adam skips parameters whose .grad is None and advances its per-parameter step count (bias correction) only when it
+        updates them.  The only parameters that have no gradient in some iterations are the proposal networks on steps where the sampler
+        ran them under no_grad (ray_samplers.py:605-610): `skip_groups` names them, and each group keeps its own Adam step count.  The LR
+        schedule (LambdaLR) advances every iteration for every group."""
         self.adam_step_count += 1
+        if not hasattr(self, "group_steps"):
+            self.group_steps = {}
         a = self.arena
         for gname in a.optimised_groups:
+            if gname in skip_groups:
+                continue
+            self.group_steps[gname] = self.group_steps.get(gname, 0) + 1
             lo, hi = a.group_range[gname]
             lr0, lr_final, max_steps = OPTIMIZERS[gname]
-            # LambdaLR: the lr used at optimiser step k (1-based) is the schedule evaluated at k-1
+            # LambdaLR: the lr used at iteration k (1-based) is the schedule evaluated at k-1
             lr = exp_decay_lr(self.adam_step_count - 1, lr0, lr_final, max_steps) if scheduled else lr0
             if lr_overrides and gname in lr_overrides:
                 lr = lr_overrides[gname]
-            ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.adam_step_count, lr, eps=1e-15)
+            ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.group_steps[gname], lr, eps=1e-15)
 
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
                    jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True) -> Dict[str, Tensor]:
@@ -333,6 +343,7 @@ class RenderEngine:
         losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
         if grad_hook is not None:
             grad_hook(self.arena)  # data-parallel gradient all-reduce
-        self.optimizer_step(scheduled=scheduled)
+        skip = () if branches[""].prop_grad else ("proposal_networks",)
+        self.optimizer_step(scheduled=scheduled, skip_groups=skip)
         self.step_cb(step)
         return losses

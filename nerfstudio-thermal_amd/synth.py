@@ -135,6 +135,18 @@ def synth_gt(ray_indices: np.ndarray, cams: Dict[str, np.ndarray], seed: int = 7
     return img, is_th
 
 
+def synth_gt_smooth(ray_indices: np.ndarray, cams: Dict[str, np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    """A learnable target: smooth colour / temperature as a function of the pixel position (per camera phase)."""
+    c = ray_indices[:, 0].astype(np.float64)
+    y = ray_indices[:, 1] / cams["height"][ray_indices[:, 0]].astype(np.float64)
+    x = ray_indices[:, 2] / cams["width"][ray_indices[:, 0]].astype(np.float64)
+    is_th = cams["is_thermal"][ray_indices[:, 0]].astype(np.float32)
+    rgb = np.stack([0.5 + 0.4 * np.sin(6.0 * x + c), 0.5 + 0.4 * np.cos(5.0 * y - c), 0.5 + 0.3 * np.sin(4.0 * (x + y))], axis=1)
+    grey = (0.5 + 0.4 * np.cos(3.0 * x - 2.0 * y + 0.5 * c))[:, None]
+    img = np.where(is_th[:, None] > 0, np.repeat(grey, 3, axis=1), rgb).astype(np.float32)
+    return img, is_th
+
+
 def synth_jitters(num_rays: int, seed: int = 3, tag: str = "") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """The three per-ray uniforms the training sampler draws (level-0 stratified, two PDF levels)."""
     return tuple(uniform(f"jitter{tag}_{i}", (num_rays, 1), 0.0, 1.0, seed) for i in range(3))
