@@ -102,9 +102,13 @@ int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float*
 
 /* ---- a9 (backward)  autograd of HashEncoding.pytorch_fwd (field_components/encodings.py:420-461) with respect to the table (and the sample
  *          position): trilinear scatter-add of g_enc [N*S, ld] (feature 2*level + f) into grid->table_grad; d_origins/d_directions optional.
- *          Used by tn_prop_density_bwd and tn_field_bwd; exposed because it is the dominant kernel of the training step. */
+ *          Used by tn_prop_density_bwd and tn_field_bwd; exposed because it is the dominant kernel of the training step.
+ *          workspace: tn_hash_scatter_workspace_bytes() of 256-byte-aligned device scratch (contents irrelevant), or NULL. With it the
+ *          coarse levels, whose few entries are hammered by every sample, are summed in private dense replicas first and folded into
+ *          table_grad afterwards; NULL adds every level straight into table_grad (same result up to summation order, slower). */
+int64_t tn_hash_scatter_workspace_bytes(void);
 int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
-                    int64_t N, int32_t S, float* d_origins, float* d_directions, tn_stream_t stream);
+                    int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream);
 
 /* ---- a11 RaySamples.get_weights (cameras/rays.py:128-150) and, optionally, DepthRenderer("median") of the same level
  *          (model_components/renderers.py:547-557; used for prop_depth_i, models/nerfacto.py:351-352). median_depth may be NULL. */

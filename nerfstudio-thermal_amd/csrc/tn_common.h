@@ -394,6 +394,19 @@ __device__ __forceinline__ void tn_ray_grad_wave(int64_t ray, float wx, float wy
 }
 
 // ---------------------------------------------------------------- the shared table-gradient scatter kernel (tn_scatter.hip)
+// Coarse levels touch only (res+1)^3 table entries and the scene contraction concentrates the samples on a few of them: atomics to one
+// 64-B line serialise (scripts/microbench/atomic_hotset.hip: 64 hot lines -> 3.5 G requests/s instead of 21 G), so a level-0 launch
+// is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R dense replicas (block b adds into replica
+// b % R, index (z*r1 + y)*r1 + x) and k_dense_reduce folds the replicas into the hashed gradient afterwards.
+#define TN_SCATTER_SCRATCH_BYTES (32ll << 20)  // replica scratch appended to every backward workspace
+struct DenseK {
+  float2* rep;                   // [R][stride] float2, zero-filled before the scatter
+  uint32_t stride;               // entries per replica (sum of r1^3 over the dense levels)
+  uint32_t level_mask;           // bit l set: level l is accumulated densely
+  int R;
+  uint32_t off[TN_MAX_LEVELS];   // entry offset of level l inside a replica
+};
 // g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
+// scratch: TN_SCATTER_SCRATCH_BYTES of device memory or NULL (every level then adds straight into the hashed gradient).
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                           int64_t N, int S, float* d_origins, float* d_directions, hipStream_t stream);
+                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream);

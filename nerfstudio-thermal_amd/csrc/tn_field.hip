@@ -122,6 +122,7 @@ struct FieldWs {
   float* gy_bo;    // [P][16]
   float* gy_h1;    // [P][64]
   float* g_enc;    // [P][32]
+  void* scatter;   // replica scratch of the table-gradient scatter (TN_SCATTER_SCRATCH_BYTES)
   int64_t bytes;
 };
 static inline FieldWs ws_layout(void* base, int64_t P, int training) {
@@ -140,8 +141,10 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     w.h1 = take(P * 64); w.hin = take(P * 64); w.hh1 = take(P * 64); w.hh2 = take(P * 64); w.y = take(P * 4);
     w.g3 = take(P * 4); w.gy_hh2 = take(P * 64); w.gy_hh1 = take(P * 64); w.g_hin = take(P * 64);
     w.gy_bo = take(P * 16); w.gy_h1 = take(P * 64); w.g_enc = take(P * 32);
+    w.scatter = take(TN_SCATTER_SCRATCH_BYTES / 4);
   } else {
     w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = nullptr;
+    w.scatter = nullptr;
   }
   w.bytes = off;
   return w;
@@ -758,7 +761,7 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
       if (rc) return rc;
     }
   }
-  rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, st);
+  rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, ws.scatter, st);
   if (rc) return rc;
   return TN_OK;
 }

@@ -127,9 +127,12 @@ __global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __
   }
 }
 
+// [P][16] x4 GEMM operands + [P] d_out, then the scatter's replica scratch (256-B aligned)
+static inline int64_t prop_scratch_offset(int64_t P) { return ((P * (16 + 16 + 16 + 16 + 1) * (int64_t)sizeof(float) + 1024 + 255) / 256) * 256; }
+
 extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
   if (num_points < 0) return TN_EINVAL;
-  return num_points * (16 + 16 + 16 + 16 + 1) * (int64_t)sizeof(float) + 1024;
+  return prop_scratch_offset(num_points) + TN_SCATTER_SCRATCH_BYTES;
 }
 
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
@@ -143,7 +146,7 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   TN_REQUIRE(net->grid.num_levels == PL, "tn_prop_density_bwd: proposal grids are built for %d levels, got %d", PL, net->grid.num_levels);
   TN_REQUIRE(net->grid.log2_hashmap_size >= 1 && net->grid.log2_hashmap_size <= 24, "tn_prop_density_bwd: bad log2_hashmap_size");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_prop_density_bwd: bad N=%lld S=%d", (long long)N, S);
-  TN_REQUIRE(((uintptr_t)workspace % 16) == 0, "tn_prop_density_bwd: workspace must be 16-byte aligned");
+  TN_REQUIRE(((uintptr_t)workspace % 256) == 0, "tn_prop_density_bwd: workspace must be 256-byte aligned");
   if (N == 0) return TN_OK;
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, net->gw0, net->gb0, net->gw1, net->gb1};
   int64_t P = N * (int64_t)S;
@@ -153,7 +156,8 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, d_density, N, S, ws_da, ws_dout, ws_enc,
                      ws_h, ws_denc);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
-  int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions, tn_s(stream));
+  int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions,
+                                   reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), tn_s(stream));
   if (rcs) return rcs;
   return tn_wgrad_launch2(ws_da, 16, 16, ws_enc, 16, PF, net->gw0, PF, net->gb0, ws_dout, 1, 1, ws_h, 16, 16, net->gw1, 16, net->gb1, P, tn_s(stream));
 }

@@ -8,6 +8,7 @@
 //   * work items in patch order (tn_patch_order) and run-length merging across consecutive samples of the wave: samples in the same
 //     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
 #include "tn_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ int seg_start4(bool head, int lane) {
   int s = head ? (lane >> 2) : 0;  // in sample units
@@ -30,7 +31,7 @@ __device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
 
 __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
-                                                      float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups) {
+                                                      float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, DenseK dk) {
   const bool want_dpos = d_origins != nullptr;
   const int lane = tn_lane();
   const int q = lane & 3, xc = q >> 1, ft = q & 1;
@@ -123,16 +124,28 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       uint32_t xi = xc ? cx : fx;
       float wxv = xc ? ox : ux;
       uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
-      const uint32_t hy[4] = {hcy, hfy, hcy, hfy};
-      const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
       const float wy[4] = {oy, uy, oy, uy};
       const float wz[4] = {oz, oz, uz, uz};
+      // wave-uniform: hashed gradient, or this block's dense replica for a hot coarse level
+      const bool dense = (dk.level_mask >> l) & 1u;
+      float2* base = g.grad + level_off;
+      uint32_t amask = g.mask;
+      if (dense) {
+        const uint32_t r1 = (uint32_t)(int)ceilf(res) + 1u, top = r1 - 1u;
+        xi = min(xi, top);  // positions are in [0,1] by construction; the clamp only keeps a corrupt input inside the replica
+        hcy = min(cy, top) * r1; hfy = min(fy, top) * r1;
+        hcz = min(cz, top) * r1 * r1; hfz = min(fz, top) * r1 * r1;
+        base = dk.rep + (size_t)(blockIdx.x % (unsigned)dk.R) * dk.stride + dk.off[l];
+        amask = 0xffffffffu;
+      }
+      const uint32_t hy[4] = {hcy, hfy, hcy, hfy};
+      const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t idx = ((xi ^ hy[k] ^ hz[k]) & g.mask) + level_off;
+        uint32_t idx = dense ? (xi + hy[k] + hz[k]) : ((xi ^ hy[k] ^ hz[k]) & amask);
         float w = wxv * wy[k] * wz[k];
         float v = seg_sum4(w * gv, start, lane);
-        if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(g.grad + idx) + ft, v);
+        if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(base + idx) + ft, v);
       }
     }
     if (want_dpos) {
@@ -165,8 +178,41 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
   }
 }
 
+// Folds the dense replicas of the coarse levels into the hashed gradient: thread = one dense entry (level, x, y, z).
+__global__ void __launch_bounds__(256) k_dense_reduce(GridK g, DenseK dk) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= dk.stride) return;
+  int l = 0;
+#pragma unroll 1
+  for (int i = 0; i < g.L; ++i)
+    if (((dk.level_mask >> i) & 1u) && dk.off[i] <= e) l = i;  // offsets grow with the level
+  float sx = 0.f, sy = 0.f;
+  for (int r = 0; r < dk.R; ++r) {
+    float2 v = dk.rep[(size_t)r * dk.stride + e];
+    sx += v.x;
+    sy += v.y;
+  }
+  if (sx == 0.0f && sy == 0.0f) return;  // untouched entries keep an exactly-zero gradient (Adam's eps = 1e-15 makes that matter)
+  const uint32_t r1 = (uint32_t)(int)ceilf(g.res[l]) + 1u;
+  uint32_t t = e - dk.off[l];
+  uint32_t x = t % r1, y = (t / r1) % r1, z = t / (r1 * r1);
+  uint32_t idx = ((x ^ (y * TN_PRIME_Y) ^ (z * TN_PRIME_Z)) & g.mask) + (uint32_t)l * g.tsize;
+  float* dst = reinterpret_cast<float*>(g.grad + idx);
+  if (sx != 0.0f) unsafeAtomicAdd(dst, sx);
+  if (sy != 0.0f) unsafeAtomicAdd(dst + 1, sy);
+}
+
+static int scatter_replicas() {
+  static int r = [] {
+    const char* e = getenv("TN_SCATTER_REPLICAS");  // tuning knob; 0 disables the dense path
+    int v = e ? atoi(e) : 16;
+    return v < 0 ? 0 : (v > 64 ? 64 : v);
+  }();
+  return r;
+}
+
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                           int64_t N, int S, float* d_origins, float* d_directions, hipStream_t stream) {
+                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
@@ -178,18 +224,48 @@ int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float
     double rounds = (double)grid_dim / 2048.0;
     if (rounds < 4.0 && (rounds - floor(rounds)) > 0.0 && (rounds - floor(rounds)) < 0.75) level_groups = 2;
   }
-  hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim, level_groups), dim3(256), 0, stream, make_gridk(grid), origins, directions, e_bins, g_enc, ld, N, S,
-                     d_origins, d_directions, level_groups);
+  // dense replicas for the coarse levels, in level order while they fit the scratch (pointless when the batch is much smaller than the level)
+  DenseK dk{};
+  dk.R = scatter_replicas();
+  if (scratch != nullptr && dk.R > 0) {
+    const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)(dk.R * sizeof(float2));
+    int64_t total = 0;
+    for (int l = 0; l < grid.num_levels; ++l) {
+      float r = grid.res[l];
+      if (!(r >= 1.0f && r <= 62.0f)) break;
+      int64_t r1 = (int64_t)ceilf(r) + 1, n = r1 * r1 * r1;
+      if (total + n > cap || n > 4 * P) break;
+      dk.off[l] = (uint32_t)total;
+      dk.level_mask |= 1u << l;
+      total += n;
+    }
+    dk.stride = (uint32_t)total;
+    dk.rep = reinterpret_cast<float2*>(scratch);
+    if (dk.level_mask) {
+      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)dk.R * dk.stride * sizeof(float2), stream);
+      TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
+    }
+  }
+  GridK gk = make_gridk(grid);
+  hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim, level_groups), dim3(256), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
+                     d_directions, level_groups, dk);
   TN_CHECK_LAUNCH("tn_grid_scatter");
+  if (dk.level_mask) {
+    hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)tn_cdiv(dk.stride, 256)), dim3(256), 0, stream, gk, dk);
+    TN_CHECK_LAUNCH("tn_grid_scatter(reduce)");
+  }
   return TN_OK;
 }
 
+extern "C" int64_t tn_hash_scatter_workspace_bytes(void) { return TN_SCATTER_SCRATCH_BYTES; }
+
 extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
-                               int64_t N, int32_t S, float* d_origins, float* d_directions, tn_stream_t stream) {
+                               int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(grid != nullptr, "tn_hash_scatter: null grid");
+  TN_REQUIRE(((uintptr_t)workspace % 256) == 0, "tn_hash_scatter: workspace must be 256-byte aligned");
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_hash_scatter: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_hash_scatter: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 24, "tn_hash_scatter: bad log2_hashmap_size");
-  return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, tn_s(stream));
+  return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, workspace, tn_s(stream));
 }

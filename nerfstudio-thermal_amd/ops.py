@@ -333,15 +333,26 @@ def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
                                    _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
 
 
+_SCATTER_WS: dict = {}
+
+
 def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashmap_size: int, res, origins: Tensor, directions: Tensor, e_bins: Tensor,
-                 g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
-    """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] into table_grad."""
+                 g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, use_workspace: bool = True) -> None:
+    """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] into table_grad.
+    use_workspace=False adds every level straight into the hashed gradient (no dense replicas for the coarse levels)."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
     ld = g_enc.shape[1]
+    ws = None
+    if use_workspace:
+        ws = _SCATTER_WS.get(str(origins.device))
+        if ws is None:
+            ws = torch.empty(int(_lib.load().tn_hash_scatter_workspace_bytes()), dtype=torch.uint8, device=origins.device)
+            _SCATTER_WS[str(origins.device)] = ws
     g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
     check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),
                                       _f32(g_enc, "g_enc", (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
-                                      _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_hash_scatter")
+                                      _f32(d_directions, "d_directions", (N, 3), True), C.c_void_p(ws.data_ptr()) if ws is not None else None,
+                                      _stream()), "tn_hash_scatter")
 
 
 # ------------------------------------------------------------------------------------------------ renderers

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-kernel summary (calls / avg / total / share) of a rocprofv3 --kernel-trace run stored in rocpd sqlite format.
+
+    python scripts/rocpd_stats.py gpurun_out/prof_x/x_results.db [out.csv] [--split-grid]
+
+--split-grid keeps launches of one kernel with different grid sizes apart (the three hash grids share k_grid_scatter).
+"""
+import csv
+import sqlite3
+import sys
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    split = "--split-grid" in sys.argv
+    con = sqlite3.connect(args[0])
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+    key = "name" + (f", {gx}" if split and gx else "")
+    rows = con.execute(f"select {key}, count(*), avg(end-start), sum(end-start) from kernels group by {key} order by 4 desc").fetchall()
+    total = sum(r[-1] for r in rows)
+    print(f"total kernel ms {total / 1e6:.3f}")
+    out = []
+    for r in rows:
+        name = r[0][:60] + (f" [grid {r[1]}]" if split and gx else "")
+        calls, avg, tot = r[-3], r[-2], r[-1]
+        out.append((name, calls, avg / 1e3, tot / 1e6, 100.0 * tot / total))
+    for name, calls, avg, tot, pct in out[:28]:
+        print(f"{name:<78} calls={calls:5d} avg_us={avg:9.1f} tot_ms={tot:8.2f} {pct:5.1f}%")
+    if len(args) > 1:
+        with open(args[1], "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "avg_us", "total_ms", "percent"])
+            for row in out:
+                w.writerow([row[0], row[1], f"{row[2]:.2f}", f"{row[3]:.3f}", f"{row[4]:.2f}"])
+
+
+if __name__ == "__main__":
+    main()

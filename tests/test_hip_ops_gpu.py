@@ -263,12 +263,20 @@ def test_hash_scatter_matches_autograd_of_hash_encode():
         g_enc = torch.zeros((N * S, ld))
         g_enc[:, : 2 * L] = torch.from_numpy(synth.uniform(f"hs_g{L}", (N * S, 2 * L), seed=SEED))
         (enc * g_enc[:, : 2 * L]).sum().backward()
-        tg = torch.zeros((L * 2**log2T, 2), device=DEV)
-        d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
-        ops.hash_scatter(g(table.detach()), tg, L, log2T, res.tolist(), g(r["origins"]), g(r["directions"]), g(e), g(g_enc), d_o, d_d)
-        assert md(tg, table.grad) <= 2e-5 * float(table.grad.abs().max()), L
-        assert md(d_o, o.grad) <= 2e-4 * float(o.grad.abs().max()), L
-        assert md(d_d, d.grad) <= 2e-4 * float(d.grad.abs().max()), L
+        # with the workspace the coarse levels go through the dense replicas + k_dense_reduce, without it straight into the hashed gradient
+        zero_patterns = []
+        for use_ws in (True, False):
+            tg = torch.zeros((L * 2**log2T, 2), device=DEV)
+            d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
+            ops.hash_scatter(g(table.detach()), tg, L, log2T, res.tolist(), g(r["origins"]), g(r["directions"]), g(e), g(g_enc), d_o, d_d,
+                             use_workspace=use_ws)
+            assert md(tg, table.grad) <= 2e-5 * float(table.grad.abs().max()), (L, use_ws)
+            assert md(d_o, o.grad) <= 2e-4 * float(o.grad.abs().max()), (L, use_ws)
+            assert md(d_d, d.grad) <= 2e-4 * float(d.grad.abs().max()), (L, use_ws)
+            zero_patterns.append((tg == 0).cpu())
+        # untouched entries must stay exactly zero on both paths (Adam's eps = 1e-15 turns any residue into a full-size update)
+        assert torch.equal(zero_patterns[0], zero_patterns[1])
+        assert torch.equal(zero_patterns[0], table.grad == 0)
 
 
 def test_render_psnr_vs_oracle():
