@@ -26,6 +26,14 @@ void tn_set_error(const char* fmt, ...);
   } while (0)
 
 static inline hipStream_t tn_s(tn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Fork/join inside one entry point: the weight-gradient GEMMs (HBM-stream + MFMA bound) and the table-gradient scatter (atomic-request
+// bound) of a backward pass are independent and use different parts of the chip, so they run side by side.  tn_fork() makes the
+// library-owned companion stream of `user` wait for everything enqueued on `user` so far and returns it; tn_join() makes `user` wait for
+// the companion.  Both are plain event record/wait pairs (capturable into a hipGraph).  Companion streams are created once per
+// (device, user stream) and live for the process.  Returns nullptr (caller then stays on `user`) if a stream/event cannot be created.
+hipStream_t tn_fork(hipStream_t user);
+void tn_join(hipStream_t user, hipStream_t companion);
 __host__ __device__ static inline int64_t tn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // POD copy of TnGrid that is passed to kernels by value
@@ -396,15 +404,20 @@ __device__ __forceinline__ void tn_ray_grad_wave(int64_t ray, float wx, float wy
 // ---------------------------------------------------------------- the shared table-gradient scatter kernel (tn_scatter.hip)
 // Coarse levels touch only (res+1)^3 table entries and the scene contraction concentrates the samples on a few of them: atomics to one
 // 64-B line serialise (scripts/microbench/atomic_hotset.hip: 64 hot lines -> 3.5 G requests/s instead of 21 G), so a level-0 launch
-// is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R dense replicas (block b adds into replica
-// b % R, index (z*r1 + y)*r1 + x) and k_dense_reduce folds the replicas into the hashed gradient afterwards.
-#define TN_SCATTER_SCRATCH_BYTES (32ll << 20)  // replica scratch appended to every backward workspace
-struct DenseK {
-  float2* rep;                   // [R][stride] float2, zero-filled before the scatter
-  uint32_t stride;               // entries per replica (sum of r1^3 over the dense levels)
-  uint32_t level_mask;           // bit l set: level l is accumulated densely
-  int R;
-  uint32_t off[TN_MAX_LEVELS];   // entry offset of level l inside a replica
+// is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R private replicas (block b adds into replica
+// b % R) and k_replica_reduce folds the replicas into the hashed gradient afterwards.  Two replica layouts:
+//   dense  : index (z*r1 + y)*r1 + x, r1 = res + 1       (coarse levels: (res+1)^3 entries, fewer than the table has slots)
+//   hashed : the level's own hashed index, 2^log2T slots  (small tables, e.g. the proposal grids' 2^17: the whole level is replicated)
+#define TN_SCATTER_SCRATCH_BYTES (64ll << 20)  // replica scratch appended to every backward workspace
+enum { TN_REP_NONE = 0, TN_REP_DENSE = 1, TN_REP_HASHED = 2 };
+struct ReplicaK {
+  float2* rep;                     // scratch, zero-filled before the scatter
+  uint32_t total;                  // sum of n[l] over the replicated levels (= threads of the reduce kernel)
+  uint32_t kinds;                  // 2 bits per level: TN_REP_*
+  uint32_t n[TN_MAX_LEVELS];       // entries of one replica of level l
+  uint32_t off[TN_MAX_LEVELS];     // scratch offset (entries) of replica 0 of level l; replica r is at off + r * n
+  uint32_t first[TN_MAX_LEVELS];   // prefix sum of n over the replicated levels (reduce-thread index of the level's entry 0)
+  uint8_t R[TN_MAX_LEVELS];        // replicas of level l
 };
 // g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
 // scratch: TN_SCATTER_SCRATCH_BYTES of device memory or NULL (every level then adds straight into the hashed gradient).

@@ -739,7 +739,11 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
   hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
                      ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
   TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
-  // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch
+  // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch, on the companion stream beside the table scatter
+  // (the GEMMs stream the saved activations from HBM, the scatter is bound by atomic requests: they overlap almost perfectly)
+  hipStream_t side = tn_fork(st);
+  hipStream_t wst = side ? side : st;
+  int rcw = TN_OK;
   {
     const int64_t* ci = camera_indices;
     WgradProb pr[WGRAD_MAX_PROBS];
@@ -753,15 +757,13 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
     int base = 0;
     for (; base < field->num_images && n < WGRAD_MAX_PROBS; base += 32)
       pr[n++] = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
-    rc = launch_wgrad_batch(pr, n, P, st);
-    if (rc) return rc;
-    for (; base < field->num_images; base += 32) {  // > 96 cameras: the remaining embedding rows
+    rcw = launch_wgrad_batch(pr, n, P, wst);
+    for (; rcw == TN_OK && base < field->num_images; base += 32) {  // > 96 cameras: the remaining embedding rows
       WgradProb e = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
-      rc = launch_wgrad_batch(&e, 1, P, st);
-      if (rc) return rc;
+      rcw = launch_wgrad_batch(&e, 1, P, wst);
     }
   }
   rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, ws.scatter, st);
-  if (rc) return rc;
-  return TN_OK;
+  if (side) tn_join(st, side);
+  return rcw ? rcw : rc;
 }

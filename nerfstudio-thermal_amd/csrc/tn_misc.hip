@@ -1,5 +1,6 @@
 // Ray generation, camera-pose correction, pixel-space losses, Adam, error plumbing.
 #include "tn_common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -13,6 +14,45 @@ void tn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* tn_last_error(void) { return g_err; }
+// ---- companion streams (tn_common.h: tn_fork / tn_join) ------------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+struct Companion {
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+};
+std::mutex g_comp_mu;
+std::map<std::pair<int, hipStream_t>, Companion> g_comp;
+Companion* companion_of(hipStream_t user) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_comp_mu);
+  auto key = std::make_pair(dev, user);
+  auto it = g_comp.find(key);
+  if (it != g_comp.end()) return &it->second;
+  if (getenv("TN_NO_FORK") != nullptr) return nullptr;  // debugging aid: everything on the caller's stream
+  Companion c;
+  if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c.join_ev, hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  return &(g_comp[key] = c);
+}
+}  // namespace
+hipStream_t tn_fork(hipStream_t user) {
+  Companion* c = companion_of(user);
+  if (c == nullptr) return nullptr;
+  if (hipEventRecord(c->fork_ev, user) != hipSuccess || hipStreamWaitEvent(c->side, c->fork_ev, 0) != hipSuccess) return nullptr;
+  return c->side;
+}
+void tn_join(hipStream_t user, hipStream_t companion) {
+  Companion* c = companion_of(user);
+  if (c == nullptr || companion != c->side) return;
+  (void)hipEventRecord(c->join_ev, c->side);
+  (void)hipStreamWaitEvent(user, c->join_ev, 0);
+}
+
 extern "C" int tn_version(void) { return 100; }
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {

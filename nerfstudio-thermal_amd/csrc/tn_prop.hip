@@ -156,8 +156,11 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, d_density, N, S, ws_da, ws_dout, ws_enc,
                      ws_h, ws_denc);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
+  // the two weight-gradient GEMMs run beside the (atomic-bound) table scatter on the companion stream
+  hipStream_t st = tn_s(stream), side = tn_fork(st);
+  int rcw = tn_wgrad_launch2(ws_da, 16, 16, ws_enc, 16, PF, net->gw0, PF, net->gb0, ws_dout, 1, 1, ws_h, 16, 16, net->gw1, 16, net->gb1, P, side ? side : st);
   int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions,
-                                   reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), tn_s(stream));
-  if (rcs) return rcs;
-  return tn_wgrad_launch2(ws_da, 16, 16, ws_enc, 16, PF, net->gw0, PF, net->gb0, ws_dout, 1, 1, ws_h, 16, 16, net->gw1, 16, net->gb1, P, tn_s(stream));
+                                   reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), st);
+  if (side) tn_join(st, side);
+  return rcw ? rcw : rcs;
 }

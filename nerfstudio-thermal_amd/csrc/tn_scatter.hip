@@ -31,7 +31,7 @@ __device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
 
 __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
-                                                      float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, DenseK dk) {
+                                                      float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, ReplicaK rk) {
   const bool want_dpos = d_origins != nullptr;
   const int lane = tn_lane();
   const int q = lane & 3, xc = q >> 1, ft = q & 1;
@@ -126,23 +126,22 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
       const float wy[4] = {oy, uy, oy, uy};
       const float wz[4] = {oz, oz, uz, uz};
-      // wave-uniform: hashed gradient, or this block's dense replica for a hot coarse level
-      const bool dense = (dk.level_mask >> l) & 1u;
+      // wave-uniform: the hashed gradient itself, or this block's private replica of the level (dense or hashed layout)
+      const uint32_t kind = (rk.kinds >> (2 * l)) & 3u;
+      const bool dense = kind == TN_REP_DENSE;
       float2* base = g.grad + level_off;
-      uint32_t amask = g.mask;
+      if (kind != TN_REP_NONE) base = rk.rep + rk.off[l] + (size_t)(blockIdx.x % (unsigned)rk.R[l]) * rk.n[l];
       if (dense) {
         const uint32_t r1 = (uint32_t)(int)ceilf(res) + 1u, top = r1 - 1u;
         xi = min(xi, top);  // positions are in [0,1] by construction; the clamp only keeps a corrupt input inside the replica
         hcy = min(cy, top) * r1; hfy = min(fy, top) * r1;
         hcz = min(cz, top) * r1 * r1; hfz = min(fz, top) * r1 * r1;
-        base = dk.rep + (size_t)(blockIdx.x % (unsigned)dk.R) * dk.stride + dk.off[l];
-        amask = 0xffffffffu;
       }
       const uint32_t hy[4] = {hcy, hfy, hcy, hfy};
       const uint32_t hz[4] = {hcz, hcz, hfz, hfz};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        uint32_t idx = dense ? (xi + hy[k] + hz[k]) : ((xi ^ hy[k] ^ hz[k]) & amask);
+        uint32_t idx = dense ? (xi + hy[k] + hz[k]) : ((xi ^ hy[k] ^ hz[k]) & g.mask);
         float w = wxv * wy[k] * wz[k];
         float v = seg_sum4(w * gv, start, lane);
         if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(base + idx) + ft, v);
@@ -178,38 +177,45 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
   }
 }
 
-// Folds the dense replicas of the coarse levels into the hashed gradient: thread = one dense entry (level, x, y, z).
-__global__ void __launch_bounds__(256) k_dense_reduce(GridK g, DenseK dk) {
+// Folds the replicas into the hashed gradient: thread = one entry of one replicated level.
+__global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= dk.stride) return;
+  if (e >= rk.total) return;
   int l = 0;
 #pragma unroll 1
   for (int i = 0; i < g.L; ++i)
-    if (((dk.level_mask >> i) & 1u) && dk.off[i] <= e) l = i;  // offsets grow with the level
+    if (((rk.kinds >> (2 * i)) & 3u) != TN_REP_NONE && rk.first[i] <= e) l = i;  // first[] grows with the level
+  const uint32_t t = e - rk.first[l], n = rk.n[l];
+  const float2* src = rk.rep + rk.off[l] + t;
   float sx = 0.f, sy = 0.f;
-  for (int r = 0; r < dk.R; ++r) {
-    float2 v = dk.rep[(size_t)r * dk.stride + e];
+  for (int r = 0; r < rk.R[l]; ++r) {
+    float2 v = src[(size_t)r * n];
     sx += v.x;
     sy += v.y;
   }
   if (sx == 0.0f && sy == 0.0f) return;  // untouched entries keep an exactly-zero gradient (Adam's eps = 1e-15 makes that matter)
+  if (((rk.kinds >> (2 * l)) & 3u) == TN_REP_HASHED) {  // one thread per table slot: a plain add
+    float2* dst = g.grad + (size_t)l * g.tsize + t;
+    float2 cur = *dst;
+    *dst = make_float2(cur.x + sx, cur.y + sy);
+    return;
+  }
   const uint32_t r1 = (uint32_t)(int)ceilf(g.res[l]) + 1u;
-  uint32_t t = e - dk.off[l];
   uint32_t x = t % r1, y = (t / r1) % r1, z = t / (r1 * r1);
   uint32_t idx = ((x ^ (y * TN_PRIME_Y) ^ (z * TN_PRIME_Z)) & g.mask) + (uint32_t)l * g.tsize;
-  float* dst = reinterpret_cast<float*>(g.grad + idx);
+  float* dst = reinterpret_cast<float*>(g.grad + idx);  // several dense entries may share a slot
   if (sx != 0.0f) unsafeAtomicAdd(dst, sx);
   if (sy != 0.0f) unsafeAtomicAdd(dst + 1, sy);
 }
 
-static int scatter_replicas() {
-  static int r = [] {
-    const char* e = getenv("TN_SCATTER_REPLICAS");  // tuning knob; 0 disables the dense path
-    int v = e ? atoi(e) : 16;
-    return v < 0 ? 0 : (v > 64 ? 64 : v);
-  }();
-  return r;
+static int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* e = getenv(name);
+  int v = e ? atoi(e) : dflt;
+  return v < lo ? lo : (v > hi ? hi : v);
 }
+// tuning knobs (0 disables the respective replica layout)
+static int dense_replicas() { static int r = env_int("TN_SCATTER_REPLICAS", 16, 0, 64); return r; }
+static int hashed_replicas() { static int r = env_int("TN_SCATTER_HASHED_REPLICAS", 4, 0, 64); return r; }
 
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
@@ -224,34 +230,52 @@ int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float
     double rounds = (double)grid_dim / 2048.0;
     if (rounds < 4.0 && (rounds - floor(rounds)) > 0.0 && (rounds - floor(rounds)) < 0.75) level_groups = 2;
   }
-  // dense replicas for the coarse levels, in level order while they fit the scratch (pointless when the batch is much smaller than the level)
-  DenseK dk{};
-  dk.R = scatter_replicas();
-  if (scratch != nullptr && dk.R > 0) {
-    const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)(dk.R * sizeof(float2));
-    int64_t total = 0;
+  // Replica plan, in level order while the scratch lasts: dense replicas for the coarse levels, then whole-level (hashed) replicas when the
+  // table is small.  Neither pays when the batch is much smaller than the replica (the zero-fill and the fold are O(replica size)).
+  ReplicaK rk{};
+  if (scratch != nullptr) {
+    const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)sizeof(float2);
+    const int64_t T = 1ll << grid.log2_hashmap_size;
+    int64_t used = 0, total = 0;
+    bool dense_ok = dense_replicas() > 0;
     for (int l = 0; l < grid.num_levels; ++l) {
       float r = grid.res[l];
-      if (!(r >= 1.0f && r <= 62.0f)) break;
-      int64_t r1 = (int64_t)ceilf(r) + 1, n = r1 * r1 * r1;
-      if (total + n > cap || n > 4 * P) break;
-      dk.off[l] = (uint32_t)total;
-      dk.level_mask |= 1u << l;
+      int64_t n = 0;
+      int kind = TN_REP_NONE, R = 0;
+      if (dense_ok && r >= 1.0f && r <= 62.0f) {
+        int64_t r1 = (int64_t)ceilf(r) + 1;
+        n = r1 * r1 * r1;
+        R = dense_replicas();
+        if (n <= T && n <= 4 * P && used + n * R <= cap) kind = TN_REP_DENSE;
+      }
+      if (kind == TN_REP_NONE) {
+        dense_ok = false;  // levels are in increasing resolution
+        n = T;
+        R = hashed_replicas();
+        if (R > 0 && T <= (1ll << 17) && n <= P && used + n * R <= cap) kind = TN_REP_HASHED;
+      }
+      if (kind == TN_REP_NONE) continue;
+      rk.kinds |= (uint32_t)kind << (2 * l);
+      rk.n[l] = (uint32_t)n;
+      rk.off[l] = (uint32_t)used;
+      rk.first[l] = (uint32_t)total;
+      rk.R[l] = (uint8_t)R;
+      used += n * R;
       total += n;
     }
-    dk.stride = (uint32_t)total;
-    dk.rep = reinterpret_cast<float2*>(scratch);
-    if (dk.level_mask) {
-      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)dk.R * dk.stride * sizeof(float2), stream);
+    rk.total = (uint32_t)total;
+    rk.rep = reinterpret_cast<float2*>(scratch);
+    if (rk.kinds) {
+      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)used * sizeof(float2), stream);
       TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
     }
   }
   GridK gk = make_gridk(grid);
   hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim, level_groups), dim3(256), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
-                     d_directions, level_groups, dk);
+                     d_directions, level_groups, rk);
   TN_CHECK_LAUNCH("tn_grid_scatter");
-  if (dk.level_mask) {
-    hipLaunchKernelGGL(k_dense_reduce, dim3((unsigned)tn_cdiv(dk.stride, 256)), dim3(256), 0, stream, gk, dk);
+  if (rk.kinds) {
+    hipLaunchKernelGGL(k_replica_reduce, dim3((unsigned)tn_cdiv(rk.total, 256)), dim3(256), 0, stream, gk, rk);
     TN_CHECK_LAUNCH("tn_grid_scatter(reduce)");
   }
   return TN_OK;

@@ -31,3 +31,13 @@ for name, net, L in grids:
     ms = bench.time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
                                                 L.e_bins, g_enc, None, None))
     print(f"{name}: sum of single-level launches {tot*1e3:.1f} us, all levels in one launch {ms*1e3:.1f} us")
+
+# no-atomics floor: an all-zero g_enc makes every lane skip its atomics (v != 0 is false), leaving loads + index math + scans
+for name, net, L in grids:
+    N, S = L.e_bins.shape[0], L.e_bins.shape[1] - 1
+    g_enc = torch.zeros((N * S, 16 if net.num_levels == 5 else 32), device=dev)
+    ms = bench.time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
+                                                L.e_bins, g_enc, None, None))
+    ms2 = bench.time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
+                                                 L.e_bins, g_enc, None, None, use_workspace=False))
+    print(f"{name}: zero-gradient launch (no atomics) {ms*1e3:.1f} us; without replica scratch {ms2*1e3:.1f} us")
