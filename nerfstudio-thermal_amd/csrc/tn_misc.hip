@@ -33,7 +33,11 @@ Companion* companion_of(hipStream_t user) {
   if (it != g_comp.end()) return &it->second;
   if (getenv("TN_NO_FORK") != nullptr) return nullptr;  // debugging aid: everything on the caller's stream
   Companion c;
-  if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  // highest priority: the companion's GEMMs are short and finish while the scatter on the caller's stream keeps the atomic units busy;
+  // at equal priority the scatter's thousands of resident blocks starve them and the join waits for a tail
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c.join_ev, hipEventDisableTiming) != hipSuccess)
     return nullptr;

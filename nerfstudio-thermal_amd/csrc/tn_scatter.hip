@@ -188,7 +188,14 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk) {
   const uint32_t t = e - rk.first[l], n = rk.n[l];
   const float2* src = rk.rep + rk.off[l] + t;
   float sx = 0.f, sy = 0.f;
-  for (int r = 0; r < rk.R[l]; ++r) {
+  const int R = rk.R[l];
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {  // four independent loads in flight (the kernel is one short latency chain per thread otherwise)
+    float2 v0 = src[(size_t)r * n], v1 = src[(size_t)(r + 1) * n], v2 = src[(size_t)(r + 2) * n], v3 = src[(size_t)(r + 3) * n];
+    sx += (v0.x + v1.x) + (v2.x + v3.x);
+    sy += (v0.y + v1.y) + (v2.y + v3.y);
+  }
+  for (; r < R; ++r) {
     float2 v = src[(size_t)r * n];
     sx += v.x;
     sy += v.y;

@@ -91,10 +91,11 @@ class RenderEngine:
         self.sampler_step = 0
         self.adam_step_count = 0
 
-    def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+    def _side_stream(self, i: int = 0):
+        side = self.__dict__.setdefault("_side", {})
+        if i not in side:
+            side[i] = torch.cuda.Stream(device=self.device)
+        return side[i]
 
     # ---------------------------------------------------------------- sampler schedule
     def update_schedule(self, step: int) -> float:
@@ -143,7 +144,23 @@ class RenderEngine:
 
     def _nears_fars(self, N: int, training: bool):
         near = self.cfg.near_plane if training else 0.0  # NearFarCollider resets the near plane at inference (scene_colliders.py:186-191)
-        return (torch.full((N,), near, device=self.device), torch.full((N,), self.cfg.far_plane, device=self.device))
+        key = (N, bool(training))
+        cache = self.__dict__.setdefault("_nf_cache", {})
+        if key not in cache:  # constants: filled once per batch size, not once per step
+            cache.clear()
+            cache[key] = (torch.full((N,), near, device=self.device), torch.full((N,), self.cfg.far_plane, device=self.device))
+        return cache[key]
+
+    def _zeros_many(self, shapes):
+        """Zero-initialised tensors carved out of ONE allocation (one fill kernel instead of one per tensor: at 2 ms per step the ~4.5 us
+        launch floor of every tiny kernel is visible).  Each view starts on a 256-byte boundary."""
+        sizes = [int(np.prod(s)) for s in shapes]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        flat = torch.zeros(tot, device=self.device)
+        return [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
 
     @staticmethod
     def _branch_outputs(b: Branch, sfx: str, training: bool) -> Dict[str, object]:
@@ -167,7 +184,7 @@ class RenderEngine:
         N = origins.shape[0]
         nears, fars = self._nears_fars(N, training)
         if training and jitters is None:
-            jitters = [torch.rand(N, device=self.device) for _ in range(3)]
+            jitters = list(torch.rand((3, N), device=self.device).unbind(0))
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
         b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
                                jitters, prop_grad=updated)
@@ -182,7 +199,7 @@ class RenderEngine:
             out["rgb_thermal"] = rgbt[..., 3:]
             return out, branches
         if training and jitters_thermal is None:
-            jitters_thermal = [torch.rand(N, device=self.device) for _ in range(3)]
+            jitters_thermal = list(torch.rand((3, N), device=self.device).unbind(0))
         # thermal sampler: never receives step_cb -> anneal stays 1.0 and always "updated" (models/thermal_nerfacto.py:222-250)
         bt = self.render_branch(self.props_thermal, self.field_thermal, self.pose_thermal, self.frozen_thermal, origins, directions, cam, nears, fars,
                                 training, 1.0, jitters_thermal, prop_grad=True)
@@ -222,9 +239,21 @@ class RenderEngine:
         bt = branches.get("_thermal")
         C = b.comp.shape[1]
         # ---- pixel losses -> d comp
-        d_comp = torch.zeros_like(b.comp)
+        # every zero-initialised accumulator of the step comes out of one allocation / one fill (see _zeros_many)
+        zshapes, zkeys = [], []
+        for sfx, br in branches.items():
+            zkeys.append(("d_comp", sfx)); zshapes.append(tuple(br.comp.shape))
+            zkeys.append(("dw2", sfx)); zshapes.append(tuple(br.levels[2].weights.shape))
+            if br.prop_grad:
+                for i in range(2):
+                    zkeys.append((f"dw{i}", sfx)); zshapes.append(tuple(br.levels[i].weights.shape))
+            if (self.pose_thermal if sfx else self.pose) is not None:
+                zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
+                zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
+        Z = dict(zip(zkeys, self._zeros_many(zshapes)))
+        d_comp = Z[("d_comp", "")]
         if self.separate:
-            d_comp_t = torch.zeros_like(bt.comp)
+            d_comp_t = Z[("d_comp", "_thermal")]
             ops.pixel_losses(b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8], d_comp, d_comp_t)
         else:
             ops.pixel_losses(b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8],
@@ -235,11 +264,11 @@ class RenderEngine:
         grads_w: Dict[str, List[Optional[Tensor]]] = {}
         for sfx, br in branches.items():
             lv = br.levels
-            dws: List[Optional[Tensor]] = [None, None, torch.zeros_like(lv[2].weights)]
+            dws: List[Optional[Tensor]] = [None, None, Z[("dw2", sfx)]]
             ops.distortion_loss(lv[2].s_bins, lv[2].weights, c.distortion_loss_mult * nsfx, L[9:10], dws[2])
             for i in range(2):
                 if br.prop_grad:
-                    dws[i] = torch.zeros_like(lv[i].weights)
+                    dws[i] = Z[(f"dw{i}", sfx)]
                 ops.interlevel_loss(lv[2].s_bins, lv[2].weights, lv[i].s_bins, lv[i].weights, c.interlevel_loss_mult, L[8:9], dws[i])
             grads_w[sfx] = dws
         # ---- per-branch backward
@@ -262,16 +291,18 @@ class RenderEngine:
             frozen = self.frozen_thermal if sfx else self.frozen_rgb
             lv = br.levels
             want_pos = pose is not None
-            d_o = torch.zeros((N, 3), device=dev) if want_pos else None
-            d_d = torch.zeros((N, 3), device=dev) if want_pos else None
+            d_o = Z[("d_o", sfx)] if want_pos else None
+            d_d = Z[("d_d", sfx)] if want_pos else None
             dws = grads_w[sfx]
             dc = d_comp_t if sfx else d_comp
             d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, dc, dws[2])
             d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dws[2])
             if d_dens_extra[sfx] is not None:
                 d_dens += d_dens_extra[sfx]
-            # The proposal networks' backward (its own tables, MLPs and scatter) is independent of the main field's: it runs on a side
-            # stream so that its non-atomic work hides under the main grid's atomic-bound scatter and both keep the atomic units busy.
+            # The proposal networks' backward (own tables, MLPs and scatter; d origins / d directions are accumulated atomically) is
+            # independent of the main field's and runs on ONE side stream: with the library's companion streams (tn_fork) that makes four
+            # streams, the number of hardware queues ROCm multiplexes streams onto by default -- a fifth stream shares a queue with another
+            # and serialises behind it (measured: one side stream per proposal level made the step 1.7x slower).
             side = None
             if br.prop_grad:
                 side = self._side_stream()

@@ -267,13 +267,15 @@ _PROP_WS: dict = {}
 
 
 def prop_density_bwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_bins: Tensor, d_density: Tensor,
-                     d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None) -> None:
+                     d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, tag: str = "") -> None:
+    """`tag` names the scratch buffer: calls that may be in flight at the same time (different streams) must use different tags."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
     need = int(_lib.load().tn_prop_workspace_bytes(N * S))
-    ws = _PROP_WS.get(str(origins.device))
+    key = (str(origins.device), tag)
+    ws = _PROP_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
-        _PROP_WS[str(origins.device)] = ws
+        _PROP_WS[key] = ws
     s = net.cstruct(need_grad=True)
     check(_lib.load().tn_prop_density_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
                                           _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), N, S, C.c_void_p(ws.data_ptr()),
