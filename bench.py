@@ -171,7 +171,7 @@ def main():
 
     import nerfstudio_thermal_amd  # noqa: F401
     from nerfstudio_thermal_amd import _lib
-    from nerfstudio_thermal_amd.parallel import GradAllReducer, broadcast_params, init_distributed, rank_seed
+    from nerfstudio_thermal_amd.parallel import OverlappedGradReducer, broadcast_params, init_distributed, rank_seed
 
     _lib.load()  # fail loudly if the HIP library is missing
     rank, local, world = init_distributed()
@@ -183,7 +183,8 @@ def main():
     rays = args.rays
     broadcast_params(arena)
     cam_t, idx, img, is_th = make_batch(device, rays, seed=rank_seed(42, rank))
-    hook = GradAllReducer(world) if world > 1 else None
+    # N > 1: the gradient all-reduce (RCCL) is issued per level range of the main table while the backward is still running
+    hook = OverlappedGradReducer(world) if world > 1 else None
 
     def barrier():
         if world > 1:

@@ -137,6 +137,16 @@ int tn_field_fwd(const TnField* field, const float* origins, const float* direct
 int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                  const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins,
                  float* d_directions, tn_stream_t stream);
+/* The same backward in phases, for data-parallel training: the table gradient of a level range is final as soon as its scatter has run,
+ * so the caller can start that range's all-reduce (DDP's bucketed reducer, pipelines/base_pipeline.py:281-283) while the next range is
+ * scattered.  phases is a bit set; tn_field_bwd == all three with levels [0, num_levels):
+ *   TN_BWD_MLP      MLP backward + weight/bias/embedding gradients (the GEMMs are enqueued on a library-owned companion stream)
+ *   TN_BWD_SCATTER  table gradient (+ d_origins/d_directions contribution) of levels [level_begin, level_end); needs TN_BWD_MLP done
+ *   TN_BWD_JOIN     make `stream` wait for the companion stream; required before the MLP gradients or the workspace are used again */
+enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4 };
+int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
+                       const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
+                       float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream);
 /* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458). */
 int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                          void* workspace, float* density, tn_stream_t stream);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libthermal_nerf_hip.so")
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
+TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN = 1, 2, 4
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -62,6 +63,7 @@ SIGNATURES = {
     "tn_field_pack_weights": (C.c_int, [C.POINTER(TnField), _p, _p]),
     "tn_field_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
     "tn_field_bwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "tn_field_bwd_phase": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
     "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_minmax_init": (C.c_int, [_p, _p]),
     "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),

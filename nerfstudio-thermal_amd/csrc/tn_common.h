@@ -34,6 +34,8 @@ static inline hipStream_t tn_s(tn_stream_t s) { return reinterpret_cast<hipStrea
 // (device, user stream) and live for the process.  Returns nullptr (caller then stays on `user`) if a stream/event cannot be created.
 hipStream_t tn_fork(hipStream_t user);
 void tn_join(hipStream_t user, hipStream_t companion);
+// join whatever companion stream `user` has (no-op if it never forked)
+void tn_join_all(hipStream_t user);
 __host__ __device__ static inline int64_t tn_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // POD copy of TnGrid that is passed to kernels by value

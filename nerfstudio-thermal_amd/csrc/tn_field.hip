@@ -720,31 +720,34 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   return TN_OK;
 }
 
-extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
-                            const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
-                            tn_stream_t stream) {
+extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
+                                  const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
+                                  float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_bwd", true);
   if (rc) return rc;
   TN_REQUIRE(origins && directions && camera_indices && e_bins && d_density && d_rgb && workspace, "tn_field_bwd: null pointer");
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
-  if (N == 0) return TN_OK;
+  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN)) == 0 && phases != 0, "tn_field_bwd: bad phase set %d", phases);
+  if (phases & TN_BWD_SCATTER)
+    TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd: bad level range [%d, %d)", level_begin,
+               level_end);
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, 1);
   hipStream_t st = tn_s(stream);
   const int C = field->num_channels;
-  size_t shmem = PACK_BWD_FLOATS * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
-                     ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
-  TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
-  // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch, on the companion stream beside the table scatter
-  // (the GEMMs stream the saved activations from HBM, the scatter is bound by atomic requests: they overlap almost perfectly)
-  hipStream_t side = tn_fork(st);
-  hipStream_t wst = side ? side : st;
   int rcw = TN_OK;
-  {
+  if (phases & TN_BWD_MLP) {
+    size_t shmem = PACK_BWD_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
+                       ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
+    TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
+    // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch, on the companion stream beside the table scatter
+    // (the GEMMs stream the saved activations from HBM, the scatter is bound by atomic requests: they overlap almost perfectly)
+    hipStream_t side = tn_fork(st);
+    hipStream_t wst = side ? side : st;
     const int64_t* ci = camera_indices;
     WgradProb pr[WGRAD_MAX_PROBS];
     int n = 0;
@@ -763,7 +766,24 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
       rcw = launch_wgrad_batch(&e, 1, P, wst);
     }
   }
-  rc = tn_grid_scatter_launch(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, ws.scatter, st);
-  if (side) tn_join(st, side);
+  if (phases & TN_BWD_SCATTER) {
+    // a level range is a grid of its own: table / gradient / resolutions shifted, g_enc columns shifted by 2 per level
+    TnGrid sub = field->grid;
+    const int64_t T2 = 2ll << sub.log2_hashmap_size;  // floats per level
+    sub.table = field->grid.table + level_begin * T2;
+    sub.table_grad = field->grid.table_grad + level_begin * T2;
+    sub.num_levels = level_end - level_begin;
+    for (int i = 0; i < TN_MAX_LEVELS; ++i) sub.res[i] = (level_begin + i < field->grid.num_levels) ? field->grid.res[level_begin + i] : 0.0f;
+    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, d_origins, d_directions, ws.scatter, st);
+  }
+  if (phases & TN_BWD_JOIN) tn_join_all(st);
   return rcw ? rcw : rc;
+}
+
+extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                            const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
+                            tn_stream_t stream) {
+  if (field == nullptr) return check_field(field, "tn_field_bwd", true);
+  return tn_field_bwd_phase(field, origins, directions, camera_indices, e_bins, d_density, d_rgb, N, S, workspace, d_origins, d_directions,
+                            TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN, 0, field->grid.num_levels, stream);
 }

@@ -50,6 +50,19 @@ hipStream_t tn_fork(hipStream_t user) {
   if (hipEventRecord(c->fork_ev, user) != hipSuccess || hipStreamWaitEvent(c->side, c->fork_ev, 0) != hipSuccess) return nullptr;
   return c->side;
 }
+void tn_join_all(hipStream_t user) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  Companion c;
+  {
+    std::lock_guard<std::mutex> lk(g_comp_mu);
+    auto it = g_comp.find(std::make_pair(dev, user));
+    if (it == g_comp.end()) return;
+    c = it->second;
+  }
+  (void)hipEventRecord(c.join_ev, c.side);
+  (void)hipStreamWaitEvent(user, c.join_ev, 0);
+}
 void tn_join(hipStream_t user, hipStream_t companion) {
   Companion* c = companion_of(user);
   if (c == nullptr || companion != c->side) return;

@@ -228,7 +228,8 @@ class RenderEngine:
         return out, branches
 
     # ---------------------------------------------------------------- losses + backward (no autograd tape)
-    def loss_and_backward(self, out: Dict[str, object], branches: Dict[str, Branch], cam: Tensor, image: Tensor, is_thermal: Tensor) -> Dict[str, Tensor]:
+    def loss_and_backward(self, out: Dict[str, object], branches: Dict[str, Branch], cam: Tensor, image: Tensor, is_thermal: Tensor,
+                          dp=None) -> Dict[str, Tensor]:
         """get_metrics_dict['distortion'] + get_loss_dict (models/thermal_nerfacto.py:253-388) and the gradient of their sum with respect to
         every parameter, accumulated into the arena's gradient buffer."""
         c = self.cfg
@@ -272,6 +273,9 @@ class RenderEngine:
                 ops.interlevel_loss(lv[2].s_bins, lv[2].weights, lv[i].s_bins, lv[i].weights, c.interlevel_loss_mult, L[8:9], dws[i])
             grads_w[sfx] = dws
         # ---- per-branch backward
+        # Overlapped data-parallel exchange only where a slice of the arena is final right after its kernel: in separate mode the
+        # cross-evaluated densities scatter into the same tables again later, so everything is exchanged by dp.finish() instead.
+        pipelined = dp is not None and not self.separate
         d_dens_extra: Dict[str, Optional[Tensor]] = {"": None, "_thermal": None}
         if self.separate and c.density_loss_mult > 0:
             a, bb = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
@@ -312,7 +316,23 @@ class RenderEngine:
                     for i in range(2):
                         dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
                         ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
-            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+                    if pipelined:  # the proposal networks' gradients are final: exchange them while the main field is still at work
+                        dp.reduce_range(*self.arena.group_range["proposal_networks"])
+            if pipelined:
+                # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
+                ph = ops._lib
+                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
+                nl = fld.num_levels
+                T2 = 2 * 2**fld.log2_hashmap_size
+                t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
+                per = -(-nl // dp.level_chunks)
+                for lb in range(0, nl, per):
+                    le = min(nl, lb + per)
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, lb, le)
+                    dp.reduce_range(t0 + lb * T2, t0 + le * T2)
+                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
+            else:
+                ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
@@ -371,9 +391,17 @@ class RenderEngine:
         self.set_anneal_for_step(step)
         self.arena.zero_grad()
         out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
-        losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
-        if grad_hook is not None:
-            grad_hook(self.arena)  # data-parallel gradient all-reduce
+        if grad_hook is not None and getattr(grad_hook, "pipelined", False):
+            # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)
+            grad_hook.begin(self.arena)
+            losses = self.loss_and_backward(out, branches, cam, image, is_thermal, dp=grad_hook)
+            # proposal networks that got no gradient this step are not stepped either: nothing to exchange for them
+            idle = [] if branches[""].prop_grad else [self.arena.group_range["proposal_networks"]]
+            grad_hook.finish(skip=idle)
+        else:
+            losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
+            if grad_hook is not None:
+                grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
         skip = () if branches[""].prop_grad else ("proposal_networks",)
         self.optimizer_step(scheduled=scheduled, skip_groups=skip)
         self.step_cb(step)

@@ -335,6 +335,21 @@ def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
                                    _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
 
 
+def field_bwd_phase(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, d_density: Tensor, d_rgb: Tensor,
+                    d_origins: Optional[Tensor], d_directions: Optional[Tensor], phases: int, level_begin: int = 0, level_end: int = 0,
+                    tag: str = "main") -> None:
+    """tn_field_bwd in phases (ops._lib.TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN): the table gradient of levels [level_begin, level_end) is final
+    when its scatter has run, so a data-parallel caller can all-reduce it while the next level range is scattered."""
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    ws = fld.workspace(N * S, True, tag)
+    s = fld.cstruct(need_grad=True)
+    check(_lib.load().tn_field_bwd_phase(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                         _i64(cam, "camera_indices", (N,)), _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)),
+                                         _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)), N, S, C.c_void_p(ws.data_ptr()),
+                                         _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
+                                         phases, level_begin, level_end, _stream()), "tn_field_bwd_phase")
+
+
 _SCATTER_WS: dict = {}
 
 

@@ -9,7 +9,7 @@ Works with backend "nccl" (= RCCL over xGMI on ROCm) and, for CPU tests, "gloo".
 from __future__ import annotations
 
 import os
-from typing import Optional
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -52,6 +52,75 @@ class GradAllReducer:
         for w in works:
             w.wait()
         flat.mul_(1.0 / self.world)
+
+
+class OverlappedGradReducer:
+    """The same mean all-reduce, issued in pieces WHILE the backward pass is still running (what DDP's bucketed reducer does for the
+    reference, pipelines/base_pipeline.py:281-283, laid out for this path's gradient arena and xGMI):
+
+      * RenderEngine.loss_and_backward calls `reduce_range(lo, hi)` as soon as a slice of the gradient arena is final -- after each level
+        range of the main table's scatter (ops.field_bwd_phase), after the proposal networks' backward on their side stream.  The collective
+        is asynchronous: RCCL's stream waits for the work enqueued so far on the CURRENT stream and then runs beside the next scatter
+        (atomic-request bound, so the two do not compete for the same resource).  xGMI rings are per-link bound: 4 x 16 MB table slices
+        plus one ~10 MB proposal slice keep every message large.
+      * `finish()` all-reduces whatever part of the live range has not been reduced yet (MLP weights, embeddings, poses), waits for all
+        of it on the current stream and applies the 1/world scale when the backend has no AVG.
+
+    Every rank runs the same Python schedule, so the collectives are issued in the same order everywhere."""
+
+    pipelined = True
+
+    def __init__(self, world_size: int, group=None, level_chunks: int = 4):
+        self.world = world_size
+        self.group = group
+        self.level_chunks = max(1, level_chunks)
+        self._works: List = []
+        self._ranges: List[Tuple[int, int]] = []
+        self._arena = None
+        self._avg = None
+
+    def _op(self):
+        if self._avg is None:
+            self._avg = dist.get_backend(self.group) == "nccl"
+        return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+
+    def begin(self, arena) -> None:
+        assert not self._works, "finish() was not called for the previous step"
+        self._arena = arena
+        self._ranges = []
+
+    def reduce_range(self, lo: int, hi: int) -> None:
+        """Asynchronous mean all-reduce of arena.grads[lo:hi]; ordered after everything already enqueued on the current stream."""
+        if hi <= lo:
+            return
+        self._ranges.append((lo, hi))
+        if dist.is_initialized():  # a 1-process group still goes through the backend (GPU tests drive RCCL that way)
+            self._works.append(dist.all_reduce(self._arena.grads[lo:hi], op=self._op(), group=self.group, async_op=True))
+
+    def finish(self, skip: Optional[List[Tuple[int, int]]] = None) -> None:
+        """Reduce the rest of the live range (minus `skip`: ranges whose gradients are not used this step), then wait for everything."""
+        lo, hi = self._arena.live_range
+        covered = sorted(self._ranges + list(skip or []))
+        cur = lo
+        rest = []
+        for a, b in covered:
+            if a > cur:
+                rest.append((cur, min(a, hi)))
+            cur = max(cur, b)
+        if cur < hi:
+            rest.append((cur, hi))
+        for a, b in rest:
+            self.reduce_range(a, b)
+        for w in self._works:
+            w.wait()  # the current stream waits for the collective
+        self._works = []
+        if dist.is_initialized() and not self._avg and self.world > 1:
+            for a, b in self._ranges:
+                self._arena.grads[a:b].mul_(1.0 / self.world)
+
+    def __call__(self, arena) -> None:  # plain grad_hook use: everything at the end
+        self.begin(arena)
+        self.finish()
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:

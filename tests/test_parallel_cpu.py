@@ -11,7 +11,7 @@ import nerfstudio_thermal_amd  # noqa: F401
 from nerfstudio_thermal_amd import synth
 from nerfstudio_thermal_amd.arena import ParamArena
 from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
-from nerfstudio_thermal_amd.parallel import GradAllReducer, broadcast_params, init_distributed, rank_seed
+from nerfstudio_thermal_amd.parallel import GradAllReducer, OverlappedGradReducer, broadcast_params, init_distributed, rank_seed
 
 
 def _free_port():
@@ -80,3 +80,48 @@ def test_two_rank_allreduce_separate_mode_chunked():
     for rank, okp, okl, okd, _, lo, hi, total in res:
         assert okp and okl and okd, res
         assert (lo, hi) == (0, total)
+
+
+def _worker_overlapped(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base = torch.from_numpy(synth.uniform("g2", (arena.total,), seed=5))
+    lo, hi = arena.live_range
+    plo, phi = arena.group_range["proposal_networks"]
+    t0, shape = arena.layout["field.mlp_base.model.0.hash_table"]
+    per_level = shape[0] * shape[1] // 16
+    results = []
+    for skip_prop in (False, True):
+        arena.grads.copy_(base * (rank + 1))
+        red = OverlappedGradReducer(world, level_chunks=4)
+        red.begin(arena)
+        if not skip_prop:
+            red.reduce_range(plo, phi)                      # proposal networks, early
+        for lb in range(0, 16, 4):                         # the main table in 4 level ranges
+            red.reduce_range(t0 + lb * per_level, t0 + (lb + 4) * per_level)
+        red.finish(skip=[(plo, phi)] if skip_prop else None)  # the rest of the live range (MLPs, embedding, pose)
+        mean = base * (sum(range(1, world + 1)) / world)
+        mine = base * (rank + 1)
+        expect = mean.clone()
+        expect[hi:] = mine[hi:]                             # outside the live range: untouched
+        if skip_prop:
+            expect[plo:phi] = mine[plo:phi]                 # idle proposal networks: not exchanged
+        results.append(bool(torch.allclose(arena.grads, expect, rtol=1e-6, atol=0)))
+    q.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_reducer_covers_live_range_once():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(r[1]) for r in res), res
