@@ -167,11 +167,15 @@ def main():
                     " many small ATen ops of this path slower; measured on the 256-thread GPU-box host at 1024 rays: 8 -> 2427, 16 -> 2286, 32 -> 1906, 64 -> 1025,"
                     " 256 -> 24 rays/s)")
     ap.add_argument("--ops", action="store_true", help="print the per-kernel timing table to stderr")
+    ap.add_argument("--dp-chunks", type=int, default=-1, help="N>1: level ranges of the main table exchanged separately (-1 = the default "
+                    "schedule 2/4/4/3/2/1 levels, n = n equal ranges, 0 = one all-reduce after the backward)")
+    ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
+                    "1-rank process group, to see what the schedule itself costs")
     args = ap.parse_args()
 
     import nerfstudio_thermal_amd  # noqa: F401
     from nerfstudio_thermal_amd import _lib
-    from nerfstudio_thermal_amd.parallel import OverlappedGradReducer, broadcast_params, init_distributed, rank_seed
+    from nerfstudio_thermal_amd.parallel import GradAllReducer, OverlappedGradReducer, broadcast_params, init_distributed, rank_seed
 
     _lib.load()  # fail loudly if the HIP library is missing
     rank, local, world = init_distributed()
@@ -184,7 +188,16 @@ def main():
     broadcast_params(arena)
     cam_t, idx, img, is_th = make_batch(device, rays, seed=rank_seed(42, rank))
     # N > 1: the gradient all-reduce (RCCL) is issued per level range of the main table while the backward is still running
-    hook = OverlappedGradReducer(world) if world > 1 else None
+    make_hook = lambda w: (OverlappedGradReducer(w) if args.dp_chunks < 0 else OverlappedGradReducer(w, level_chunks=args.dp_chunks)  # noqa: E731
+                           if args.dp_chunks > 0 else GradAllReducer(w))
+    hook = make_hook(world) if world > 1 else None
+    if args.force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+        hook = make_hook(1)
+        if args.dp_chunks == 0:
+            hook.world = 2  # GradAllReducer returns early at world 1: make it issue the collective (the 1/2 scale does not matter here)
 
     def barrier():
         if world > 1:
@@ -249,7 +262,7 @@ def main():
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

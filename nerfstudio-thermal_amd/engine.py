@@ -322,12 +322,9 @@ class RenderEngine:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
-                nl = fld.num_levels
                 T2 = 2 * 2**fld.log2_hashmap_size
                 t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
-                per = -(-nl // dp.level_chunks)
-                for lb in range(0, nl, per):
-                    le = min(nl, lb + per)
+                for lb, le in dp.level_ranges(fld.num_levels):
                     ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, lb, le)
                     dp.reduce_range(t0 + lb * T2, t0 + le * T2)
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
@@ -362,7 +359,7 @@ class RenderEngine:
         return losses
 
     # ---------------------------------------------------------------- optimiser
-    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=()) -> None:
+    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None) -> None:
         """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307).
 
         torch.optim.Adam skips parameters whose .grad is None and advances its per-parameter step count (bias correction) only when it
@@ -373,17 +370,25 @@ class RenderEngine:
         if not hasattr(self, "group_steps"):
             self.group_steps = {}
         a = self.arena
+        hyper = {}
         for gname in a.optimised_groups:
             if gname in skip_groups:
                 continue
             self.group_steps[gname] = self.group_steps.get(gname, 0) + 1
-            lo, hi = a.group_range[gname]
             lr0, lr_final, max_steps = OPTIMIZERS[gname]
             # LambdaLR: the lr used at iteration k (1-based) is the schedule evaluated at k-1
             lr = exp_decay_lr(self.adam_step_count - 1, lr0, lr_final, max_steps) if scheduled else lr0
             if lr_overrides and gname in lr_overrides:
                 lr = lr_overrides[gname]
-            ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], self.group_steps[gname], lr, eps=1e-15)
+            hyper[gname] = (self.group_steps[gname], lr)
+        if ranges is None:
+            ranges = [a.group_range[g] for g in hyper]
+        for lo, hi in ranges:  # each range lies inside one optimiser group (Adam is element-wise: any partition of a group is the same update)
+            gname = next(g for g in a.optimised_groups if a.group_range[g][0] <= lo and hi <= a.group_range[g][1])
+            if gname not in hyper:
+                continue
+            step, lr = hyper[gname]
+            ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], step, lr, eps=1e-15)
 
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
                    jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True) -> Dict[str, Tensor]:
@@ -396,13 +401,16 @@ class RenderEngine:
             grad_hook.begin(self.arena)
             losses = self.loss_and_backward(out, branches, cam, image, is_thermal, dp=grad_hook)
             # proposal networks that got no gradient this step are not stepped either: nothing to exchange for them
-            idle = [] if branches[""].prop_grad else [self.arena.group_range["proposal_networks"]]
-            grad_hook.finish(skip=idle)
+            skip = () if branches[""].prop_grad else ("proposal_networks",)
+            idle = [self.arena.group_range[g] for g in skip]
+            # Adam range by range, each as soon as its exchange has landed: the update of the first table levels runs while the last ones
+            # are still on the wire
+            self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
         else:
             losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
             if grad_hook is not None:
                 grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
-        skip = () if branches[""].prop_grad else ("proposal_networks",)
-        self.optimizer_step(scheduled=scheduled, skip_groups=skip)
+            skip = () if branches[""].prop_grad else ("proposal_networks",)
+            self.optimizer_step(scheduled=scheduled, skip_groups=skip)
         self.step_cb(step)
         return losses

@@ -70,14 +70,33 @@ class OverlappedGradReducer:
 
     pipelined = True
 
-    def __init__(self, world_size: int, group=None, level_chunks: int = 4):
+    def __init__(self, world_size: int, group=None, level_chunks=(2, 4, 4, 3, 2, 1)):
+        """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The first exchange can only
+        start after the first scatter and the last one cannot hide behind any, so the ranges are small at both ends: when the ring is the
+        slower side (few GPUs, one xGMI link each way) it starts after 2 levels instead of 6, and the exposed tail is one level (4 MB)."""
         self.world = world_size
         self.group = group
-        self.level_chunks = max(1, level_chunks)
+        self.level_chunks = level_chunks
         self._works: List = []
         self._ranges: List[Tuple[int, int]] = []
         self._arena = None
         self._avg = None
+
+    def level_ranges(self, num_levels: int) -> List[Tuple[int, int]]:
+        if isinstance(self.level_chunks, int):
+            per = -(-num_levels // max(1, self.level_chunks))
+            sizes = [per] * max(1, self.level_chunks)
+        else:
+            sizes = list(self.level_chunks)
+        out, lb = [], 0
+        for n in sizes:
+            if lb >= num_levels:
+                break
+            out.append((lb, min(num_levels, lb + n)))
+            lb += n
+        if lb < num_levels:
+            out.append((lb, num_levels))
+        return out
 
     def _op(self):
         if self._avg is None:
@@ -96,27 +115,38 @@ class OverlappedGradReducer:
         self._ranges.append((lo, hi))
         if dist.is_initialized():  # a 1-process group still goes through the backend (GPU tests drive RCCL that way)
             self._works.append(dist.all_reduce(self._arena.grads[lo:hi], op=self._op(), group=self.group, async_op=True))
+        else:
+            self._works.append(None)
 
-    def finish(self, skip: Optional[List[Tuple[int, int]]] = None) -> None:
-        """Reduce the rest of the live range (minus `skip`: ranges whose gradients are not used this step), then wait for everything."""
+    def finish_iter(self, skip: Optional[List[Tuple[int, int]]] = None):
+        """Issue the exchange of the rest of the live range (minus `skip`: ranges whose gradients are not used this step; split at the
+        optimiser-group boundaries), then yield every exchanged range (lo, hi) in issue order, each as soon as the current stream has been
+        made to wait for it -- so the caller's Adam launch for an early range runs while later ranges are still on the wire."""
         lo, hi = self._arena.live_range
+        cuts = sorted({b for g in self._arena.optimised_groups for b in self._arena.group_range[g]})
         covered = sorted(self._ranges + list(skip or []))
         cur = lo
         rest = []
-        for a, b in covered:
+        for a, b in covered + [(hi, hi)]:
             if a > cur:
-                rest.append((cur, min(a, hi)))
+                pts = [cur] + [c for c in cuts if cur < c < min(a, hi)] + [min(a, hi)]
+                rest += [(p, q) for p, q in zip(pts[:-1], pts[1:]) if q > p]
             cur = max(cur, b)
-        if cur < hi:
-            rest.append((cur, hi))
         for a, b in rest:
             self.reduce_range(a, b)
-        for w in self._works:
-            w.wait()  # the current stream waits for the collective
+        scale = dist.is_initialized() and not self._avg and self.world > 1
+        works, ranges = self._works, self._ranges
         self._works = []
-        if dist.is_initialized() and not self._avg and self.world > 1:
-            for a, b in self._ranges:
+        for w, (a, b) in zip(works, ranges):
+            if w is not None:
+                w.wait()  # the current stream waits for the collective
+            if scale:
                 self._arena.grads[a:b].mul_(1.0 / self.world)
+            yield a, b
+
+    def finish(self, skip: Optional[List[Tuple[int, int]]] = None) -> None:
+        for _ in self.finish_iter(skip):
+            pass
 
     def __call__(self, arena) -> None:  # plain grad_hook use: everything at the end
         self.begin(arena)

@@ -94,13 +94,20 @@ def _worker_overlapped(rank, world, port, q):
     results = []
     for skip_prop in (False, True):
         arena.grads.copy_(base * (rank + 1))
-        red = OverlappedGradReducer(world, level_chunks=4)
+        red = OverlappedGradReducer(world)
+        assert red.level_ranges(16) == [(0, 2), (2, 6), (6, 10), (10, 13), (13, 15), (15, 16)]
+        assert OverlappedGradReducer(world, level_chunks=4).level_ranges(16) == [(0, 4), (4, 8), (8, 12), (12, 16)]
         red.begin(arena)
         if not skip_prop:
             red.reduce_range(plo, phi)                      # proposal networks, early
-        for lb in range(0, 16, 4):                         # the main table in 4 level ranges
-            red.reduce_range(t0 + lb * per_level, t0 + (lb + 4) * per_level)
-        red.finish(skip=[(plo, phi)] if skip_prop else None)  # the rest of the live range (MLPs, embedding, pose)
+        for lb, le in red.level_ranges(16):                # the main table in shrinking level ranges
+            red.reduce_range(t0 + lb * per_level, t0 + le * per_level)
+        # the rest of the live range (embedding, MLPs, pose) is issued by finish_iter, split at the optimiser-group boundaries
+        seen = list(red.finish_iter(skip=[(plo, phi)] if skip_prop else None))
+        cover = sorted(seen + ([(plo, phi)] if skip_prop else []))
+        assert cover[0][0] == lo and cover[-1][1] == hi and all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:])), cover  # exact partition
+        bounds = {b for g in arena.optimised_groups for b in arena.group_range[g]}
+        assert all(not any(a < c < b for c in bounds) for a, b in seen), seen  # no range straddles two optimiser groups
         mean = base * (sum(range(1, world + 1)) / world)
         mine = base * (rank + 1)
         expect = mean.clone()
