@@ -72,18 +72,19 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# HBM-side traffic per launch from rocprofv3 PMC passes (profiles/r01_pmc_summary.md; N = 4096, shared mode): read bytes = TCC_EA0_RDREQ x 64 B
-# (the calibrated form for these 8-byte gathers; FETCH_SIZE under-reports wide streams 2x on gfx950), write bytes = WRITE_SIZE x 1024.
+# HBM-side traffic per launch from rocprofv3 PMC passes (profiles/r01_pmc_summary.md, scripts/pmc_passes.sh; N = 4096, shared mode): read bytes =
+# TCC_EA0_RDREQ x 64 B (the calibrated form for these 8-byte gathers; FETCH_SIZE under-reports wide streams 2x on gfx950), write bytes =
+# WRITE_SIZE x 1024.  A scatter entry point = zero-fill of the replica scratch + k_grid_scatter + k_replica_reduce: all three are counted.
 PMC_TRAFFIC_BYTES = {
-    "k_grid_scatter(main grid)": 332.9e6 + 347.9e6,
-    "k_grid_scatter(prop0 grid)": 47.6e6 + 193.2e6,
-    "k_grid_scatter(prop1 grid)": 27.2e6 + 119.2e6,
-    "k_field_encode": 347.2e6 + 26.4e6,
+    "k_grid_scatter(main grid)": (274.1e6 + 352.8e6) + (22.5e6 + 2.3e6) + 16.2e6,
+    "k_grid_scatter(prop0 grid)": (47.1e6 + 193.2e6) + (13.8e6 + 2.7e6) + 24.0e6,
+    "k_grid_scatter(prop1 grid)": (26.3e6 + 118.6e6) + (10.9e6 + 2.9e6) + 17.8e6,
+    "k_field_encode": 346.4e6 + 26.4e6,
     "k_prop_fwd(level0)": 12.1e6 + 4.1e6,
     "k_prop_fwd(level1)": 12.4e6 + 1.5e6,
 }
 ATOMIC_REQ_PEAK = 21.0e9  # 64-B atomic requests/s, measured by scripts/microbench/atomic_shapes.hip on MI355X
-PMC_ATOMIC_REQUESTS = {"k_grid_scatter(main grid)": 9.96e6, "k_grid_scatter(prop0 grid)": 5.46e6, "k_grid_scatter(prop1 grid)": 3.41e6}
+PMC_ATOMIC_REQUESTS = {"k_grid_scatter(main grid)": 10.0e6, "k_grid_scatter(prop0 grid)": 5.45e6, "k_grid_scatter(prop1 grid)": 3.37e6}
 
 
 def kernel_roofline(eng, cam_t, idx):
