@@ -5,6 +5,9 @@
 //   * 4 lanes per sample: lane q = (x-corner choice, feature) = [f.x, f.y, c.x, c.y].  The floor and ceil corners differ by 1 in x, and
 //     the reference's hash (x*1 ^ y*P1 ^ z*P2) & mask keeps x in the low bits, so 7 times out of 8 the two entries (2 x float2 = 16 B or
 //     within one 64-B line) are served by ONE request: a sample costs ~4.5 requests per level instead of 16.
+//     The four lanes must be ADJACENT (one quad): the atomic path works quad by quad, and with one lane in each 16-lane row (which would let
+//     the scans below run as DPP row shifts) a run tail activates four quads instead of one -- measured 20 % slower overall even though
+//     the all-lanes-active microbenchmark (scripts/microbench/atomic_lane_map.hip) sees no difference.
 //   * work items in patch order (tn_patch_order) and run-length merging across consecutive samples of the wave: samples in the same
 //     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
 #include "tn_common.h"
