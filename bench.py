@@ -41,6 +41,7 @@ def build_engine(device, mode="shared", seed=0):
 
 
 def make_batch(device, num_rays, seed):
+    """Pre-staged pixel batch (kernel_roofline and the parity-style fixed batch)."""
     from nerfstudio_thermal_amd import synth
 
     cams = synth.synth_cameras()
@@ -51,10 +52,23 @@ def make_batch(device, num_rays, seed):
     return cam_t, t(idx), t(img), t(is_th)
 
 
-def one_step(eng, cam_t, idx, img, is_th, step, hook):
+def make_image_cache(device):
+    """The 8 synthetic training images (4 RGB 640x480, 4 thermal 160x120) resident in HBM, in dataset order."""
+    from nerfstudio_thermal_amd import ops, synth
+
+    cams = synth.synth_cameras()
+    imgs = [torch.from_numpy(im) for im in synth.synth_images(cams)]
+    n = len(imgs)
+    return ops.ImageCache.build(imgs, torch.from_numpy(cams["is_thermal"].astype(np.float32)), torch.arange(n), device)
+
+
+def one_step(eng, cam_t, cache, num_rays, step, hook):
     from nerfstudio_thermal_amd import ops
 
-    # datamanager.next_train: RayGenerator on the pre-staged pixel batch (data/datamanagers/base_datamanager.py:538-547)
+    # datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): draw this step's 2x2 pixel patches over the jagged image list and
+    # gather their ground truth (PatchPixelSampler, on the device), then RayGenerator
+    u = torch.rand((num_rays // 4, 3), device=cache.buffer.device)
+    idx, img, is_th = ops.sample_pixels(cache, num_rays, u, 2)
     o, d, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
     return eng.train_step(o, d, idx[:, 0].contiguous(), img, is_th, step, grad_hook=hook)
 
@@ -187,7 +201,9 @@ def main():
     cfg, arena, eng = build_engine(device, mode=args.mode)
     rays = args.rays
     broadcast_params(arena)
+    torch.manual_seed(rank_seed(42, rank))  # every rank draws its own pixels (scripts/train.py:97)
     cam_t, idx, img, is_th = make_batch(device, rays, seed=rank_seed(42, rank))
+    cache = make_image_cache(device)
     # N > 1: the gradient all-reduce (RCCL) is issued per level range of the main table while the backward is still running
     make_hook = lambda w: (OverlappedGradReducer(w) if args.dp_chunks < 0 else OverlappedGradReducer(w, level_chunks=args.dp_chunks)  # noqa: E731
                            if args.dp_chunks > 0 else GradAllReducer(w))
@@ -206,13 +222,13 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        one_step(eng, cam_t, idx, img, is_th, step, hook)
+        one_step(eng, cam_t, cache, rays, step, hook)
         step += 1
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = one_step(eng, cam_t, idx, img, is_th, step, hook)
+        losses = one_step(eng, cam_t, cache, rays, step, hook)
         step += 1
     torch.cuda.synchronize()
     barrier()
@@ -251,7 +267,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
+            "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (pixel sampling+raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
                                    "256/96 proposal + 48 field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
                        "rays_per_gpu": rays, "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roofline,

@@ -66,6 +66,19 @@ int tn_version(void);
 /* bytes of device scratch tn_field_* need for `num_points` samples (packed weights + saved activations). */
 int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
 
+/* ---- N2  PatchPixelSampler.sample on a jagged image list + ground-truth gather (data/pixel_samplers.py:296-337 collate_image_dataset_batch_list,
+ *          :389-441 PatchPixelSampler.sample_method without masks; what VanillaDataManager.next_train does on the host every step,
+ *          data/datamanagers/base_datamanager.py:538-547).  The cached training images stay resident in HBM:
+ * images: all images back to back, image i is [height[i], width[i], 3] fp32 starting at float offset image_offsets[i];
+ * is_thermal [num_images] fp32 by batch position; image_idx [num_images] int64 = dataset (camera) index of each batch position;
+ * u [num_rays / patch^2, 3] fp32 uniforms in [0,1) -- exactly what torch.rand returns in the reference, image after image (column 0 unused).
+ * Every image gets (num_rays / num_images) / patch^2 patches and the last one the remainder, which must be a whole number of patches
+ * (the reference asserts the same).  patch_size 1..8.
+ * Outputs: ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal_out [N]. */
+int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+                     const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
+                     int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, tn_stream_t stream);
+
 /* ---- a1  RayGenerator.forward -> Cameras._generate_rays_from_coords (model_components/ray_generators.py:40-55,
  *          cameras/cameras.py:598-655,781-786,886-909; undistortion cameras/camera_utils.py:409-446).
  * ray_indices [N,3] int64 (camera,row,col); c2w [C,3,4]; fx,fy,cx,cy [C]; distortion [C,6] (k1,k2,k3,k4,p1,p2) or NULL. */

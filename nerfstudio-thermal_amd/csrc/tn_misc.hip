@@ -108,6 +108,54 @@ __device__ __forceinline__ void undistort(float xd, float yd, const float* __res
   xo = x; yo = y;
 }
 
+// ---- N2: patch pixel sampler + ground-truth gather (one thread per ray) ---------------------------------------------------------
+__global__ void k_sample_pixels(const float* __restrict__ images, const int64_t* __restrict__ image_offsets, const int32_t* __restrict__ heights,
+                                const int32_t* __restrict__ widths, const float* __restrict__ is_thermal, const int64_t* __restrict__ image_idx,
+                                int num_images, const float* __restrict__ u, int64_t N, int ps, int64_t rays_per_image,
+                                int64_t* __restrict__ ray_indices, float* __restrict__ image, float* __restrict__ is_thermal_out) {
+  const int pp = ps * ps;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = rays_per_image > 0 ? r / rays_per_image : num_images - 1;  // every image holds rays_per_image rays, the last one the rest
+    if (i > num_images - 1) i = num_images - 1;
+    int64_t local = r - i * rays_per_image;
+    int64_t patch = local / pp;
+    int k = (int)(local - patch * pp);
+    int dy = k / ps, dx = k - dy * ps;
+    const float* up = u + (i * (rays_per_image / pp) + patch) * 3;
+    int H = heights[i], W = widths[i];
+    // torch: floor(rand * [1, H - ps, W - ps]) in fp32 (float32 x int64 promotes to float32), then + patch offsets
+    int64_t y = (int64_t)floorf(up[1] * (float)(H - ps) + (float)dy);
+    int64_t x = (int64_t)floorf(up[2] * (float)(W - ps) + (float)dx);
+    ray_indices[r * 3 + 0] = image_idx[i];
+    ray_indices[r * 3 + 1] = y;
+    ray_indices[r * 3 + 2] = x;
+    const float* px = images + image_offsets[i] + (y * W + x) * 3;
+    image[r * 3 + 0] = px[0];
+    image[r * 3 + 1] = px[1];
+    image[r * 3 + 2] = px[2];
+    is_thermal_out[r] = is_thermal[i];
+  }
+}
+
+extern "C" int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+                                const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
+                                int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, tn_stream_t stream) {
+  if (num_rays == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(images && image_offsets && heights && widths && is_thermal && image_idx && u && ray_indices && image && is_thermal_out,
+             "tn_sample_pixels: null pointer");
+  TN_REQUIRE(num_rays > 0 && num_images >= 1 && patch_size >= 1 && patch_size <= 8, "tn_sample_pixels: bad num_rays=%lld num_images=%d patch_size=%d",
+             (long long)num_rays, num_images, patch_size);
+  const int64_t pp = (int64_t)patch_size * patch_size;
+  const int64_t per = ((num_rays / num_images) / pp) * pp;  // rays of every image but the last
+  const int64_t last = num_rays - (int64_t)(num_images - 1) * per;
+  TN_REQUIRE(last > 0 && last % pp == 0, "tn_sample_pixels: %lld rays over %d images do not split into whole %dx%d patches", (long long)num_rays,
+             num_images, patch_size, patch_size);
+  hipLaunchKernelGGL(k_sample_pixels, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), images, image_offsets,
+                     heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size, per, ray_indices, image, is_thermal_out);
+  TN_CHECK_LAUNCH("tn_sample_pixels");
+  return TN_OK;
+}
+
 __global__ void k_raygen(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w, const float* __restrict__ fx,
                          const float* __restrict__ fy, const float* __restrict__ cx, const float* __restrict__ cy,
                          const float* __restrict__ distortion, int any_distortion, int num_cameras, int64_t N, float* __restrict__ origins,

@@ -152,6 +152,51 @@ class FieldParams:
         return cur
 
 
+# ------------------------------------------------------------------------------------------------ N2 pixel sampling
+@dataclass
+class ImageCache:
+    """The cached training images resident in HBM (what CacheDataloader keeps on the host for the reference, data/utils/dataloaders.py:39-162):
+    all images back to back in one fp32 buffer, in batch order."""
+
+    buffer: Tensor        # [sum H_i*W_i*3] fp32
+    offsets: Tensor       # [num_images] int64, float offset of image i
+    heights: Tensor       # [num_images] int32
+    widths: Tensor        # [num_images] int32
+    is_thermal: Tensor    # [num_images] fp32, by batch position
+    image_idx: Tensor     # [num_images] int64, dataset (camera) index of each batch position
+
+    @staticmethod
+    def build(images: Sequence[Tensor], is_thermal: Tensor, image_idx: Tensor, device) -> "ImageCache":
+        offs, hs, ws, tot = [], [], [], 0
+        for im in images:
+            if im.dim() != 3 or im.shape[2] != 3:
+                raise ValueError("images must be [H,W,3]")
+            offs.append(tot)
+            hs.append(im.shape[0])
+            ws.append(im.shape[1])
+            tot += im.numel()
+        buf = torch.cat([im.reshape(-1).to(torch.float32) for im in images]).to(device)
+        return ImageCache(buf, torch.tensor(offs, dtype=torch.int64, device=device), torch.tensor(hs, dtype=torch.int32, device=device),
+                          torch.tensor(ws, dtype=torch.int32, device=device), is_thermal.to(device, torch.float32).contiguous(),
+                          image_idx.to(device, torch.int64).contiguous())
+
+
+def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int = 2):
+    """PatchPixelSampler.sample + ground-truth gather on the device -> ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal [N].
+    u [num_rays / patch^2, 3]: the uniforms the reference would draw with torch.rand, image after image."""
+    n_img = cache.offsets.shape[0]
+    dev = cache.buffer.device
+    if u.device != dev or u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (num_rays // (patch_size * patch_size), 3):
+        raise ValueError(f"u must be a contiguous fp32 [{num_rays // (patch_size * patch_size)}, 3] tensor on {dev}")
+    idx = torch.empty((num_rays, 3), dtype=torch.int64, device=dev)
+    img = torch.empty((num_rays, 3), dtype=torch.float32, device=dev)
+    is_th = torch.empty((num_rays,), dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    check(_lib.load().tn_sample_pixels(p(cache.buffer), p(cache.offsets), p(cache.heights), p(cache.widths), p(cache.is_thermal), p(cache.image_idx),
+                                       n_img, p(u), num_rays, patch_size, p(idx), p(img), p(is_th), _stream()), "tn_sample_pixels")
+    return idx, img, is_th
+
+
 # ------------------------------------------------------------------------------------------------ a1 / a4
 def raygen(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, distortion: Optional[Tensor]):
     N, Cn = ray_indices.shape[0], c2w.shape[0]

@@ -147,6 +147,23 @@ def synth_gt_smooth(ray_indices: np.ndarray, cams: Dict[str, np.ndarray]) -> Tup
     return img, is_th
 
 
+def synth_images(cams: Dict[str, np.ndarray]) -> list:
+    """Per-camera training images [H,W,3] float32 (thermal frames grey x3, as ThermalDataset stores them): synth_gt_smooth on every pixel."""
+    out = []
+    for c in range(cams["c2w"].shape[0]):
+        H, W = int(cams["height"][c]), int(cams["width"][c])
+        yy, xx = np.meshgrid(np.arange(H, dtype=np.int64), np.arange(W, dtype=np.int64), indexing="ij")
+        idx = np.stack([np.full(H * W, c, dtype=np.int64), yy.reshape(-1), xx.reshape(-1)], axis=1)
+        img, _ = synth_gt_smooth(idx, cams)
+        out.append(img.reshape(H, W, 3))
+    return out
+
+
+def synth_patch_uniforms(num_patches: int, seed: int = 9, tag: str = "") -> np.ndarray:
+    """[num_patches, 3] uniforms in [0,1): what PatchPixelSampler draws per image batch (column 0 is drawn and unused for a single image)."""
+    return uniform(f"patch_u{tag}", (num_patches, 3), 0.0, 1.0, seed)
+
+
 def synth_jitters(num_rays: int, seed: int = 3, tag: str = "") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """The three per-ray uniforms the training sampler draws (level-0 stratified, two PDF levels)."""
     return tuple(uniform(f"jitter{tag}_{i}", (num_rays, 1), 0.0, 1.0, seed) for i in range(3))

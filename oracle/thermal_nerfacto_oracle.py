@@ -612,6 +612,43 @@ def undistort_opencv(coords: Tensor, dist: Tensor, eps: float = 1e-3, iters: int
     return torch.stack([x, y], dim=-1)
 
 
+def sample_pixels(images: List[Tensor], is_thermal: Tensor, image_idx: Tensor, num_rays: int, u: Tensor, patch_size: int = 2):
+    """PatchPixelSampler.sample on a jagged image list (no masks): data/pixel_samplers.py:296-337 (collate_image_dataset_batch_list),
+    :389-441 (PatchPixelSampler.sample_method, else-branch), as VanillaDataManager.next_train draws it (base_datamanager.py:538-547).
+
+    images: one [H_i, W_i, 3] tensor per batch position; is_thermal [num_images] (by batch position); image_idx [num_images] = the dataset
+    (camera) index of each batch position; u [total_patches, 3] = the uniforms torch.rand would return, image after image.
+    Every image gets (num_rays // num_images) // patch^2 patches, the last one the remainder; a patch is patch x patch adjacent pixels in
+    row-major order.  Returns indices [N,3] int64 (camera,row,col), image [N,3], is_thermal [N]."""
+    num_images = len(images)
+    pp = patch_size * patch_size
+    per = num_rays // num_images
+    all_idx, all_img, pos = [], [], 0
+    produced = 0
+    for i in range(num_images):
+        H, W, _ = images[i].shape
+        n_i = per if i < num_images - 1 else num_rays - (num_images - 1) * produced
+        sub = n_i // pp
+        ui = u[pos:pos + sub]
+        pos += sub
+        ind = ui * torch.tensor([1, H - patch_size, W - patch_size])  # float32 x int64 -> float32
+        ind = ind.view(sub, 1, 1, 3).broadcast_to(sub, patch_size, patch_size, 3).clone()
+        yys, xxs = torch.meshgrid(torch.arange(patch_size), torch.arange(patch_size), indexing="ij")
+        ind[:, ..., 1] += yys
+        ind[:, ..., 2] += xxs
+        ind = torch.floor(ind).long().flatten(0, 2)
+        ind[:, 0] = i
+        produced = ind.shape[0]
+        all_idx.append(ind)
+        all_img.append(images[i][ind[:, 1], ind[:, 2]])
+    indices = torch.cat(all_idx, dim=0)
+    c = indices[:, 0].clone()
+    image = torch.cat(all_img, dim=0)
+    assert image.shape[0] == num_rays
+    indices[:, 0] = image_idx[c]
+    return indices, image, is_thermal[c]
+
+
 def generate_rays(
     ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, distortion: Optional[Tensor]
 ):

@@ -92,3 +92,24 @@ def oracle_grad_sensitivity(golden_dir, mode):
                    abs(float(p0[k].grad.norm() - p1[k].grad.norm())) / max(float(p0[k].grad.norm()), 1e-12))
     _SENS_CACHE[mode] = sens
     return sens
+
+
+def pixel_batch(golden_dir):
+    """The jagged image batch of tests/golden/pixels.npz (oracle/make_golden_pixels.py): images in batch order, is_thermal by batch
+    position, image_idx = camera of each position, the uniforms the sampler draws, and the reference's outputs."""
+    import os
+
+    g = np.load(os.path.join(golden_dir, "pixels.npz"))
+    cams = synth.synth_cameras()
+    imgs = synth.synth_images(cams)
+    order = g["batch_order"].astype(np.int64)
+    n = int(g["num_rays"])
+    per = (n // len(order)) // 4
+    return {
+        "images": [torch.from_numpy(imgs[c]) for c in order],
+        "is_thermal": torch.from_numpy(cams["is_thermal"][order].astype(np.float32)),
+        "image_idx": torch.from_numpy(order),
+        "u": torch.from_numpy(synth.synth_patch_uniforms(per * len(order))),
+        "num_rays": n,
+        "ref": {k: torch.from_numpy(g[k]) for k in ("indices", "image", "is_thermal")},
+    }

@@ -442,3 +442,31 @@ def test_empty_single_and_eval_chunk_sizes():
     with torch.no_grad():
         ref = orc.get_outputs(params, ocfg, r["origins"][sub], r["directions"][sub], r["camera_indices"][sub], training=False)
     assert md(out["rgbt"][sub], torch.cat([ref["rgb"], ref["rgb_thermal"]], -1)) <= 1e-3
+
+
+def test_sample_pixels_matches_reference_golden(golden_dir):
+    """N2: tn_sample_pixels == the reference's PatchPixelSampler on the jagged RGB + thermal batch (bit-exact: indices and gathered pixels),
+    then the full data path sample -> raygen against the oracle, and the edge cases of the split over images."""
+    from helpers import pixel_batch
+
+    b = pixel_batch(golden_dir)
+    cache = ops.ImageCache.build(b["images"], b["is_thermal"], b["image_idx"], DEV)
+    idx, img, is_th = ops.sample_pixels(cache, b["num_rays"], g(b["u"]))
+    assert torch.equal(idx.cpu(), b["ref"]["indices"])
+    assert torch.equal(img.cpu(), b["ref"]["image"])
+    assert torch.equal(is_th.cpu(), b["ref"]["is_thermal"])
+    # sampled indices feed the ray generator exactly like the host-side batch does
+    cams = synth.synth_cameras()
+    t = lambda k: torch.from_numpy(cams[k])  # noqa: E731
+    o, d, _, _ = ops.raygen(idx, *(g(t(k)) for k in ("c2w", "fx", "fy", "cx", "cy", "distortion")))
+    ro, rd, _, _ = orc.generate_rays(b["ref"]["indices"], t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    assert md(o, ro) <= 1e-6 and md(d, rd) <= 2e-6
+    # larger / ragged splits against the oracle: the last image takes the remainder; patch sizes 1, 2, 4
+    for n, ps in ((4096, 2), (8 * 36 + 12, 2), (8 * 7 + 3, 1), (8 * 64, 4)):
+        u = torch.from_numpy(synth.synth_patch_uniforms(n // (ps * ps), seed=n))
+        want = orc.sample_pixels(b["images"], b["is_thermal"], b["image_idx"], n, u, ps)
+        got = ops.sample_pixels(cache, n, g(u), ps)
+        for a, w in zip(got, want):
+            assert torch.equal(a.cpu(), w), (n, ps)
+    with pytest.raises(RuntimeError):  # 8*4+2 rays do not split into whole 2x2 patches
+        ops.sample_pixels(cache, 34, g(torch.zeros((8, 3))), 2)

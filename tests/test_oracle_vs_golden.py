@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import thermal_nerfacto_oracle as orc
-from helpers import golden_inputs, make_params, maxdiff, sample_indices, tiny_cfg, GOLDEN_RAYS, SEED
+from helpers import pixel_batch, golden_inputs, make_params, maxdiff, sample_indices, tiny_cfg, GOLDEN_RAYS, SEED
 from nerfstudio_thermal_amd import synth
 
 
@@ -160,6 +160,18 @@ def test_model_train_losses_grads_adam(golden_dir, mode):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="live reference not present")
+def test_pixel_sampler(golden_dir):
+    """N2: the oracle's PatchPixelSampler restatement against the reference's own output on a jagged RGB + thermal image list."""
+    b = pixel_batch(golden_dir)
+    idx, img, is_th = orc.sample_pixels(b["images"], b["is_thermal"], b["image_idx"], b["num_rays"], b["u"])
+    assert torch.equal(idx, b["ref"]["indices"])
+    assert torch.equal(img, b["ref"]["image"])
+    assert torch.equal(is_th, b["ref"]["is_thermal"])
+    # structure: 2x2 patches of adjacent pixels, N/num_images rays per image in batch order
+    assert torch.equal(idx[1::4, 2], idx[0::4, 2] + 1) and torch.equal(idx[2::4, 1], idx[0::4, 1] + 1)
+    assert torch.equal(idx[:, 0].view(len(b["images"]), -1)[:, 0], b["image_idx"])
+
+
 def test_oracle_matches_live_reference_hash_encoding():
     """Where the reference tree exists (build container) compare directly, on a fresh random case."""
     import ref_import
