@@ -4,6 +4,9 @@
     python scripts/rocpd_stats.py gpurun_out/prof_x/x_results.db [out.csv] [--split-grid]
 
 --split-grid keeps launches of one kernel with different grid sizes apart (the three hash grids share k_grid_scatter).
+--tail N additionally prints the mean over the LAST N launches of every (kernel, grid): bench.py times its roofline kernels alone after the
+training steps (12 launches each), so the tail is the stand-alone duration, while the all-launch mean includes the in-step launches that
+overlap with other streams (companion-stream GEMMs, proposal-network backward) and are stretched by them.
 """
 import csv
 import sqlite3
@@ -11,7 +14,7 @@ import sys
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--tail"]
     split = "--split-grid" in sys.argv
     con = sqlite3.connect(args[0])
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
@@ -27,6 +30,13 @@ def main():
         out.append((name, calls, avg / 1e3, tot / 1e6, 100.0 * tot / total))
     for name, calls, avg, tot, pct in out[:28]:
         print(f"{name:<78} calls={calls:5d} avg_us={avg:9.1f} tot_ms={tot:8.2f} {pct:5.1f}%")
+    if "--tail" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--tail") + 1])
+        print(f"\nstand-alone launches (last {n} of each):")
+        for r in rows[:12]:
+            q = f"select end-start from kernels where name=? {'and ' + gx + '=?' if split and gx else ''} order by start desc limit {n}"
+            d = [x[0] for x in con.execute(q, (r[0], r[1]) if split and gx else (r[0],))]
+            print(f"{r[0][:60]:<62}{(' [grid %d]' % r[1]) if split and gx else '':<16} tail_avg_us={sum(d) / len(d) / 1e3:9.1f}")
     if len(args) > 1:
         with open(args[1], "w", newline="") as f:
             w = csv.writer(f)
