@@ -186,6 +186,15 @@ int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int3
                        const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
                        tn_stream_t stream);
 
+/* Both of the above for one branch in ONE launch (the "K7" entry point of SURVEY 8b): distortion on the fine level + interlevel against each of
+ * the num_props (<= TN_MAX_PROP_LEVELS) proposal levels.  s_bins_prop / weights_prop / S_prop / d_weights_prop are HOST arrays of num_props
+ * entries (device pointers / sizes); d_weights_prop[i] and d_weights_fine may be NULL.  Same accumulation semantics as the single calls. */
+#define TN_MAX_PROP_LEVELS 4
+int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                       const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                       float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                       float* interlevel_out, float* d_weights_fine, tn_stream_t stream);
+
 /* ---- a19  ThermalNerfactoModel.get_loss_dict pixel terms (models/thermal_nerfacto.py:284-354, model_components/losses.py:602-651,
  *          utils/rgbt_utils.py:6-32): rgb MSE, thermal MSE x thermal_mult, 2x2-patch TV, cross-channel gradient loss.
  * pred_rgb [N,3], pred_thermal [N,1] (for shared mode both are views of one [N,4] buffer: pass strides in floats),

@@ -72,6 +72,7 @@ SIGNATURES = {
     "tn_composite_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
     "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
+    "tn_proposal_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),

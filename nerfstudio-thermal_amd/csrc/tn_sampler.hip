@@ -485,8 +485,8 @@ extern "C" int tn_composite_bwd(const float* rgb, const float* weights, const fl
 // per ray: L = sum_ij w_i w_j |m_i - m_j| + (1/3) sum_i w_i^2 (t_{i+1}-t_i),  m = bin centres in s-space
 //   dL/dw_i = 2 sum_j w_j |m_i - m_j| + (2/3) w_i (t_{i+1}-t_i)      (s-space bins carry no gradient)
 // loss_out += mult * mean_over_rays(L)
-__global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S,
-                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_weights) {
+__device__ __forceinline__ void distortion_body(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S, float mult,
+                                                float* __restrict__ loss_out, float* __restrict__ d_weights) {
   __shared__ float sh_w[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
   __shared__ float sh_m[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
   int lane = tn_lane();
@@ -524,6 +524,11 @@ __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S,
+                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_weights) {
+  distortion_body(s_bins, weights, N, S, mult, loss_out, d_weights);
+}
+
 extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
                                   tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
@@ -544,9 +549,9 @@ extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int
 //   d wp_k = sum_i ([lo_i <= k <= hi_i] - [hi_i < k < lo_i]) * g_i,   g_i = -2 clip(w_i - w_outer_i,0) / (w_i + eps) / (N*S_f)
 // The gradient is summed directly over the covering fine intervals (all g_i have one sign): no difference-array / prefix-sum, whose
 // cancellation residue (1e-16) would become full-size Adam steps on table entries whose true gradient is exactly 0.
-__global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
-                                                      const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N,
-                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
+__device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
+                                                const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N, float mult,
+                                                float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
   __shared__ float sh_cp[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
   __shared__ float sh_cy[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
   __shared__ float sh_g[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
@@ -635,6 +640,39 @@ __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
+                                                      const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N,
+                                                      float mult, float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
+  interlevel_body(c_bins, w_fine, Sf, p_bins, w_prop, Sp, N, mult, loss_out, d_w_prop);
+}
+
+// K7: distortion + every interlevel term of one branch in ONE launch -- blockIdx.y = 0 is the distortion loss of the fine level,
+// blockIdx.y = 1 + i the interlevel loss against proposal level i.  The three are independent (different outputs), each ~15 us: one launch
+// runs them side by side instead of back to back.
+struct PropLossArgs {
+  const float* s_bins_fine;
+  const float* w_fine;
+  int Sf;
+  int num_props;
+  const float* s_bins_prop[TN_MAX_PROP_LEVELS];
+  const float* w_prop[TN_MAX_PROP_LEVELS];
+  float* d_w_prop[TN_MAX_PROP_LEVELS];
+  int Sp[TN_MAX_PROP_LEVELS];
+  int64_t N;
+  float distortion_mult, interlevel_mult;
+  float* distortion_out;
+  float* interlevel_out;
+  float* d_w_fine;
+};
+__global__ void __launch_bounds__(BLOCK) k_proposal_losses(PropLossArgs a) {
+  if (blockIdx.y == 0) {
+    distortion_body(a.s_bins_fine, a.w_fine, a.N, a.Sf, a.distortion_mult, a.distortion_out, a.d_w_fine);
+  } else {
+    int i = blockIdx.y - 1;
+    interlevel_body(a.s_bins_fine, a.w_fine, a.Sf, a.s_bins_prop[i], a.w_prop[i], a.Sp[i], a.N, a.interlevel_mult, a.interlevel_out, a.d_w_prop[i]);
+  }
+}
+
 extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
                                   const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
                                   tn_stream_t stream) {
@@ -646,5 +684,28 @@ extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights
   hipLaunchKernelGGL(k_interlevel, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), dim3(BLOCK), 0, tn_s(stream), s_bins_fine, weights_fine, S_fine,
                      s_bins_prop, weights_prop, S_prop, N, mult, loss_out, d_weights_prop);
   TN_CHECK_LAUNCH("tn_interlevel_loss");
+  return TN_OK;
+}
+
+extern "C" int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                                  const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                                  float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                                  float* interlevel_out, float* d_weights_fine, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(s_bins_fine && weights_fine && distortion_out && interlevel_out, "tn_proposal_losses: null pointer");
+  TN_REQUIRE(N > 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES, "tn_proposal_losses: bad N=%lld S_fine=%d", (long long)N, S_fine);
+  TN_REQUIRE(num_props >= 0 && num_props <= TN_MAX_PROP_LEVELS && (num_props == 0 || (s_bins_prop && weights_prop && S_prop && d_weights_prop)),
+             "tn_proposal_losses: bad proposal level list (num_props=%d, at most %d)", num_props, TN_MAX_PROP_LEVELS);
+  PropLossArgs a{};
+  a.s_bins_fine = s_bins_fine; a.w_fine = weights_fine; a.Sf = S_fine; a.num_props = num_props; a.N = N;
+  a.distortion_mult = distortion_mult; a.interlevel_mult = interlevel_mult;
+  a.distortion_out = distortion_out; a.interlevel_out = interlevel_out; a.d_w_fine = d_weights_fine;
+  for (int i = 0; i < num_props; ++i) {
+    TN_REQUIRE(s_bins_prop[i] && weights_prop[i] && S_prop[i] >= 1 && S_prop[i] <= TN_MAX_SAMPLES, "tn_proposal_losses: bad proposal level %d", i);
+    a.s_bins_prop[i] = s_bins_prop[i]; a.w_prop[i] = weights_prop[i]; a.Sp[i] = S_prop[i]; a.d_w_prop[i] = d_weights_prop[i];
+  }
+  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), 1 + num_props);
+  hipLaunchKernelGGL(k_proposal_losses, grid, dim3(BLOCK), 0, tn_s(stream), a);
+  TN_CHECK_LAUNCH("tn_proposal_losses");
   return TN_OK;
 }

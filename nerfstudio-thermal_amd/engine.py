@@ -266,11 +266,12 @@ class RenderEngine:
         for sfx, br in branches.items():
             lv = br.levels
             dws: List[Optional[Tensor]] = [None, None, Z[("dw2", sfx)]]
-            ops.distortion_loss(lv[2].s_bins, lv[2].weights, c.distortion_loss_mult * nsfx, L[9:10], dws[2])
             for i in range(2):
                 if br.prop_grad:
                     dws[i] = Z[(f"dw{i}", sfx)]
-                ops.interlevel_loss(lv[2].s_bins, lv[2].weights, lv[i].s_bins, lv[i].weights, c.interlevel_loss_mult, L[8:9], dws[i])
+            # distortion + both interlevel terms: one launch (they are independent and ~15 us each)
+            ops.proposal_losses(lv[2].s_bins, lv[2].weights, [(lv[i].s_bins, lv[i].weights, dws[i]) for i in range(2)],
+                                c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, L[9:10], L[8:9], dws[2])
             grads_w[sfx] = dws
         # ---- per-branch backward
         # Overlapped data-parallel exchange only where a slice of the arena is final right after its kernel: in separate mode the

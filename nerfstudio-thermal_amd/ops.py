@@ -461,6 +461,29 @@ def interlevel_loss(s_fine: Tensor, w_fine: Tensor, s_prop: Tensor, w_prop: Tens
                                          _stream()), "tn_interlevel_loss")
 
 
+def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, interlevel_mult: float, distortion_out: Tensor,
+                    interlevel_out: Tensor, d_w_fine: Optional[Tensor]) -> None:
+    """distortion_loss on the fine level + interlevel_loss against every proposal level, one launch (tn_proposal_losses).
+    props: list of (s_bins [N,Sp+1], weights [N,Sp], d_weights [N,Sp] or None)."""
+    N, Sf = w_fine.shape
+    n = len(props)
+    sb = (C.c_void_p * max(n, 1))()
+    wp = (C.c_void_p * max(n, 1))()
+    dw = (C.c_void_p * max(n, 1))()
+    sp = (C.c_int32 * max(n, 1))()
+    for i, (s_p, w_p, d_p) in enumerate(props):
+        Sp = w_p.shape[1]
+        sb[i] = _f32(s_p, "s_prop", (N, Sp + 1)).value
+        wp[i] = _f32(w_p, "w_prop", (N, Sp)).value
+        v = _f32(d_p, "d_w_prop", (N, Sp), True)
+        dw[i] = v.value if v is not None else None
+        sp[i] = Sp
+    check(_lib.load().tn_proposal_losses(_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N,
+                                         float(distortion_mult), float(interlevel_mult), _f32(distortion_out, "distortion"),
+                                         _f32(interlevel_out, "interlevel"), _f32(d_w_fine, "d_w_fine", (N, Sf), True), _stream()),
+          "tn_proposal_losses")
+
+
 def pixel_losses(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
                  losses_out: Tensor, d_pred_rgb: Optional[Tensor], d_pred_thermal: Optional[Tensor]) -> None:
     """pred_rgb [N,3] / pred_thermal [N,1] may be strided views of one [N,4] buffer (shared mode)."""

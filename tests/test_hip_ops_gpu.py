@@ -360,6 +360,20 @@ def test_proposal_losses():
     assert md(dw2, wl[2].grad[..., 0]) <= 1e-5 * float(wl[2].grad.abs().max())
     assert md(dw0, wl[0].grad[..., 0]) <= 1e-4 * float(wl[0].grad.abs().max())
     assert md(dw1, wl[1].grad[..., 0]) <= 1e-4 * float(wl[1].grad.abs().max())
+    # the fused entry point (distortion + both interlevel terms in one launch) produces the same values and gradients, zero pattern included
+    loss_f = torch.zeros(8, device=DEV)
+    f2, f0, f1 = torch.zeros_like(dw2), torch.zeros_like(dw0), torch.zeros_like(dw1)
+    fine_s, fine_w = g(sl[2].s_bins), g(wl[2].detach()[..., 0])
+    ops.proposal_losses(fine_s, fine_w, [(g(sl[0].s_bins), g(wl[0].detach()[..., 0]), f0), (g(sl[1].s_bins), g(wl[1].detach()[..., 0]), f1)],
+                        0.002, 1.0, loss_f[0:1], loss_f[1:2], f2)
+    assert abs(float(loss_f[0]) - float(loss[0])) <= 1e-6 * abs(float(loss[0])) and abs(float(loss_f[1]) - float(loss[1])) <= 1e-5 * abs(float(loss[1]))
+    for a, b in ((f2, dw2), (f0, dw0), (f1, dw1)):
+        assert torch.equal(a, b)  # per-ray arithmetic is identical, only the launch differs
+    # gradients are optional per level (proposal networks that are not updated this step)
+    loss_h = torch.zeros(8, device=DEV)
+    ops.proposal_losses(fine_s, fine_w, [(g(sl[0].s_bins), g(wl[0].detach()[..., 0]), None), (g(sl[1].s_bins), g(wl[1].detach()[..., 0]), None)],
+                        0.002, 1.0, loss_h[0:1], loss_h[1:2], None)
+    assert abs(float(loss_h[1]) - float(loss[1])) <= 1e-5 * abs(float(loss[1]))
 
 
 def test_pixel_losses_l1_camera_reg():
