@@ -185,50 +185,6 @@ __device__ __forceinline__ float2 tn_encode_level(const float2* __restrict__ tab
   return tn_level_interp(f, lc.ox, lc.oy, lc.oz);
 }
 
-// Backward of one level: scatter-add g (gradient of the 2 features) into the table gradient with the trilinear weights,
-// and return d(enc . g)/d(p) (needs the corner values).  Weight of corner i is the product of its per-axis factors:
-// x: c -> ox, f -> 1-ox etc.
-__device__ __forceinline__ void tn_level_bwd(const float2* __restrict__ table, float2* __restrict__ grad, float px, float py, float pz, float res,
-                                             uint32_t mask, uint32_t level_off, float gx, float gy, bool want_dpos, float& dpx, float& dpy,
-                                             float& dpz) {
-  LevelCorners lc;
-  tn_level_corners(px, py, pz, res, mask, level_off, lc);
-  float ox = lc.ox, oy = lc.oy, oz = lc.oz, ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
-  // corner i: (x is c?, y is c?, z is c?)   f0 ccc, f1 cfc, f2 ffc, f3 fcc, f4 ccf, f5 cff, f6 fff, f7 fcf
-  const float wxs[8] = {ox, ox, ux, ux, ox, ox, ux, ux};
-  const float wys[8] = {oy, uy, uy, oy, oy, uy, uy, oy};
-  const float wzs[8] = {oz, oz, oz, oz, uz, uz, uz, uz};
-  if (grad != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float w = wxs[i] * wys[i] * wzs[i];
-      if (w != 0.0f) {
-        float* dst = reinterpret_cast<float*>(grad + lc.idx[i]);
-        unsafeAtomicAdd(dst, w * gx);
-        unsafeAtomicAdd(dst + 1, w * gy);
-      }
-    }
-  }
-  if (want_dpos) {
-    float2 f[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
-    // sign of d(weight)/d(offset): +1 for "c" factors (offset), -1 for "f" factors (1-offset)
-    const float sxs[8] = {1, 1, -1, -1, 1, 1, -1, -1};
-    const float sys[8] = {1, -1, -1, 1, 1, -1, -1, 1};
-    const float szs[8] = {1, 1, 1, 1, -1, -1, -1, -1};
-    float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = f[i].x * gx + f[i].y * gy;
-      ax += v * sxs[i] * wys[i] * wzs[i];
-      ay += v * wxs[i] * sys[i] * wzs[i];
-      az += v * wxs[i] * wys[i] * szs[i];
-    }
-    dpx += ax * res; dpy += ay * res; dpz += az * res;
-  }
-}
-
 // ---------------------------------------------------------------- wave primitives (64 lanes)
 __device__ __forceinline__ int tn_lane() { return threadIdx.x & 63; }
 
@@ -267,10 +223,6 @@ __device__ __forceinline__ double tn_excl_from_incl_d(double incl, int lane) {
   double t = __shfl_up(incl, 1, 64);
   return lane == 0 ? 0.0 : t;
 }
-__device__ __forceinline__ float tn_excl_from_incl(float incl, int lane) {
-  float t = __shfl_up(incl, 1, 64);
-  return lane == 0 ? 0.0f : t;
-}
 __device__ __forceinline__ float tn_rexcl_from_incl(float incl, int lane) {
   float t = __shfl_down(incl, 1, 64);
   return lane == 63 ? 0.0f : t;
@@ -297,110 +249,6 @@ __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int6
   int nr = (N - r0) < 4 ? (int)(N - r0) : 4;
   s = w / nr;
   ray = r0 + (w - s * nr);
-}
-
-// ---------------------------------------------------------------- segmented (run-length) reductions across the wave
-// Consecutive lanes are consecutive samples along a ray, so on the coarse levels long runs of lanes fall into the SAME grid cell and
-// would add into the same 8 table entries.  A run is reduced in registers first and only its last lane issues the atomics: on the
-// proposal grids that removes ~9 of every 10 atomic requests (global float atomics are the bound of the backward pass).
-__device__ __forceinline__ int tn_seg_start(bool head, int lane) {
-  int s = head ? lane : 0;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(s, o, 64);
-    if (lane >= o) s = s > t ? s : t;
-  }
-  return s;
-}
-// inclusive sum over [segment start, lane]
-__device__ __forceinline__ float tn_seg_sum(float v, int start, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    float t = __shfl_up(v, o, 64);
-    if (lane - o >= start) v += t;
-  }
-  return v;
-}
-
-// Wave-cooperative backward of one level.  EVERY lane of the wave must call this (dead lanes pass gx = gy = 0).
-__device__ __forceinline__ void tn_level_bwd_wave(const float2* __restrict__ table, float2* __restrict__ grad, float px, float py, float pz, float res,
-                                                  uint32_t mask, uint32_t level_off, float gx, float gy, bool want_dpos, float& dpx, float& dpy,
-                                                  float& dpz, int lane) {
-  LevelCorners lc;
-  tn_level_corners(px, py, pz, res, mask, level_off, lc);
-  float ox = lc.ox, oy = lc.oy, oz = lc.oz, ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
-  // run key: the floor cell plus, per axis, whether ceil == floor (exact lattice coordinate)
-  float sx = px * res, sy = py * res, sz = pz * res;
-  uint32_t fx = (uint32_t)(int)floorf(sx), fy = (uint32_t)(int)floorf(sy), fz = (uint32_t)(int)floorf(sz);
-  uint32_t k1 = fx | (fy << 16);
-  uint32_t k2 = fz | ((ox == 0.0f) ? 1u << 16 : 0u) | ((oy == 0.0f) ? 1u << 17 : 0u) | ((oz == 0.0f) ? 1u << 18 : 0u);
-  uint32_t p1 = __shfl_up(k1, 1, 64), p2 = __shfl_up(k2, 1, 64);
-  bool head = (lane == 0) || (k1 != p1) || (k2 != p2);
-  int start = tn_seg_start(head, lane);
-  int next_head = __shfl_down((int)head, 1, 64);
-  bool tail = (lane == 63) || (next_head != 0);
-  const float wxs[8] = {ox, ox, ux, ux, ox, ox, ux, ux};
-  const float wys[8] = {oy, uy, uy, oy, oy, uy, uy, oy};
-  const float wzs[8] = {oz, oz, oz, oz, uz, uz, uz, uz};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float w = wxs[i] * wys[i] * wzs[i];
-    float vx = tn_seg_sum(w * gx, start, lane);
-    float vy = tn_seg_sum(w * gy, start, lane);
-    if (tail && (vx != 0.0f || vy != 0.0f)) {
-      float* dst = reinterpret_cast<float*>(grad + lc.idx[i]);
-      unsafeAtomicAdd(dst, vx);
-      unsafeAtomicAdd(dst + 1, vy);
-    }
-  }
-  if (want_dpos && (gx != 0.0f || gy != 0.0f)) {
-    float2 f[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
-    const float sxs[8] = {1, 1, -1, -1, 1, 1, -1, -1};
-    const float sys[8] = {1, -1, -1, 1, 1, -1, -1, 1};
-    const float szs[8] = {1, 1, 1, 1, -1, -1, -1, -1};
-    float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = f[i].x * gx + f[i].y * gy;
-      ax += v * sxs[i] * wys[i] * wzs[i];
-      ay += v * wxs[i] * sys[i] * wzs[i];
-      az += v * wxs[i] * wys[i] * szs[i];
-    }
-    dpx += ax * res; dpy += ay * res; dpz += az * res;
-  }
-}
-
-// d origins / d directions of a ray.  In patch order lane l of a wave works on ray (l & 3) of its 4-ray group, so the wave reduces the
-// four interleaved classes with a stride-4 butterfly and lanes 0..3 issue the atomics.  Waves that straddle groups (only possible when
-// 4*S is not a multiple of 64) fall back to a run-length reduction over consecutive lanes.
-// EVERY lane must call this (dead lanes: w = 0 and any ray id).
-__device__ __forceinline__ void tn_ray_grad_wave(int64_t ray, float wx, float wy, float wz, float tmid, float* __restrict__ d_origins,
-                                                 float* __restrict__ d_directions, int lane) {
-  float v[6] = {wx, wy, wz, wx * tmid, wy * tmid, wz * tmid};
-  int r32 = (int)ray;
-  int lead = __shfl(r32, lane & 3, 64);
-  if (__all(r32 == lead)) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      float r = v[q];
-#pragma unroll
-      for (int o = 4; o < 64; o <<= 1) r += __shfl_xor(r, o, 64);
-      if (lane < 4 && r != 0.0f) atomicAdd((q < 3 ? d_origins : d_directions) + ray * 3 + (q % 3), r);
-    }
-    return;
-  }
-  int prev = __shfl_up(r32, 1, 64);
-  bool head = (lane == 0) || (prev != r32);
-  int start = tn_seg_start(head, lane);
-  int next_head = __shfl_down((int)head, 1, 64);
-  bool tail = (lane == 63) || (next_head != 0);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    float r = tn_seg_sum(v[q], start, lane);
-    if (tail && r != 0.0f) atomicAdd((q < 3 ? d_origins : d_directions) + ray * 3 + (q % 3), r);
-  }
 }
 
 // ---------------------------------------------------------------- the shared table-gradient scatter kernel (tn_scatter.hip)
