@@ -68,9 +68,9 @@ def one_step(eng, cam_t, cache, num_rays, step, hook):
     # datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): draw this step's 2x2 pixel patches over the jagged image list and
     # gather their ground truth (PatchPixelSampler, on the device), then RayGenerator
     u = torch.rand((num_rays // 4, 3), device=cache.buffer.device)
-    idx, img, is_th = ops.sample_pixels(cache, num_rays, u, 2)
+    idx, img, is_th, cam = ops.sample_pixels(cache, num_rays, u, 2, want_camera_indices=True)
     o, d, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
-    return eng.train_step(o, d, idx[:, 0].contiguous(), img, is_th, step, grad_hook=hook)
+    return eng.train_step(o, d, cam, img, is_th, step, grad_hook=hook)
 
 
 def time_ms(fn, iters=10, warmup=2):

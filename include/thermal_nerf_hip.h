@@ -74,10 +74,12 @@ int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
  * u [num_rays / patch^2, 3] fp32 uniforms in [0,1) -- exactly what torch.rand returns in the reference, image after image (column 0 unused).
  * Every image gets (num_rays / num_images) / patch^2 patches and the last one the remainder, which must be a whole number of patches
  * (the reference asserts the same).  patch_size 1..8.
- * Outputs: ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal_out [N]. */
+ * Outputs: ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal_out [N], camera_indices [N] int64 (= ray_indices[:,0] as the
+ * contiguous vector the field kernels take; may be NULL). */
 int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                      const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
-                     int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, tn_stream_t stream);
+                     int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
+                     tn_stream_t stream);
 
 /* ---- a1  RayGenerator.forward -> Cameras._generate_rays_from_coords (model_components/ray_generators.py:40-55,
  *          cameras/cameras.py:598-655,781-786,886-909; undistortion cameras/camera_utils.py:409-446).
@@ -215,6 +217,12 @@ int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans
  * step is 1-based. */
 int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
                  double beta1, double beta2, double eps, tn_stream_t stream);
+/* The same for several ranges of one set of arenas in ONE launch: range k covers elements [offsets[k], offsets[k] + counts[k]) (offsets
+ * multiples of 4) with its own 1-based step count and learning rate -- the optimiser groups of engine/optimizers.py:86-112.  offsets, counts,
+ * steps, lrs are HOST arrays of num_ranges (<= 8) entries. */
+int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                        const int64_t* counts, const int32_t* steps, const double* lrs, double beta1, double beta2, double eps,
+                        tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
 #ifdef __cplusplus

@@ -49,7 +49,7 @@ SIGNATURES = {
     "tn_version": (C.c_int, []),
     "tn_field_workspace_bytes": (_i64, [_i64, _i32]),
     "tn_prop_workspace_bytes": (_i64, [_i64]),
-    "tn_sample_pixels": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p]),
+    "tn_sample_pixels": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "tn_raygen": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
     "tn_pose_apply_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_pose_apply_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
@@ -77,6 +77,7 @@ SIGNATURES = {
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),
     "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
+    "tn_adam_step_ranges": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _d, _d, _d, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
 }
 

@@ -112,7 +112,8 @@ __device__ __forceinline__ void undistort(float xd, float yd, const float* __res
 __global__ void k_sample_pixels(const float* __restrict__ images, const int64_t* __restrict__ image_offsets, const int32_t* __restrict__ heights,
                                 const int32_t* __restrict__ widths, const float* __restrict__ is_thermal, const int64_t* __restrict__ image_idx,
                                 int num_images, const float* __restrict__ u, int64_t N, int ps, int64_t rays_per_image,
-                                int64_t* __restrict__ ray_indices, float* __restrict__ image, float* __restrict__ is_thermal_out) {
+                                int64_t* __restrict__ ray_indices, float* __restrict__ image, float* __restrict__ is_thermal_out,
+                                int64_t* __restrict__ camera_indices) {
   const int pp = ps * ps;
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
     int64_t i = rays_per_image > 0 ? r / rays_per_image : num_images - 1;  // every image holds rays_per_image rays, the last one the rest
@@ -127,6 +128,7 @@ __global__ void k_sample_pixels(const float* __restrict__ images, const int64_t*
     int64_t y = (int64_t)floorf(up[1] * (float)(H - ps) + (float)dy);
     int64_t x = (int64_t)floorf(up[2] * (float)(W - ps) + (float)dx);
     ray_indices[r * 3 + 0] = image_idx[i];
+    if (camera_indices != nullptr) camera_indices[r] = image_idx[i];
     ray_indices[r * 3 + 1] = y;
     ray_indices[r * 3 + 2] = x;
     const float* px = images + image_offsets[i] + (y * W + x) * 3;
@@ -139,7 +141,8 @@ __global__ void k_sample_pixels(const float* __restrict__ images, const int64_t*
 
 extern "C" int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                                 const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
-                                int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, tn_stream_t stream) {
+                                int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
+                                tn_stream_t stream) {
   if (num_rays == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(images && image_offsets && heights && widths && is_thermal && image_idx && u && ray_indices && image && is_thermal_out,
              "tn_sample_pixels: null pointer");
@@ -151,7 +154,7 @@ extern "C" int tn_sample_pixels(const float* images, const int64_t* image_offset
   TN_REQUIRE(last > 0 && last % pp == 0, "tn_sample_pixels: %lld rays over %d images do not split into whole %dx%d patches", (long long)num_rays,
              num_images, patch_size, patch_size);
   hipLaunchKernelGGL(k_sample_pixels, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), images, image_offsets,
-                     heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size, per, ray_indices, image, is_thermal_out);
+                     heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size, per, ray_indices, image, is_thermal_out, camera_indices);
   TN_CHECK_LAUNCH("tn_sample_pixels");
   return TN_OK;
 }
@@ -386,13 +389,7 @@ extern "C" int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, 
 
 // ------------------------------------------------------------------------------------------------ pixel losses
 // losses_out[0..3] += {rgb_loss, thermal_loss, tv_pixel_loss, cross_channel_loss}; losses_out[4] (scratch) = number of RGB rays.
-__global__ void k_count_rgb(const float* __restrict__ is_thermal, int64_t N, float* __restrict__ out) {
-  float c = 0.0f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) c += (is_thermal[i] == 0.0f) ? 1.0f : 0.0f;
-  c = tn_wave_sum(c);
-  if ((threadIdx.x & 63) == 0 && c != 0.0f) atomicAdd(out, c);
-}
-
+// Every block counts the RGB rays itself (N floats, a few KB): no separate count kernel / memset in front of the loss kernel.
 __device__ __forceinline__ float sgn(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // one thread per 2x2 patch (4 consecutive rays; is_thermal is constant inside a patch: PatchPixelSampler(patch_size=2))
@@ -400,7 +397,16 @@ __global__ void k_pixel_losses(const float* __restrict__ pred_rgb, int rs, const
                                const float* __restrict__ is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult,
                                float* __restrict__ losses, float* __restrict__ d_rgb, float* __restrict__ d_th) {
   float l_rgb = 0.f, l_th = 0.f, l_tv = 0.f, l_cc = 0.f;
-  float n_rgb_rays = losses[4];
+  __shared__ float sh_cnt[4];
+  {
+    float cnt = 0.0f;  // exact: a count of at most 2^24 ones
+    for (int64_t i = threadIdx.x; i < N; i += blockDim.x) cnt += (is_thermal[i] == 0.0f) ? 1.0f : 0.0f;
+    cnt = tn_wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) sh_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+  }
+  float n_rgb_rays = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) losses[4] = n_rgb_rays;
   float n_patches = n_rgb_rays / 4.0f;
   int64_t Q = N / 4;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
@@ -471,9 +477,6 @@ extern "C" int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const 
   TN_REQUIRE(N >= 0 && N % 4 == 0, "tn_pixel_losses: N=%lld must be a multiple of 4 (2x2 patches)", (long long)N);
   TN_REQUIRE(rgb_stride >= 3 && thermal_stride >= 1, "tn_pixel_losses: bad strides");
   if (N == 0) return TN_OK;
-  hipError_t e = hipMemsetAsync(losses_out + 4, 0, sizeof(float), tn_s(stream));
-  if (e != hipSuccess) { tn_set_error("tn_pixel_losses: %s", hipGetErrorString(e)); return TN_ELAUNCH; }
-  hipLaunchKernelGGL(k_count_rgb, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 256)), dim3(256), 0, tn_s(stream), is_thermal, N, losses_out + 4);
   hipLaunchKernelGGL(k_pixel_losses, dim3((unsigned)std::min<int64_t>(tn_cdiv(N / 4, 256), 256)), dim3(256), 0, tn_s(stream), pred_rgb, rgb_stride,
                      pred_thermal, thermal_stride, image, is_thermal, N, thermal_mult, tv_mult, cross_mult, losses_out, d_pred_rgb, d_pred_thermal);
   TN_CHECK_LAUNCH("tn_pixel_losses");
@@ -509,9 +512,10 @@ extern "C" int tn_l1_loss(const float* x, const float* y, int64_t count, float g
 // ------------------------------------------------------------------------------------------------ Adam
 // torch.optim.Adam single-tensor arithmetic (no amsgrad / weight decay):
 //   m = m*b1 + g*(1-b1) ; v = v*b2 + (1-b2)*g*g ; p += -(lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
-                       float* __restrict__ pt, const float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt, int tail, float b1,
-                       float b2, float omb1, float omb2, float neg_step, float bc2_sqrt, float eps) {
+__device__ __forceinline__ void adam_body(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v,
+                                          int64_t n4, float* __restrict__ pt, const float* __restrict__ gt, float* __restrict__ mt,
+                                          float* __restrict__ vt, int tail, float b1, float b2, float omb1, float omb2, float neg_step,
+                                          float bc2_sqrt, float eps) {
 #define ADAM1(P, G, M, V)                         \
   {                                               \
     float m_new_ = M * b1 + G * omb1;             \
@@ -537,6 +541,26 @@ __global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, flo
   }
 #undef ADAM1
 }
+__global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v, int64_t n4,
+                       float* __restrict__ pt, const float* __restrict__ gt, float* __restrict__ mt, float* __restrict__ vt, int tail, float b1,
+                       float b2, float omb1, float omb2, float neg_step, float bc2_sqrt, float eps) {
+  adam_body(p, g, m, v, n4, pt, gt, mt, vt, tail, b1, b2, omb1, omb2, neg_step, bc2_sqrt, eps);
+}
+// several ranges of the same arenas (one per optimiser group: own step count and learning rate) in one launch; blockIdx.y = range
+#define TN_ADAM_MAX_RANGES 8
+struct AdamRanges {
+  int64_t off[TN_ADAM_MAX_RANGES], cnt[TN_ADAM_MAX_RANGES];
+  float neg_step[TN_ADAM_MAX_RANGES], bc2_sqrt[TN_ADAM_MAX_RANGES];
+};
+__global__ void k_adam_ranges(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRanges r, float b1,
+                              float b2, float omb1, float omb2, float eps) {
+  const int k = blockIdx.y;
+  const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
+  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) return;  // short ranges need few blocks
+  adam_body(reinterpret_cast<float4*>(p + off), reinterpret_cast<const float4*>(g + off), reinterpret_cast<float4*>(m + off),
+            reinterpret_cast<float4*>(v + off), n4, p + off + n4 * 4, g + off + n4 * 4, m + off + n4 * 4, v + off + n4 * 4, (int)(n - n4 * 4), b1, b2, omb1,
+            omb2, r.neg_step[k], r.bc2_sqrt[k], eps);
+}
 
 extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
                             double beta1, double beta2, double eps, tn_stream_t stream) {
@@ -557,5 +581,37 @@ extern "C" int tn_adam_step(float* params, const float* grads, float* exp_avg, f
                      params + n4 * 4, grads + n4 * 4, exp_avg + n4 * 4, exp_avg_sq + n4 * 4, tail, (float)beta1, (float)beta2, (float)(1.0 - beta1),
                      (float)(1.0 - beta2), neg_step, bc2_sqrt, (float)eps);
   TN_CHECK_LAUNCH("tn_adam_step");
+  return TN_OK;
+}
+
+extern "C" int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                   const int64_t* counts, const int32_t* steps, const double* lrs, double beta1, double beta2, double eps,
+                                   tn_stream_t stream) {
+  if (num_ranges == 0) return TN_OK;
+  TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges: null pointer");
+  TN_REQUIRE(num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES, "tn_adam_step_ranges: %d ranges (at most %d)", num_ranges, TN_ADAM_MAX_RANGES);
+  TN_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
+             "tn_adam_step_ranges: arena pointers must be 16-byte aligned");
+  AdamRanges r{};
+  int64_t max_n4 = 0;
+  int n = 0;
+  for (int k = 0; k < num_ranges; ++k) {
+    TN_REQUIRE(offsets[k] >= 0 && offsets[k] % 4 == 0 && counts[k] >= 0 && steps[k] >= 1, "tn_adam_step_ranges: bad range %d (offset %lld count %lld step %d)",
+               k, (long long)offsets[k], (long long)counts[k], steps[k]);
+    if (counts[k] == 0) continue;
+    double bc1 = 1.0 - pow(beta1, (double)steps[k]);
+    double bc2 = 1.0 - pow(beta2, (double)steps[k]);
+    r.off[n] = offsets[k];
+    r.cnt[n] = counts[k];
+    r.neg_step[n] = (float)(-(lrs[k] / bc1));
+    r.bc2_sqrt[n] = (float)sqrt(bc2);
+    max_n4 = std::max<int64_t>(max_n4, counts[k] / 4);
+    ++n;
+  }
+  if (n == 0) return TN_OK;
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256), 256 * 16));
+  hipLaunchKernelGGL(k_adam_ranges, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+  TN_CHECK_LAUNCH("tn_adam_step_ranges");
   return TN_OK;
 }

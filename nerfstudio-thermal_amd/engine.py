@@ -235,13 +235,13 @@ class RenderEngine:
         c = self.cfg
         N = image.shape[0]
         dev = self.device
-        L = torch.zeros(16, device=dev)  # 0 rgb 1 thermal 2 tv 3 cross 4 (scratch) 8 interlevel 9 distortion 10 density 11 camreg 12 camreg_thermal
         b = branches[""]
         bt = branches.get("_thermal")
         C = b.comp.shape[1]
         # ---- pixel losses -> d comp
         # every zero-initialised accumulator of the step comes out of one allocation / one fill (see _zeros_many)
-        zshapes, zkeys = [], []
+        # L: 0 rgb 1 thermal 2 tv 3 cross 4 (scratch) 8 interlevel 9 distortion 10 density 11 camreg 12 camreg_thermal
+        zshapes, zkeys = [(16,)], [("L", "")]
         for sfx, br in branches.items():
             zkeys.append(("d_comp", sfx)); zshapes.append(tuple(br.comp.shape))
             zkeys.append(("dw2", sfx)); zshapes.append(tuple(br.levels[2].weights.shape))
@@ -252,6 +252,7 @@ class RenderEngine:
                 zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
                 zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
         Z = dict(zip(zkeys, self._zeros_many(zshapes)))
+        L = Z[("L", "")]
         d_comp = Z[("d_comp", "")]
         if self.separate:
             d_comp_t = Z[("d_comp", "_thermal")]
@@ -382,8 +383,9 @@ class RenderEngine:
             if lr_overrides and gname in lr_overrides:
                 lr = lr_overrides[gname]
             hyper[gname] = (self.group_steps[gname], lr)
-        if ranges is None:
-            ranges = [a.group_range[g] for g in hyper]
+        if ranges is None:  # every group at once: one launch
+            ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [a.group_range[g] + hyper[g] for g in hyper], eps=1e-15)
+            return
         for lo, hi in ranges:  # each range lies inside one optimiser group (Adam is element-wise: any partition of a group is the same update)
             gname = next(g for g in a.optimised_groups if a.group_range[g][0] <= lo and hi <= a.group_range[g][1])
             if gname not in hyper:

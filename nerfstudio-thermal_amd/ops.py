@@ -181,8 +181,9 @@ class ImageCache:
                           image_idx.to(device, torch.int64).contiguous())
 
 
-def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int = 2):
-    """PatchPixelSampler.sample + ground-truth gather on the device -> ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal [N].
+def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int = 2, want_camera_indices: bool = False):
+    """PatchPixelSampler.sample + ground-truth gather on the device -> ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal [N]
+    (+ camera_indices [N] int64 with want_camera_indices=True: ray_indices[:,0] as a contiguous vector).
     u [num_rays / patch^2, 3]: the uniforms the reference would draw with torch.rand, image after image."""
     n_img = cache.offsets.shape[0]
     dev = cache.buffer.device
@@ -191,10 +192,12 @@ def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int =
     idx = torch.empty((num_rays, 3), dtype=torch.int64, device=dev)
     img = torch.empty((num_rays, 3), dtype=torch.float32, device=dev)
     is_th = torch.empty((num_rays,), dtype=torch.float32, device=dev)
+    cam = torch.empty((num_rays,), dtype=torch.int64, device=dev) if want_camera_indices else None
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     check(_lib.load().tn_sample_pixels(p(cache.buffer), p(cache.offsets), p(cache.heights), p(cache.widths), p(cache.is_thermal), p(cache.image_idx),
-                                       n_img, p(u), num_rays, patch_size, p(idx), p(img), p(is_th), _stream()), "tn_sample_pixels")
-    return idx, img, is_th
+                                       n_img, p(u), num_rays, patch_size, p(idx), p(img), p(is_th), p(cam) if cam is not None else None, _stream()),
+          "tn_sample_pixels")
+    return (idx, img, is_th, cam) if want_camera_indices else (idx, img, is_th)
 
 
 # ------------------------------------------------------------------------------------------------ a1 / a4
@@ -523,3 +526,23 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
             raise ValueError("Adam arenas must have equal length")
     check(_lib.load().tn_adam_step(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n, int(step),
                                    float(lr), float(beta1), float(beta2), float(eps), _stream()), "tn_adam_step")
+
+
+def adam_step_ranges(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, ranges, beta1: float = 0.9, beta2: float = 0.999,
+                     eps: float = 1e-15) -> None:
+    """Adam over several ranges of the same flat arenas in one launch.  ranges: list of (lo, hi, step, lr), element offsets multiples of 4."""
+    n = len(ranges)
+    if n == 0:
+        return
+    for t in (grads, exp_avg, exp_avg_sq):
+        if t.numel() != params.numel():
+            raise ValueError("Adam arenas must have equal length")
+    for lo, hi, _, _ in ranges:
+        if not (0 <= lo <= hi <= params.numel()):
+            raise ValueError(f"Adam range [{lo}, {hi}) outside the arena")
+    offs = (C.c_int64 * n)(*[r[0] for r in ranges])
+    cnts = (C.c_int64 * n)(*[r[1] - r[0] for r in ranges])
+    steps = (C.c_int32 * n)(*[int(r[2]) for r in ranges])
+    lrs = (C.c_double * n)(*[float(r[3]) for r in ranges])
+    check(_lib.load().tn_adam_step_ranges(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n,
+                                          offs, cnts, steps, lrs, float(beta1), float(beta2), float(eps), _stream()), "tn_adam_step_ranges")

@@ -428,6 +428,18 @@ def test_adam_matches_torch_optim():
         opt.step()
         ops.adam_step(hp, g(grad), m, v, step, 1e-2)
         assert md(hp, ref_p) <= 2e-6, step
+    # several optimiser groups (own step count / learning rate) of one arena in one launch == one launch per group, bit for bit
+    bounds = [(0, 40000, 3, 1e-2), (40000, 40064, 1, 6e-4), (40064, 99996, 7, 2e-3), (99996, n, 2, 1e-3)]  # last range: 7 elements (tail only)
+    grad = g(torch.from_numpy(synth.uniform("agr", (n,), seed=SEED)) * 1e-3)
+    a = [t.clone() for t in (hp, m, v)]
+    b = [t.clone() for t in (hp, m, v)]
+    for lo, hi, st, lr in bounds:
+        ops.adam_step(a[0][lo:hi], grad[lo:hi], a[1][lo:hi], a[2][lo:hi], st, lr)
+    ops.adam_step_ranges(b[0], grad, b[1], b[2], bounds)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        ops.adam_step_ranges(b[0], grad, b[1], b[2], [(2, 10, 1, 1e-3)])  # offsets must be multiples of 4
 
 
 def test_empty_single_and_eval_chunk_sizes():
@@ -465,7 +477,8 @@ def test_sample_pixels_matches_reference_golden(golden_dir):
 
     b = pixel_batch(golden_dir)
     cache = ops.ImageCache.build(b["images"], b["is_thermal"], b["image_idx"], DEV)
-    idx, img, is_th = ops.sample_pixels(cache, b["num_rays"], g(b["u"]))
+    idx, img, is_th, cam_idx = ops.sample_pixels(cache, b["num_rays"], g(b["u"]), want_camera_indices=True)
+    assert torch.equal(cam_idx, idx[:, 0])
     assert torch.equal(idx.cpu(), b["ref"]["indices"])
     assert torch.equal(img.cpu(), b["ref"]["image"])
     assert torch.equal(is_th.cpu(), b["ref"]["is_thermal"])
