@@ -72,6 +72,26 @@ def _psnr(pred: Tensor, gt: Tensor) -> Tensor:
     return -10.0 * torch.log10(torch.mean((pred - gt) ** 2))
 
 
+def _ssim(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5, k1: float = 0.01, k2: float = 0.03) -> Tensor:
+    """Structural similarity (Wang et al. 2004) of [1,C,H,W] images with a Gaussian window; reflect padding, borders cropped, mean over
+    channels and pixels; data range = max - min over both images (torchmetrics' default when data_range is None)."""
+    C = pred.shape[1]
+    ax = torch.arange(kernel_size, dtype=pred.dtype, device=pred.device) - (kernel_size - 1) / 2.0
+    g1 = torch.exp(-(ax / sigma) ** 2 / 2.0)
+    g1 = g1 / g1.sum()
+    win = (g1[:, None] * g1[None, :]).expand(C, 1, kernel_size, kernel_size).contiguous()
+    rng = torch.maximum(pred.max() - pred.min(), gt.max() - gt.min())
+    c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
+    pad = (kernel_size - 1) // 2
+    p = torch.nn.functional.pad(pred, (pad, pad, pad, pad), mode="reflect")
+    t = torch.nn.functional.pad(gt, (pad, pad, pad, pad), mode="reflect")
+    f = lambda x: torch.nn.functional.conv2d(x, win, groups=C)  # noqa: E731
+    mu_p, mu_t = f(p), f(t)
+    s_pp, s_tt, s_pt = f(p * p) - mu_p * mu_p, f(t * t) - mu_t * mu_t, f(p * t) - mu_p * mu_t
+    ssim = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))
+    return ssim[..., pad:-pad, pad:-pad].mean() if ssim.shape[-1] > 2 * pad and ssim.shape[-2] > 2 * pad else ssim.mean()
+
+
 # loss pieces for the autograd-compatible path (small [N,S] element-wise torch ops on the device; the fused path uses the loss kernels)
 def _sdist(rs) -> Tensor:
     return rs.s_bins
@@ -466,6 +486,59 @@ class ThermalNerfactoModel(nn.Module):
                 if isinstance(v, Tensor):
                     lists[k].append(v.to(input_device))
         return {k: torch.cat(v).view(h, w, -1) for k, v in lists.items()}
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Tensor]:
+        """models/base_model.py:165-175: one full image of `camera` -- anything with the Cameras fields for ONE camera: camera_to_worlds [3,4],
+        fx, fy, cx, cy, width, height, optional distortion_params [6] and camera index (attribute `camera_index`, default 0; it selects the
+        pose correction / appearance row, as Cameras.generate_rays(camera_indices=0) + set_camera_indices do for an eval camera)."""
+        if obb_box is not None:
+            raise NotImplementedError("obb_box cropping is outside the thermal-nerfacto path")
+        dev = self.device
+        g = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev).reshape(-1)  # noqa: E731
+        H, W = int(torch.as_tensor(camera.height).reshape(-1)[0]), int(torch.as_tensor(camera.width).reshape(-1)[0])
+        yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        idx = torch.stack([torch.zeros(H * W, dtype=torch.int64, device=dev), yy.reshape(-1), xx.reshape(-1)], dim=1).contiguous()
+        dist = getattr(camera, "distortion_params", None)
+        dist = None if dist is None else g(dist).reshape(1, 6).contiguous()
+        c2w = torch.as_tensor(camera.camera_to_worlds, dtype=torch.float32, device=dev).reshape(1, 3, 4).contiguous()
+        o, d, area, norm = ops.raygen(idx, c2w, g(camera.fx)[:1], g(camera.fy)[:1], g(camera.cx)[:1], g(camera.cy)[:1], dist)
+        cam_index = int(getattr(camera, "camera_index", 0))
+        bundle = RayBundle(origins=o.view(H, W, 3), directions=d.view(H, W, 3), pixel_area=area.view(H, W, 1),
+                           camera_indices=torch.full((H, W, 1), cam_index, dtype=torch.int64, device=dev), metadata={"directions_norm": norm.view(H, W, 1)})
+        return self.get_outputs_for_camera_ray_bundle(bundle)
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Any]):
+        """models/thermal_nerfacto.py:490-564 for one eval image: PSNR / SSIM of the spectrum the image belongs to, and the side-by-side images.
+        PSNR = torchmetrics PeakSignalNoiseRatio(data_range=1.0).  SSIM follows the published algorithm with torchmetrics' defaults (11x11
+        Gaussian window, sigma 1.5, k1 0.01, k2 0.03, data range from the inputs); torchmetrics is not installed here, so it is NOT pinned
+        against it.  LPIPS needs pretrained network weights that are not available offline: the key is omitted.  The accumulation / depth
+        images are returned raw (the reference colour-maps them for the viewer: presentation only)."""
+        dev = self.device
+        is_th = batch["is_thermal"]
+        is_thermal_image = bool(is_th) if not hasattr(is_th, "__len__") else bool(torch.as_tensor(is_th).reshape(-1)[0])
+        gt = batch["image"].to(dev)[..., :3].float()
+        gt_rgbt = rgb_to_rgbt_image(gt.reshape(-1, 3), torch.full((gt.shape[0] * gt.shape[1],), float(is_thermal_image), device=dev)).view(*gt.shape[:2], 4)
+        gt_rgb, gt_thermal = gt_rgbt[..., :3], gt_rgbt[..., 3:]
+        pred_rgb, pred_th = outputs["rgb"], outputs["rgb_thermal"]
+        gt_img = gt_thermal.expand(-1, -1, 3) if is_thermal_image else gt_rgb
+        images = {"img": torch.cat([gt_img, pred_rgb, pred_th.expand(-1, -1, 3)], dim=1)}
+        if self.config.density_mode == "separate":
+            images["accumulation"] = torch.cat([outputs["accumulation"], outputs["accumulation_thermal"]], dim=1)
+            images["depth"] = torch.cat([outputs["depth"], outputs["depth_thermal"]], dim=1)
+        else:
+            images["accumulation"], images["depth"] = outputs["accumulation"], outputs["depth"]
+        for i in range(self.config.num_proposal_iterations):
+            images[f"prop_depth_{i}"] = outputs[f"prop_depth_{i}"]
+        chw = lambda t: torch.moveaxis(t, -1, 0)[None, ...]  # noqa: E731
+        metrics: Dict[str, float] = {}
+        if not is_thermal_image:
+            metrics["psnr_rgb"] = float(_psnr(chw(pred_rgb), chw(gt_rgb)))
+            metrics["ssim_rgb"] = float(_ssim(chw(pred_rgb), chw(gt_rgb)))
+        else:
+            metrics["psnr_thermal"] = float(_psnr(chw(pred_th), chw(gt_thermal)))
+            metrics["ssim_thermal"] = float(_ssim(chw(pred_th), chw(gt_thermal)))
+        return metrics, images
 
     def load_model(self, loaded_state: Dict[str, Any]) -> None:
         state = {k.replace("module.", ""): v for k, v in loaded_state["model"].items()}
