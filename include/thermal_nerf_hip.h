@@ -138,6 +138,13 @@ int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t
                     const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S, float* s_bins, float* e_bins,
                     tn_stream_t stream);
 
+/* a11 + a7 back to back, as ProposalNetworkSampler.generate_ray_samples always calls them (ray_samplers.py:593-611): the weights of the
+ * previous level (written to weights_prev [N,S_prev]; median_prev [N] optional) and the bins of the next level, one launch, the weights
+ * handed over in registers.  Bit-identical to tn_weights_fwd followed by tn_pdf_resample. */
+int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,
+                        const float* u_lin, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
+                        float* weights_prev, float* median_prev, float* s_bins, float* e_bins, tn_stream_t stream);
+
 /* ---- a12/a13/a14  Field.forward = NerfactoField.get_density + get_outputs with ThermalNerfactoField.mlp_head
  *          (fields/base_field.py:114-133, fields/nerfacto_field.py:205-229,272-348, fields/thermal_nerfacto_field.py:91-99).
  * camera_indices [N] int64; training!=0 uses emb[camera], else mean(emb) (use_average_appearance_embedding=True).

@@ -60,6 +60,7 @@ SIGNATURES = {
     "tn_hash_scatter": (C.c_int, [C.POINTER(TnGrid), _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
     "tn_weights_fwd": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tn_weights_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "tn_weights_resample": (C.c_int, [_p, _p, _p, _i32, _f, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "tn_pdf_resample": (C.c_int, [_p, _p, _i32, _f, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_field_pack_weights": (C.c_int, [C.POINTER(TnField), _p, _p]),
     "tn_field_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -46,11 +46,8 @@ extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const 
 // ------------------------------------------------------------------------------------------------ weights
 // lane l owns samples [l*ITEMS, (l+1)*ITEMS) of its ray.
 template <int ITEMS>
-__global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__ e_bins, const float* __restrict__ density, int64_t N, int S,
-                                                       float* __restrict__ weights, float* __restrict__ median_depth) {
-  int lane = tn_lane();
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-  if (ray >= N) return;  // whole wave exits together
+__device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, const float* __restrict__ density, int S, int64_t ray,
+                                             float* __restrict__ weights, float* __restrict__ median_depth, int lane, float (&w)[ITEMS]) {
   const float* eb = e_bins + ray * (S + 1);
   const float* dn = density + ray * S;
   float dd[ITEMS], mid[ITEMS];
@@ -68,7 +65,6 @@ __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__
   }
   double incl = tn_wave_incl_scan_d(loc, lane);
   double run = tn_excl_from_incl_d(incl, lane);  // exclusive prefix over earlier lanes
-  float w[ITEMS];
   double wloc = 0.0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
@@ -106,6 +102,15 @@ __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__
     best = __shfl(v, owner, 64);
     if (lane == 0) median_depth[ray] = best;
   }
+}
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__ e_bins, const float* __restrict__ density, int64_t N, int S,
+                                                       float* __restrict__ weights, float* __restrict__ median_depth) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;  // whole wave exits together
+  float w[ITEMS];
+  weights_body<ITEMS>(e_bins, density, S, ray, weights, median_depth, lane, w);
 }
 
 extern "C" int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
@@ -181,20 +186,13 @@ extern "C" int tn_weights_bwd(const float* e_bins, const float* density, const f
 }
 
 // ------------------------------------------------------------------------------------------------ PDF resample
+// w_raw[k] = weight of sample lane*ITEMS + k of the previous level (0 beyond Sp): from memory (k_pdf_resample) or straight from the
+// registers of weights_body (k_weights_pdf).
 template <int ITEMS>
-__global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict__ s_bins_prev, const float* __restrict__ weights_prev, int Sp,
-                                                        float anneal, const float* __restrict__ u_lin, const float* __restrict__ jitter,
-                                                        const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
-                                                        float* __restrict__ s_bins, float* __restrict__ e_bins) {
-  __shared__ float sh_cdf[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
-  __shared__ float sh_bins[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
-  int lane = tn_lane();
-  int wv = threadIdx.x >> 6;
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-  if (ray >= N) return;  // no block-level barrier below: waves are independent
-  float* cdf = sh_cdf[wv];
-  float* pb = sh_bins[wv];
-  const float* wp = weights_prev + ray * Sp;
+__device__ __forceinline__ void pdf_body(const float (&w_raw)[ITEMS], const float* __restrict__ s_bins_prev, int Sp, float anneal,
+                                         const float* __restrict__ u_lin, const float* __restrict__ jitter, const float* __restrict__ nears,
+                                         const float* __restrict__ fars, int S, int64_t ray, float* __restrict__ s_bins, float* __restrict__ e_bins,
+                                         float* cdf, float* pb, int lane) {
   const float* bp = s_bins_prev + ray * (Sp + 1);
   float w[ITEMS];
   double loc = 0.0;
@@ -203,7 +201,7 @@ __global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict_
     int i = lane * ITEMS + k;
     w[k] = 0.0f;
     if (i < Sp) {
-      float x = wp[i];
+      float x = w_raw[k];
       if (anneal != 1.0f) x = powf(x, anneal);  // torch.pow(weights, anneal); pow(x,1) is the identity
       w[k] = x + 0.01f;                        // histogram_padding
     }
@@ -255,6 +253,44 @@ __global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict_
     s_bins[ray * nb + j] = b;
     e_bins[ray * nb + j] = tn_s_to_euclid(b, s_near, s_far);
   }
+}
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict__ s_bins_prev, const float* __restrict__ weights_prev, int Sp,
+                                                        float anneal, const float* __restrict__ u_lin, const float* __restrict__ jitter,
+                                                        const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
+                                                        float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  __shared__ float sh_cdf[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  __shared__ float sh_bins[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+  if (ray >= N) return;  // no block-level barrier below: waves are independent
+  float w_raw[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    w_raw[k] = (i < Sp) ? weights_prev[ray * Sp + i] : 0.0f;
+  }
+  pdf_body<ITEMS>(w_raw, s_bins_prev, Sp, anneal, u_lin, jitter, nears, fars, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
+}
+// RaySamples.get_weights of a proposal level and the PDF resampling it feeds, one wave per ray, the weights handed over in registers
+// (the two are always called back to back by ProposalNetworkSampler.generate_ray_samples, ray_samplers.py:593-611).
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK) k_weights_pdf(const float* __restrict__ e_bins_prev, const float* __restrict__ density_prev,
+                                                       const float* __restrict__ s_bins_prev, int Sp, float anneal,
+                                                       const float* __restrict__ u_lin, const float* __restrict__ jitter,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
+                                                       float* __restrict__ weights_prev, float* __restrict__ median_prev,
+                                                       float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  __shared__ float sh_cdf[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  __shared__ float sh_bins[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+  if (ray >= N) return;
+  float w[ITEMS];
+  weights_body<ITEMS>(e_bins_prev, density_prev, Sp, ray, weights_prev, median_prev, lane, w);
+  pdf_body<ITEMS>(w, s_bins_prev, Sp, anneal, u_lin, jitter, nears, fars, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
 }
 
 extern "C" int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
@@ -707,5 +743,24 @@ extern "C" int tn_proposal_losses(const float* s_bins_fine, const float* weights
   dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), 1 + num_props);
   hipLaunchKernelGGL(k_proposal_losses, grid, dim3(BLOCK), 0, tn_s(stream), a);
   TN_CHECK_LAUNCH("tn_proposal_losses");
+  return TN_OK;
+}
+
+extern "C" int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,
+                                   const float* u_lin, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
+                                   float* weights_prev, float* median_prev, float* s_bins, float* e_bins, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(e_bins_prev && density_prev && s_bins_prev && u_lin && nears && fars && weights_prev && s_bins && e_bins, "tn_weights_resample: null pointer");
+  TN_REQUIRE(N > 0 && S >= 1 && S <= TN_MAX_SAMPLES && S_prev >= 1 && S_prev <= TN_MAX_SAMPLES, "tn_weights_resample: bad N=%lld S=%d S_prev=%d",
+             (long long)N, S, S_prev);
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+#define LAUNCH_WP(I)                                                                                                                         \
+  hipLaunchKernelGGL(k_weights_pdf<I>, grid, block, 0, tn_s(stream), e_bins_prev, density_prev, s_bins_prev, S_prev, anneal, u_lin, jitter, nears, \
+                     fars, N, S, weights_prev, median_prev, s_bins, e_bins)
+  if (S_prev <= 64) LAUNCH_WP(1);
+  else if (S_prev <= 128) LAUNCH_WP(2);
+  else LAUNCH_WP(4);
+#undef LAUNCH_WP
+  TN_CHECK_LAUNCH("tn_weights_resample");
   return TN_OK;
 }

@@ -127,12 +127,12 @@ class RenderEngine:
             if lvl == 0:
                 s, e = ops.spaced_bins(nears, fars, S, jit)
             else:
+                # weights of the previous level + this level's bins in one launch (get_weights -> PDFSampler, ray_samplers.py:593-611)
                 prev = levels[-1]
-                s, e = ops.pdf_resample(prev.s_bins, prev.weights, S, anneal, nears, fars, jit)
+                prev.weights, prev.median, s, e = ops.weights_resample(prev.e_bins, prev.density, prev.s_bins, S, anneal, nears, fars, jit)
             L = Level(S=S, s_bins=s, e_bins=e)
             if lvl < len(self.counts) - 1:
                 L.density = ops.prop_density_fwd(props[lvl], origins, directions, e)
-                L.weights, L.median = ops.weights_fwd(e, L.density, want_median=True)
             levels.append(L)
         last = levels[-1]
         last.density, rgb, _ = ops.field_fwd(fld, origins, directions, cam, last.e_bins, training, tag=tag)

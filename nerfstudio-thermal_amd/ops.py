@@ -284,6 +284,23 @@ def pdf_resample(s_bins_prev: Tensor, weights_prev: Tensor, S: int, anneal: floa
     return s, e
 
 
+def weights_resample(e_bins_prev: Tensor, density_prev: Tensor, s_bins_prev: Tensor, S: int, anneal: float, nears: Tensor, fars: Tensor,
+                     jitter: Optional[Tensor] = None, want_median: bool = True):
+    """weights_fwd of the previous level + pdf_resample into the next one in a single launch (tn_weights_resample).
+    -> weights_prev [N,Sp], median_prev [N,1] or None, s_bins [N,S+1], e_bins [N,S+1]"""
+    N, Sp = density_prev.shape
+    dev = density_prev.device
+    w = torch.empty((N, Sp), device=dev)
+    med = torch.empty((N, 1), device=dev) if want_median else None
+    s = torch.empty((N, S + 1), device=dev)
+    e = torch.empty((N, S + 1), device=dev)
+    check(_lib.load().tn_weights_resample(_f32(e_bins_prev, "e_bins_prev", (N, Sp + 1)), _f32(density_prev, "density_prev", (N, Sp)),
+                                          _f32(s_bins_prev, "s_bins_prev", (N, Sp + 1)), Sp, float(anneal), _f32(_lin_table("pdf", S, dev), "u"),
+                                          _ray_scalar(jitter, "jitter", N, True), _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S,
+                                          _f32(w, "w"), _f32(med, "median", optional=True), _f32(s, "s"), _f32(e, "e"), _stream()), "tn_weights_resample")
+    return w, med, s, e
+
+
 def weights_fwd(e_bins: Tensor, density: Tensor, want_median: bool = False):
     N, S = density.shape
     w = torch.empty((N, S), device=density.device)

@@ -124,6 +124,17 @@ def test_spaced_pdf_weights_chain(train):
     s2 = orc.pdf_resample(s1, w1, 48, j2 if train else None)
     hs2, _ = ops.pdf_resample(g(s1), g(w1[..., 0]), 48, 1.0, g(nears), g(fars), g(j2) if train else None)
     assert outlier_fraction(hs2, s2, 2e-6) <= 0.005
+    # the fused entry point (weights of a level + bins of the next, one launch) is bit-identical to the two calls, for every ITEMS variant
+    for Sp, Sn, hs, he, hd, jit, ann in ((256, 96, hs0, he0, g(dens[..., 0]), j1, 0.37), (96, 48, g(s1), g(e1), g(dens1[..., 0]), j2, 1.0),
+                                         (96, 20, g(s1), g(e1), g(dens1[..., 0]), j2, 1.0)):
+        jj = g(jit) if train else None
+        w_a, med_a = ops.weights_fwd(he, hd, want_median=True)
+        s_a, e_a = ops.pdf_resample(hs, w_a, Sn, ann, g(nears), g(fars), jj)
+        w_b, med_b, s_b, e_b = ops.weights_resample(he, hd, hs, Sn, ann, g(nears), g(fars), jj)
+        for a, b in ((w_a, w_b), (med_a, med_b), (s_a, s_b), (e_a, e_b)):
+            assert torch.equal(a, b), (Sp, Sn)
+    w64 = ops.weights_resample(he0[:, :65].contiguous(), g(dens[:, :64, 0]), hs0[:, :65].contiguous(), 32, 1.0, g(nears), g(fars), None, want_median=False)
+    assert w64[1] is None and w64[2].shape == (N, 33)  # ITEMS = 1 path, median optional
 
 
 @pytest.mark.parametrize("S", [48, 96, 256, 7])
