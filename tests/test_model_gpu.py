@@ -238,3 +238,31 @@ def test_non_default_config_matches_oracle():
             continue
         rn = float(g_ref.double().norm())
         assert abs(float(got.double().norm()) - rn) <= 2e-2 * rn + 1e-12, (name, float(got.double().norm()), rn)
+
+
+def test_full_size_training_run_is_stable():
+    """BASELINE config 1 end to end (default table sizes, 4096 rays, new pixels every step as in bench.py): 300 fused steps stay finite,
+    the photometric losses fall, the proposal networks are stepped exactly on the scheduled iterations, and the result is reproducible
+    up to float-atomic noise."""
+    import bench
+
+    dev = torch.device(DEV, 0)
+    finals = []
+    for rep in range(2):
+        torch.manual_seed(1234)
+        cfg, arena, eng = bench.build_engine(dev)
+        cam_t, _, _, _ = bench.make_batch(dev, 4096, 42)
+        cache = bench.make_image_cache(dev)
+        hist = []
+        for step in range(300):
+            losses = bench.one_step(eng, cam_t, cache, 4096, step, None)
+            if step % 20 == 0 or step == 299:
+                hist.append({k: float(v) for k, v in losses.items()})
+        assert all(np.isfinite(v) for h in hist for v in h.values()), hist[-1]
+        first, last = hist[0], hist[-1]
+        assert last["rgb_loss"] < first["rgb_loss"] / 3 and last["thermal_loss"] < first["thermal_loss"] / 3, (first, last)
+        assert eng.group_steps["fields"] == 300 and 10 < eng.group_steps["proposal_networks"] < 300  # proposal nets: only on scheduled steps
+        assert bool(torch.isfinite(arena.params).all())
+        finals.append(last)
+    for k in finals[0]:
+        assert abs(finals[0][k] - finals[1][k]) <= 0.25 * abs(finals[0][k]) + 1e-8, (k, finals[0][k], finals[1][k])
