@@ -508,3 +508,24 @@ def test_sample_pixels_matches_reference_golden(golden_dir):
             assert torch.equal(a.cpu(), w), (n, ps)
     with pytest.raises(RuntimeError):  # 8*4+2 rays do not split into whole 2x2 patches
         ops.sample_pixels(cache, 34, g(torch.zeros((8, 3))), 2)
+
+
+def test_renderer_properties_of_the_reference_suite():
+    """The property checks of the reference's tests/model_components/test_renderers.py:11-82 (uniform weights over 10 samples: max(rgb) > 0.9,
+    zero colours -> 0, accumulation > 0.9, median / expected depth > 0), run through tn_composite_fwd / tn_weights_fwd for RGB, RGBT and
+    1-channel renders."""
+    S = 10
+    w = torch.full((3, S), 1.0 / S, device=DEV)
+    e = torch.linspace(0.0, 101.0, S + 1, device=DEV).repeat(3, 1).contiguous()
+    for Cn in (3, 4, 1):
+        ones = torch.ones((3, S, Cn), device=DEV)
+        for training in (True, False):
+            comp, acc, med, exp = ops.composite_fwd(ones, w, e, training)
+            assert float(comp.max()) > 0.9 and float(acc.max()) > 0.9
+            assert float(med.min()) > 0 and float(exp.min()) > 0
+            comp0, _, _, _ = ops.composite_fwd(ones * 0, w, e, training)
+            assert float(comp0.abs().max()) <= 1e-6
+    # weights from densities: a dense slab gives (almost) all weight to the first samples and the weights sum to < = 1
+    dens = torch.full((3, S), 5.0, device=DEV)
+    hw, med = ops.weights_fwd(e, dens, want_median=True)
+    assert float(hw.sum(1).max()) <= 1.0 + 1e-6 and float(hw[:, 0].min()) > 0.99 and float(med.min()) > 0

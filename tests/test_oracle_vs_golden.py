@@ -160,6 +160,24 @@ def test_model_train_losses_grads_adam(golden_dir, mode):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="live reference not present")
+def test_reference_known_answer_tests():
+    """The two numerical facts the reference's own test-suite pins on this path, restated against the oracle (and, for the HIP kernels, through
+    the parity tests that compare them with the oracle): spherical-harmonics orthonormality (tests/utils/test_math.py:7-16: N = 1e6 unit
+    vectors, seed 0, sh^T sh / N * 4 pi = I to 1.5e-2) and one Frustums.get_positions value (tests/cameras/test_rays.py:11-30)."""
+    torch.manual_seed(0)
+    n = 1000000
+    dx = torch.normal(0, 1, size=(n, 3))
+    dx = dx / torch.linalg.norm(dx, dim=-1, keepdim=True)
+    sh = orc.sh16(dx)
+    for levels in range(1, 5):  # components_from_spherical_harmonics(levels): the first levels^2 components
+        k = levels * levels
+        m = (sh[:, :k].T @ sh[:, :k]) / n * 4 * torch.pi
+        torch.testing.assert_close(m, torch.eye(k), rtol=0, atol=1.5e-2)
+    smp = orc.Samples(s_bins=torch.tensor([[0.0, 1.0]]), e_bins=torch.tensor([[2.0, 3.0]]))
+    pos = smp.positions(torch.tensor([[0.0, 1.0, 2.0]]), torch.tensor([[0.0, 1.0, 0.0]]))
+    assert pos.reshape(-1).tolist() == pytest.approx([0.0, 3.5, 2.0], abs=1e-6)
+
+
 def test_pixel_sampler(golden_dir):
     """N2: the oracle's PatchPixelSampler restatement against the reference's own output on a jagged RGB + thermal image list."""
     b = pixel_batch(golden_dir)
