@@ -13,15 +13,6 @@
 #include "tn_common.h"
 #include <stdlib.h>
 
-__device__ __forceinline__ int seg_start4(bool head, int lane) {
-  int s = head ? (lane >> 2) : 0;  // in sample units
-#pragma unroll
-  for (int o = 4; o < 64; o <<= 1) {
-    int t = __shfl_up(s, o, 64);
-    if (lane >= o) s = s > t ? s : t;
-  }
-  return s;
-}
 __device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
   int sl = lane >> 2;
 #pragma unroll
@@ -120,9 +111,12 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       uint32_t k2 = fz | ((ox == 0.0f) ? 1u << 16 : 0u) | ((oy == 0.0f) ? 1u << 17 : 0u) | ((oz == 0.0f) ? 1u << 18 : 0u);
       uint32_t p1 = __shfl_up(k1, 4, 64), p2 = __shfl_up(k2, 4, 64);
       bool head = (lane < 4) || (k1 != p1) || (k2 != p2);
-      int start = seg_start4(head, lane);
-      int next_head = __shfl_down((int)head, 4, 64);
-      bool tail = (lane >= 60) || (next_head != 0);
+      // run start / run tail from ONE ballot instead of a 4-step shuffle scan plus a shuffle: the four lanes of a sample agree on `head`, so
+      // the highest set bit at or below this lane lies in the head sample of its run (the kernel is bound by the latency of these dependent
+      // cross-lane chains: TCC_EA0_ATOMIC_LEVEL shows the atomic pipe under-filled on the proposal grids, not over-subscribed)
+      const unsigned long long H = __ballot(head);
+      const int start = (63 - __clzll(H & (~0ull >> (63 - lane)))) >> 2;  // in sample units
+      const bool tail = (lane >= 60) || ((H >> (lane + 4)) & 1ull);
       // this lane's x corner and its 4 (y,z) partners: (c,c) (f,c) (c,f) (f,f)
       uint32_t xi = xc ? cx : fx;
       float wxv = xc ? ox : ux;
