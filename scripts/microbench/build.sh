@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds the atomic microbenchmarks for gfx950 next to their sources (cross-compiles without a GPU); run them on the GPU box, e.g.
+#   gpurun -- 'timeout 120 scripts/microbench/atomic_shapes'
+set -e
+cd "$(dirname "$0")"
+for f in atomic_*.hip; do
+  hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-result "$f" -o "${f%.hip}"
+done
+ls -1 atomic_* | grep -v '\.hip$'
