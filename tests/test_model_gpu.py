@@ -240,6 +240,27 @@ def test_non_default_config_matches_oracle():
         assert abs(float(got.double().norm()) - rn) <= 2e-2 * rn + 1e-12, (name, float(got.double().norm()), rn)
 
 
+def test_full_size_separate_mode_run_is_stable():
+    """BASELINE config 2 (separate density fields + density loss, default table sizes): 80 fused steps stay finite and the losses fall."""
+    import bench
+
+    dev = torch.device(DEV, 0)
+    torch.manual_seed(4321)
+    cfg, arena, eng = bench.build_engine(dev, mode="separate")
+    cam_t, _, _, _ = bench.make_batch(dev, 4096, 42)
+    cache = bench.make_image_cache(dev)
+    hist = []
+    for step in range(80):
+        losses = bench.one_step(eng, cam_t, cache, 4096, step, None)
+        if step % 20 == 0 or step == 79:
+            hist.append({k: float(v) for k, v in losses.items()})
+    assert all(np.isfinite(v) for h in hist for v in h.values()), hist[-1]
+    assert "density_loss" in hist[-1] and "camera_opt_regularizer_thermal" in hist[-1]
+    assert hist[-1]["rgb_loss"] < hist[0]["rgb_loss"] / 2 and hist[-1]["thermal_loss"] < hist[0]["thermal_loss"] / 2, (hist[0], hist[-1])
+    assert eng.group_steps["fields_thermal"] == 80 and eng.group_steps["proposal_networks_thermal"] == 80  # the thermal sampler always updates
+    assert bool(torch.isfinite(arena.params).all())
+
+
 def test_full_size_training_run_is_stable():
     """BASELINE config 1 end to end (default table sizes, 4096 rays, new pixels every step as in bench.py): 300 fused steps stay finite,
     the photometric losses fall, the proposal networks are stepped exactly on the scheduled iterations, and the result is reproducible
