@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       const uint32_t kind = (rk.kinds >> (2 * l)) & 3u;
       const bool dense = kind == TN_REP_DENSE;
       float2* base = g.grad + level_off;
-      if (kind != TN_REP_NONE) base = rk.rep + rk.off[l] + (size_t)(blockIdx.x % (unsigned)rk.R[l]) * rk.n[l];
+      if (kind != TN_REP_NONE) base = rk.rep + rk.off[l] + (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % (unsigned)rk.R[l]) * rk.n[l];  // replica per WAVE: the waves of a block walk adjacent samples
       if (dense) {
         const uint32_t r1 = (uint32_t)(int)ceilf(res) + 1u, top = r1 - 1u;
         xi = min(xi, top);  // positions are in [0,1] by construction; the clamp only keeps a corrupt input inside the replica
