@@ -6,8 +6,8 @@ Everything here is launch plumbing; the arithmetic lives in libthermal_nerf_hip.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from dataclasses import dataclass
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch

@@ -15,7 +15,7 @@ from __future__ import annotations
 from collections import defaultdict
 from dataclasses import dataclass
 from enum import Enum, auto
-from typing import Any, Callable, Dict, List, Optional, Tuple
+from typing import Any, Callable, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -24,7 +24,7 @@ from torch import Tensor, nn
 from . import ops
 from .arena import ParamArena
 from .config import ThermalNerfactoModelConfig
-from .engine import Branch, RenderEngine
+from .engine import RenderEngine
 from .model_components import (
     AccumulationRenderer,
     CameraOptimizer,

@@ -12,7 +12,7 @@ swapped corner would pass a 1e-3 check (hard part 1).
 from __future__ import annotations
 
 import zlib
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 
