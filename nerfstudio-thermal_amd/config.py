@@ -33,7 +33,7 @@ class ThermalNerfactoModelConfig:
     enable_collider: bool = True
     collider_params: Optional[Dict[str, float]] = field(default_factory=lambda: {"near_plane": 2.0, "far_plane": 6.0})
     loss_coefficients: Dict[str, float] = field(default_factory=lambda: {"rgb_loss_coarse": 1.0, "rgb_loss_fine": 1.0})
-    eval_num_rays_per_chunk: int = 1 << 15
+    eval_num_rays_per_chunk: int = 4096  # the class default; method_configs["thermal-nerfacto"] (and plugin.py) set 1 << 15
     prompt: Optional[str] = None
     # NerfactoModelConfig
     near_plane: float = 0.05
