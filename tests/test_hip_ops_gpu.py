@@ -529,3 +529,29 @@ def test_renderer_properties_of_the_reference_suite():
     dens = torch.full((3, S), 5.0, device=DEV)
     hw, med = ops.weights_fwd(e, dens, want_median=True)
     assert float(hw.sum(1).max()) <= 1.0 + 1e-6 and float(hw[:, 0].min()) > 0.99 and float(med.min()) > 0
+
+
+def test_out_of_box_and_degenerate_rays_match_oracle():
+    """Selector / contraction edge cases: origins far outside the scene box, positions exactly on the contraction boundary (|x|_inf = 1),
+    a zero direction (every sample at the origin of the ray), a ray parked at 1e9 (contracted radius rounds to 2 -> unit-cube face -> selector off)."""
+    ocfg, params, cfg, arena = setup_pair()
+    N, S = 8, 96
+    o = torch.tensor([[0.0, 0.0, 0.0], [5.0, -7.0, 3.0], [1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [100.0, 100.0, 100.0], [0.3, 0.2, -0.9], [0.0, 0.0, 1e-30], [1e9, -1e9, 3e8]])
+    d = torch.tensor([[0.0, 0.0, 1.0], [-0.5, 0.7, -0.3], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], [-1.0, -1.0, -1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    d = torch.where(d.norm(dim=1, keepdim=True) > 0, d / d.norm(dim=1, keepdim=True).clamp_min(1e-30), d)
+    nears, fars = torch.zeros(N, 1), torch.full((N, 1), 1000.0)
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    pos = smp.positions(o, d)
+    with torch.no_grad():
+        ref_p = orc.prop_density(params, "proposal_networks", 1, ocfg, pos)
+        ref_f, _, _, _ = orc.field_density(params, "field", ocfg, pos)
+    hp = ops.prop_density_fwd(prop_params(arena, "proposal_networks", 1, cfg), g(o), g(d), g(e))
+    hf = ops.field_density_fwd(field_params(arena, "field", cfg), g(o), g(d), g(e))
+    for got, ref, name in ((hp, ref_p[..., 0], "proposal"), (hf, ref_f[..., 0], "field")):
+        ref = ref.to(DEV)
+        same_zero = (got == 0) == (ref == 0)
+        assert bool(same_zero.all()), (name, int((~same_zero).sum()))  # the selector switches off exactly the same samples
+        rel = ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max()
+        assert float(rel) <= 1e-4, (name, float(rel))
+    assert float((hp[7] == 0).float().mean()) == 1.0 and float((hp[:7] == 0).float().mean()) == 0.0  # only the ray at 1e9 is switched off
