@@ -555,3 +555,27 @@ def test_out_of_box_and_degenerate_rays_match_oracle():
         rel = ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max()
         assert float(rel) <= 1e-4, (name, float(rel))
     assert float((hp[7] == 0).float().mean()) == 1.0 and float((hp[:7] == 0).float().mean()) == 0.0  # only the ray at 1e9 is switched off
+
+
+def test_non_finite_inputs_follow_torch_nan_to_num():
+    """RaySamples.get_weights ends in torch.nan_to_num (cameras/rays.py:148) and the eval renderers sanitise the colours
+    (model_components/renderers.py:118-120): infinite / huge densities and NaN colours must come out as torch produces them."""
+    N, S = 6, 48
+    nears, fars = torch.full((N, 1), 0.05), torch.full((N, 1), 1000.0)
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    dens = torch.from_numpy(synth.uniform("nf_dens", (N, S, 1), 0.0, 2.0, SEED))
+    dens[0, 5] = float("inf")
+    dens[1, :] = 3.0e38
+    dens[2, 10] = float("inf"); dens[2, 11] = float("inf")
+    dens[3, 0] = float("inf")
+    dens[4, :] = 0.0
+    w_ref = orc.get_weights(smp.deltas, dens)
+    assert bool(torch.isfinite(w_ref).all())
+    hw, _ = ops.weights_fwd(g(e), g(dens[..., 0]))
+    assert bool(torch.isfinite(hw).all()) and md(hw, w_ref[..., 0]) <= 2e-6
+    rgb = torch.from_numpy(synth.uniform("nf_rgb", (N, S, 4), 0.0, 1.0, SEED))
+    rgb[0, 3, 1] = float("nan"); rgb[2, 7, 0] = float("inf"); rgb[5, :, 3] = float("-inf")
+    ref = orc.composite_rgb(rgb, w_ref, training=False)  # eval path: nan_to_num before, clamp after
+    comp, acc, _, _ = ops.composite_fwd(g(rgb), hw, g(e), training=False)
+    assert bool(torch.isfinite(comp).all()) and md(comp, ref) <= 1e-5
