@@ -169,6 +169,20 @@ enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4 };
 int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                        const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                        float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream);
+/* Data-parallel exchange of the COARSE levels in dense form.  Levels whose (res+1)^3 cells are fewer than the table's slots are accumulated
+ * in dense per-cell replicas anyway; their slice of the table gradient is almost all zeros (332 k possible non-zeros in 2.6 M slots for
+ * levels 0-4 of the default grid), so a data-parallel run exchanges the per-cell sums (2.65 MB) instead of the table slice (20 MB):
+ *   n = tn_field_dense_count(field, N*S, lb, le)      float2 cells of levels [lb, le) if ALL of them are dense levels for this batch size, else 0
+ *   tn_field_bwd_scatter_dense(..., lb, le, dense_sum) as TN_BWD_SCATTER of that range, but the per-cell sums go to dense_sum [n,2] (written, not
+ *                                                     accumulated) and the table gradient of the range is left untouched
+ *   (all-reduce dense_sum)
+ *   tn_field_dense_fold(field, N*S, lb, le, dense_sum) hashes the sums into the table gradient (accumulating), as the plain scatter would have. */
+int64_t tn_field_dense_count(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end);
+int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                               void* workspace, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end, float* dense_sum,
+                               tn_stream_t stream);
+int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
+                        tn_stream_t stream);
 /* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458). */
 int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                          void* workspace, float* density, tn_stream_t stream);

@@ -271,5 +271,9 @@ struct ReplicaK {
 };
 // g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
 // scratch: TN_SCATTER_SCRATCH_BYTES of device memory or NULL (every level then adds straight into the hashed gradient).
+// dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
+// of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream);
+                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum = nullptr);
+int64_t tn_grid_dense_count(const TnGrid& grid, int64_t P);
+int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream);

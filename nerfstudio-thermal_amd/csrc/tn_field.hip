@@ -720,6 +720,17 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   return TN_OK;
 }
 
+// a level range is a grid of its own: table / gradient / resolutions shifted (g_enc columns shift by 2 per level at the call site)
+static TnGrid level_range_grid(const TnGrid& g, int level_begin, int level_end) {
+  TnGrid sub = g;
+  const int64_t T2 = 2ll << g.log2_hashmap_size;  // floats per level
+  sub.table = g.table + level_begin * T2;
+  sub.table_grad = g.table_grad ? g.table_grad + level_begin * T2 : nullptr;
+  sub.num_levels = level_end - level_begin;
+  for (int i = 0; i < TN_MAX_LEVELS; ++i) sub.res[i] = (level_begin + i < g.num_levels) ? g.res[level_begin + i] : 0.0f;
+  return sub;
+}
+
 extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                                   const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                                   float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream) {
@@ -767,13 +778,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     }
   }
   if (phases & TN_BWD_SCATTER) {
-    // a level range is a grid of its own: table / gradient / resolutions shifted, g_enc columns shifted by 2 per level
-    TnGrid sub = field->grid;
-    const int64_t T2 = 2ll << sub.log2_hashmap_size;  // floats per level
-    sub.table = field->grid.table + level_begin * T2;
-    sub.table_grad = field->grid.table_grad + level_begin * T2;
-    sub.num_levels = level_end - level_begin;
-    for (int i = 0; i < TN_MAX_LEVELS; ++i) sub.res[i] = (level_begin + i < field->grid.num_levels) ? field->grid.res[level_begin + i] : 0.0f;
+    TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, d_origins, d_directions, ws.scatter, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);
@@ -786,4 +791,34 @@ extern "C" int tn_field_bwd(const TnField* field, const float* origins, const fl
   if (field == nullptr) return check_field(field, "tn_field_bwd", true);
   return tn_field_bwd_phase(field, origins, directions, camera_indices, e_bins, d_density, d_rgb, N, S, workspace, d_origins, d_directions,
                             TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN, 0, field->grid.num_levels, stream);
+}
+
+// ---- data-parallel exchange of the coarse levels in dense form (see include/thermal_nerf_hip.h) -----------------------------------
+extern "C" int64_t tn_field_dense_count(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end) {
+  if (field == nullptr || level_begin < 0 || level_begin >= level_end || level_end > field->grid.num_levels) return 0;
+  return tn_grid_dense_count(level_range_grid(field->grid, level_begin, level_end), num_points);
+}
+
+extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                                          void* workspace, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end,
+                                          float* dense_sum, tn_stream_t stream) {
+  if (N == 0) return TN_OK;
+  int rc = check_field(field, "tn_field_bwd_scatter_dense", true);
+  if (rc) return rc;
+  TN_REQUIRE(origins && directions && e_bins && workspace && dense_sum, "tn_field_bwd_scatter_dense: null pointer");
+  TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd_scatter_dense: d_origins and d_directions must both be given or both NULL");
+  TN_REQUIRE(N > 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd_scatter_dense: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd_scatter_dense: bad level range [%d, %d)",
+             level_begin, level_end);
+  FieldWs ws = ws_layout(workspace, N * (int64_t)S, 1);
+  return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S,
+                                d_origins, d_directions, ws.scatter, tn_s(stream), dense_sum);
+}
+
+extern "C" int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
+                                   tn_stream_t stream) {
+  int rc = check_field(field, "tn_field_dense_fold", true);
+  if (rc) return rc;
+  TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels && num_points > 0, "tn_field_dense_fold: bad arguments");
+  return tn_grid_dense_fold(level_range_grid(field->grid, level_begin, level_end), num_points, dense_sum, tn_s(stream));
 }

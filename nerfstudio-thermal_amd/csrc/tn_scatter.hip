@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
 }
 
 // Folds the replicas into the hashed gradient: thread = one entry of one replicated level.
-__global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk) {
+__global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, float2* __restrict__ dense_out) {
   uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= rk.total) return;
   int l = 0;
@@ -196,6 +196,10 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk) {
     float2 v = src[(size_t)r * n];
     sx += v.x;
     sy += v.y;
+  }
+  if (dense_out != nullptr) {  // data-parallel exchange of the coarse levels: hand the per-cell sums over un-hashed (tn_field_dense_fold follows)
+    dense_out[e] = make_float2(sx, sy);
+    return;
   }
   if (sx == 0.0f && sy == 0.0f) return;  // untouched entries keep an exactly-zero gradient (Adam's eps = 1e-15 makes that matter)
   if (((rk.kinds >> (2 * l)) & 3u) == TN_REP_HASHED) {  // one thread per table slot: a plain add
@@ -221,8 +225,45 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
 static int dense_replicas() { static int r = env_int("TN_SCATTER_REPLICAS", 16, 0, 64); return r; }
 static int hashed_replicas() { static int r = env_int("TN_SCATTER_HASHED_REPLICAS", 4, 0, 64); return r; }
 
+// Replica plan, in level order while the scratch lasts: dense replicas for the coarse levels, then whole-level (hashed) replicas when the
+// table is small.  Neither pays when the batch is much smaller than the replica (the zero-fill and the fold are O(replica size)).
+// Fills everything of rk except rk.rep; returns the scratch entries (float2) the plan uses.  Depends only on the grid and P.
+static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
+  const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)sizeof(float2);
+  const int64_t T = 1ll << grid.log2_hashmap_size;
+  int64_t used = 0, total = 0;
+  bool dense_ok = dense_replicas() > 0;
+  for (int l = 0; l < grid.num_levels; ++l) {
+    float r = grid.res[l];
+    int64_t n = 0;
+    int kind = TN_REP_NONE, R = 0;
+    if (dense_ok && r >= 1.0f && r <= 62.0f) {
+      int64_t r1 = (int64_t)ceilf(r) + 1;
+      n = r1 * r1 * r1;
+      R = dense_replicas();
+      if (n <= T && n <= 4 * P && used + n * R <= cap) kind = TN_REP_DENSE;
+    }
+    if (kind == TN_REP_NONE) {
+      dense_ok = false;  // levels are in increasing resolution
+      n = T;
+      R = hashed_replicas();
+      if (R > 0 && T <= (1ll << 17) && n <= P && used + n * R <= cap) kind = TN_REP_HASHED;
+    }
+    if (kind == TN_REP_NONE) continue;
+    rk.kinds |= (uint32_t)kind << (2 * l);
+    rk.n[l] = (uint32_t)n;
+    rk.off[l] = (uint32_t)used;
+    rk.first[l] = (uint32_t)total;
+    rk.R[l] = (uint8_t)R;
+    used += n * R;
+    total += n;
+  }
+  rk.total = (uint32_t)total;
+  return used;
+}
+
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
+                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
@@ -234,54 +275,68 @@ int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float
     double rounds = (double)grid_dim / 2048.0;
     if (rounds < 4.0 && (rounds - floor(rounds)) > 0.0 && (rounds - floor(rounds)) < 0.75) level_groups = 2;
   }
-  // Replica plan, in level order while the scratch lasts: dense replicas for the coarse levels, then whole-level (hashed) replicas when the
-  // table is small.  Neither pays when the batch is much smaller than the replica (the zero-fill and the fold are O(replica size)).
   ReplicaK rk{};
+  int64_t used = 0;
   if (scratch != nullptr) {
-    const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)sizeof(float2);
-    const int64_t T = 1ll << grid.log2_hashmap_size;
-    int64_t used = 0, total = 0;
-    bool dense_ok = dense_replicas() > 0;
-    for (int l = 0; l < grid.num_levels; ++l) {
-      float r = grid.res[l];
-      int64_t n = 0;
-      int kind = TN_REP_NONE, R = 0;
-      if (dense_ok && r >= 1.0f && r <= 62.0f) {
-        int64_t r1 = (int64_t)ceilf(r) + 1;
-        n = r1 * r1 * r1;
-        R = dense_replicas();
-        if (n <= T && n <= 4 * P && used + n * R <= cap) kind = TN_REP_DENSE;
-      }
-      if (kind == TN_REP_NONE) {
-        dense_ok = false;  // levels are in increasing resolution
-        n = T;
-        R = hashed_replicas();
-        if (R > 0 && T <= (1ll << 17) && n <= P && used + n * R <= cap) kind = TN_REP_HASHED;
-      }
-      if (kind == TN_REP_NONE) continue;
-      rk.kinds |= (uint32_t)kind << (2 * l);
-      rk.n[l] = (uint32_t)n;
-      rk.off[l] = (uint32_t)used;
-      rk.first[l] = (uint32_t)total;
-      rk.R[l] = (uint8_t)R;
-      used += n * R;
-      total += n;
-    }
-    rk.total = (uint32_t)total;
+    used = plan_replicas(grid, P, rk);
     rk.rep = reinterpret_cast<float2*>(scratch);
     if (rk.kinds) {
       hipError_t e = hipMemsetAsync(scratch, 0, (size_t)used * sizeof(float2), stream);
       TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
     }
   }
+  if (dense_sum != nullptr) {
+    bool all_dense = scratch != nullptr;
+    for (int l = 0; l < grid.num_levels; ++l) all_dense = all_dense && (((rk.kinds >> (2 * l)) & 3u) == TN_REP_DENSE);
+    TN_REQUIRE(all_dense, "tn_grid_scatter: dense_sum wanted but not every level of the range is accumulated densely");
+  }
   GridK gk = make_gridk(grid);
   hipLaunchKernelGGL(k_grid_scatter, dim3(grid_dim, level_groups), dim3(256), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
                      d_directions, level_groups, rk);
   TN_CHECK_LAUNCH("tn_grid_scatter");
   if (rk.kinds) {
-    hipLaunchKernelGGL(k_replica_reduce, dim3((unsigned)tn_cdiv(rk.total, 256)), dim3(256), 0, stream, gk, rk);
+    hipLaunchKernelGGL(k_replica_reduce, dim3((unsigned)tn_cdiv(rk.total, 256)), dim3(256), 0, stream, gk, rk, reinterpret_cast<float2*>(dense_sum));
     TN_CHECK_LAUNCH("tn_grid_scatter(reduce)");
   }
+  return TN_OK;
+}
+
+// number of dense cells (float2 entries) of a grid whose levels are ALL accumulated densely for `num_points` samples, else 0
+int64_t tn_grid_dense_count(const TnGrid& grid, int64_t P) {
+  if (P <= 0 || grid.num_levels < 1 || grid.num_levels > TN_MAX_LEVELS) return 0;
+  ReplicaK rk{};
+  (void)plan_replicas(grid, P, rk);
+  for (int l = 0; l < grid.num_levels; ++l)
+    if (((rk.kinds >> (2 * l)) & 3u) != TN_REP_DENSE) return 0;
+  return (int64_t)rk.total;
+}
+
+// dense per-cell sums (as k_replica_reduce hands them over) -> hashed table gradient; thread = one cell
+__global__ void __launch_bounds__(256) k_dense_fold(GridK g, ReplicaK rk, const float2* __restrict__ dense_sum) {
+  uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rk.total) return;
+  float2 v = dense_sum[e];
+  if (v.x == 0.0f && v.y == 0.0f) return;
+  int l = 0;
+#pragma unroll 1
+  for (int i = 0; i < g.L; ++i)
+    if (rk.first[i] <= e) l = i;
+  const uint32_t t = e - rk.first[l];
+  const uint32_t r1 = (uint32_t)(int)ceilf(g.res[l]) + 1u;
+  uint32_t x = t % r1, y = (t / r1) % r1, z = t / (r1 * r1);
+  uint32_t idx = ((x ^ (y * TN_PRIME_Y) ^ (z * TN_PRIME_Z)) & g.mask) + (uint32_t)l * g.tsize;
+  float* dst = reinterpret_cast<float*>(g.grad + idx);
+  if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
+  if (v.y != 0.0f) unsafeAtomicAdd(dst + 1, v.y);
+}
+int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream) {
+  TN_REQUIRE(grid.table_grad && dense_sum, "tn_grid_dense_fold: null pointer");
+  ReplicaK rk{};
+  (void)plan_replicas(grid, P, rk);
+  for (int l = 0; l < grid.num_levels; ++l)
+    TN_REQUIRE(((rk.kinds >> (2 * l)) & 3u) == TN_REP_DENSE, "tn_grid_dense_fold: level %d of the range is not accumulated densely", l);
+  hipLaunchKernelGGL(k_dense_fold, dim3((unsigned)tn_cdiv(rk.total, 256)), dim3(256), 0, stream, make_gridk(grid), rk, reinterpret_cast<const float2*>(dense_sum));
+  TN_CHECK_LAUNCH("tn_grid_dense_fold");
   return TN_OK;
 }
 
@@ -295,5 +350,5 @@ extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const f
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_hash_scatter: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_hash_scatter: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 24, "tn_hash_scatter: bad log2_hashmap_size");
-  return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, workspace, tn_s(stream));
+  return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, workspace, tn_s(stream), nullptr);
 }

@@ -326,7 +326,19 @@ class RenderEngine:
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
                 T2 = 2 * 2**fld.log2_hashmap_size
                 t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
-                for lb, le in dp.level_ranges(fld.num_levels):
+                P = N * self.counts[-1]
+                # the coarse levels first, exchanged as dense per-cell sums (their table slice is almost all zeros): the longest prefix of levels
+                # that are all dense-replica levels at this batch size
+                nd = 0
+                while nd < fld.num_levels and ops.field_dense_count(fld, P, 0, nd + 1) > 0:
+                    nd += 1
+                if nd > 0:
+                    cells = ops.field_dense_count(fld, P, 0, nd)
+                    dense = torch.empty((cells, 2), device=dev)
+                    ops.field_bwd_scatter_dense(fld, br.origins, br.directions, lv[2].e_bins, d_o, d_d, 0, nd, dense)
+                    dp.reduce_tensor(dense, (t0, t0 + nd * T2), lambda fld=fld, P=P, nd=nd, dense=dense: ops.field_dense_fold(fld, P, 0, nd, dense))
+                for lb, le in dp.level_ranges(fld.num_levels - nd):
+                    lb, le = lb + nd, le + nd
                     ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, lb, le)
                     dp.reduce_range(t0 + lb * T2, t0 + le * T2)
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)

@@ -415,6 +415,30 @@ def field_bwd_phase(fld: FieldParams, origins: Tensor, directions: Tensor, cam: 
                                          phases, level_begin, level_end, _stream()), "tn_field_bwd_phase")
 
 
+def field_dense_count(fld: FieldParams, num_points: int, level_begin: int, level_end: int) -> int:
+    """float2 cells of table levels [level_begin, level_end) if all of them are accumulated densely at this batch size, else 0."""
+    s = fld.cstruct(need_grad=True)
+    return int(_lib.load().tn_field_dense_count(C.byref(s), num_points, level_begin, level_end))
+
+
+def field_bwd_scatter_dense(fld: FieldParams, origins: Tensor, directions: Tensor, e_bins: Tensor, d_origins: Optional[Tensor],
+                            d_directions: Optional[Tensor], level_begin: int, level_end: int, dense_sum: Tensor, tag: str = "main") -> None:
+    """The scatter phase of field_bwd_phase for a range of dense levels, with the per-cell sums written to dense_sum [n,2] instead of the table."""
+    N, S = e_bins.shape[0], e_bins.shape[1] - 1
+    ws = fld.workspace(N * S, True, tag)
+    s = fld.cstruct(need_grad=True)
+    check(_lib.load().tn_field_bwd_scatter_dense(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                                 _f32(e_bins, "e_bins", (N, S + 1)), N, S, C.c_void_p(ws.data_ptr()),
+                                                 _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
+                                                 level_begin, level_end, _f32(dense_sum, "dense_sum"), _stream()), "tn_field_bwd_scatter_dense")
+
+
+def field_dense_fold(fld: FieldParams, num_points: int, level_begin: int, level_end: int, dense_sum: Tensor) -> None:
+    """Hash the (exchanged) per-cell sums into the table gradient of levels [level_begin, level_end)."""
+    s = fld.cstruct(need_grad=True)
+    check(_lib.load().tn_field_dense_fold(C.byref(s), num_points, level_begin, level_end, _f32(dense_sum, "dense_sum"), _stream()), "tn_field_dense_fold")
+
+
 _SCATTER_WS: dict = {}
 
 

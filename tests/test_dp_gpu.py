@@ -93,3 +93,37 @@ def test_field_bwd_phases_equal_whole(golden_dir):
             assert float((a - bb).abs().max()) <= 2e-6 * float(a.abs().max()), k
     with pytest.raises(RuntimeError):
         ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, None, None, _lib.TN_BWD_SCATTER, 3, 17)
+
+
+def test_dense_exchange_of_coarse_levels_full_size(rccl_group):
+    """BASELINE config 1 sizes: the coarse table levels (0-4 at 4096 rays) go through tn_field_bwd_scatter_dense -> all-reduce of the per-cell
+    sums -> tn_field_dense_fold instead of the 20 MB table slice.  Gradients (zero pattern included) must equal the plain backward's."""
+    import bench
+    from nerfstudio_thermal_amd import synth
+
+    dev = torch.device(DEV, 0)
+    cam_t, idx, img, is_th = bench.make_batch(dev, 4096, 42)
+    o, d, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
+    cam = idx[:, 0].contiguous()
+    jit = [torch.from_numpy(j).to(dev).reshape(-1).contiguous() for j in synth.synth_jitters(4096, seed=5)]
+    grads = []
+    for hook in (None, OverlappedGradReducer(1)):
+        cfg, arena, eng = bench.build_engine(dev)
+        assert ops.field_dense_count(eng.field, 4096 * 48, 0, 5) == 4913 + 12167 + 29791 + 79507 + 205379
+        assert ops.field_dense_count(eng.field, 4096 * 48, 0, 6) == 0  # level 5 (res 80) has more cells than the table has slots
+        arena.zero_grad()
+        out, branches = eng.get_outputs(o, d, cam, True, jit)
+        if hook is None:
+            eng.loss_and_backward(out, branches, cam, img, is_th)
+        else:
+            hook.begin(arena)
+            eng.loss_and_backward(out, branches, cam, img, is_th, dp=hook)
+            covered = list(hook.finish_iter())
+            lo, hi = arena.live_range
+            assert sorted(covered)[0][0] == lo and sorted(covered)[-1][1] == hi
+        torch.cuda.synchronize()
+        grads.append(arena.grads.clone())
+    g0, g1 = grads
+    scale = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 2e-6 * scale, float((g0 - g1).abs().max()) / scale
+    assert torch.equal(g0 == 0, g1 == 0)

@@ -132,3 +132,43 @@ def test_two_rank_overlapped_reducer_covers_live_range_once():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(all(r[1]) for r in res), res
+
+
+def _worker_dense(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base = torch.from_numpy(synth.uniform("g3", (arena.total,), seed=7))
+    arena.grads.copy_(base * (rank + 1))
+    lo, hi = arena.live_range
+    t0, shape = arena.layout["field.mlp_base.model.0.hash_table"]
+    per_level = shape[0] * shape[1] // 16
+    a, b = t0, t0 + 3 * per_level  # "coarse levels" 0..2 stand-in: exchanged through a side tensor, written back by `after`
+    side = (base[a:b] * (rank + 1)).clone()
+    arena.grads[a:b].zero_()
+    red = OverlappedGradReducer(world)
+    red.begin(arena)
+    done = []
+    red.reduce_tensor(side, (a, b), lambda: (arena.grads[a:b].copy_(side), done.append(True)))
+    seen = list(red.finish_iter())
+    mean = base * (sum(range(1, world + 1)) / world)
+    ok = bool(torch.allclose(arena.grads[lo:hi], mean[lo:hi], rtol=1e-6, atol=0)) and done == [True] and (a, b) in seen
+    cover = sorted(seen)
+    ok = ok and cover[0][0] == lo and cover[-1][1] == hi and all(x[1] == y[0] for x, y in zip(cover[:-1], cover[1:]))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_side_tensor_exchange_stands_for_an_arena_range():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dense, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
