@@ -318,8 +318,10 @@ class RenderEngine:
                     for i in range(2):
                         dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
                         ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
-                    if pipelined:  # the proposal networks' gradients are final: exchange them while the main field is still at work
-                        dp.reduce_range(*self.arena.group_range["proposal_networks"])
+                        if pipelined:  # this network's gradients are final: exchange them while the next one / the main field is still at work
+                            glo, ghi = self.arena.group_range["proposal_networks"]
+                            first = [self.arena.layout[f"proposal_networks.{k}.mlp_base.0.hash_table"][0] for k in range(2)]
+                            dp.reduce_range(first[i] if i else glo, first[i + 1] if i + 1 < 2 else ghi)
             if pipelined:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
