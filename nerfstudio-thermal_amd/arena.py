@@ -28,8 +28,10 @@ def field_shapes(prefix: str, cfg: ThermalNerfactoModelConfig, num_images: int, 
     din = 16 + 15 + cfg.appearance_embed_dim
     return OrderedDict(
         [
-            (f"{prefix}.embedding_appearance.embedding.weight", (num_images, cfg.appearance_embed_dim)),
+            # the table first: the small tensors (MLPs, appearance embedding) then form ONE contiguous tail of the group, next to the pose
+            # parameters of the following group -- a single small collective in data-parallel runs
             (f"{prefix}.mlp_base.model.0.hash_table", (T * cfg.num_levels, F)),
+            (f"{prefix}.embedding_appearance.embedding.weight", (num_images, cfg.appearance_embed_dim)),
             (f"{prefix}.mlp_base.model.1.layers.0.weight", (cfg.hidden_dim, cfg.num_levels * F)),
             (f"{prefix}.mlp_base.model.1.layers.0.bias", (cfg.hidden_dim,)),
             (f"{prefix}.mlp_base.model.1.layers.1.weight", (16, cfg.hidden_dim)),

@@ -145,8 +145,18 @@ class OverlappedGradReducer:
                 pts = [cur] + [c for c in cuts if cur < c < min(a, hi)] + [min(a, hi)]
                 rest += [(p, q) for p, q in zip(pts[:-1], pts[1:]) if q > p]
             cur = max(cur, b)
+        # adjacent leftovers travel as ONE collective (small messages are latency-bound: ~20-30 us each on the ring), but are handed to the
+        # optimiser group by group
+        merged: List[List[Tuple[int, int]]] = []
         for a, b in rest:
-            self.reduce_range(a, b)
+            if merged and merged[-1][-1][1] == a:
+                merged[-1].append((a, b))
+            else:
+                merged.append([(a, b)])
+        parts = {}
+        for grp in merged:
+            self.reduce_range(grp[0][0], grp[-1][1])
+            parts[len(self._ranges) - 1] = grp
         scale = dist.is_initialized() and not self._avg and self.world > 1
         works, ranges, after = self._works, self._ranges, self._after
         self._works = []
@@ -160,7 +170,8 @@ class OverlappedGradReducer:
                 fn()
             elif scale:
                 self._arena.grads[a:b].mul_(1.0 / self.world)
-            yield a, b
+            for piece in parts.get(k, [(a, b)]):
+                yield piece
 
     def finish(self, skip: Optional[List[Tuple[int, int]]] = None) -> None:
         for _ in self.finish_iter(skip):
