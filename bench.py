@@ -63,13 +63,14 @@ def make_image_cache(device):
 
 
 def one_step(eng, cam_t, cache, num_rays, step, hook):
-    from nerfstudio_thermal_amd import ops
+    # datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): this step's 2x2 pixel patches over the jagged image list, their
+    # ground truth and the rays, all on the device (nerfstudio_thermal_amd/data.py)
+    dm = getattr(eng, "_bench_dm", None)
+    if dm is None or dm.num_rays != num_rays or dm.cache is not cache:
+        from nerfstudio_thermal_amd.data import DeviceDataManager
 
-    # datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): draw this step's 2x2 pixel patches over the jagged image list and
-    # gather their ground truth (PatchPixelSampler, on the device), then RayGenerator
-    u = torch.rand((num_rays // 4, 3), device=cache.buffer.device)
-    idx, img, is_th, cam = ops.sample_pixels(cache, num_rays, u, 2, want_camera_indices=True)
-    o, d, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
+        dm = eng._bench_dm = DeviceDataManager(cache, cam_t, num_rays, 2)
+    o, d, cam, img, is_th = dm.next_train(step)
     return eng.train_step(o, d, cam, img, is_th, step, grad_hook=hook)
 
 

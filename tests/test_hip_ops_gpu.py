@@ -579,3 +579,28 @@ def test_non_finite_inputs_follow_torch_nan_to_num():
     ref = orc.composite_rgb(rgb, w_ref, training=False)  # eval path: nan_to_num before, clamp after
     comp, acc, _, _ = ops.composite_fwd(g(rgb), hw, g(e), training=False)
     assert bool(torch.isfinite(comp).all()) and md(comp, ref) <= 1e-5
+
+
+def test_device_data_manager_batches(golden_dir):
+    """DeviceDataManager.next_train == sample_pixels + raygen on the uniforms it draws (with and without the one-step-ahead prefetch), fresh
+    pixels every call, ground truth gathered from the cached images."""
+    from helpers import pixel_batch
+    from nerfstudio_thermal_amd.data import DeviceDataManager
+
+    b = pixel_batch(golden_dir)
+    cache = ops.ImageCache.build(b["images"], b["is_thermal"], b["image_idx"], DEV)
+    cams = synth.synth_cameras()
+    cam_t = {k: g(torch.from_numpy(cams[k])) for k in ("c2w", "fx", "fy", "cx", "cy", "distortion")}
+    for prefetch in (False, True):
+        torch.manual_seed(11)
+        dm = DeviceDataManager(cache, cam_t, 256, 2, prefetch=prefetch)
+        got = [dm.next_train(i) for i in range(3)]
+        torch.cuda.synchronize()
+        torch.manual_seed(11)
+        for o, d, cam, img, is_th in got:
+            u = torch.rand((64, 3), device=DEV)
+            idx, img_r, th_r, cam_r = ops.sample_pixels(cache, 256, u, 2, want_camera_indices=True)
+            o_r, d_r, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
+            for a, r in ((o, o_r), (d, d_r), (cam, cam_r), (img, img_r), (is_th, th_r)):
+                assert torch.equal(a, r), prefetch
+        assert not torch.equal(got[0][2], got[1][2]) or not torch.equal(got[0][3], got[1][3])  # a new batch every call
