@@ -526,12 +526,20 @@ __device__ __forceinline__ void adam_body(float4* __restrict__ p, const float4* 
     V = v_new_;                                   \
   }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 pp = p[i], gg = g[i], mm4 = m[i], vv4 = v[i];
+    // gradients and moments are touched once per step: stream them past the caches (non-temporal) so that the parameters -- the hash tables the
+    // next forward gathers from -- are what stays in the Infinity Cache
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float4 pp = p[i];
+    v4f gg = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g) + i);
+    v4f mm4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m) + i);
+    v4f vv4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v) + i);
     ADAM1(pp.x, gg.x, mm4.x, vv4.x)
     ADAM1(pp.y, gg.y, mm4.y, vv4.y)
     ADAM1(pp.z, gg.z, mm4.z, vv4.z)
     ADAM1(pp.w, gg.w, mm4.w, vv4.w)
-    p[i] = pp; m[i] = mm4; v[i] = vv4;
+    p[i] = pp;
+    __builtin_nontemporal_store(mm4, reinterpret_cast<v4f*>(m) + i);
+    __builtin_nontemporal_store(vv4, reinterpret_cast<v4f*>(v) + i);
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
     int i = threadIdx.x;
