@@ -521,14 +521,14 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ dY, int ldy
           av[u][a] = (ok && o < out_dim && cam == (int64_t)(out_base + o)) ? 1.0f : 0.0f;
         } else {
           // multiply by a 0/1 mask instead of selecting: a select lets hipcc sink the load back under a branch
-          av[u][a] = dY[pc * ldy + oc] * ((ok && o < out_dim) ? 1.0f : 0.0f);
+          av[u][a] = __builtin_nontemporal_load(dY + pc * ldy + oc) * ((ok && o < out_dim) ? 1.0f : 0.0f);  // streamed once: keep the tables cached
         }
       }
 #pragma unroll
       for (int b = 0; b < MI; ++b) {
         int i = 32 * b + j;
         int ic = i < in_dim ? i : in_dim - 1;
-        bv[u][b] = X[pc * ldx + x_col0 + ic] * ((ok && i < in_dim) ? 1.0f : 0.0f);
+        bv[u][b] = __builtin_nontemporal_load(X + pc * ldx + x_col0 + ic) * ((ok && i < in_dim) ? 1.0f : 0.0f);
       }
     }
     // keep the whole batch of loads in flight: without the fence hipcc sinks each load next to the MFMA that consumes it (vmcnt(0..3)),
