@@ -254,12 +254,11 @@ __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int6
 // ---------------------------------------------------------------- the shared table-gradient scatter kernel (tn_scatter.hip)
 // Coarse levels touch only (res+1)^3 table entries and the scene contraction concentrates the samples on a few of them: atomics to one
 // 64-B line serialise (scripts/microbench/atomic_hotset.hip: 64 hot lines -> 3.5 G requests/s instead of 21 G), so a level-0 launch
-// is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R private replicas (block b adds into replica
-// b % R) and k_replica_reduce folds the replicas into the hashed gradient afterwards.  Two replica layouts:
-//   dense  : index (z*r1 + y)*r1 + x, r1 = res + 1       (coarse levels: (res+1)^3 entries, fewer than the table has slots)
-//   hashed : the level's own hashed index, 2^log2T slots  (small tables, e.g. the proposal grids' 2^17: the whole level is replicated)
+// is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R private replicas (a wave adds into replica
+// (wave-id) % R: the waves of a block walk adjacent samples) in the dense layout index (z*r1 + y)*r1 + x, r1 = res + 1, and
+// k_replica_reduce folds the replicas into the hashed gradient afterwards.
 #define TN_SCATTER_SCRATCH_BYTES (64ll << 20)  // replica scratch appended to every backward workspace
-enum { TN_REP_NONE = 0, TN_REP_DENSE = 1, TN_REP_HASHED = 2 };
+enum { TN_REP_NONE = 0, TN_REP_DENSE = 1 };
 struct ReplicaK {
   float2* rep;                     // scratch, zero-filled before the scatter
   uint32_t total;                  // sum of n[l] over the replicated levels (= threads of the reduce kernel)

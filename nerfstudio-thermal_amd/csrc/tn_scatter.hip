@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
       uint32_t hcy = cy * TN_PRIME_Y, hfy = fy * TN_PRIME_Y, hcz = cz * TN_PRIME_Z, hfz = fz * TN_PRIME_Z;
       const float wy[4] = {oy, uy, oy, uy};
       const float wz[4] = {oz, oz, uz, uz};
-      // wave-uniform: the hashed gradient itself, or this block's private replica of the level (dense or hashed layout)
+      // wave-uniform: the hashed gradient itself, or this wave's private dense replica of the level
       const uint32_t kind = (rk.kinds >> (2 * l)) & 3u;
       const bool dense = kind == TN_REP_DENSE;
       float2* base = g.grad + level_off;
@@ -202,12 +202,6 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
     return;
   }
   if (sx == 0.0f && sy == 0.0f) return;  // untouched entries keep an exactly-zero gradient (Adam's eps = 1e-15 makes that matter)
-  if (((rk.kinds >> (2 * l)) & 3u) == TN_REP_HASHED) {  // one thread per table slot: a plain add
-    float2* dst = g.grad + (size_t)l * g.tsize + t;
-    float2 cur = *dst;
-    *dst = make_float2(cur.x + sx, cur.y + sy);
-    return;
-  }
   const uint32_t r1 = (uint32_t)(int)ceilf(g.res[l]) + 1u;
   uint32_t x = t % r1, y = (t / r1) % r1, z = t / (r1 * r1);
   uint32_t idx = ((x ^ (y * TN_PRIME_Y) ^ (z * TN_PRIME_Z)) & g.mask) + (uint32_t)l * g.tsize;
@@ -221,35 +215,30 @@ static int env_int(const char* name, int dflt, int lo, int hi) {
   int v = e ? atoi(e) : dflt;
   return v < lo ? lo : (v > hi ? hi : v);
 }
-// tuning knobs (0 disables the respective replica layout)
+// tuning knob (0 disables the replicas)
 static int dense_replicas() { static int r = env_int("TN_SCATTER_REPLICAS", 16, 0, 64); return r; }
-static int hashed_replicas() { static int r = env_int("TN_SCATTER_HASHED_REPLICAS", 4, 0, 64); return r; }
 
-// Replica plan, in level order while the scratch lasts: dense replicas for the coarse levels, then whole-level (hashed) replicas when the
-// table is small.  Neither pays when the batch is much smaller than the replica (the zero-fill and the fold are O(replica size)).
-// Fills everything of rk except rk.rep; returns the scratch entries (float2) the plan uses.  Depends only on the grid and P.
+// Replica plan: dense replicas for the coarse levels, in level order while they qualify and the scratch lasts.  (Whole-level replicas in
+// the table's own hashed layout were tried for the small proposal tables: 7 % on that kernel alone, nothing -- slightly negative -- on the
+// step, because of the extra zero-fill and fold; removed.)  A replica does not pay when the batch is much smaller than it (the zero-fill and
+// the fold are O(replica size)).  Fills everything of rk except rk.rep; returns the scratch entries (float2) the plan uses.  Depends only on
+// the grid and P.
 static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
   const int64_t cap = TN_SCATTER_SCRATCH_BYTES / (int64_t)sizeof(float2);
   const int64_t T = 1ll << grid.log2_hashmap_size;
   int64_t used = 0, total = 0;
-  bool dense_ok = dense_replicas() > 0;
+  if (dense_replicas() <= 0) return 0;
   for (int l = 0; l < grid.num_levels; ++l) {
     float r = grid.res[l];
     int64_t n = 0;
     int kind = TN_REP_NONE, R = 0;
-    if (dense_ok && r >= 1.0f && r <= 62.0f) {
+    if (r >= 1.0f && r <= 62.0f) {
       int64_t r1 = (int64_t)ceilf(r) + 1;
       n = r1 * r1 * r1;
       R = dense_replicas();
       if (n <= T && n <= 4 * P && used + n * R <= cap) kind = TN_REP_DENSE;
     }
-    if (kind == TN_REP_NONE) {
-      dense_ok = false;  // levels are in increasing resolution
-      n = T;
-      R = hashed_replicas();
-      if (R > 0 && T <= (1ll << 17) && n <= P && used + n * R <= cap) kind = TN_REP_HASHED;
-    }
-    if (kind == TN_REP_NONE) continue;
+    if (kind == TN_REP_NONE) break;  // levels are in increasing resolution: no dense level after the first that does not qualify
     rk.kinds |= (uint32_t)kind << (2 * l);
     rk.n[l] = (uint32_t)n;
     rk.off[l] = (uint32_t)used;

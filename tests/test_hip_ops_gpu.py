@@ -258,8 +258,8 @@ def test_field_default_table_size_hash_parity():
 
 def test_hash_scatter_matches_autograd_of_hash_encode():
     """tn_hash_scatter alone: d table and d position of the reference hash encoding, for a 5-level and a 16-level grid, N not a multiple of 4."""
-    # replica layouts of the scatter (tn_common.h): (5, 13) -> level 0 dense, levels 1-4 hashed replicas; (16, 12) -> all hashed replicas;
-    # (5, 10) with 37 rays -> batch smaller than... still hashed; use_workspace=False -> plain atomics everywhere
+    # replica plan of the scatter (tn_common.h): (5, 13) -> level 0 through dense replicas, levels 1-4 straight into the hashed gradient;
+    # (16, 12) and (5, 10): tables smaller than level 0's 4913 cells -> no replicas at all; use_workspace=False -> plain atomics everywhere
     for L, log2T, maxr, S, N in ((5, 13, 256, 96, 37), (16, 12, 2048, 48, 101), (5, 10, 256, 96, 7)):
         r = rays(N)
         nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
