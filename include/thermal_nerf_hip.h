@@ -118,10 +118,11 @@ int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float*
 /* ---- a9 (backward)  autograd of HashEncoding.pytorch_fwd (field_components/encodings.py:420-461) with respect to the table (and the sample
  *          position): trilinear scatter-add of g_enc [N*S, ld] (feature 2*level + f) into grid->table_grad; d_origins/d_directions optional.
  *          Used by tn_prop_density_bwd and tn_field_bwd; exposed because it is the dominant kernel of the training step.
- *          workspace: tn_hash_scatter_workspace_bytes() of 256-byte-aligned device scratch (contents irrelevant), or NULL. With it the
- *          coarse levels, whose few entries are hammered by every sample, are summed in private dense replicas first and folded into
- *          table_grad afterwards; NULL adds every level straight into table_grad (same result up to summation order, slower). */
-int64_t tn_hash_scatter_workspace_bytes(void);
+ *          workspace: tn_hash_scatter_workspace_bytes(N*S, num_levels) of 256-byte-aligned device scratch (contents irrelevant), or NULL.
+ *          With it the scatter is atomic-free: every contribution is written once as a (slot, value) record into the bucket of its
+ *          2^12-slot table slice and the buckets are summed in LDS (coarse levels are pre-merged in registers); NULL adds every
+ *          contribution straight into table_grad with global float atomics (same result up to summation order, several times slower). */
+int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t num_levels);
 int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
                     int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream);
 

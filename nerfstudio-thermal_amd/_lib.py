@@ -56,7 +56,7 @@ SIGNATURES = {
     "tn_spaced_bins": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_prop_density_fwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _i64, _i32, _p, _p]),
     "tn_prop_density_bwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
-    "tn_hash_scatter_workspace_bytes": (_i64, []),
+    "tn_hash_scatter_workspace_bytes": (_i64, [_i64, _i32]),
     "tn_hash_scatter": (C.c_int, [C.POINTER(TnGrid), _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
     "tn_weights_fwd": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tn_weights_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),

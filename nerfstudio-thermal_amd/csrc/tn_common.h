@@ -257,7 +257,21 @@ __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int6
 // is 2x slower than a fine level with 8x the requests.  Such levels are accumulated into R private replicas (a wave adds into replica
 // (wave-id) % R: the waves of a block walk adjacent samples) in the dense layout index (z*r1 + y)*r1 + x, r1 = res + 1, and
 // k_replica_reduce folds the replicas into the hashed gradient afterwards.
-#define TN_SCATTER_SCRATCH_BYTES (64ll << 20)  // replica scratch appended to every backward workspace
+#define TN_SCATTER_SCRATCH_BYTES (64ll << 20)  // replica scratch of the atomic path (part of every backward workspace)
+// The default path is atomic-free ("binned", tn_scatter.hip): contributions are written once as (slot, value) records into buckets of
+// 2^TN_BIN_SLICE_LOG2 consecutive table slots and summed per bucket in LDS.  Scratch per level: room for 16 records per sample (twice the
+// 8 corners: the hash spreads the records evenly, coarse levels are merged before they are written) plus slack for small batches.
+#define TN_BIN_SLICE_LOG2 12
+#define TN_BIN_MAX_SLICES 256
+static inline int64_t tn_bin_level_records(int64_t P) { return 16 * P + TN_BIN_MAX_SLICES * 1032; }
+static inline int64_t tn_bin_bytes(int64_t P, int num_levels) {
+  return 256 + (int64_t)num_levels * TN_BIN_MAX_SLICES * 4 + (int64_t)num_levels * tn_bin_level_records(P) * (2 + 8);
+}
+// bytes of scatter scratch a backward workspace carries for P samples on a grid of num_levels levels
+static inline int64_t tn_scatter_scratch_bytes(int64_t P, int num_levels) {
+  int64_t b = tn_bin_bytes(P, num_levels);
+  return ((b > TN_SCATTER_SCRATCH_BYTES ? b : TN_SCATTER_SCRATCH_BYTES) + 255) / 256 * 256;
+}
 enum { TN_REP_NONE = 0, TN_REP_DENSE = 1 };
 struct ReplicaK {
   float2* rep;                     // scratch, zero-filled before the scatter
@@ -269,7 +283,7 @@ struct ReplicaK {
   uint8_t R[TN_MAX_LEVELS];        // replicas of level l
 };
 // g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
-// scratch: TN_SCATTER_SCRATCH_BYTES of device memory or NULL (every level then adds straight into the hashed gradient).
+// scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,

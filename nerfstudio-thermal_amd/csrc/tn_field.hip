@@ -122,7 +122,7 @@ struct FieldWs {
   float* gy_bo;    // [P][16]
   float* gy_h1;    // [P][64]
   float* g_enc;    // [P][32]
-  void* scatter;   // replica scratch of the table-gradient scatter (TN_SCATTER_SCRATCH_BYTES)
+  void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
   int64_t bytes;
 };
 static inline FieldWs ws_layout(void* base, int64_t P, int training) {
@@ -141,7 +141,7 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     w.h1 = take(P * 64); w.hin = take(P * 64); w.hh1 = take(P * 64); w.hh2 = take(P * 64); w.y = take(P * 4);
     w.g3 = take(P * 4); w.gy_hh2 = take(P * 64); w.gy_hh1 = take(P * 64); w.g_hin = take(P * 64);
     w.gy_bo = take(P * 16); w.gy_h1 = take(P * 64); w.g_enc = take(P * 32);
-    w.scatter = take(TN_SCATTER_SCRATCH_BYTES / 4);
+    w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
   } else {
     w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = nullptr;
     w.scatter = nullptr;

@@ -132,7 +132,7 @@ static inline int64_t prop_scratch_offset(int64_t P) { return ((P * (16 + 16 + 1
 
 extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
   if (num_points < 0) return TN_EINVAL;
-  return prop_scratch_offset(num_points) + TN_SCATTER_SCRATCH_BYTES;
+  return prop_scratch_offset(num_points) + tn_scatter_scratch_bytes(num_points, PL);
 }
 
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,

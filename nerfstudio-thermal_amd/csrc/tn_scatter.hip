@@ -12,6 +12,9 @@
 //     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
 #include "tn_common.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
+#include <algorithm>
 
 __device__ __forceinline__ float seg_sum4(float v, int start, int lane) {
   int sl = lane >> 2;
@@ -210,6 +213,390 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
   if (sy != 0.0f) unsafeAtomicAdd(dst + 1, sy);
 }
 
+// ======================================================================================================================================
+// Atomic-free ("binned") path -- the default.  Global float atomics execute at the memory side at ~20 G 64-byte requests/s whatever the
+// kernel does (MI355X_MICROARCH.md, Global float atomics), plain coalesced stores run 4-5x faster, so every contribution is WRITTEN once
+// and summed on chip:
+//   pass 1  k_grid_bin : lane = sample (patch order).  Per level: 8 corner slots + values; runs of consecutive samples in one grid cell are
+//           summed in registers on the coarser levels (segmented wave scan); the surviving (slot, value) records are ranked per bucket
+//           (bucket = 2^TN_BIN_SLICE_LOG2 consecutive slots of one level) with LDS counters, staged in LDS in bucket order, and copied out
+//           as contiguous runs into the buckets' global arrays (one returning integer atomic per block, level and bucket reserves the run).
+//   pass 2  k_grid_fold: block = (bucket, chunk of its records): sums the records into an LDS image of the bucket's slots (slot locks + plain
+//           read-modify-write, see below), then adds the non-zero slots into the table gradient with coalesced plain read-modify-writes
+//           (atomics only when a bucket is split over several chunks).
+// A bucket that overflows its capacity (never on hashed levels with anything like a real batch) falls back to global atomics for the excess,
+// so the result is right for any input.  The sample position's gradient comes out of pass 1 (same corner gathers as the forward).
+// What was measured on the way here (lane-serialised LDS float atomics, microsecond barrier intervals, XCD-skewed block order):
+// profiles/r02_scatter_alternatives.md.
+struct BinK {
+  uint16_t* idx;     // [L][nslices][cap] slot inside the bucket
+  float2* val;       // same shape
+  uint32_t* count;   // [L][nslices], zeroed before pass 1
+  uint32_t cap;      // records per bucket (multiple of 8)
+  uint32_t level_stride;  // records between levels = nslices * cap
+  int slice_log2;    // log2 slots per bucket
+  int nslices;       // buckets per level (power of two, <= TN_BIN_MAX_SLICES)
+  uint32_t merge_mask;  // bit l: sum runs of same-cell neighbours at level l before writing
+  // fold work items: a bucket's records are cut into chunks of chunk[l] records, one block each; level l owns blocks [blk0[l], blk0[l+1]).
+  // Coarse levels have few live slots per bucket and hundreds of records per slot: nearly every record of a pass finds its slot taken and
+  // falls back to the serialised LDS float atomic, so their buckets are cut into small chunks that spread over many CUs.
+  uint32_t chunk[TN_MAX_LEVELS];
+  uint32_t blk0[TN_MAX_LEVELS + 1];
+  uint32_t sparse_mask;  // bit l: level l is sparse (float atomics in the fold instead of slot locks)
+  unsigned long long* trace;  // TN_FOLD_TRACE diagnostics: per fold block {start, after load+zero, after passes, end} wall-clock stamps, or NULL
+};
+
+#define BIN_THREADS 256
+#define BIN_MAX_COUNTERS 1024  // (levels handled by one block) x (buckets per level)
+
+// corner slots of one level + run structure of the wave (which lanes write: the last lane of every run of same-cell samples)
+struct BinLevel {
+  uint32_t idx[8];            // table slots of the 8 corners (inside the level)
+  float wx[2], wy[2], wz[2];  // [0] floor corner, [1] ceil corner
+  bool emit;
+  int start;    // first lane of this lane's run (merge levels)
+  int maxlen;   // longest run of the wave (merge levels)
+};
+__device__ __forceinline__ void bin_level(const Contracted& c, float res, uint32_t mask, bool merge, bool live, int lane, BinLevel& b) {
+  const float sx = c.px * res, sy = c.py * res, sz = c.pz * res;
+  const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+  const uint32_t fx = (uint32_t)(int)fxf, fy = (uint32_t)(int)fyf, fz = (uint32_t)(int)fzf;
+  const uint32_t cx = (uint32_t)(int)ceilf(sx), cy = (uint32_t)(int)ceilf(sy), cz = (uint32_t)(int)ceilf(sz);
+  const float ox = sx - fxf, oy = sy - fyf, oz = sz - fzf;
+  b.wx[0] = 1.0f - ox; b.wx[1] = ox;
+  b.wy[0] = 1.0f - oy; b.wy[1] = oy;
+  b.wz[0] = 1.0f - oz; b.wz[1] = oz;
+  const uint32_t hx[2] = {fx, cx}, hy[2] = {fy * TN_PRIME_Y, cy * TN_PRIME_Y}, hz[2] = {fz * TN_PRIME_Z, cz * TN_PRIME_Z};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) b.idx[k] = (hx[k & 1] ^ hy[(k >> 1) & 1] ^ hz[k >> 2]) & mask;  // k = (z, y, x) corner bits
+  b.emit = live;
+  b.start = lane;
+  b.maxlen = 1;
+  if (merge) {
+    // runs of consecutive lanes in one cell (same floor corner, same on-lattice flags => same 8 slots)
+    const uint32_t k1 = fx | (fy << 16);
+    const uint32_t k2 = fz | ((ox == 0.0f) ? 1u << 16 : 0u) | ((oy == 0.0f) ? 1u << 17 : 0u) | ((oz == 0.0f) ? 1u << 18 : 0u);
+    const uint32_t p1 = __shfl_up(k1, 1, 64), p2 = __shfl_up(k2, 1, 64);
+    const bool head = (lane == 0) || (k1 != p1) || (k2 != p2) || !live;
+    const unsigned long long H = __ballot(head);
+    b.start = 63 - __clzll(H & (~0ull >> (63 - lane)));
+    const bool tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
+    int m = lane - b.start + 1;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) m = max(m, __shfl_xor(m, o2, 64));
+    b.maxlen = m;
+    b.emit = live && tail;
+  }
+}
+template <bool WANT_DPOS>
+__global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                          const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
+                                                          float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, BinK bk) {
+  __shared__ uint32_t s_cnt[BIN_MAX_COUNTERS], s_loff[BIN_MAX_COUNTERS], s_gbase[BIN_MAX_COUNTERS];
+  __shared__ uint32_t s_tot[TN_MAX_LEVELS];
+  __shared__ uint32_t s_idx[BIN_THREADS * 8];
+  __shared__ float2 s_val[BIN_THREADS * 8];
+  const int lane = tn_lane();
+  const int tid = threadIdx.x;
+  const int ns = bk.nslices;
+  const int64_t P = N * (int64_t)S;
+  int64_t i = (int64_t)blockIdx.x * BIN_THREADS + tid;
+  const bool live = i < P;
+  if (!live) i = P - 1;
+  int64_t ray;
+  int s;
+  tn_patch_order(i, N, S, ray, s);
+  const int64_t p = ray * S + s;
+  const float* o = origins + ray * 3;
+  const float* d = directions + ray * 3;
+  const float* eb = e_bins + ray * (S + 1) + s;
+  const float st = eb[0], en = eb[1];
+  const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+  const int nlev = (g.L - (int)blockIdx.y + level_groups - 1) / level_groups;  // levels of this block: blockIdx.y + li * level_groups
+  // ---- phase A: how many records this block sends to every bucket, one reservation per bucket for all levels at once (a returning global
+  // atomic takes microseconds: inside the level loop it was the critical path)
+  for (int t = tid; t < nlev * ns; t += BIN_THREADS) s_cnt[t] = 0;
+  __syncthreads();
+#pragma unroll 1
+  for (int li = 0; li < nlev; ++li) {
+    const int l = blockIdx.y + li * level_groups;
+    BinLevel b;
+    bin_level(c, g.res[l], g.mask, (bk.merge_mask >> l) & 1u, live, lane, b);
+    if (b.emit) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&s_cnt[li * ns + (b.idx[k] >> bk.slice_log2)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int li = tid >> 6; li < nlev; li += BIN_THREADS / 64) {  // one wave per level
+    const int l = blockIdx.y + li * level_groups;
+    uint32_t run = 0;
+    for (int base = 0; base < ns; base += 64) {
+      const int sl = base + lane;
+      const uint32_t cnt = sl < ns ? s_cnt[li * ns + sl] : 0u;
+      uint32_t inc = cnt;
+#pragma unroll
+      for (int o2 = 1; o2 < 64; o2 <<= 1) {
+        const uint32_t t = __shfl_up(inc, o2, 64);
+        if (lane >= o2) inc += t;
+      }
+      if (sl < ns) {
+        s_loff[li * ns + sl] = run + inc - cnt;
+        s_gbase[li * ns + sl] = cnt ? atomicAdd(&bk.count[(size_t)l * ns + sl], cnt) : 0u;
+        s_cnt[li * ns + sl] = 0;  // becomes the rank counter of phase B
+      }
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) s_tot[li] = run;
+  }
+  __syncthreads();
+  // ---- phase B: values, ranks, staging in bucket order, coalesced copy-out
+  float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+  const uint32_t smask = (1u << bk.slice_log2) - 1u;
+#pragma unroll 1
+  for (int li = 0; li < nlev; ++li) {
+    const int l = blockIdx.y + li * level_groups;
+    const float res = g.res[l];
+    const bool merge = (bk.merge_mask >> l) & 1u;
+    BinLevel b;
+    bin_level(c, res, g.mask, merge, live, lane, b);
+    const float2 gv = live ? *reinterpret_cast<const float2*>(g_enc + p * ld + 2 * l) : make_float2(0.f, 0.f);
+    if (WANT_DPOS) {
+      // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
+      const float2* tb = g.table + (size_t)l * g.tsize;
+      float sk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 t = tb[b.idx[k]];
+        sk[k] = gv.x * t.x + gv.y * t.y;
+      }
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ax += b.wy[u] * b.wz[v] * (sk[1 + 2 * u + 4 * v] - sk[0 + 2 * u + 4 * v]);
+          ay += b.wx[u] * b.wz[v] * (sk[u + 2 + 4 * v] - sk[u + 0 + 4 * v]);
+          az += b.wx[u] * b.wy[v] * (sk[u + 2 * v + 4] - sk[u + 2 * v + 0]);
+        }
+      dpx += ax * res;
+      dpy += ay * res;
+      dpz += az * res;
+    }
+    float vx[8], vy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = b.wx[k & 1] * b.wy[(k >> 1) & 1] * b.wz[k >> 2];
+      vx[k] = w * gv.x;
+      vy[k] = w * gv.y;
+    }
+    if (merge) {
+      for (int o2 = 1; o2 < b.maxlen; o2 <<= 1) {  // wave-uniform bound; the run's last lane ends up with the run's sums
+        const bool take = lane - o2 >= b.start;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float tx = __shfl_up(vx[k], o2, 64), ty = __shfl_up(vy[k], o2, 64);
+          if (take) { vx[k] += tx; vy[k] += ty; }
+        }
+      }
+    }
+    if (b.emit) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int cidx = li * ns + (b.idx[k] >> bk.slice_log2);
+        const uint32_t pos = s_loff[cidx] + atomicAdd(&s_cnt[cidx], 1u);
+        s_idx[pos] = b.idx[k];
+        s_val[pos] = make_float2(vx[k], vy[k]);
+      }
+    }
+    __syncthreads();
+    const uint32_t total = s_tot[li];
+    for (uint32_t j = tid; j < total; j += BIN_THREADS) {
+      const uint32_t id = s_idx[j];
+      const float2 v = s_val[j];
+      const uint32_t sl = id >> bk.slice_log2;
+      const uint32_t gpos = s_gbase[li * ns + sl] + (j - s_loff[li * ns + sl]);
+      if (gpos < bk.cap) {
+        const size_t at = (size_t)l * bk.level_stride + (size_t)sl * bk.cap + gpos;
+        bk.idx[at] = (uint16_t)(id & smask);
+        bk.val[at] = v;
+      } else {  // bucket full: add straight into the gradient
+        float* dst = reinterpret_cast<float*>(g.grad + (size_t)l * g.tsize + id);
+        if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
+        if (v.y != 0.0f) unsafeAtomicAdd(dst + 1, v.y);
+      }
+    }
+    __syncthreads();  // the staging area is reused by the next level
+  }
+  if (WANT_DPOS) {
+    float wxg, wyg, wzg;
+    tn_contract_bwd(c, dpx, dpy, dpz, wxg, wyg, wzg);
+    if (!live) { wxg = wyg = wzg = 0.0f; }
+    const float tm = (st + en) / 2.0f;
+    float v[6] = {wxg, wyg, wzg, wxg * tm, wyg * tm, wzg * tm};
+    // patch order: lanes 4 apart are consecutive depths of one ray when the group holds 4 rays
+    const int r32 = (int)ray;
+    const int lead = __shfl(r32, lane & 3, 64);
+    if (__all(r32 == lead)) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float r = v[k];
+        r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 8, 64);
+        r += __shfl_xor(r, 16, 64);
+        r += __shfl_xor(r, 32, 64);
+        if (lane < 4 && r != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), r);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (v[k] != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), v[k]);
+    }
+  }
+}
+
+#define FOLD_THREADS 512
+// How the fold sums a bucket's records in LDS.  LDS float atomics are no way to do it: ds_add_f32 is serialised lane by lane on gfx950
+// (~3 cycles per ACTIVE lane + ~20 per instruction, conflicts or not: scripts/microbench/lds_atomic_rate.hip; integer LDS atomics take 5-11
+// cycles per wave-instruction).  Block-wide passes separated by barriers are no way either: a barrier interval costs ~1 us with 32 waves on
+// the CU whatever it contains (profiles/r02_scatter_alternatives.md).  So every slot has a LOCK bit (one integer atomic OR claims it): the
+// claimant adds its record with a plain LDS read-modify-write and releases the bit with an atomic AND.  A wave's LDS instructions execute in
+// order, so the release is ordered behind the write, and no barrier is needed between records: the waves run through their records
+// independently.  A record that finds its slot locked is retried after the wave's other records.  Buckets of the SPARSE levels (a few dozen
+// live slots hammered by thousands of records) would spin on their locks: they go through the float atomic instead, whose cost does not
+// depend on conflicts.
+struct FoldRecs {
+  uint32_t idp[4];  // slots of records (2u, 2u+1) as two 16-bit halves
+  float2 vals[8];
+  uint32_t ok;      // bit j: record j exists and is non-zero
+  __device__ __forceinline__ uint32_t id(int j) const { return (j & 1) ? (idp[j >> 1] >> 16) : (idp[j >> 1] & 0xffffu); }
+};
+__device__ __forceinline__ void fold_load(const uint16_t* __restrict__ ip, const float2* __restrict__ vp, uint32_t first, uint32_t end, FoldRecs& r) {
+  // 8 records per thread as 4 pairs: every load instruction of a wave covers one contiguous piece
+  r.ok = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const uint32_t rec = first + u * 128;  // even
+    uint32_t iw = 0;
+    float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rec < end) {  // the bucket's capacity is even: the pair never leaves the bucket
+      iw = *reinterpret_cast<const uint32_t*>(ip + rec);
+      vq = *reinterpret_cast<const float4*>(vp + rec);
+    }
+    r.idp[u] = iw;
+    r.vals[2 * u] = make_float2(vq.x, vq.y);
+    r.vals[2 * u + 1] = make_float2(vq.z, vq.w);
+    if (rec < end && (vq.x != 0.0f || vq.y != 0.0f)) r.ok |= 1u << (2 * u);
+    if (rec + 1 < end && (vq.z != 0.0f || vq.w != 0.0f)) r.ok |= 2u << (2 * u);
+  }
+}
+// claim the slot's lock bit; true = this lane holds it now
+__device__ __forceinline__ bool fold_claim(uint32_t* lock, uint32_t id) {
+  const uint32_t bit = 1u << (id & 31u);
+  return !(__hip_atomic_fetch_or(&lock[id >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit);
+}
+__device__ __forceinline__ void fold_add_release(float2* acc, uint32_t* lock, uint32_t id, float2 v) {
+  float2 a = acc[id];
+  a.x += v.x;
+  a.y += v.y;
+  acc[id] = a;
+  (void)__hip_atomic_fetch_and(&lock[id >> 5], ~(1u << (id & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk) {
+  extern __shared__ float s_mem[];  // [2 << slice_log2] sums, then [(1 << slice_log2) / 32] lock words
+  uint32_t l = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.L; ++i)
+    if (blockIdx.x >= bk.blk0[i]) l = i;
+  const uint32_t chunk = bk.chunk[l], chunks_per_bucket = (bk.cap + chunk - 1) / chunk;
+  // chunk-major inside a level: consecutive blocks = the same chunk of consecutive buckets.  Blocks go to the 8 XCDs round-robin by index, and
+  // only the first chunk or two of a bucket hold records: bucket-major order put every live block of the sparse levels on XCDs 0 and 4
+  // (4 chunks per bucket), which then ran twice as long as the other six.
+  const uint32_t ch = (blockIdx.x - bk.blk0[l]) / bk.nslices, sl = (blockIdx.x - bk.blk0[l]) % bk.nslices;
+  (void)chunks_per_bucket;
+  const uint32_t count = min(bk.count[l * bk.nslices + sl], bk.cap);
+  const uint32_t begin = ch * chunk;
+  if (begin >= count) return;  // whole block leaves together
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x] = wall_clock64();
+  const uint32_t end = min(count, begin + chunk);
+  const bool split = count > chunk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t slots = 1u << bk.slice_log2;
+  const uint32_t words = (slots + 31) / 32;
+  float2* acc = reinterpret_cast<float2*>(s_mem);
+  uint32_t* lock = reinterpret_cast<uint32_t*>(s_mem + 2 * slots);
+  const size_t base = (size_t)l * bk.level_stride + (size_t)sl * bk.cap;  // multiple of 8 records
+  const uint16_t* ip = bk.idx + base;
+  const float2* vp = bk.val + base;
+  const uint32_t mine = wave * 512 + 2 * lane;
+  FoldRecs cur, nxt;
+  fold_load(ip, vp, begin + mine, end, cur);  // in flight while the LDS image is cleared
+  {
+    float4* z = reinterpret_cast<float4*>(s_mem);
+    const uint32_t nf = 4 * slots + words, n4 = nf / 4;
+    for (uint32_t t = tid; t < n4; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t t = 4 * n4 + tid; t < nf; t += FOLD_THREADS) s_mem[t] = 0.0f;
+  }
+  __syncthreads();
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x + 1] = wall_clock64();
+  const bool sparse = (bk.sparse_mask >> l) & 1u;
+  float* acc2 = s_mem + 2 * slots + words;  // second image: float atomics only (a float atomic racing a plain read-modify-write would be lost)
+  for (uint32_t blk = begin + wave * 512; blk < end; blk += FOLD_THREADS * 8) {  // per wave: no barrier inside
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if ((cur.ok >> j) & 1u) {
+        const uint32_t id = cur.id(j);
+        if (!sparse && fold_claim(lock, id)) {
+          fold_add_release(acc, lock, id, cur.vals[j]);
+        } else {  // slot busy (or a sparse level, where it nearly always is): no spinning, the float atomic takes it
+          if (cur.vals[j].x != 0.0f) unsafeAtomicAdd(&acc2[2 * id], cur.vals[j].x);
+          if (cur.vals[j].y != 0.0f) unsafeAtomicAdd(&acc2[2 * id + 1], cur.vals[j].y);
+        }
+      }
+      if (j == 0) {
+        // the next 8 records: issued only now, AFTER this iteration's records have been waited for -- the compiler waits with vmcnt(0),
+        // so loads issued before that wait would be waited for too and the memory latency would be paid in every iteration
+        nxt.ok = 0;
+        if (blk + FOLD_THREADS * 8 < end) fold_load(ip, vp, blk + FOLD_THREADS * 8 + 2 * lane, end, nxt);
+      }
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x + 2] = wall_clock64();
+  float2* dst = g.grad + (size_t)l * g.tsize + ((size_t)sl << bk.slice_log2);
+  for (uint32_t t0 = 0; t0 < slots; t0 += FOLD_THREADS * 8) {
+    float2 v[8], cv[8];
+    bool nz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // every load first (one round trip for the 8 slots of a thread), then the stores
+      const uint32_t t = t0 + u * FOLD_THREADS + tid;
+      nz[u] = false;
+      if (t < slots) {
+        const float2 a1 = acc[t], a2 = reinterpret_cast<const float2*>(s_mem + 2 * slots + words)[t];
+        v[u] = make_float2(a1.x + a2.x, a1.y + a2.y);
+        nz[u] = v[u].x != 0.0f || v[u].y != 0.0f;  // untouched slots keep an exactly-zero gradient
+        if (nz[u] && !split) cv[u] = dst[t];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t t = t0 + u * FOLD_THREADS + tid;
+      if (!nz[u]) continue;
+      if (!split) {
+        dst[t] = make_float2(cv[u].x + v[u].x, cv[u].y + v[u].y);
+      } else {
+        if (v[u].x != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t), v[u].x);
+        if (v[u].y != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t) + 1, v[u].y);
+      }
+    }
+  }
+  if (bk.trace) {
+    __syncthreads();
+    if (threadIdx.x == 0) bk.trace[16 * blockIdx.x + 3] = wall_clock64();
+  }
+}
+
 static int env_int(const char* name, int dflt, int lo, int hi) {
   const char* e = getenv(name);
   int v = e ? atoi(e) : dflt;
@@ -251,12 +638,111 @@ static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
   return used;
 }
 
+// TN_SCATTER_MODE: 1 = binned (default), 0 = atomics with dense replicas (the round-1 path; also what the dense data-parallel exchange uses)
+static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); return m; }
+static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 8192, 1024, 32768) & ~1023; return r; }
+static int merge_res() { static int r = env_int("TN_SCATTER_MERGE_RES", 256, 0, 1 << 20); return r; }
+
+static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
+                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
+  const int64_t P = N * (int64_t)S;
+  const int L = grid.num_levels;
+  BinK bk{};
+  bk.slice_log2 = std::min(TN_BIN_SLICE_LOG2, grid.log2_hashmap_size);
+  bk.nslices = 1 << (grid.log2_hashmap_size - bk.slice_log2);
+  TN_REQUIRE(bk.nslices <= TN_BIN_MAX_SLICES, "tn_grid_scatter: table too large for the binned path");
+  // per level tn_bin_level_records(P) records, split evenly over the buckets
+  const int64_t cap = (tn_bin_level_records(P) / bk.nslices) & ~7ll;
+  TN_REQUIRE(cap * bk.nslices < (1ll << 32), "tn_grid_scatter: batch too large for the binned path");
+  bk.cap = (uint32_t)cap;
+  bk.level_stride = (uint32_t)(cap * bk.nslices);
+  char* base = reinterpret_cast<char*>(scratch);
+  bk.count = reinterpret_cast<uint32_t*>(base);
+  const int64_t cnt_bytes = 256 + (int64_t)L * TN_BIN_MAX_SLICES * 4;
+  bk.val = reinterpret_cast<float2*>(base + cnt_bytes);
+  bk.idx = reinterpret_cast<uint16_t*>(base + cnt_bytes + (int64_t)L * tn_bin_level_records(P) * 8);
+  uint32_t nblk = 0;
+  for (int l = 0; l < L; ++l) {
+    if (grid.res[l] <= (float)merge_res()) bk.merge_mask |= 1u << l;
+    // live slots of the level: (res+1)^3 cells hashed into 2^log2T slots; below half of the table the buckets are sparse and hot
+    const double r1 = ceil((double)grid.res[l]) + 1.0;
+    const double T = (double)(1ll << grid.log2_hashmap_size), live = std::min(r1 * r1 * r1, T);
+    // ... or so many samples per live slot that a slot's lock would nearly always be found taken (the proposal grids: 256 samples per ray)
+    const bool sparse = r1 * r1 * r1 < 0.5 * T || 8.0 * (double)P > 16.0 * live;
+    bk.chunk[l] = sparse ? (uint32_t)fold_chunk_sparse() : 32768u;
+    if (sparse) bk.sparse_mask |= 1u << l;
+    bk.blk0[l] = nblk;
+    nblk += (uint32_t)(bk.nslices * tn_cdiv(bk.cap, bk.chunk[l]));
+  }
+  bk.blk0[L] = nblk;
+  hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4, stream);
+  TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
+  GridK gk = make_gridk(grid);
+  const int blocks = (int)tn_cdiv(P, BIN_THREADS);
+  // enough resident work for every CU: split the levels over blockIdx.y while the batch alone gives fewer than ~6 blocks per CU
+  int level_groups = 1;
+  while (level_groups < L && ((int64_t)blocks * level_groups < 256 * 6 || tn_cdiv(L, level_groups) * bk.nslices > BIN_MAX_COUNTERS)) level_groups *= 2;
+  level_groups = std::min(level_groups, L);
+  if (d_origins != nullptr)
+    hipLaunchKernelGGL(k_grid_bin<true>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S,
+                       d_origins, d_directions, level_groups, bk);
+  else
+    hipLaunchKernelGGL(k_grid_bin<false>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S,
+                       d_origins, d_directions, level_groups, bk);
+  TN_CHECK_LAUNCH("tn_grid_scatter(bin)");
+  const size_t shmem = ((size_t)(4u << bk.slice_log2) + (((1u << bk.slice_log2) + 31) / 32) + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_fold), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((4u << TN_BIN_SLICE_LOG2) + ((1u << TN_BIN_SLICE_LOG2) / 32) + 1) * sizeof(float)));
+    attr_set = true;
+  }
+  static int trace_on = env_int("TN_FOLD_TRACE", 0, 0, 1);
+  static unsigned long long* trace_buf = nullptr;
+  if (trace_on) {  // diagnostics only: synchronises and prints
+    if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)1 << 22);
+    (void)hipMemsetAsync(trace_buf, 0, (size_t)nblk * 128, stream);
+    bk.trace = trace_buf;
+  }
+  hipLaunchKernelGGL(k_grid_fold, dim3(nblk), dim3(FOLD_THREADS), shmem, stream, gk, bk);
+  if (trace_on) {
+    std::vector<unsigned long long> h((size_t)nblk * 16);
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (uint32_t b = 0; b < nblk; ++b)
+      if (h[16 * b]) { t0 = std::min(t0, h[16 * b]); t1 = std::max(t1, h[16 * b + 3]); }
+    fprintf(stderr, "[fold trace] %u blocks, span %.1f us (wall clock 100 MHz)\n", nblk, (t1 - t0) / 100.0);
+    if (const char* dump = getenv("TN_FOLD_TRACE_FILE")) {
+      if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+    for (int l = 0; l < L; ++l) {
+      double a = 0, b2 = 0, c = 0, first = 1e30, last = 0; int n = 0;
+      double st[9] = {0};
+      for (uint32_t b = bk.blk0[l]; b < bk.blk0[l + 1]; ++b) {
+        const unsigned long long* q = &h[16 * b];
+        if (!q[0]) continue;
+        ++n; a += (q[1] - q[0]) / 100.0; b2 += (q[2] - q[1]) / 100.0; c += (q[3] - q[2]) / 100.0;
+        first = std::min(first, (q[0] - t0) / 100.0); last = std::max(last, (q[3] - t0) / 100.0);
+        unsigned long long prev = q[1];
+        for (int k = 0; k < 9; ++k) { if (q[4 + k]) { st[k] += (q[4 + k] - prev) / 100.0; prev = q[4 + k]; } }
+      }
+      if (n) fprintf(stderr, "  level %2d: %4d active blocks, mean us: setup %.1f passes %.1f flush %.1f; first start %.1f last end %.1f | 1st iteration: passes %.2f %.2f %.2f %.2f retries %.2f %.2f %.2f sync %.2f float-atomics %.2f\n", l, n, a / n, b2 / n, c / n, first, last,
+                     st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n, st[6] / n, st[7] / n, st[8] / n);
+    }
+  }
+  TN_CHECK_LAUNCH("tn_grid_scatter(fold)");
+  return TN_OK;
+}
+
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
+  if (scratch != nullptr && dense_sum == nullptr && scatter_mode() == 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 &&
+      P * 8 < (1ll << 31))
+    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream);
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
   // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups
   int level_groups = 1;
@@ -329,7 +815,10 @@ int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hi
   return TN_OK;
 }
 
-extern "C" int64_t tn_hash_scatter_workspace_bytes(void) { return TN_SCATTER_SCRATCH_BYTES; }
+extern "C" int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t num_levels) {
+  if (num_points < 0 || num_levels < 1 || num_levels > TN_MAX_LEVELS) return TN_EINVAL;
+  return tn_scatter_scratch_bytes(num_points, num_levels);
+}
 
 extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
                                int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream) {

@@ -450,9 +450,10 @@ def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashma
     ld = g_enc.shape[1]
     ws = None
     if use_workspace:
+        need = int(_lib.load().tn_hash_scatter_workspace_bytes(N * S, num_levels))
         ws = _SCATTER_WS.get(str(origins.device))
-        if ws is None:
-            ws = torch.empty(int(_lib.load().tn_hash_scatter_workspace_bytes()), dtype=torch.uint8, device=origins.device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
             _SCATTER_WS[str(origins.device)] = ws
     g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
     check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),

@@ -1,0 +1,194 @@
+"""The PRODUCTION configuration of the backward against the CPU oracle at BASELINE sizes: 4096 rays in 2x2 pixel patches from the
+synthetic cameras, 2^19-slot main table (16 levels) / 2^17-slot proposal tables (5 levels), 48 / 256 / 96 samples per ray placed by a
+PDF resampling (so they pile up as a trained proposal sampler piles them up).
+
+At these sizes tn_hash_scatter runs in its production shape (all 16 levels binned, 64 buckets per level, coarse levels pre-merged;
+TN_SCATTER_MODE=0: 5 dense-replica levels + level groups), which the small-table op tests never reach.  The oracle side is plain
+autograd through oracle.hash_encode / field_density / field_color / prop_density on the CPU (seconds per case).
+"""
+import numpy as np
+import pytest
+import torch
+
+import thermal_nerfacto_oracle as orc
+from helpers import SEED
+from nerfstudio_thermal_amd import ops, synth
+from nerfstudio_thermal_amd.arena import ParamArena
+from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+from nerfstudio_thermal_amd.netparams import field_params, prop_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+N_RAYS = 4096
+
+
+def g(x):
+    return x.to(DEV).contiguous()
+
+
+def md(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
+
+
+def patch_rays(n=N_RAYS, seed=42):
+    """Rays of the bench workload: 2x2 patches, N/8 rays per camera, grouped by camera."""
+    cams = synth.synth_cameras()
+    idx = torch.from_numpy(synth.synth_ray_indices(cams, n, seed=seed))
+    t = lambda k: torch.from_numpy(cams[k])  # noqa: E731
+    o, d, _, _ = orc.generate_rays(idx, t("c2w"), t("fx"), t("fy"), t("cx"), t("cy"), t("distortion"))
+    return o, d, idx[:, 0].contiguous()
+
+
+def resampled_bins(n, S, tag):
+    """[n, S+1] bins from a PDF resampling of 256 spaced bins with peaky synthetic weights (train-mode jitter)."""
+    j0, j1, _ = (torch.from_numpy(j) for j in synth.synth_jitters(n))
+    nears, fars = torch.ones(n, 1) * 0.05, torch.ones(n, 1) * 1000.0
+    s0 = orc.spaced_bins(n, 256, j0)
+    if S == 256:
+        return s0, orc.s_to_euclidean(s0, nears, fars)
+    w = torch.from_numpy(synth.uniform(f"fs_w_{tag}", (n, 256, 1), 0.0, 1.0, SEED)) ** 6
+    s = orc.pdf_resample(s0, w, S, j1)
+    return s, orc.s_to_euclidean(s, nears, fars)
+
+
+def touched_slots(p_unit, res, log2T):
+    """bool [L * 2^log2T]: table slots that receive at least one (possibly zero-weight) contribution: the 8 ceil/floor corners of every sample."""
+    T = 1 << log2T
+    pts = p_unit.detach().reshape(-1, 3).numpy().astype(np.float32)
+    out = np.zeros(len(res) * T, dtype=bool)
+    P1, P2 = np.uint64(2654435761), np.uint64(805459861)
+    for l, r in enumerate(np.asarray(res, dtype=np.float32)):
+        sc = pts * r
+        f, c = np.floor(sc).astype(np.int64).astype(np.uint64), np.ceil(sc).astype(np.int64).astype(np.uint64)
+        for x in (f[:, 0], c[:, 0]):
+            for y in (f[:, 1], c[:, 1]):
+                for z in (f[:, 2], c[:, 2]):
+                    out[l * T + ((x ^ (y * P1) ^ (z * P2)) % np.uint64(T)).astype(np.int64)] = True
+    return torch.from_numpy(out)
+
+
+def check_table_grad(got, ref, tol_rel, what, touched=None, relu_flips=0):
+    """every entry within tol_rel of the largest entry (a deterministic 200k-entry sample first, then the whole table) and the zero
+    pattern: a slot no sample touches must be EXACTLY zero (Adam's eps = 1e-15 turns any residue into a full-size step); where the oracle's
+    zero is an exact cancellation of several contributions, a different summation order may leave a residue below the tolerance.
+
+    relu_flips: entries allowed beyond the tolerance when the gradient comes through the MLPs.  Of the 38 M hidden ReLU units of a
+    4096 x 48 batch a handful sit within fp32 rounding of zero, and the MFMA chain and ATen's GEMM round differently: for those samples the
+    ReLU derivative is 1 on one side and 0 on the other, and the 128 table entries each of them touches move by up to a percent of the
+    largest entry (scripts/debug_field_bwd.py: 121 of 16.7 M entries above 2.4e-4, mean |difference| 6e-9 of the largest entry)."""
+    got = got.detach().cpu()
+    scale = float(ref.abs().max())
+    assert scale > 0
+    dif = (got - ref).abs()
+    assert float(dif.mean()) <= 1e-6 * scale, (what, float(dif.mean()), scale)
+    bad = int((dif > tol_rel * scale).sum())
+    assert bad <= relu_flips, (what, bad, float(dif.max()), scale)
+    if relu_flips:
+        assert float(dif.max()) <= 5e-3 * scale, (what, float(dif.max()), scale)
+    differ = (got == 0) != (ref == 0)
+    assert int(differ.sum()) <= 4, (what, int(differ.sum()))
+    if touched is not None:
+        assert not bool(got[~touched].any()), what + ": an untouched slot has a non-zero gradient"
+        assert not bool(ref[~touched].any())
+
+
+def test_main_grid_scatter_production_shape():
+    """tn_hash_scatter alone on the 16 x 2^19 grid, 4096 x 48 samples: d table (every entry + exact zero pattern), d origins, d directions."""
+    L, log2T, S = 16, 19, 48
+    o0, d0, _ = patch_rays()
+    _, e = resampled_bins(N_RAYS, S, "main")
+    smp = orc.Samples(s_bins=e, e_bins=e)
+    table = (torch.from_numpy(synth.uniform("fs_table", (L * 2**log2T, 2), seed=SEED)) * 0.5).requires_grad_(True)
+    o = o0.clone().requires_grad_(True)
+    d = d0.clone().requires_grad_(True)
+    res = orc.level_resolutions(L, 16, 2048)
+    p, _ = orc.unit_cube_positions(smp.positions(o, d))
+    enc = orc.hash_encode(p.view(-1, 3), table, res, log2T)
+    g_enc = torch.from_numpy(synth.uniform("fs_g", (N_RAYS * S, 2 * L), seed=SEED))
+    (enc * g_enc).sum().backward()
+    tg = torch.zeros((L * 2**log2T, 2), device=DEV)
+    d_o, d_d = torch.zeros((N_RAYS, 3), device=DEV), torch.zeros((N_RAYS, 3), device=DEV)
+    ops.hash_scatter(g(table.detach()), tg, L, log2T, res.tolist(), g(o0), g(d0), g(e), g(g_enc), d_o, d_d)
+    touched = touched_slots(p, res, log2T)
+    check_table_grad(tg, table.grad, 2e-5, "main grid", touched)
+    assert md(d_o, o.grad) <= 2e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 2e-4 * float(d.grad.abs().max())
+    # accumulation semantics: a second call adds the same gradient again
+    ops.hash_scatter(g(table.detach()), tg, L, log2T, res.tolist(), g(o0), g(d0), g(e), g(g_enc), None, None)
+    check_table_grad(tg * 0.5, table.grad, 2e-5, "main grid, accumulated twice", touched)
+
+
+def test_field_bwd_production_shape():
+    """tn_field_fwd + tn_field_bwd at 4096 x 48 samples on the default field: density/rgb forward and EVERY gradient vs oracle autograd."""
+    ocfg = orc.OracleConfig(density_mode="shared")
+    shapes = {k: v for k, v in orc.param_shapes(ocfg).items() if k.startswith("field.")}
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=SEED).items()}
+    cfg = ThermalNerfactoModelConfig(density_mode="shared")
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    S = 48
+    o0, d0, cam = patch_rays()
+    _, e = resampled_bins(N_RAYS, S, "field")
+    smp = orc.Samples(s_bins=e, e_bins=e)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = o0.clone().requires_grad_(True)
+    d = d0.clone().requires_grad_(True)
+    dens, geo, pre, _ = orc.field_density(p, "field", ocfg, smp.positions(o, d))
+    rgb = orc.field_color(p, "field", ocfg, d.detach(), geo, cam, True)
+    fld = field_params(arena, "field", cfg, with_grads=True)
+    hd, hrgb, hpre = ops.field_fwd(fld, g(o0), g(d0), g(cam), g(e), True, want_pre=True)
+    assert md(hpre, pre[..., 0]) <= 2e-5
+    assert md(hd, dens[..., 0]) <= 1e-4  # north_star: 1e-4 abs on density on identical samples
+    assert md(hrgb, rgb) <= 1e-4
+    # upstream gradients of the size a real step produces (weights * d loss): small for density, O(1) for colour
+    gd = torch.from_numpy(synth.uniform("fs_gd", (N_RAYS, S, 1), seed=SEED)) * 1e-2
+    gc = torch.from_numpy(synth.uniform("fs_gc", (N_RAYS, S, 4), seed=SEED))
+    ((dens * gd).sum() + (rgb * gc).sum()).backward()
+    arena.zero_grad()
+    d_o = torch.zeros((N_RAYS, 3), device=DEV)
+    d_d = torch.zeros((N_RAYS, 3), device=DEV)
+    ops.field_bwd(fld, g(o0), g(d0), g(cam), g(e), g(gd[..., 0]), g(gc), d_o, d_d)
+    k = orc.field_keys("field")
+    check_table_grad(arena.grad_view(k["table"]), p[k["table"]].grad, 3e-4, "field table", relu_flips=512)  # the scatter alone holds 2e-5 above
+    for short in ("w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
+        ref = p[k[short]].grad
+        scale = float(ref.abs().max())
+        assert md(arena.grad_view(k[short]), ref) <= 3e-4 * scale, (short, md(arena.grad_view(k[short]), ref), scale)
+    assert md(d_o, o.grad) <= 3e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
+
+
+@pytest.mark.parametrize("lvl,S", [(0, 256), (1, 96)])
+def test_prop_bwd_production_shape(lvl, S):
+    """tn_prop_density_fwd/bwd at 4096 rays on the default 5 x 2^17 proposal grids."""
+    ocfg = orc.OracleConfig(density_mode="shared")
+    shapes = {k: v for k, v in orc.param_shapes(ocfg).items() if k.startswith("proposal_networks.")}
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=SEED).items()}
+    cfg = ThermalNerfactoModelConfig(density_mode="shared")
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    o0, d0, _ = patch_rays()
+    _, e = resampled_bins(N_RAYS, S, f"prop{lvl}")
+    smp = orc.Samples(s_bins=e, e_bins=e)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = o0.clone().requires_grad_(True)
+    d = d0.clone().requires_grad_(True)
+    dens = orc.prop_density(p, "proposal_networks", lvl, ocfg, smp.positions(o, d))
+    net = prop_params(arena, "proposal_networks", lvl, cfg, with_grads=True)
+    hd = ops.prop_density_fwd(net, g(o0), g(d0), g(e))
+    ref = dens[..., 0].detach()
+    assert md(hd / ref.to(DEV).clamp_min(1e-6), (ref / ref.clamp_min(1e-6))) <= 5e-5
+    gd = torch.from_numpy(synth.uniform(f"fs_gp{lvl}", (N_RAYS, S, 1), seed=SEED)) * 1e-2
+    (dens * gd).sum().backward()
+    arena.zero_grad()
+    d_o = torch.zeros((N_RAYS, 3), device=DEV)
+    d_d = torch.zeros((N_RAYS, 3), device=DEV)
+    ops.prop_density_bwd(net, g(o0), g(d0), g(e), g(gd[..., 0]), d_o, d_d)
+    k = orc.prop_keys("proposal_networks", lvl)
+    check_table_grad(arena.grad_view(k["table"]), p[k["table"]].grad, 2e-4, f"prop{lvl} table", relu_flips=64)
+    for short in ("w0", "b0", "w1", "b1"):
+        r = p[k[short]].grad
+        scale = float(r.abs().max())
+        assert md(arena.grad_view(k[short]), r) <= 3e-4 * scale, (short, md(arena.grad_view(k[short]), r), scale)
+    assert md(d_o, o.grad) <= 3e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
