@@ -1,6 +1,9 @@
 """Generate golden vectors from the REFERENCE itself (build container only; test infrastructure).
 
-    python oracle/make_golden.py            # writes tests/golden/*.npz
+    python oracle/make_golden.py            # writes tests/golden/*.npz (the "tiny" set: 2^12 / 2^10 tables, 32 rays)
+    python oracle/make_golden.py --default  # writes tests/golden/model_{shared,separate}_default.npz: the reference at its DEFAULT table
+                                            # sizes (16 x 2^19 main, 5 x 2^17 proposal) on 64 rays; only the rays and the outputs are stored,
+                                            # the 22 M / 39 M parameters are regenerated on both sides by synth.synth_params
 
 Imports /root/reference through oracle/ref_import.py, builds the reference's own
 ThermalNerfactoModel (implementation="torch") at a small table size, loads the
@@ -41,8 +44,10 @@ from nerfstudio.model_components.ray_generators import RayGenerator  # noqa: E40
 from nerfstudio.models.thermal_nerfacto import ThermalNerfactoModelConfig  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-TINY = dict(log2_hashmap_size=12, prop_log2_hashmap_size=10)
-N_RAYS = 32
+DEFAULT = "--default" in sys.argv
+TINY = {} if DEFAULT else dict(log2_hashmap_size=12, prop_log2_hashmap_size=10)  # {} = the reference's defaults
+N_RAYS = 64 if DEFAULT else 32
+SUFFIX = "_default" if DEFAULT else ""
 SEED = 0
 
 
@@ -232,6 +237,9 @@ def golden_model(mode: str, rb_src):
     jit = [torch.from_numpy(j) for j in synth.synth_jitters(N_RAYS)]
     jit_t = [torch.from_numpy(j) for j in synth.synth_jitters(N_RAYS, tag="_thermal")]
     out = {"mode": mode, "num_rays": N_RAYS}
+    if DEFAULT:  # the tiny set reads its rays from raygen.npz
+        out["rays/origins"], out["rays/directions"] = tonp(rb_src.origins), tonp(rb_src.directions)
+        out["rays/camera_indices"] = tonp(rb_src.camera_indices)
 
     def bundle():
         return RayBundle(origins=rb_src.origins.clone(), directions=rb_src.directions.clone(),
@@ -301,10 +309,13 @@ def golden_model(mode: str, rb_src):
         p = sd[k].detach().reshape(-1)
         ii = sample_indices(k, p.numel())
         out[f"adam_val/{k}"] = tonp(p[torch.from_numpy(ii)])
-    np.savez_compressed(os.path.join(GOLDEN, f"model_{mode}.npz"), **out)
+    np.savez_compressed(os.path.join(GOLDEN, f"model_{mode}{SUFFIX}.npz"), **out)
     # the checkpoint contract: every state_dict key of the reference model with its shape and dtype (default table sizes differ only in shape)
     import json
 
+    if DEFAULT:
+        print(mode, "default sizes", {k: float(v) for k, v in losses.items()})
+        return
     with open(os.path.join(GOLDEN, f"state_dict_keys_{mode}.json"), "w") as f:
         json.dump({k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}, f, indent=0, sort_keys=True)
     print(mode, {k: float(v) for k, v in losses.items()})
@@ -313,6 +324,12 @@ def golden_model(mode: str, rb_src):
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
+    if DEFAULT:
+        cams, ref = reference_cameras()
+        rb = RayGenerator(ref)(torch.from_numpy(synth.synth_ray_indices(cams, N_RAYS)))
+        for mode in ("shared", "separate"):
+            golden_model(mode, rb)
+        return
     rb = golden_raygen()
     golden_units()
     for mode in ("shared", "separate"):

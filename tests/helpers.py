@@ -17,6 +17,18 @@ def tiny_cfg(mode="shared", **kw):
     return orc.OracleConfig(density_mode=mode, **{**TINY, **kw})
 
 
+# golden sets produced by oracle/make_golden.py from the reference itself: name -> (table-size overrides, rays, file suffix)
+SIZES = {"tiny": (TINY, GOLDEN_RAYS, ""), "default": ({}, 64, "_default")}
+
+
+def size_cfg(size, mode="shared", **kw):
+    return orc.OracleConfig(density_mode=mode, **{**SIZES[size][0], **kw})
+
+
+def golden_file(golden_dir, mode, size="tiny"):
+    return np.load(os.path.join(golden_dir, f"model_{mode}{SIZES[size][2]}.npz"))
+
+
 def make_params(cfg, seed=SEED, requires_grad=False):
     p = {k: torch.from_numpy(v) for k, v in synth.synth_params(orc.param_shapes(cfg), seed=seed).items()}
     if requires_grad:
@@ -25,17 +37,23 @@ def make_params(cfg, seed=SEED, requires_grad=False):
     return p
 
 
-def golden_inputs(golden_dir):
-    g = np.load(os.path.join(golden_dir, "raygen.npz"))
+def golden_inputs(golden_dir, size="tiny"):
+    n = SIZES[size][1]
+    if size == "tiny":
+        g = np.load(os.path.join(golden_dir, "raygen.npz"))
+        rays = {k: g[k] for k in ("origins", "directions", "camera_indices")}
+    else:  # the default-size set carries its own rays
+        g = golden_file(golden_dir, "shared", size)
+        rays = {k: g[f"rays/{k}"] for k in ("origins", "directions", "camera_indices")}
     cams = synth.synth_cameras()
-    idx = synth.synth_ray_indices(cams, GOLDEN_RAYS)
+    idx = synth.synth_ray_indices(cams, n)
     img, is_th = synth.synth_gt(idx, cams)
     return {
         "cams": cams, "ray_indices": idx, "image": torch.from_numpy(img), "is_thermal": torch.from_numpy(is_th),
-        "origins": torch.from_numpy(g["origins"]), "directions": torch.from_numpy(g["directions"]),
-        "camera_indices": torch.from_numpy(g["camera_indices"])[:, 0],
-        "jitters": [torch.from_numpy(j) for j in synth.synth_jitters(GOLDEN_RAYS)],
-        "jitters_thermal": [torch.from_numpy(j) for j in synth.synth_jitters(GOLDEN_RAYS, tag="_thermal")],
+        "origins": torch.from_numpy(rays["origins"]), "directions": torch.from_numpy(rays["directions"]),
+        "camera_indices": torch.from_numpy(rays["camera_indices"])[:, 0],
+        "jitters": [torch.from_numpy(j) for j in synth.synth_jitters(n)],
+        "jitters_thermal": [torch.from_numpy(j) for j in synth.synth_jitters(n, tag="_thermal")],
     }
 
 

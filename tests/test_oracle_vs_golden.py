@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import thermal_nerfacto_oracle as orc
-from helpers import pixel_batch, golden_inputs, make_params, maxdiff, sample_indices, tiny_cfg, GOLDEN_RAYS, SEED
+from helpers import pixel_batch, golden_file, golden_inputs, make_params, maxdiff, sample_indices, size_cfg, GOLDEN_RAYS, SEED
 from nerfstudio_thermal_amd import synth
 
 
@@ -87,12 +87,14 @@ def test_raygen(golden_dir):
 EVAL_KEYS = ["rgb", "rgb_thermal", "accumulation", "depth", "expected_depth", "density", "prop_depth_0", "prop_depth_1"]
 
 
+# "default": the reference at its default table sizes (16 x 2^19 / 5 x 2^17), 64 rays -- SURVEY 8c's second golden set
+@pytest.mark.parametrize("size", ["tiny", "default"])
 @pytest.mark.parametrize("mode", ["shared", "separate"])
-def test_model_eval(golden_dir, mode):
-    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
-    cfg = tiny_cfg(mode)
+def test_model_eval(golden_dir, mode, size):
+    g = golden_file(golden_dir, mode, size)
+    cfg = size_cfg(size, mode)
     params = make_params(cfg)
-    gi = golden_inputs(golden_dir)
+    gi = golden_inputs(golden_dir, size)
     with torch.no_grad():
         out = orc.get_outputs(params, cfg, gi["origins"], gi["directions"], gi["camera_indices"], training=False)
     keys = list(EVAL_KEYS)
@@ -106,12 +108,13 @@ def test_model_eval(golden_dir, mode):
         assert maxdiff(out[k], ref) <= 2e-6, (k, maxdiff(out[k], ref))
 
 
+@pytest.mark.parametrize("size", ["tiny", "default"])
 @pytest.mark.parametrize("mode", ["shared", "separate"])
-def test_model_train_losses_grads_adam(golden_dir, mode):
-    g = np.load(os.path.join(golden_dir, f"model_{mode}.npz"))
-    cfg = tiny_cfg(mode)
+def test_model_train_losses_grads_adam(golden_dir, mode, size):
+    g = golden_file(golden_dir, mode, size)
+    cfg = size_cfg(size, mode)
     params = make_params(cfg, requires_grad=True)
-    gi = golden_inputs(golden_dir)
+    gi = golden_inputs(golden_dir, size)
     out = orc.get_outputs(
         params, cfg, gi["origins"], gi["directions"], gi["camera_indices"], training=True,
         anneal=float(g["train/anneal"]), jitters=gi["jitters"], jitters_thermal=gi["jitters_thermal"],
