@@ -156,7 +156,8 @@ int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t str
 int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                  int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
                  tn_stream_t stream);
-/* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated). */
+/* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated).
+ * d_rgb = NULL: density-only backward of tn_field_density_fwd(training != 0) (see there). */
 int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                  const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins,
                  float* d_directions, tn_stream_t stream);
@@ -184,9 +185,11 @@ int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const
                                tn_stream_t stream);
 int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
                         tn_stream_t stream);
-/* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458). */
+/* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458): get_density without get_outputs.
+ * training != 0 keeps what the backward needs in `workspace` (sized with tn_field_workspace_bytes(N*S, 1)); that backward is
+ * tn_field_bwd / tn_field_bwd_phase with d_rgb = NULL: the colour head, its three weight gradients and the appearance embedding are skipped. */
 int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                         void* workspace, float* density, tn_stream_t stream);
+                         int32_t training, void* workspace, float* density, tn_stream_t stream);
 
 /* ---- a15/a16  RGBRenderer / RGBTRenderer (background "last_sample"), AccumulationRenderer, DepthRenderer median+expected
  *          (model_components/renderers.py:118-133,238-245,292-307,418-425,509,547-576).

@@ -69,7 +69,7 @@ SIGNATURES = {
     "tn_field_dense_count": (_i64, [C.POINTER(TnField), _i64, _i32, _i32]),
     "tn_field_bwd_scatter_dense": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _p]),
     "tn_field_dense_fold": (C.c_int, [C.POINTER(TnField), _i64, _i32, _i32, _p, _p]),
-    "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_minmax_init": (C.c_int, [_p, _p]),
     "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "tn_clip_depth": (C.c_int, [_p, _p, _i64, _p]),

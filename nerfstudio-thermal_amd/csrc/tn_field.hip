@@ -17,6 +17,7 @@
 // h = lane>>5), accumulator register r in [0,16) holds feature row  R(r,h) = (r&3) + 8*(r>>2) + 4*h  of a 32-row tile.
 // Exact fp32: the MFMA is a k-ordered fmaf chain (no reduced precision), which the 1e-4 density tolerance needs.
 #include "tn_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -345,9 +346,12 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
 #undef AF
 }
 
-// density only (no head): cross-evaluated density2 / density2_thermal
+// density only (no head): cross-evaluated density2 / density2_thermal.  TRAIN keeps what the density-only backward needs: relu(layer 0) and
+// the density logit (in head-input slot 16, where the full forward leaves it).
+template <bool TRAIN>
 __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __restrict__ pack, const float* __restrict__ enc,
-                                                               const float* __restrict__ sel, int64_t P, float* __restrict__ density) {
+                                                               const float* __restrict__ sel, int64_t P, float* __restrict__ density,
+                                                               float* __restrict__ h1s, float* __restrict__ hins) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
     *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
@@ -367,17 +371,24 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0 = MFMA(AF(0, 0, 0, r), in0[r], a0); a1 = MFMA(AF(0, 1, 0, r), in0[r], a1); }
     a0 = relu16(a0); a1 = relu16(a1);
+    if (TRAIN && valid) { store_tile(h1s, p, 64, 0, h, a0); store_tile(h1s, p, 64, 1, h, a1); }
     f32x16 bo = bias_tile(lbias, 1, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
-    if (valid && h == 0) density[p] = expf(bo[0]) * sel[p];
+    if (valid && h == 0) {
+      density[p] = expf(bo[0]) * sel[p];
+      if (TRAIN) hins[p * 64 + 16] = bo[0];
+    }
   }
 #undef AF
 }
 
 // ---- backward MLP chain ---------------------------------------------------------------------------------------------------
+// DENS_ONLY: backward of k_field_density_only<true> -- no colour gradient, so the head layers, their saved activations and d_rgb are never
+// touched; only the density logit's row of the base output carries a gradient.
+template <bool DENS_ONLY>
 __global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
                                                           const float* __restrict__ d_rgb, const float* __restrict__ d_density, int64_t P, int C,
                                                           const float* __restrict__ h1s, const float* __restrict__ hins,
@@ -400,6 +411,8 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restric
     int64_t p = tile * TILE + j;
     bool valid = p < P;
     int64_t pc = valid ? p : P - 1;
+    f32x16 di0 = zero16;
+    if (!DENS_ONLY) {
     // ---- sigmoid backward: g3_c = d_rgb_c * y (1-y) ; rows 0..3 live in half 0, registers 0..3
     float g3[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid && h == 0) {
@@ -433,13 +446,14 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restric
     if (valid) { store_tile(gy_hh1, p, 64, 0, h, dc0); store_tile(gy_hh1, p, 64, 1, h, dc1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---- d head-input slots = Wslot^T . d hh1
-    f32x16 di0 = zero16, di1 = zero16;
+    f32x16 di1 = zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
     if (valid) { store_tile(g_hin, p, 64, 0, h, di0); store_tile(g_hin, p, 64, 1, h, di1); }
     __builtin_amdgcn_sched_barrier(0);
+    }  // !DENS_ONLY
     // ---- d base_out rows: slots 16..31 = registers 8..15 of tile 0; row 0 (half 0, reg 0) takes the trunc_exp gradient instead
     float dbo[8];
 #pragma unroll
@@ -702,20 +716,24 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
 }
 
 extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                                    void* workspace, float* density, tn_stream_t stream) {
+                                    int32_t training, void* workspace, float* density, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_density_fwd", false);
   if (rc) return rc;
   TN_REQUIRE(origins && directions && e_bins && workspace && density, "tn_field_density_fwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_density_fwd: bad N=%lld S=%d", (long long)N, S);
-  if (N == 0) return TN_OK;
   int64_t P = N * (int64_t)S;
-  FieldWs ws = ws_layout(workspace, P, 0);
+  FieldWs ws = ws_layout(workspace, P, training ? 1 : 0);
   rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
   if (rc) return rc;
   size_t shmem = PACK_FWD_TOTAL * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL(k_field_density_only, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density);
+  if (training) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_density_only<true>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density, ws.h1, ws.hin);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_density_only<false>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density, nullptr, nullptr);
+  }
   TN_CHECK_LAUNCH("tn_field_density_fwd");
   return TN_OK;
 }
@@ -737,7 +755,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_bwd", true);
   if (rc) return rc;
-  TN_REQUIRE(origins && directions && camera_indices && e_bins && d_density && d_rgb && workspace, "tn_field_bwd: null pointer");
+  TN_REQUIRE(origins && directions && camera_indices && e_bins && d_density && workspace, "tn_field_bwd: null pointer");
+  const bool dens_only = d_rgb == nullptr;  // backward of tn_field_density_fwd(training): no colour path at all
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN)) == 0 && phases != 0, "tn_field_bwd: bad phase set %d", phases);
@@ -751,9 +770,15 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   int rcw = TN_OK;
   if (phases & TN_BWD_MLP) {
     size_t shmem = PACK_BWD_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_mlp_bwd, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin, ws.hh1,
-                       ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
+    if (dens_only) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL(k_field_mlp_bwd<true>, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin,
+                         ws.hh1, ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL(k_field_mlp_bwd<false>, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin,
+                         ws.hh1, ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
+    }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
     // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch, on the companion stream beside the table scatter
     // (the GEMMs stream the saved activations from HBM, the scatter is bound by atomic requests: they overlap almost perfectly)
@@ -762,13 +787,15 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     const int64_t* ci = camera_indices;
     WgradProb pr[WGRAD_MAX_PROBS];
     int n = 0;
-    pr[n++] = make_prob(ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, field->ghw1, 64, field->ghb1);
-    pr[n++] = make_prob(ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, field->ghw0, 63, field->ghb0, 1);
-    pr[n++] = make_prob(ws.g3, 4, C, ws.hh2, 64, 64, 0, field->ghw2, 64, field->ghb2);
+    if (!dens_only) {
+      pr[n++] = make_prob(ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, field->ghw1, 64, field->ghb1);
+      pr[n++] = make_prob(ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, field->ghw0, 63, field->ghb0, 1);
+      pr[n++] = make_prob(ws.g3, 4, C, ws.hh2, 64, 64, 0, field->ghw2, 64, field->ghb2);
+    }
     pr[n++] = make_prob(ws.gy_bo, 16, 16, ws.h1, 64, 64, 0, field->gw1, 64, field->gb1);
     pr[n++] = make_prob(ws.gy_h1, 64, 64, ws.enc, 32, 32, 0, field->gw0, 32, field->gb0);
     // appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(head input slot 32+e); 32 cameras per problem
-    int base = 0;
+    int base = dens_only ? field->num_images : 0;  // the embedding only feeds the colour head
     for (; base < field->num_images && n < WGRAD_MAX_PROBS; base += 32)
       pr[n++] = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
     rcw = launch_wgrad_batch(pr, n, P, wst);

@@ -206,9 +206,9 @@ class RenderEngine:
         out.update(self._branch_outputs(bt, "_thermal", training))
         branches["_thermal"] = bt
         if self.cfg.density_loss_mult > 0 or not training:
-            if training:
-                d2, _, _ = ops.field_fwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, True, tag="cross")
-                d2t, _, _ = ops.field_fwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, True, tag="cross")
+            if training:  # density path only, activations kept for the density-only backward
+                d2 = ops.field_density_fwd(self.field, bt.origins, bt.directions, bt.levels[-1].e_bins, training=True, tag="cross")
+                d2t = ops.field_density_fwd(self.field_thermal, b.origins, b.directions, b.levels[-1].e_bins, training=True, tag="cross")
             else:
                 d2 = ops.field_density_fwd(self.field, bt.origins, bt.directions, bt.levels[-1].e_bins)
                 d2t = ops.field_density_fwd(self.field_thermal, b.origins, b.directions, b.levels[-1].e_bins)
@@ -351,10 +351,10 @@ class RenderEngine:
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
         if self.separate and c.density_loss_mult > 0:
             # density2 = field at the thermal branch's samples/rays; density2_thermal = field_thermal at the rgb branch's
-            zeros_rgb = torch.zeros((N, self.counts[-1], self.field.num_channels), device=dev)
-            zeros_t = torch.zeros((N, self.counts[-1], 1), device=dev)
-            ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, zeros_rgb, bt._d_o, bt._d_d, tag="cross")
-            ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, zeros_t, b._d_o, b._d_d, tag="cross")
+            # density-only backward: the colour head saw these samples with a zero gradient (models/thermal_nerfacto.py:447-458 calls
+            # get_density only), so its backward, its three weight-gradient GEMMs and the embedding rows are skipped
+            ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, None, bt._d_o, bt._d_d, tag="cross")
+            ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, None, b._d_o, b._d_d, tag="cross")
         for sfx, br in branches.items():
             pose = self.pose_thermal if sfx else self.pose
             if pose is None:

@@ -211,13 +211,12 @@ class _RenderFn(torch.autograd.Function):
             d_od[sfx] = (d_o, d_d)
         if g_d2 is not None or g_d2t is not None:
             b, bt = branches[""], branches["_thermal"]
-            S2 = eng.counts[-1]
             if g_d2 is not None:
-                ops.field_bwd(eng.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2[..., 0].contiguous(),
-                              torch.zeros((N, S2, eng.field.num_channels), device=dev), *d_od["_thermal"], tag="cross")
+                ops.field_bwd(eng.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2[..., 0].contiguous(), None, *d_od["_thermal"],
+                              tag="cross")
             if g_d2t is not None:
-                ops.field_bwd(eng.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t[..., 0].contiguous(),
-                              torch.zeros((N, S2, 1), device=dev), *d_od[""], tag="cross")
+                ops.field_bwd(eng.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t[..., 0].contiguous(), None, *d_od[""],
+                              tag="cross")
         for sfx, br in branches.items():
             pose = eng.pose_thermal if sfx else eng.pose
             if pose is None:

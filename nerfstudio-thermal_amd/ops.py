@@ -370,32 +370,30 @@ def field_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
     return dens, rgb, pre
 
 
-def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_bins: Tensor, repack: bool = True) -> Tensor:
+def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_bins: Tensor, repack: bool = True, training: bool = False,
+                      tag: str = "density_only") -> Tensor:
+    """get_density alone.  training=True keeps the activations of the density path in the workspace `tag` for field_bwd(..., d_rgb=None)."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
-    # uses its own scratch so that a training workspace (saved activations) is not clobbered
-    key = "ws_density_only"
-    need = int(_lib.load().tn_field_workspace_bytes(N * S, 0))
-    ws = fld._ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
-        fld._ws[key] = ws
+    # its own scratch (by tag) so that the workspace of the full forward (saved activations) is not clobbered
+    ws = fld.workspace(N * S, training, tag)
     s = fld.cstruct()
     if repack:
         check(_lib.load().tn_field_pack_weights(C.byref(s), C.c_void_p(ws.data_ptr()), _stream()), "tn_field_pack_weights")
     dens = torch.empty((N, S), device=origins.device)
     check(_lib.load().tn_field_density_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
-                                           _f32(e_bins, "e_bins", (N, S + 1)), N, S, C.c_void_p(ws.data_ptr()), _f32(dens, "density"), _stream()),
-          "tn_field_density_fwd")
+                                           _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()),
+                                           _f32(dens, "density"), _stream()), "tn_field_density_fwd")
     return dens
 
 
-def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, d_density: Tensor, d_rgb: Tensor,
+def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, e_bins: Tensor, d_density: Tensor, d_rgb: Optional[Tensor],
               d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, tag: str = "main") -> None:
+    """d_rgb=None: density-only backward of field_density_fwd(training=True, tag=tag)."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
     ws = fld.workspace(N * S, True, tag)
     s = fld.cstruct(need_grad=True)
     check(_lib.load().tn_field_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
-                                   _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)),
+                                   _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), _f32(d_rgb, "d_rgb", (N, S, fld.num_channels), True),
                                    N, S, C.c_void_p(ws.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True),
                                    _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
 

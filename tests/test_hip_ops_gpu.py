@@ -233,6 +233,42 @@ def test_field_fwd_bwd(mode, training):
     assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
 
 
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_field_density_only_fwd_bwd(mode):
+    """get_density alone with its own backward (density2 / density2_thermal of separate mode, models/thermal_nerfacto.py:447-458): every
+    gradient of the density path vs oracle autograd, and nothing of the colour head is touched."""
+    ocfg, params, cfg, arena = setup_pair(mode)
+    N, S = 100, 48
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    prefix = "field_thermal" if mode == "separate" else "field"
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = r["origins"].clone().requires_grad_(True)
+    d = r["directions"].clone().requires_grad_(True)
+    dens, _, _, _ = orc.field_density(p, prefix, ocfg, smp.positions(o, d))
+    gd = torch.from_numpy(synth.uniform("gfd_only", (N, S, 1), seed=SEED))
+    (dens * gd).sum().backward()
+    fld = field_params(arena, prefix, cfg, with_grads=True)
+    hd = ops.field_density_fwd(fld, g(r["origins"]), g(r["directions"]), g(e), training=True, tag="cross")
+    assert md(hd, dens[..., 0]) <= 1e-4
+    arena.zero_grad()
+    d_o = torch.zeros((N, 3), device=DEV)
+    d_d = torch.zeros((N, 3), device=DEV)
+    ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(r["camera_indices"]), g(e), g(gd[..., 0]), None, d_o, d_d, tag="cross")
+    k = orc.field_keys(prefix)
+    for short in ("table", "w0", "b0", "w1", "b1"):
+        ref = p[k[short]].grad
+        scale = float(ref.abs().max())
+        assert md(arena.grad_view(k[short]), ref) <= 3e-4 * scale, (short, md(arena.grad_view(k[short]), ref), scale)
+    for short in ("hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
+        assert p[k[short]].grad is None
+        assert float(arena.grad_view(k[short]).abs().max()) == 0.0, short
+    assert md(d_o, o.grad) <= 3e-4 * float(o.grad.abs().max())
+    assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
+
+
 def test_field_default_table_size_hash_parity():
     """Full 2^19-entry tables / 2047-resolution top level: exercises the uint32 hash against the oracle's int64 one."""
     ocfg = orc.OracleConfig(density_mode="shared")

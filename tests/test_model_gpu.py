@@ -244,18 +244,19 @@ def test_non_default_config_matches_oracle():
         assert abs(float(got.double().norm()) - rn) <= 2e-2 * rn + 1e-12, (name, float(got.double().norm()), rn)
 
 
-def test_full_size_separate_mode_run_is_stable():
+@pytest.mark.parametrize("rays", [4096, 8192])  # 8192 = the batch BASELINE config 2 names
+def test_full_size_separate_mode_run_is_stable(rays):
     """BASELINE config 2 (separate density fields + density loss, default table sizes): 80 fused steps stay finite and the losses fall."""
     import bench
 
     dev = torch.device(DEV, 0)
     torch.manual_seed(4321)
     cfg, arena, eng = bench.build_engine(dev, mode="separate")
-    cam_t, _, _, _ = bench.make_batch(dev, 4096, 42)
+    cam_t, _, _, _ = bench.make_batch(dev, rays, 42)
     cache = bench.make_image_cache(dev)
     hist = []
     for step in range(80):
-        losses = bench.one_step(eng, cam_t, cache, 4096, step, None)
+        losses = bench.one_step(eng, cam_t, cache, rays, step, None)
         if step % 20 == 0 or step == 79:
             hist.append({k: float(v) for k, v in losses.items()})
     assert all(np.isfinite(v) for h in hist for v in h.values()), hist[-1]
