@@ -310,14 +310,18 @@ class RenderEngine:
             # streams, the number of hardware queues ROCm multiplexes streams onto by default -- a fifth stream shares a queue with another
             # and serialises behind it (measured: one side stream per proposal level made the step 1.7x slower).
             side = None
+            # Without the overlapped exchange only the level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the side
+            # stream; the level-1 network follows the main field on the main stream.  Both on the side stream left the main stream idle
+            # for the last ~250 us of every proposal-update step (rocprofv3 timeline of the step).
+            on_side = (0, 1) if pipelined else (0,)
             if br.prop_grad:
                 side = self._side_stream()
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)  # dws[i], d_o, d_d are produced/zeroed on the main stream
                 with torch.cuda.stream(side):
-                    for i in range(2):
+                    for i in on_side:
                         dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
-                        ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+                        ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d, tag=f"side{i}")
                         if pipelined:  # this network's gradients are final: exchange them while the next one / the main field is still at work
                             glo, ghi = self.arena.group_range["proposal_networks"]
                             first = [self.arena.layout[f"proposal_networks.{k}.mlp_base.0.hash_table"][0] for k in range(2)]
@@ -346,6 +350,10 @@ class RenderEngine:
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
             else:
                 ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+                if br.prop_grad:
+                    for i in (1,):
+                        dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
+                        ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d, tag="main1")
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
