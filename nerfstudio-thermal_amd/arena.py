@@ -14,6 +14,7 @@ models/thermal_nerfacto.py:138-186) but belong to no optimiser group: they sit a
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
@@ -62,6 +63,19 @@ def prop_shapes(prefix: str, cfg: ThermalNerfactoModelConfig) -> "OrderedDict[st
 
 class ParamArena:
     ALIGN = 64  # floats (256 B): every tensor starts on a 256-byte boundary
+    _arenas: list = []  # weak references to the live arenas, so that an optimiser can find the arena a Parameter is a view of
+
+    @classmethod
+    def owner_of(cls, p: torch.Tensor):
+        ptr = p.data_ptr()
+        for ref in cls._arenas:
+            a = ref()
+            if a is None:
+                continue
+            lo = a.params.data_ptr()
+            if p.device == a.params.device and lo <= ptr < lo + a.params.numel() * 4:
+                return a
+        return None
 
     def __init__(self, cfg: ThermalNerfactoModelConfig, num_images: int, device):
         separate = cfg.density_mode == "separate"
@@ -100,6 +114,8 @@ class ParamArena:
         self.grads = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        ParamArena._arenas[:] = [r for r in ParamArena._arenas if r() is not None]
+        ParamArena._arenas.append(weakref.ref(self))
 
     # ---------------------------------------------------------------- views
     def _view(self, buf: torch.Tensor, name: str) -> torch.Tensor:

@@ -188,7 +188,7 @@ class RenderEngine:
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
         b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
                                jitters, prop_grad=updated)
-        if training and updated:
+        if updated:  # eval renders included, as ProposalNetworkSampler.generate_ray_samples does (ray_samplers.py:612-613)
             self.steps_since_update = 0
         out = self._branch_outputs(b, "", training)
         branches = {"": b}
@@ -414,6 +414,50 @@ class RenderEngine:
                 continue
             step, lr = hyper[gname]
             ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], step, lr, eps=1e-15)
+
+    # ---------------------------------------------------------------- checkpoint of the fused path's optimiser state
+    def optimizer_state_dict(self) -> Dict[str, object]:
+        """What Trainer.save_checkpoint stores beside the model (engine/trainer.py:424-447: "optimizers" = torch.optim.Adam.state_dict()
+        per parameter group, "schedulers" = LambdaLR.state_dict()), read out of the arena: state[i] = {step, exp_avg, exp_avg_sq} for the i-th
+        parameter of the group in get_param_groups() order.  Plus the sampler's update counters, which the reference loses on resume."""
+        a = self.arena
+        steps = getattr(self, "group_steps", {})
+        opt, sched = {}, {}
+        for g in a.optimised_groups:
+            lr0, lr_final, max_steps = OPTIMIZERS[g]
+            k = int(steps.get(g, 0))
+            state = {}
+            if k > 0:
+                for i, name in enumerate(a.group_keys[g]):
+                    state[i] = {"step": torch.tensor(float(k)), "exp_avg": a._view(a.exp_avg, name).detach().clone(),
+                                "exp_avg_sq": a._view(a.exp_avg_sq, name).detach().clone()}
+            opt[g] = {"state": state, "param_groups": [{"lr": exp_decay_lr(max(self.adam_step_count, 0), lr0, lr_final, max_steps), "betas": (0.9, 0.999),
+                                                        "eps": 1e-15, "weight_decay": 0, "amsgrad": False, "initial_lr": lr0,
+                                                        "params": list(range(len(a.group_keys[g])))}]}
+            sched[g] = {"last_epoch": self.adam_step_count, "_step_count": self.adam_step_count + 1, "base_lrs": [lr0]}
+        return {"optimizers": opt, "schedulers": sched,
+                "sampler": {"steps_since_update": self.steps_since_update, "step": self.sampler_step, "anneal": self.anneal}}
+
+    def load_optimizer_state_dict(self, state: Dict[str, object]) -> None:
+        """Inverse of optimizer_state_dict; also accepts a checkpoint written by the reference Trainer (same layout, no "sampler" entry)."""
+        a = self.arena
+        self.group_steps = {}
+        for g, od in state.get("optimizers", {}).items():
+            if g not in a.group_keys:
+                continue
+            for i, st in od.get("state", {}).items():
+                name = a.group_keys[g][int(i)]
+                a._view(a.exp_avg, name).copy_(torch.as_tensor(st["exp_avg"]).to(a.device, torch.float32).reshape(a.layout[name][1]))
+                a._view(a.exp_avg_sq, name).copy_(torch.as_tensor(st["exp_avg_sq"]).to(a.device, torch.float32).reshape(a.layout[name][1]))
+                self.group_steps[g] = max(self.group_steps.get(g, 0), int(float(st["step"])))
+        sched = state.get("schedulers", {})
+        if sched:
+            self.adam_step_count = int(max(int(v.get("last_epoch", 0)) for v in sched.values()))
+        else:
+            self.adam_step_count = max(self.group_steps.values(), default=0)
+        smp = state.get("sampler")
+        if smp:
+            self.steps_since_update, self.sampler_step, self.anneal = int(smp["steps_since_update"]), int(smp["step"]), float(smp["anneal"])
 
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
                    jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True) -> Dict[str, Tensor]:

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 from torch import Tensor, nn
 
+from . import autograd_ops as F
 from . import ops
 from .arena import ParamArena
 from .config import ThermalNerfactoModelConfig
@@ -92,65 +93,12 @@ def _ssim(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5, k
     return ssim[..., pad:-pad, pad:-pad].mean() if ssim.shape[-1] > 2 * pad and ssim.shape[-2] > 2 * pad else ssim.mean()
 
 
-# loss pieces for the autograd-compatible path (small [N,S] element-wise torch ops on the device; the fused path uses the loss kernels)
-def _sdist(rs) -> Tensor:
-    return rs.s_bins
-
-
-def _outer(t0s, t0e, t1s, t1e, y1):
-    cy1 = torch.cat([torch.zeros_like(y1[..., :1]), torch.cumsum(y1, dim=-1)], dim=-1)
-    lo = torch.clamp(torch.searchsorted(t1s.contiguous(), t0s.contiguous(), side="right") - 1, 0, y1.shape[-1] - 1)
-    hi = torch.clamp(torch.searchsorted(t1e.contiguous(), t0e.contiguous(), side="right"), 0, y1.shape[-1] - 1)
-    return torch.take_along_dim(cy1[..., 1:], hi, dim=-1) - torch.take_along_dim(cy1[..., :-1], lo, dim=-1)
-
-
-def interlevel_loss(weights_list, ray_samples_list) -> Tensor:
-    """model_components/losses.py:117-135."""
-    c = _sdist(ray_samples_list[-1]).detach()
-    w = weights_list[-1][..., 0].detach()
-    total = 0.0
-    for rs, wp in zip(ray_samples_list[:-1], weights_list[:-1]):
-        cp = _sdist(rs)
-        w_outer = _outer(c[..., :-1], c[..., 1:], cp[..., :-1], cp[..., 1:], wp[..., 0])
-        total = total + torch.mean(torch.clip(w - w_outer, min=0) ** 2 / (w + 1.0e-7))
-    return total
-
-
-def distortion_loss(weights_list, ray_samples_list) -> Tensor:
-    """model_components/losses.py:139-158."""
-    t = _sdist(ray_samples_list[-1])
-    w = weights_list[-1][..., 0]
-    ut = (t[..., 1:] + t[..., :-1]) / 2
-    dut = torch.abs(ut[..., :, None] - ut[..., None, :])
-    inter = torch.sum(w * torch.sum(w[..., None, :] * dut, dim=-1), dim=-1)
-    intra = torch.sum(w**2 * (t[..., 1:] - t[..., :-1]), dim=-1) / 3
-    return torch.mean(inter + intra)
-
-
 def rgb_to_rgbt_image(image: Tensor, is_thermal: Tensor) -> Tensor:
     """utils/rgbt_utils.py:6-32."""
     rgbt = torch.zeros(image.shape[:-1] + (4,), device=image.device)
     rgbt[..., :3] = image * (1 - is_thermal)[:, None]
     rgbt[..., 3] = image[..., 0] * is_thermal
     return rgbt
-
-
-def tv_pixel_loss(pred_thermal: Tensor, is_thermal: Tensor) -> Tensor:
-    """model_components/losses.py:602-620."""
-    p = pred_thermal[(1 - is_thermal).bool()].view(-1, 4)
-    return 0.25 * torch.mean((p[:, 0] - p[:, 1]).abs() + (p[:, 0] - p[:, 2]).abs() + (p[:, 1] - p[:, 3]).abs() + (p[:, 2] - p[:, 3]).abs())
-
-
-def cross_channel_loss(pred_thermal: Tensor, gt_rgb: Tensor, is_thermal: Tensor) -> Tensor:
-    """model_components/losses.py:623-651."""
-    keep = (1 - is_thermal).bool()
-
-    def grad(img):
-        q = img.view(-1, 4)
-        return torch.stack((q[:, 1] - q[:, 0], q[:, 2] - q[:, 0], q[:, 3] - q[:, 1], q[:, 3] - q[:, 2]))
-
-    diff = (grad(pred_thermal[keep]) - grad(gt_rgb[keep].mean(-1, keepdim=True))).abs()
-    return 0.25 * (diff[0] + diff[1] + diff[2] + diff[3]).mean()
 
 
 class _RenderFn(torch.autograd.Function):
@@ -160,7 +108,13 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, origins, directions, cam, jitters, jitters_thermal, *params):
         eng: RenderEngine = model.engine
-        eng.arena.zero_grad()  # one backward per training forward (what Trainer.train_iteration does)
+        # The backward kernels ACCUMULATE into the arena's gradient buffer, and autograd usually leaves `param.grad` aliased to it (the views
+        # returned by backward are adopted, not copied).  A forward that finds such aliased gradients still alive is a further micro-step of
+        # gradient accumulation (engine/trainer.py:464-477: several forward/backward passes before one optimiser step): the buffer must then
+        # keep what it holds.  Otherwise (the Trainer zeroed the gradients: set_to_none) this is a fresh step and the buffer is cleared.
+        ctx.accumulating = model._grads_alias_arena()
+        if not ctx.accumulating:
+            eng.arena.zero_grad()
         out, branches = eng.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
         ctx.model, ctx.out, ctx.branches, ctx.cam = model, out, branches, cam
         tensors = []
@@ -187,6 +141,17 @@ class _RenderFn(torch.autograd.Function):
         if eng.separate and "density2" in out:
             g_d2, g_d2t = next(it), next(it)
         z = lambda ref: torch.zeros_like(ref)  # noqa: E731
+        # gradient accumulation with a parameter whose .grad is NOT the arena view (autograd summed two gradient sources into a buffer of its
+        # own, e.g. the pose: render + regulariser): its slice of the arena still holds the previous micro-steps, so this backward must start
+        # from zero there and hand out only its own contribution
+        detached = {}
+        if ctx.accumulating:
+            for n in model._param_names:
+                g = model._params[n].grad
+                view = model.arena.grad_view(n)
+                if g is not None and g.data_ptr() != view.data_ptr():
+                    detached[n] = view.clone()
+                    view.zero_()
         d_od = {}
         for sfx, br in branches.items():
             g_comp, g_dens, g_w = per[sfx]
@@ -223,8 +188,28 @@ class _RenderFn(torch.autograd.Function):
                 continue
             ops.pose_apply_bwd(pose, eng.frozen_thermal if sfx else eng.frozen_rgb, cam, br.directions_in, *d_od[sfx],
                                eng.pose_thermal_grad if sfx else eng.pose_grad)
-        # hand the arena's gradient views to autograd as the parameters' gradients
-        pg = [model.arena.grad_view(n) for n in model._param_names]
+        # Hand the arena's gradient views to autograd as the parameters' gradients.  None (= "no gradient", as under the reference's no_grad)
+        # for every parameter this step did not differentiate: the proposal networks on iterations where the sampler did not update them
+        # (ray_samplers.py:591,605-610) and the thermal twins that shared mode never evaluates -- torch.optim.Adam skips a parameter whose
+        # .grad is None, whereas a zero gradient would advance its step count and let it coast on its momentum.  None also for a parameter
+        # whose .grad already IS the arena view (gradient accumulation): the kernels have added into it in place.
+        live = set()
+        for sfx, br in branches.items():
+            live.update(model.arena.group_keys["fields_thermal" if sfx else "fields"])
+            live.update(model.arena.group_keys["camera_opt_thermal" if sfx else "camera_opt"])
+            if br.prop_grad:
+                live.update(model.arena.group_keys["proposal_networks_thermal" if sfx else "proposal_networks"])
+        pg = []
+        for n in model._param_names:
+            p = model._params[n]
+            view = model.arena.grad_view(n)
+            aliased = p.grad is not None and p.grad.data_ptr() == view.data_ptr()
+            if n in detached:
+                own = view.clone()
+                view.add_(detached[n])  # the arena keeps the running total
+                pg.append(own if n in live else None)
+            else:
+                pg.append(view if (n in live and not aliased) else None)
         return (None, None, None, None, None, None, *pg)
 
 
@@ -415,48 +400,62 @@ class ThermalNerfactoModel(nn.Module):
                 out[f"ray_samples_list{sfx}"] = [ray_samples_from_level(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
         return out
 
+    def _grads_alias_arena(self) -> bool:
+        for n in self._param_names:
+            g = self._params[n].grad
+            if g is not None and g.data_ptr() == self.arena.grad_view(n).data_ptr():
+                return True
+        return False
+
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
-        """models/thermal_nerfacto.py:253-282."""
+        """models/thermal_nerfacto.py:253-282.  The PSNRs are masked means (no boolean indexing: that would synchronise the device every
+        iteration); the distortion loss is the kernel (value + gradient in one pass, no [N,S,S] tape)."""
         m: Dict[str, Any] = {}
         is_th = batch["is_thermal"].to(self.device).float()
-        gt = rgb_to_rgbt_image(batch["image"].to(self.device)[..., :3], is_th)
-        rgb_rays, th_rays = (1 - is_th).bool(), is_th.bool()
-        m["psnr_rgb"] = self.psnr(gt[..., :3][rgb_rays], outputs["rgb"][rgb_rays].detach())
-        m["psnr_thermal"] = self.psnr(gt[..., 3:][th_rays], outputs["rgb_thermal"][th_rays].detach())
+        img = batch["image"].to(self.device)[..., :3]
+        with torch.no_grad():
+            rgb_w, th_w = (1 - is_th)[:, None], is_th[:, None]
+            se_rgb = (((img - outputs["rgb"]) ** 2) * rgb_w).sum() / (3.0 * rgb_w.sum())
+            se_th = (((img[..., :1] - outputs["rgb_thermal"]) ** 2) * th_w).sum() / th_w.sum()
+            m["psnr_rgb"] = -10.0 * torch.log10(se_rgb)
+            m["psnr_thermal"] = -10.0 * torch.log10(se_th)
         if self.training:
             m["distortion"] = 0
             for s in self.output_suffixes:
-                m["distortion"] = m["distortion"] + distortion_loss(outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"])
+                m["distortion"] = m["distortion"] + F.DistortionLoss.apply(outputs[f"weights_list{s}"][-1], outputs[f"ray_samples_list{s}"][-1].s_bins)
         self.camera_optimizer.get_metrics_dict(m)
         if self.config.density_mode == "separate":
             self.camera_optimizer_thermal.get_metrics_dict(m)
         return m
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
-        """models/thermal_nerfacto.py:284-388."""
+        """models/thermal_nerfacto.py:284-388, every term through its loss kernel (autograd_ops): the pixel terms in one launch, the density
+        cross terms with the reference's detach asymmetry, interlevel per proposal level, the camera regularisers."""
         c = self.config
         ld: Dict[str, Any] = {}
         is_th = batch["is_thermal"].to(self.device).float()
-        pred = torch.cat((outputs["rgb"], outputs["rgb_thermal"]), dim=1)
-        gt = rgb_to_rgbt_image(batch["image"].to(self.device)[..., :3], is_th)
-        ld["rgb_loss"] = self.rgb_loss(gt[..., :3] * (1 - is_th)[:, None], pred[..., :3] * (1 - is_th)[:, None])
-        ld["thermal_loss"] = c.thermal_loss_mult * self.rgb_loss(gt[..., 3:] * is_th[:, None], pred[..., 3:] * is_th[:, None])
+        img = batch["image"].to(self.device)[..., :3].contiguous()
+        rgb_l, th_l, tv_l, cross_l = F.PixelLosses.apply(outputs["rgb"], outputs["rgb_thermal"], img, is_th, c.thermal_loss_mult,
+                                                         c.tv_pixel_loss_mult, c.cross_channel_loss_mult)
+        ld["rgb_loss"], ld["thermal_loss"] = rgb_l, th_l
         if c.density_mode == "separate" and c.density_loss_mult > 0:
             a, b = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
-            ld["density_loss"] = (a * self.density_loss(outputs["density2"].detach(), outputs["density_thermal"])
-                                  + a * self.density_loss(outputs["density"].detach(), outputs["density2_thermal"])
-                                  + b * self.density_loss(outputs["density2"], outputs["density_thermal"].detach())
-                                  + b * self.density_loss(outputs["density"], outputs["density2_thermal"].detach()))
+            # a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|   (:336-344)
+            ld["density_loss"] = (F.AsymmetricL1.apply(outputs["density2"], outputs["density_thermal"], b, a)
+                                  + F.AsymmetricL1.apply(outputs["density"], outputs["density2_thermal"], b, a))
         if c.tv_pixel_loss_mult > 0:
-            ld["tv_pixel_loss"] = c.tv_pixel_loss_mult * tv_pixel_loss(pred[..., 3:], is_th)
+            ld["tv_pixel_loss"] = tv_l
         if c.cross_channel_loss_mult > 0:
-            ld["cross_channel_loss"] = c.cross_channel_loss_mult * cross_channel_loss(pred[..., 3:], gt[..., :3], is_th)
+            ld["cross_channel_loss"] = cross_l
         if self.training:
             ld["interlevel_loss"] = 0
             ld["distortion_loss"] = 0
             assert metrics_dict is not None and "distortion" in metrics_dict
             for s in self.output_suffixes:
-                ld["interlevel_loss"] = ld["interlevel_loss"] + c.interlevel_loss_mult * interlevel_loss(outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"])
+                ws, rs = outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"]
+                for i in range(len(ws) - 1):
+                    ld["interlevel_loss"] = ld["interlevel_loss"] + c.interlevel_loss_mult * F.InterlevelLoss.apply(ws[i], rs[i].s_bins, ws[-1].detach(),
+                                                                                                                  rs[-1].s_bins)
                 ld["distortion_loss"] = ld["distortion_loss"] + c.distortion_loss_mult * metrics_dict["distortion"]
             self.camera_optimizer.get_loss_dict(ld)
             if c.density_mode == "separate":

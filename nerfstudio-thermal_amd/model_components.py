@@ -168,10 +168,10 @@ class CameraOptimizer(nn.Module):
 
     def get_loss_dict(self, loss_dict: dict) -> None:
         if self.config.mode != "off":
-            loss_dict[f"camera_opt_regularizer{self.suffix}"] = (
-                self.pose_adjustment[:, :3].norm(dim=-1).mean() * self.config.trans_l2_penalty
-                + self.pose_adjustment[:, 3:].norm(dim=-1).mean() * self.config.rot_l2_penalty
-            ) * self.config.penalty_scale
+            from .autograd_ops import CameraRegularizer
+
+            loss_dict[f"camera_opt_regularizer{self.suffix}"] = CameraRegularizer.apply(
+                self.pose_adjustment, self.config.trans_l2_penalty, self.config.rot_l2_penalty, self.config.penalty_scale)
 
     def get_metrics_dict(self, metrics_dict: dict) -> None:
         if self.config.mode != "off":

@@ -1,0 +1,133 @@
+"""Optimiser side of the drop-in path: torch.optim.Adam's interface over the flat parameter arena.
+
+The reference builds one `torch.optim.Adam(lr, eps=1e-15)` per parameter group from `AdamOptimizerConfig._target`
+(engine/optimizers.py:40-112, configs/method_configs.py:274-307) and steps them all after `loss.backward()`
+(engine/trainer.py:489-499).  `HipFusedAdam` is a `torch.optim.Optimizer` with the same constructor arguments and state layout
+(`state[p] = {"step", "exp_avg", "exp_avg_sq"}`), so `Optimizers`, LR schedulers, `state_dict()` / `load_state_dict()` and checkpoints
+work unchanged, but `step()` is one `tn_adam_step_ranges` launch over the group's slice of the arena: the moments are views of the arena's
+moment buffers, and a gradient that autograd left aliased to the arena's gradient buffer is consumed in place.
+
+Parameters whose `.grad` is None are skipped and keep their step count, exactly as torch.optim.Adam does (the proposal networks on
+iterations where the sampler ran them under no_grad, model_components/ray_samplers.py:605-610).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .arena import ParamArena
+
+
+class HipFusedAdam(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, **kwargs):
+        if weight_decay != 0.0 or kwargs.get("amsgrad", False) or kwargs.get("maximize", False):
+            raise NotImplementedError("HipFusedAdam implements plain Adam (weight_decay = 0, no amsgrad): what the thermal-nerfacto optimisers use")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0))
+        self._where: Dict[int, tuple] = {}  # id(p) -> (arena, offset, numel)
+        for group in self.param_groups:
+            for p in group["params"]:
+                arena = ParamArena.owner_of(p)
+                if arena is None:
+                    raise ValueError("HipFusedAdam only optimises parameters that live in a ParamArena (ThermalNerfactoModel.get_param_groups())")
+                off = (p.data_ptr() - arena.params.data_ptr()) // 4
+                self._where[id(p)] = (arena, off, p.numel())
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": arena.exp_avg[off:off + p.numel()].view(p.shape),
+                                 "exp_avg_sq": arena.exp_avg_sq[off:off + p.numel()].view(p.shape)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            runs: List[list] = []  # [arena, lo, hi, step]
+            for p in sorted((q for q in group["params"] if q.grad is not None), key=lambda q: self._where[id(q)][1]):
+                arena, off, n = self._where[id(p)]
+                gview = arena.grads[off:off + n]
+                if p.grad.data_ptr() != gview.data_ptr():  # autograd kept its own buffer (e.g. two gradient sources were summed)
+                    gview.copy_(p.grad.reshape(-1))
+                st = self.state[p]
+                st["step"] += 1
+                k = int(st["step"].item())
+                # merge with the previous run across the alignment padding (its gradient is zero: Adam leaves it untouched)
+                if runs and runs[-1][0] is arena and runs[-1][3] == k and off - runs[-1][2] < ParamArena.ALIGN and off % 4 == 0:
+                    runs[-1][2] = off + n
+                else:
+                    runs.append([arena, off, off + n, k])
+            for i in range(0, len(runs), 8):
+                chunk = runs[i:i + 8]
+                a = chunk[0][0]
+                assert all(r[0] is a for r in chunk)
+                ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq,
+                                     [(r[1], (r[2] + 3) // 4 * 4, r[3], group["lr"]) for r in chunk], beta1=b1, beta2=b2, eps=group["eps"])
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the state tensors; copy them back into the arena so that the moments stay views of it."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group["params"]:
+                arena, off, n = self._where[id(p)]
+                st = self.state.get(p)
+                if not st:
+                    continue
+                for key, buf in (("exp_avg", arena.exp_avg), ("exp_avg_sq", arena.exp_avg_sq)):
+                    view = buf[off:off + n].view(p.shape)
+                    if st[key].data_ptr() != view.data_ptr():
+                        view.copy_(st[key].to(view.device, view.dtype))
+                        st[key] = view
+                st["step"] = torch.as_tensor(float(st["step"])).cpu()
+
+
+def exponential_decay_lambda(lr_init: float, lr_final: float, max_steps: int):
+    """ExponentialDecayScheduler without warm-up (engine/schedulers.py:109-141) as a LambdaLR multiplier."""
+
+    def f(step):
+        t = float(np.clip(step / max_steps, 0, 1))
+        return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)) / lr_init
+
+    return f
+
+
+class Optimizers:
+    """engine/optimizers.py:73-210 for this model: one optimiser (+ scheduler) per parameter group, stepped together."""
+
+    def __init__(self, param_groups: Dict[str, List[torch.nn.Parameter]], table: Optional[Dict[str, tuple]] = None, optimizer_cls=HipFusedAdam):
+        from .engine import OPTIMIZERS
+
+        table = table or OPTIMIZERS
+        self.optimizers, self.schedulers, self.parameters = {}, {}, {}
+        for name, params in param_groups.items():
+            lr, lr_final, max_steps = table[name]
+            self.optimizers[name] = optimizer_cls(params, lr=lr, eps=1e-15)
+            self.parameters[name] = params
+            self.schedulers[name] = torch.optim.lr_scheduler.LambdaLR(self.optimizers[name], exponential_decay_lambda(lr, lr_final, max_steps))
+
+    def zero_grad_all(self) -> None:
+        for o in self.optimizers.values():
+            o.zero_grad()
+
+    def optimizer_step_all(self, step: int = 0) -> None:
+        for o in self.optimizers.values():
+            o.step()
+
+    def scheduler_step_all(self, step: int = 0) -> None:
+        for s in self.schedulers.values():
+            s.step()
+
+    def state_dict(self):
+        return {"optimizers": {k: v.state_dict() for k, v in self.optimizers.items()}, "schedulers": {k: v.state_dict() for k, v in self.schedulers.items()}}
+
+    def load_state_dict(self, state) -> None:
+        for k, v in state["optimizers"].items():
+            self.optimizers[k].load_state_dict(v)
+        for k, v in state.get("schedulers", {}).items():
+            self.schedulers[k].load_state_dict(v)
