@@ -3,13 +3,17 @@
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --mode separate --rays 8192          # BASELINE configs[2]
+    python bench.py --path model-api                     # the reference Trainer's call sequence instead of the fused step
 
-A "step" is one Trainer.train_iteration of the reference (engine/trainer.py:455-499) on a synthetic batch: ray generation for 4096 rays per
-GPU (configs[1]: density_mode=shared, 256/96 proposal + 48 field samples, 2^19/2^17 tables), forward, every loss, backward, gradient
-all-reduce (N>1) and Adam over all parameter groups.  Inputs (cameras, ray indices, ground truth) are resident in HBM before the timed
+A "step" is one Trainer.train_iteration of the reference (engine/trainer.py:455-499) on a synthetic batch: pixel sampling + ray generation
+for 4096 rays per GPU (configs[1]: density_mode=shared, 256/96 proposal + 48 field samples, 2^19/2^17 tables), forward, every loss,
+backward, gradient all-reduce (N>1) and Adam over all parameter groups.  Inputs (cameras, images) are resident in HBM before the timed
 region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -23,6 +27,17 @@ import torch  # noqa: E402
 
 RAYS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources: PMC figures (profiles/*_pmc.json) are only quoted while they were measured on these very kernels."""
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(ROOT, "nerfstudio-thermal_amd", "csrc", "*.h*"))):
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode())
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def build_engine(device, mode="shared", seed=0):
@@ -38,6 +53,22 @@ def build_engine(device, mode="shared", seed=0):
     arena.load({k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=seed).items()})
     eng = RenderEngine(cfg, arena, 8, [0, 0, 0, 0, 1, 1, 1, 1])
     return cfg, arena, eng
+
+
+def build_model(device, mode="shared", seed=0):
+    """The drop-in object: ThermalNerfactoModel behind the reference's Model API, same synthetic weights as build_engine."""
+    import nerfstudio_thermal_amd  # noqa: F401
+    from nerfstudio_thermal_amd import synth
+    from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+    from nerfstudio_thermal_amd.model import SceneBox
+
+    cfg = ThermalNerfactoModelConfig(density_mode=mode)
+    model = cfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=8, metadata={"is_thermal": [0, 0, 0, 0, 1, 1, 1, 1]},
+                      device=device)
+    shapes = {n: s for n, (_, s) in model.arena.layout.items()}
+    model.arena.load({k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=seed).items()})
+    model.train()
+    return cfg, model.arena, model
 
 
 def make_batch(device, num_rays, seed):
@@ -62,16 +93,46 @@ def make_image_cache(device):
     return ops.ImageCache.build(imgs, torch.from_numpy(cams["is_thermal"].astype(np.float32)), torch.arange(n), device)
 
 
-def one_step(eng, cam_t, cache, num_rays, step, hook):
-    # datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): this step's 2x2 pixel patches over the jagged image list, their
-    # ground truth and the rays, all on the device (nerfstudio_thermal_amd/data.py)
-    dm = getattr(eng, "_bench_dm", None)
+def _datamanager(owner, cam_t, cache, num_rays):
+    dm = getattr(owner, "_bench_dm", None)
     if dm is None or dm.num_rays != num_rays or dm.cache is not cache:
         from nerfstudio_thermal_amd.data import DeviceDataManager
 
-        dm = eng._bench_dm = DeviceDataManager(cache, cam_t, num_rays, 2)
-    o, d, cam, img, is_th = dm.next_train(step)
+        dm = owner._bench_dm = DeviceDataManager(cache, cam_t, num_rays, 2)
+    return dm
+
+
+def one_step(eng, cam_t, cache, num_rays, step, hook):
+    """Fused step.  datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): this step's 2x2 pixel patches over the jagged image
+    list, their ground truth and the rays, all on the device (nerfstudio_thermal_amd/data.py); then RenderEngine.train_step."""
+    o, d, cam, img, is_th = _datamanager(eng, cam_t, cache, num_rays).next_train(step)
     return eng.train_step(o, d, cam, img, is_th, step, grad_hook=hook)
+
+
+def one_step_api(model, optimizers, cam_t, cache, num_rays, step):
+    """The reference Trainer's own sequence (engine/trainer.py:455-499) on the drop-in objects: callbacks, zero_grad, model(ray_bundle),
+    get_metrics_dict, get_loss_dict, reduce(add).backward(), optimiser + scheduler steps."""
+    import functools
+
+    from nerfstudio_thermal_amd.model import TrainingCallbackLocation as Loc
+    from nerfstudio_thermal_amd.rays import RayBundle
+
+    o, d, cam, img, is_th = _datamanager(model, cam_t, cache, num_rays).next_train(step)
+    cbs = model.__dict__.setdefault("_bench_cbs", model.get_training_callbacks())
+    for cb in cbs:
+        cb.run_callback_at_location(step, Loc.BEFORE_TRAIN_ITERATION)
+    optimizers.zero_grad_all()
+    rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
+    batch = {"image": img, "is_thermal": is_th}
+    out = model(rb)
+    metrics = model.get_metrics_dict(out, batch)
+    losses = model.get_loss_dict(out, batch, metrics)
+    functools.reduce(torch.add, losses.values()).backward()
+    optimizers.optimizer_step_all(step)
+    optimizers.scheduler_step_all(step)
+    for cb in cbs:
+        cb.run_callback_at_location(step, Loc.AFTER_TRAIN_ITERATION)
+    return losses
 
 
 def time_ms(fn, iters=10, warmup=2):
@@ -87,24 +148,30 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# HBM-side traffic per launch from rocprofv3 PMC passes (profiles/r01_pmc_summary.md, scripts/pmc_passes.sh; N = 4096, shared mode): read bytes =
-# TCC_EA0_RDREQ x 64 B (the calibrated form for these 8-byte gathers; FETCH_SIZE under-reports wide streams 2x on gfx950), write bytes =
-# WRITE_SIZE x 1024.  A scatter entry point = zero-fill of the replica scratch + k_grid_scatter + k_replica_reduce: all three are counted.
-PMC_TRAFFIC_BYTES = {
-    "k_grid_scatter(main grid)": (274.1e6 + 352.8e6) + (22.5e6 + 2.3e6) + 16.2e6,
-    "k_grid_scatter(prop0 grid)": (47.1e6 + 193.2e6) + (13.8e6 + 2.7e6) + 24.0e6,
-    "k_grid_scatter(prop1 grid)": (26.3e6 + 118.6e6) + (10.9e6 + 2.9e6) + 17.8e6,
-    "k_field_encode": 346.4e6 + 26.4e6,
-    "k_prop_fwd(level0)": 12.1e6 + 4.1e6,
-    "k_prop_fwd(level1)": 12.4e6 + 1.5e6,
+# bench row -> kernels of profiles/r02_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
+PMC_KEYS = {
+    "scatter(main grid)": ["k_grid_bin<true> 196608x2", "k_grid_fold 196608x2"],
+    "scatter(prop0 grid)": ["k_grid_bin<true> 1048576x1", "k_grid_fold 1048576x1"],
+    "scatter(prop1 grid)": ["k_grid_bin<true> 393216x1", "k_grid_fold 393216x1"],
+    "k_prop_fwd(level0)": ["k_prop_fwd 1048576x1"],
+    "k_prop_fwd(level1)": ["k_prop_fwd 393216x1"],
 }
-ATOMIC_REQ_PEAK = 21.0e9  # 64-B atomic requests/s, measured by scripts/microbench/atomic_shapes.hip on MI355X
-PMC_ATOMIC_REQUESTS = {"k_grid_scatter(main grid)": 10.0e6, "k_grid_scatter(prop0 grid)": 5.45e6, "k_grid_scatter(prop1 grid)": 3.37e6}
+
+
+def load_pmc():
+    """PMC figures measured by scripts/pmc_passes.sh, or (None, why) when they were taken on other kernel sources than the ones running."""
+    if not os.path.exists(PMC_JSON):
+        return None, "no profiles/r02_pmc.json"
+    with open(PMC_JSON) as f:
+        j = json.load(f)
+    if j.get("source_hash") != source_hash():
+        return None, f"profiles/r02_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
+    return j["kernels"], None
 
 
 def kernel_roofline(eng, cam_t, idx):
     """Live HIP-event timing (torch.cuda.Event on torch's current stream = the stream every kernel of this library is launched on) of the
-    hash-grid gather / scatter kernels, each launched alone as a single-kernel C-ABI call.  Algorithmic bytes: gather =
+    hash-grid gather / scatter entry points, each launched alone as a single C-ABI call.  Algorithmic bytes: gather =
     points x levels x 8 corners x 8 B; scatter-add = read-modify-write = 2 x that."""
     from nerfstudio_thermal_amd import ops
 
@@ -126,12 +193,26 @@ def kernel_roofline(eng, cam_t, idx):
         g_enc = torch.randn((N * L.S, ld), device=o.device) * 1e-3
         ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
                                               L.e_bins, g_enc, d_o, d_d))
-        rows.append((f"k_grid_scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
+        rows.append((f"scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
     eng.arena.zero_grad()
     return rows
 
 
-def cpu_baseline(num_rays, steps, threads):
+def step_algorithmic_bytes(arena, mode, rays, update_frac):
+    """(N x bytes_ray + bytes_step) of one train step, no cache credit.  Per ray: forward gathers 161 792 B (separate: 421 888 B
+    incl. the two cross-evaluated densities); backward scatter-add 98 304 B per main-grid backward (shared 1, separate 4: two branches + two
+    cross terms) and 225 280 B per proposal-network backward (shared: on update steps; separate: the thermal sampler updates every step).
+    Per step: Adam 28 B per optimised parameter (proposal groups only when they are stepped)."""
+    fwd = 161792 if mode == "shared" else 421888
+    main_bwd = 98304 * (1 if mode == "shared" else 4)
+    prop_bwd = 225280 * (update_frac + (1.0 if mode == "separate" else 0.0))
+    n_prop = sum(int(np.prod(arena.layout[k][1])) for k in arena.group_keys["proposal_networks"])
+    n_all = arena.num_optimised()
+    adam = 28.0 * (n_all - (1.0 - update_frac) * n_prop)
+    return rays * (fwd + main_bwd + prop_bwd) + adam
+
+
+def cpu_baseline(num_rays, steps, threads, mode="shared"):
     """Oracle (pure-PyTorch restatement of the reference torch path, pinned to reference goldens) timed on the host cores:
     forward + losses + backward + Adam, same workload definition, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -139,7 +220,7 @@ def cpu_baseline(num_rays, steps, threads):
     from nerfstudio_thermal_amd import synth
 
     torch.set_num_threads(threads)
-    cfg = orc.OracleConfig(density_mode="shared")
+    cfg = orc.OracleConfig(density_mode=mode)
     params = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.synth_params(orc.param_shapes(cfg), seed=0).items()}
     cams = synth.synth_cameras()
     idx = torch.from_numpy(synth.synth_ray_indices(cams, num_rays, seed=42))
@@ -152,7 +233,8 @@ def cpu_baseline(num_rays, steps, threads):
         t0 = time.perf_counter()
         o, d, _, _ = orc.generate_rays(idx, tc["c2w"], tc["fx"], tc["fy"], tc["cx"], tc["cy"], tc["distortion"])
         jit = [torch.rand(num_rays, 1) for _ in range(3)]
-        out = orc.get_outputs(params, cfg, o, d, idx[:, 0], training=True, anneal=1.0, jitters=jit)
+        jit_t = [torch.rand(num_rays, 1) for _ in range(3)]
+        out = orc.get_outputs(params, cfg, o, d, idx[:, 0], training=True, anneal=1.0, jitters=jit, jitters_thermal=jit_t)
         losses = orc.loss_dict(params, cfg, out, img, is_th, training=True)
         sum(losses.values()).backward()
         with torch.no_grad():
@@ -165,8 +247,7 @@ def cpu_baseline(num_rays, steps, threads):
         if step > 0:
             times.append(time.perf_counter() - t0)
     t = float(np.median(times))
-    return {"value": num_rays / t, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps (after 1 warm-up) of the same {num_rays}-ray shared-density train step (fwd+losses+bwd+Adam), median {t:.2f} s/step"}
+    return num_rays / t, t
 
 
 def main():
@@ -176,15 +257,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="shared", choices=["shared", "separate"], help="density_mode (default = BASELINE configs[1]; separate = configs[2])")
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU per step (configs[2] uses 8192)")
+    ap.add_argument("--path", default="fused", choices=["fused", "model-api"], help="fused: RenderEngine.train_step (no autograd tape); model-api: the "
+                    "reference Trainer's sequence forward -> get_metrics_dict -> get_loss_dict -> backward -> optimisers on ThermalNerfactoModel")
+    ap.add_argument("--api-optimizer", default="hip", choices=["hip", "torch"], help="--path model-api: HipFusedAdam (one launch per group over the arena) or "
+                    "torch.optim.Adam on the same parameters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=RAYS_PER_GPU)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(host cores, 16): more threads make the"
                     " many small ATen ops of this path slower; measured on the 256-thread GPU-box host at 1024 rays: 8 -> 2427, 16 -> 2286, 32 -> 1906, 64 -> 1025,"
                     " 256 -> 24 rays/s)")
     ap.add_argument("--ops", action="store_true", help="print the per-kernel timing table to stderr")
     ap.add_argument("--dp-chunks", type=int, default=-1, help="N>1: level ranges of the main table exchanged separately (-1 = the default "
-                    "schedule 2/4/4/3/2/1 levels, n = n equal ranges, 0 = one all-reduce after the backward)")
+                    "schedule, n = n equal ranges, 0 = one all-reduce after the backward)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
     args = ap.parse_args()
@@ -198,8 +282,17 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    api = args.path == "model-api"
+    assert not (api and world > 1), "--path model-api is a single-GPU measurement (multi-GPU runs use the fused step with the overlapped exchange)"
 
-    cfg, arena, eng = build_engine(device, mode=args.mode)
+    if api:
+        from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
+
+        cfg, arena, model = build_model(device, mode=args.mode)
+        eng = model.engine
+        optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam if args.api_optimizer == "hip" else torch.optim.Adam)
+    else:
+        cfg, arena, eng = build_engine(device, mode=args.mode)
     rays = args.rays
     broadcast_params(arena)
     torch.manual_seed(rank_seed(42, rank))  # every rank draws its own pixels (scripts/train.py:97)
@@ -210,8 +303,10 @@ def main():
                            if args.dp_chunks > 0 else GradAllReducer(w))
     hook = make_hook(world) if world > 1 else None
     if args.force_dp and world == 1:
+        from nerfstudio_thermal_amd.parallel import free_port
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         hook = make_hook(1)
         if args.dp_chunks == 0:
@@ -221,15 +316,22 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    def run(step):
+        if api:
+            return one_step_api(model, optimizers, cam_t, cache, rays, step)
+        return one_step(eng, cam_t, cache, rays, step, hook)
+
     step = 0
     for _ in range(args.warmup):
-        one_step(eng, cam_t, cache, rays, step, hook)
+        run(step)
         step += 1
     torch.cuda.synchronize()
     barrier()
+    updates = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = one_step(eng, cam_t, cache, rays, step, hook)
+        losses = run(step)
+        updates += int(eng.steps_since_update == 1)  # reset to 0 on an iteration that updates the proposal networks, then step_cb adds 1
         step += 1
     torch.cuda.synchronize()
     barrier()
@@ -248,13 +350,26 @@ def main():
                 print(f"{name:60s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s algorithmic", file=sys.stderr)
         name, ms, nbytes = max(rows, key=lambda r: r[1])
         achieved = nbytes / (ms * 1e-3) / 1e9
+        pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
+        traffic = None
+        if pmc is not None and all(k in pmc for k in PMC_KEYS.get(name, ["?"])):
+            traffic = sum(pmc[k]["traffic_bytes"] for k in PMC_KEYS[name])
+        upd = updates / max(args.steps, 1)
+        step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd)
+        step_gbs = step_bytes / (dt / args.steps) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": PMC_TRAFFIC_BYTES.get(name) if (rays == 4096 and args.mode == "shared") else None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-                    "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows}}
-        if name in PMC_ATOMIC_REQUESTS:
-            # what actually bounds the scatter: 64-byte atomic requests at the memory side (microbenchmarked peak 21 G requests/s)
-            rate = PMC_ATOMIC_REQUESTS[name] / (ms * 1e-3)
-            roofline["atomic_requests"] = {"per_launch": PMC_ATOMIC_REQUESTS[name], "achieved_per_s": rate, "peak_per_s": ATOMIC_REQ_PEAK, "frac": rate / ATOMIC_REQ_PEAK}
+                    "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
+                    "note": "the scatter entry point = k_grid_bin + k_grid_fold; both run on the LDS unit, not on HBM (profiles/r02_scatter_alternatives.md)",
+                    "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows},
+                    # SURVEY 8d's whole-step figure: (N x bytes_ray + bytes_step) / t_step against the HBM peak
+                    "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "proposal_update_fraction": upd}}
+        if pmc is None:
+            roofline["traffic_unavailable"] = why
+        else:
+            roofline["traffic_all_kernels"] = {n: sum(pmc[k]["traffic_bytes"] for k in ks) for n, ks in PMC_KEYS.items() if all(k in pmc for k in ks)}
+            roofline["mfma_busy_frac"] = {k.split(" ")[0]: v["mfma_busy_frac"] for k, v in pmc.items()
+                                          if k.split(" ")[0] in ("k_field_mlp_fwd<true>", "k_field_mlp_bwd<false>", "k_wgrad_batch") and "mfma_busy_frac" in v}
+            roofline["pmc_source"] = "profiles/r02_pmc.json"
         result = {
             "metric": "train rays/sec (4096-ray batch, 96 samples/ray)",
             "value": world * rays * args.steps / dt,
@@ -270,13 +385,22 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (pixel sampling+raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
                                    "256/96 proposal + 48 field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
-                       "rays_per_gpu": rays, "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam)" if api else ""),
+                       "final_loss": final_loss},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode == "shared":
+        if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
             cores = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            result["cpu_baseline"] = cpu_baseline(args.cpu_rays, args.cpu_steps, cores)
+            v, t = cpu_baseline(rays, args.cpu_steps if args.mode == "shared" else max(2, args.cpu_steps // 2), cores, args.mode)
+            result["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": cores, "kind": "port",
+                                      "sample": f"{args.cpu_steps if args.mode == 'shared' else max(2, args.cpu_steps // 2)} steps (after 1 warm-up) of the same "
+                                                f"{rays}-ray {args.mode}-density train step (fwd+losses+bwd+Adam) by the oracle, median {t:.2f} s/step"}
+            if args.mode == "shared":  # comparability with the figures of SURVEY 6 / BASELINE.md: 8 threads, and 1 thread on a quarter batch
+                v8, t8 = cpu_baseline(rays, 2, min(8, os.cpu_count() or 1), args.mode)
+                v1, t1 = cpu_baseline(rays // 4, 1, 1, args.mode)
+                result["cpu_baseline"]["other_thread_counts"] = {"8": {"value": v8, "s_per_step": t8, "steps": 2},
+                                                                 "1": {"value": v1, "s_per_step": t1, "steps": 1, "rays": rays // 4}}
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     barrier()

@@ -29,12 +29,13 @@ def _scalar_grads_equal(gs) -> Optional[Tensor]:
 
 
 class PixelLosses(torch.autograd.Function):
-    """rgb MSE, thermal MSE x thermal_mult, 2x2-patch TV x tv_mult, cross-channel x cross_mult (tn_pixel_losses) -> four scalars.
-    pred_rgb [N,3] and pred_thermal [N,1] may be views of one [N,4] buffer (shared mode)."""
+    """rgb MSE, thermal MSE x thermal_mult, 2x2-patch TV x tv_mult, cross-channel x cross_mult (tn_pixel_losses) -> four scalars + the number
+    of RGB rays of the batch (not differentiable; the PSNR metrics are derived from it).  pred_rgb [N,3] and pred_thermal [N,1] may be
+    views of one [N,4] buffer (shared mode)."""
 
     @staticmethod
     def forward(ctx, pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float,
-                cross_mult: float) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+                cross_mult: float) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         N = pred_rgb.shape[0]
         shared = (pred_rgb.stride(0) == 4 and pred_thermal.stride(0) == 4 and pred_thermal.data_ptr() == pred_rgb.data_ptr() + 12)
         if shared:
@@ -46,10 +47,12 @@ class PixelLosses(torch.autograd.Function):
         L = torch.zeros(8, device=pred_rgb.device)
         ops.pixel_losses(pred_rgb, pred_thermal, image.contiguous(), is_thermal.contiguous(), thermal_mult, tv_mult, cross_mult, L, d_rgb, d_th)
         ctx.save_for_backward(d_rgb, d_th)
-        return L[0], L[1], L[2], L[3]
+        n_rgb = L[4]
+        ctx.mark_non_differentiable(n_rgb)
+        return L[0], L[1], L[2], L[3], n_rgb
 
     @staticmethod
-    def backward(ctx, g0, g1, g2, g3):
+    def backward(ctx, g0, g1, g2, g3, _g4):
         d_rgb, d_th = ctx.saved_tensors
         g = _scalar_grads_equal((g0, g1, g2, g3))
         if g is None:

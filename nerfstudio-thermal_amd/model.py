@@ -37,7 +37,7 @@ from .model_components import (
     RGBTRenderer,
     ThermalNerfactoField,
 )
-from .rays import RayBundle, ray_samples_from_level
+from .rays import LazyRaySamples, RayBundle
 
 
 class TrainingCallbackLocation(Enum):
@@ -397,7 +397,7 @@ class ThermalNerfactoModel(nn.Module):
             for sfx, br in branches.items():
                 bundle = RayBundle(origins=br.origins, directions=br.directions, pixel_area=ray_bundle.pixel_area, camera_indices=ray_bundle.camera_indices,
                                    nears=nears[:, None], fars=fars[:, None])
-                out[f"ray_samples_list{sfx}"] = [ray_samples_from_level(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
+                out[f"ray_samples_list{sfx}"] = [LazyRaySamples(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
         return out
 
     def _grads_alias_arena(self) -> bool:
@@ -407,18 +407,30 @@ class ThermalNerfactoModel(nn.Module):
                 return True
         return False
 
-    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
-        """models/thermal_nerfacto.py:253-282.  The PSNRs are masked means (no boolean indexing: that would synchronise the device every
-        iteration); the distortion loss is the kernel (value + gradient in one pass, no [N,S,S] tape)."""
-        m: Dict[str, Any] = {}
+    def _pixel_terms(self, outputs, batch):
+        """The four pixel losses + the RGB-ray count, ONE kernel launch shared by get_metrics_dict (PSNRs) and get_loss_dict."""
+        key = (id(outputs), id(batch))
+        cached = self.__dict__.get("_pixel_cache")
+        if cached is not None and cached[0] == key and cached[1] is outputs:
+            return cached[2]
+        c = self.config
         is_th = batch["is_thermal"].to(self.device).float()
-        img = batch["image"].to(self.device)[..., :3]
+        img = batch["image"].to(self.device)[..., :3].contiguous()
+        terms = F.PixelLosses.apply(outputs["rgb"], outputs["rgb_thermal"], img, is_th, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult)
+        self._pixel_cache = (key, outputs, terms)
+        return terms
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
+        """models/thermal_nerfacto.py:253-282.  The PSNRs come out of the pixel-loss kernel's sums (mean squared error over the RGB rays /
+        the thermal rays = the masked-mean losses rescaled by the ray counts): no boolean indexing, which would synchronise the device every
+        iteration.  The distortion loss is the kernel (value + gradient in one pass, no [N,S,S] tape)."""
+        m: Dict[str, Any] = {}
+        rgb_l, th_l, _, _, n_rgb = self._pixel_terms(outputs, batch)
         with torch.no_grad():
-            rgb_w, th_w = (1 - is_th)[:, None], is_th[:, None]
-            se_rgb = (((img - outputs["rgb"]) ** 2) * rgb_w).sum() / (3.0 * rgb_w.sum())
-            se_th = (((img[..., :1] - outputs["rgb_thermal"]) ** 2) * th_w).sum() / th_w.sum()
-            m["psnr_rgb"] = -10.0 * torch.log10(se_rgb)
-            m["psnr_thermal"] = -10.0 * torch.log10(se_th)
+            n = float(outputs["rgb"].shape[0])
+            # rgb_loss = sum over RGB rays of |gt - pred|^2 / (3 n); thermal_loss = thermal_mult * sum over thermal rays / n
+            m["psnr_rgb"] = -10.0 * torch.log10(rgb_l.detach() * n / n_rgb)
+            m["psnr_thermal"] = -10.0 * torch.log10(th_l.detach() * (n / self.config.thermal_loss_mult) / (n - n_rgb))
         if self.training:
             m["distortion"] = 0
             for s in self.output_suffixes:
@@ -433,10 +445,7 @@ class ThermalNerfactoModel(nn.Module):
         cross terms with the reference's detach asymmetry, interlevel per proposal level, the camera regularisers."""
         c = self.config
         ld: Dict[str, Any] = {}
-        is_th = batch["is_thermal"].to(self.device).float()
-        img = batch["image"].to(self.device)[..., :3].contiguous()
-        rgb_l, th_l, tv_l, cross_l = F.PixelLosses.apply(outputs["rgb"], outputs["rgb_thermal"], img, is_th, c.thermal_loss_mult,
-                                                         c.tv_pixel_loss_mult, c.cross_channel_loss_mult)
+        rgb_l, th_l, tv_l, cross_l, _ = self._pixel_terms(outputs, batch)
         ld["rgb_loss"], ld["thermal_loss"] = rgb_l, th_l
         if c.density_mode == "separate" and c.density_loss_mult > 0:
             a, b = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult

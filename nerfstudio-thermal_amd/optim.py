@@ -27,6 +27,8 @@ class HipFusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("HipFusedAdam implements plain Adam (weight_decay = 0, no amsgrad): what the thermal-nerfacto optimisers use")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0.0))
         self._where: Dict[int, tuple] = {}  # id(p) -> (arena, offset, numel)
+        self._steps: Dict[int, int] = {}    # id(p) -> Adam step count (torch keeps a tensor per parameter; a Python int costs nothing per step)
+        self._plans: Dict[int, tuple] = {}
         for group in self.param_groups:
             for p in group["params"]:
                 arena = ParamArena.owner_of(p)
@@ -37,28 +39,59 @@ class HipFusedAdam(torch.optim.Optimizer):
                 self.state[p] = {"step": torch.tensor(0.0), "exp_avg": arena.exp_avg[off:off + p.numel()].view(p.shape),
                                  "exp_avg_sq": arena.exp_avg_sq[off:off + p.numel()].view(p.shape)}
 
+    def _group_plan(self, gi: int):
+        """Per group, once: (parameter, address its gradient has when autograd left it aliased to the arena, arena offset, numel) in arena
+        order, and the merged ranges of the whole group (alignment padding between neighbours carries a zero gradient: Adam leaves it alone)."""
+        plan = self._plans.get(gi)
+        if plan is None:
+            rows, runs = [], []
+            for p in self.param_groups[gi]["params"]:
+                arena, off, n = self._where[id(p)]
+                rows.append((p, arena.grads.data_ptr() + 4 * off, off, n, arena))
+                if runs and runs[-1][0] is arena and 0 <= off - runs[-1][2] < ParamArena.ALIGN:
+                    runs[-1][2] = off + n
+                else:
+                    runs.append([arena, off, off + n])
+            plan = self._plans[gi] = (rows, runs)
+        return plan
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        steps = self._steps
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            runs: List[list] = []  # [arena, lo, hi, step]
-            for p in sorted((q for q in group["params"] if q.grad is not None), key=lambda q: self._where[id(q)][1]):
-                arena, off, n = self._where[id(p)]
-                gview = arena.grads[off:off + n]
-                if p.grad.data_ptr() != gview.data_ptr():  # autograd kept its own buffer (e.g. two gradient sources were summed)
-                    gview.copy_(p.grad.reshape(-1))
-                st = self.state[p]
-                st["step"] += 1
-                k = int(st["step"].item())
-                # merge with the previous run across the alignment padding (its gradient is zero: Adam leaves it untouched)
-                if runs and runs[-1][0] is arena and runs[-1][3] == k and off - runs[-1][2] < ParamArena.ALIGN and off % 4 == 0:
-                    runs[-1][2] = off + n
-                else:
-                    runs.append([arena, off, off + n, k])
+            rows, full_runs = self._group_plan(gi)
+            # fast path (every iteration of a normal run): every parameter of the group has a gradient, in place in the arena, same step count
+            k0 = steps.get(id(rows[0][0]), 0) if rows else 0
+            fast = bool(rows)
+            for p, gptr, _, _, _ in rows:
+                g = p.grad
+                if g is None or g.data_ptr() != gptr or steps.get(id(p), 0) != k0:
+                    fast = False
+                    break
+            if fast:
+                k = k0 + 1
+                for row in rows:
+                    steps[id(row[0])] = k
+                runs = [(r[0], r[1], r[2], k) for r in full_runs]
+            else:
+                runs = []
+                for p, gptr, off, n, arena in rows:
+                    g = p.grad
+                    if g is None:
+                        continue  # torch.optim.Adam skips it too, and does not advance its step count
+                    if g.data_ptr() != gptr:  # autograd kept its own buffer (e.g. two gradient sources were summed)
+                        arena.grads[off:off + n].copy_(g.reshape(-1))
+                    k = steps.get(id(p), 0) + 1
+                    steps[id(p)] = k
+                    if runs and runs[-1][0] is arena and runs[-1][3] == k and 0 <= off - runs[-1][2] < ParamArena.ALIGN:
+                        runs[-1][2] = off + n
+                    else:
+                        runs.append([arena, off, off + n, k])
             for i in range(0, len(runs), 8):
                 chunk = runs[i:i + 8]
                 a = chunk[0][0]
@@ -66,6 +99,15 @@ class HipFusedAdam(torch.optim.Optimizer):
                 ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq,
                                      [(r[1], (r[2] + 3) // 4 * 4, r[3], group["lr"]) for r in chunk], beta1=b1, beta2=b2, eps=group["eps"])
         return loss
+
+    def _sync_step_tensors(self) -> None:
+        for group in self.param_groups:
+            for p in group["params"]:
+                self.state[p]["step"] = torch.tensor(float(self._steps.get(id(p), 0)))
+
+    def state_dict(self):
+        self._sync_step_tensors()  # the per-parameter step counts are kept as Python ints between checkpoints
+        return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)
@@ -84,17 +126,38 @@ class HipFusedAdam(torch.optim.Optimizer):
                     if st[key].data_ptr() != view.data_ptr():
                         view.copy_(st[key].to(view.device, view.dtype))
                         st[key] = view
-                st["step"] = torch.as_tensor(float(st["step"])).cpu()
+                self._steps[id(p)] = int(float(st["step"]))
+                st["step"] = torch.tensor(float(self._steps[id(p)]))
 
 
-def exponential_decay_lambda(lr_init: float, lr_final: float, max_steps: int):
-    """ExponentialDecayScheduler without warm-up (engine/schedulers.py:109-141) as a LambdaLR multiplier."""
+class ExponentialDecayLR:
+    """ExponentialDecayScheduler without warm-up (engine/schedulers.py:109-141): lr(step) = exp(lerp(log lr_init, log lr_final, step/max_steps)).
+    Same numbers as the LambdaLR the reference builds, same `last_epoch` in its state_dict, a few microseconds per step instead of ~150."""
 
-    def f(step):
-        t = float(np.clip(step / max_steps, 0, 1))
-        return float(np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)) / lr_init
+    def __init__(self, optimizer: torch.optim.Optimizer, lr_init: float, lr_final: float, max_steps: int):
+        self.optimizer, self.lr_init, self.lr_final, self.max_steps = optimizer, lr_init, lr_final, max_steps
+        self.last_epoch = 0
+        self._apply()
 
-    return f
+    def _apply(self) -> None:
+        t = float(np.clip(self.last_epoch / self.max_steps, 0, 1))
+        lr = float(np.exp(np.log(self.lr_init) * (1 - t) + np.log(self.lr_final) * t))
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1, "base_lrs": [self.lr_init]}
+
+    def load_state_dict(self, state) -> None:
+        self.last_epoch = int(state["last_epoch"])
+        self._apply()
 
 
 class Optimizers:
@@ -109,7 +172,7 @@ class Optimizers:
             lr, lr_final, max_steps = table[name]
             self.optimizers[name] = optimizer_cls(params, lr=lr, eps=1e-15)
             self.parameters[name] = params
-            self.schedulers[name] = torch.optim.lr_scheduler.LambdaLR(self.optimizers[name], exponential_decay_lambda(lr, lr_final, max_steps))
+            self.schedulers[name] = ExponentialDecayLR(self.optimizers[name], lr, lr_final, max_steps)
 
     def zero_grad_all(self) -> None:
         for o in self.optimizers.values():

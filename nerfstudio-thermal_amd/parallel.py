@@ -15,14 +15,25 @@ import torch
 import torch.distributed as dist
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (for single-process rendezvous; a fixed default collides as soon as two jobs share a host)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world_size)."""
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, local_rank, world_size).
+    MASTER_ADDR / MASTER_PORT come from the launcher (torchrun always sets them); there is deliberately no fixed fallback port."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: launch with torch.distributed.run (it picks and exports the port)")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -137,3 +137,25 @@ def ray_samples_from_level(bundle: RayBundle, s_bins: Tensor, e_bins: Tensor, ne
                                 spacing_ends=s_bins[..., 1:, None], spacing_to_euclidean_fn=s2e)
     rs.s_bins, rs.e_bins = s_bins, e_bins
     return rs
+
+
+class LazyRaySamples:
+    """One level of the engine's dense bins that BECOMES the reference's RaySamples on first use of any of its fields.  The training loop
+    only ever reads `s_bins` / `e_bins` from the entries of `ray_samples_list` (the loss kernels take the dense bins); building the full
+    Frustums / RaySamples views for three levels costs ~60 tensor operations per iteration on the host, so they are built on demand."""
+
+    def __init__(self, bundle: RayBundle, s_bins: Tensor, e_bins: Tensor, nears: Tensor, fars: Tensor):
+        self.s_bins, self.e_bins = s_bins, e_bins
+        self._args = (bundle, nears, fars)
+        self._real: Optional[RaySamples] = None
+
+    def materialize(self) -> RaySamples:
+        if self._real is None:
+            bundle, nears, fars = self._args
+            self._real = ray_samples_from_level(bundle, self.s_bins, self.e_bins, nears, fars)
+        return self._real
+
+    def __getattr__(self, name):  # only reached for attributes not set in __init__: the RaySamples fields and methods
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
