@@ -188,6 +188,7 @@ class RenderEngine:
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
         b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
                                jitters, prop_grad=updated)
+        self.last_updated = bool(updated)  # did the proposal networks of the RGB sampler get gradients in this forward?
         if updated:  # eval renders included, as ProposalNetworkSampler.generate_ray_samples does (ray_samplers.py:612-613)
             self.steps_since_update = 0
         out = self._branch_outputs(b, "", training)

@@ -106,7 +106,7 @@ class _RenderFn(torch.autograd.Function):
     Tensor outputs (per branch): comp [N,C], density [N,S2,1], weights of the 3 levels [N,S,1]; separate mode adds density2 / density2_thermal."""
 
     @staticmethod
-    def forward(ctx, model, origins, directions, cam, jitters, jitters_thermal, *params):
+    def forward(ctx, model, holder, origins, directions, cam, jitters, jitters_thermal, *params):
         eng: RenderEngine = model.engine
         # The backward kernels ACCUMULATE into the arena's gradient buffer, and autograd usually leaves `param.grad` aliased to it (the views
         # returned by backward are adopted, not copied).  A forward that finds such aliased gradients still alive is a further micro-step of
@@ -116,19 +116,26 @@ class _RenderFn(torch.autograd.Function):
         if not ctx.accumulating:
             eng.arena.zero_grad()
         out, branches = eng.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
-        ctx.model, ctx.out, ctx.branches, ctx.cam = model, out, branches, cam
+        # The node keeps the engine, the arena's parameters and the branches (plain tensors) -- NOT the model and NOT the output dict: the
+        # caller fills that dict with this node's own outputs, and a node that reaches its outputs (directly or through the model) is a
+        # reference cycle that only the cyclic garbage collector frees: ~30 MB of activations per iteration piled up until it ran.
+        ctx.eng, ctx.branches, ctx.cam = eng, branches, cam
+        ctx.names, ctx.params = model._param_names, params
+        ctx.has_cross = bool(eng.separate and "density2" in out)
         tensors = []
         for sfx, br in branches.items():
             tensors += [br.comp, out[f"density{sfx}"]] + out[f"weights_list{sfx}"]
-        if eng.separate and "density2" in out:
+        if ctx.has_cross:
             tensors += [out["density2"], out["density2_thermal"]]
-        model._last_out, model._last_branches = out, branches
+        holder.append((out, branches))
         return tuple(tensors)
 
     @staticmethod
     def backward(ctx, *grads):
-        model, out, branches, cam = ctx.model, ctx.out, ctx.branches, ctx.cam
-        eng: RenderEngine = model.engine
+        eng: RenderEngine = ctx.eng
+        branches, cam = ctx.branches, ctx.cam
+        arena = eng.arena
+        params = dict(zip(ctx.names, ctx.params))
         dev = eng.device
         it = iter(grads)
         N = cam.shape[0]
@@ -138,7 +145,7 @@ class _RenderFn(torch.autograd.Function):
             g_w = [next(it) for _ in range(3)]
             per[sfx] = (g_comp, g_dens, g_w)
         g_d2 = g_d2t = None
-        if eng.separate and "density2" in out:
+        if ctx.has_cross:
             g_d2, g_d2t = next(it), next(it)
         z = lambda ref: torch.zeros_like(ref)  # noqa: E731
         # gradient accumulation with a parameter whose .grad is NOT the arena view (autograd summed two gradient sources into a buffer of its
@@ -146,9 +153,9 @@ class _RenderFn(torch.autograd.Function):
         # from zero there and hand out only its own contribution
         detached = {}
         if ctx.accumulating:
-            for n in model._param_names:
-                g = model._params[n].grad
-                view = model.arena.grad_view(n)
+            for n in ctx.names:
+                g = params[n].grad
+                view = arena.grad_view(n)
                 if g is not None and g.data_ptr() != view.data_ptr():
                     detached[n] = view.clone()
                     view.zero_()
@@ -195,14 +202,14 @@ class _RenderFn(torch.autograd.Function):
         # whose .grad already IS the arena view (gradient accumulation): the kernels have added into it in place.
         live = set()
         for sfx, br in branches.items():
-            live.update(model.arena.group_keys["fields_thermal" if sfx else "fields"])
-            live.update(model.arena.group_keys["camera_opt_thermal" if sfx else "camera_opt"])
+            live.update(arena.group_keys["fields_thermal" if sfx else "fields"])
+            live.update(arena.group_keys["camera_opt_thermal" if sfx else "camera_opt"])
             if br.prop_grad:
-                live.update(model.arena.group_keys["proposal_networks_thermal" if sfx else "proposal_networks"])
+                live.update(arena.group_keys["proposal_networks_thermal" if sfx else "proposal_networks"])
         pg = []
-        for n in model._param_names:
-            p = model._params[n]
-            view = model.arena.grad_view(n)
+        for n in ctx.names:
+            p = params[n]
+            view = arena.grad_view(n)
             aliased = p.grad is not None and p.grad.data_ptr() == view.data_ptr()
             if n in detached:
                 own = view.clone()
@@ -210,7 +217,7 @@ class _RenderFn(torch.autograd.Function):
                 pg.append(own if n in live else None)
             else:
                 pg.append(view if (n in live and not aliased) else None)
-        return (None, None, None, None, None, None, *pg)
+        return (None, None, None, None, None, None, None, *pg)
 
 
 class ThermalNerfactoModel(nn.Module):
@@ -380,8 +387,9 @@ class ThermalNerfactoModel(nn.Module):
             out, branches = eng.get_outputs(o, d, cam, self.training, jitters, jitters_thermal)
         else:
             params = [self._params[n] for n in self._param_names]
-            flat = _RenderFn.apply(self, o, d, cam, jitters, jitters_thermal, *params)
-            out, branches = self._last_out, self._last_branches
+            holder: list = []
+            flat = _RenderFn.apply(self, holder, o, d, cam, jitters, jitters_thermal, *params)
+            out, branches = holder.pop()
             it = iter(flat)
             for sfx in branches:
                 out[f"rgb{sfx}"] = next(it)

@@ -69,7 +69,7 @@ class HashMLPDensityField(nn.Module):
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         rb = ray_samples.frustums
-        if ray_samples.e_bins is not None and rb.origins.shape[-2] == 1:
+        if ray_samples.e_bins is not None:  # samples of whole rays from this package's samplers: positions are formed in-kernel
             d = self.density_from_bins(rb.origins[..., 0, :].contiguous(), rb.directions[..., 0, :].contiguous(), ray_samples.e_bins)
             return d.unsqueeze(-1), None
         return self.density_fn(rb.get_positions()), None
@@ -102,17 +102,18 @@ class ThermalNerfactoField(nn.Module):
         if compute_normals:
             raise NotImplementedError("predict_normals is outside the HIP hot path")
         fr = ray_samples.frustums
-        if ray_samples.e_bins is None or fr.origins.shape[-2] != 1:
-            raise ValueError("ThermalNerfactoField.forward needs RaySamples built by RayBundle.get_ray_samples / the proposal sampler")
-        cam = ray_samples.camera_indices.reshape(-1).contiguous()
-        dens, rgb, _ = ops.field_fwd(self.fld, fr.origins[..., 0, :].contiguous(), fr.directions[..., 0, :].contiguous(), cam, ray_samples.e_bins,
+        if ray_samples.ndim != 2 or ray_samples.camera_indices is None:
+            raise ValueError("ThermalNerfactoField.forward needs a [num_rays, num_samples] RaySamples with camera indices (RayBundle.get_ray_samples / "
+                             "the proposal sampler)")
+        cam = ray_samples.camera_indices[..., 0, 0].contiguous()
+        dens, rgb, _ = ops.field_fwd(self.fld, fr.origins[..., 0, :].contiguous(), fr.directions[..., 0, :].contiguous(), cam, ray_samples.dense_bins(),
                                      training=self.training)
         return {FieldHeadNames.RGB: rgb, FieldHeadNames.DENSITY: dens.unsqueeze(-1)}
 
     def get_density(self, ray_samples: RaySamples) -> Tuple[Tensor, None]:
         """Density only.  The geometry feature vector the reference returns beside it never leaves the fused kernel."""
         fr = ray_samples.frustums
-        d = ops.field_density_fwd(self.fld, fr.origins[..., 0, :].contiguous(), fr.directions[..., 0, :].contiguous(), ray_samples.e_bins)
+        d = ops.field_density_fwd(self.fld, fr.origins[..., 0, :].contiguous(), fr.directions[..., 0, :].contiguous(), ray_samples.dense_bins())
         return d.unsqueeze(-1), None
 
     def get_outputs(self, ray_samples: RaySamples, density_embedding: Optional[Tensor] = None) -> Dict[FieldHeadNames, Tensor]:
@@ -222,7 +223,7 @@ class PDFSampler(nn.Module):
         N = ray_bundle.origins.shape[0]
         if self.train_stratified and self.training and jitter is None:
             jitter = torch.rand(N, device=ray_bundle.origins.device)
-        s, e = ops.pdf_resample(ray_samples.s_bins, weights[..., 0].contiguous(), S, anneal, ray_bundle.nears, ray_bundle.fars, jitter)
+        s, e = ops.pdf_resample(ray_samples.dense_spacing_bins(), weights[..., 0].contiguous(), S, anneal, ray_bundle.nears, ray_bundle.fars, jitter)
         return ray_samples_from_level(ray_bundle, s, e, ray_bundle.nears, ray_bundle.fars)
 
     forward = generate_ray_samples
@@ -329,5 +330,5 @@ class DepthRenderer(nn.Module):
         N, S = weights.shape[0], weights.shape[1]
         w = weights[..., 0].contiguous()
         dummy_rgb = torch.zeros((N, S, 1), device=w.device)
-        _, _, med, exp = ops.composite_fwd(dummy_rgb, w, ray_samples.e_bins, True, want_depth=True)
+        _, _, med, exp = ops.composite_fwd(dummy_rgb, w, ray_samples.dense_bins(), True, want_depth=True)
         return med if self.method == "median" else exp

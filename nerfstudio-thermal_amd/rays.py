@@ -1,48 +1,34 @@
-"""Boundary types of the hot path: RayBundle / RaySamples / Frustums with the reference's field names and methods
-(cameras/rays.py:32-295), minus the generic TensorDataclass machinery: the HIP path keeps rays flat [N, ...] and a level's samples
-dense [N, S, ...].  `RaySamples.get_weights` and `Frustums.get_positions` run on the device through the C ABI.
+"""Boundary types of the hot path: RayBundle / RaySamples / Frustums with the reference's field names, batch semantics and methods
+(cameras/rays.py:32-295 over utils/tensor_dataclass.py:27-350, restated in tensor_dataclass.py): broadcast on construction, `[...]`
+indexing, reshape / flatten / broadcast_to / to over the batch dimensions of every field, dict fields and the nested Frustums included.
+`RaySamples.get_weights` runs on the device through the C ABI.  The kernels take a level's samples as dense per-ray bins [N, S+1]; a
+RaySamples produced by this package carries them in the plain attributes `s_bins` / `e_bins` (not dataclass fields: they do not follow
+indexing or reshaping, and are rebuilt from the frustums when missing).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, fields
+import random
+from dataclasses import dataclass, field
 from typing import Callable, Dict, Optional
 
 import torch
 from torch import Tensor
 
 from . import ops
-
-
-def _map(obj, fn):
-    kw = {}
-    for f in fields(obj):
-        v = getattr(obj, f.name)
-        if isinstance(v, Tensor):
-            kw[f.name] = fn(v)
-        elif isinstance(v, dict):
-            kw[f.name] = {k: (fn(x) if isinstance(x, Tensor) else x) for k, x in v.items()}
-        elif hasattr(v, "__dataclass_fields__"):
-            kw[f.name] = _map(v, fn)
-        else:
-            kw[f.name] = v
-    return type(obj)(**kw)
+from .tensor_dataclass import TensorDataclass
 
 
 @dataclass
-class Frustums:
-    origins: Tensor  # [N,1,3] (broadcast along samples) or [N,S,3]
-    directions: Tensor
-    starts: Tensor  # [N,S,1]
-    ends: Tensor
-    pixel_area: Tensor
-    offsets: Optional[Tensor] = None
-
-    @property
-    def shape(self):
-        return self.starts.shape[:-1]
+class Frustums(TensorDataclass):
+    origins: Tensor  # [*bs, 3]
+    directions: Tensor  # [*bs, 3]
+    starts: Tensor  # [*bs, 1]
+    ends: Tensor  # [*bs, 1]
+    pixel_area: Tensor  # [*bs, 1]
+    offsets: Optional[Tensor] = None  # [*bs, 3]
 
     def get_positions(self) -> Tensor:
-        """cameras/rays.py:49-58 (element-wise; evaluated by torch on the device: it is not on the fused path, which recomputes positions in-kernel)."""
+        """cameras/rays.py:49-58 (element-wise; evaluated by torch on the device: the fused path recomputes positions in-kernel)."""
         pos = self.origins + self.directions * (self.starts + self.ends) / 2
         if self.offsets is not None:
             pos = pos + self.offsets
@@ -51,63 +37,68 @@ class Frustums:
     def get_start_positions(self) -> Tensor:
         return self.origins + self.directions * self.starts
 
+    def set_offsets(self, offsets) -> None:
+        self.offsets = offsets
+
 
 @dataclass
-class RaySamples:
+class RaySamples(TensorDataclass):
     frustums: Frustums
-    camera_indices: Optional[Tensor] = None
-    deltas: Optional[Tensor] = None
-    spacing_starts: Optional[Tensor] = None
+    camera_indices: Optional[Tensor] = None  # [*bs, 1]
+    deltas: Optional[Tensor] = None  # [*bs, 1]
+    spacing_starts: Optional[Tensor] = None  # [*bs, num_samples, 1]
     spacing_ends: Optional[Tensor] = None
     spacing_to_euclidean_fn: Optional[Callable] = None
     metadata: Optional[Dict[str, Tensor]] = None
     times: Optional[Tensor] = None
-    # dense level tensors kept for the kernels (not reference fields)
-    s_bins: Optional[Tensor] = field(default=None, repr=False)
-    e_bins: Optional[Tensor] = field(default=None, repr=False)
 
-    @property
-    def shape(self):
-        return self.frustums.shape
+    # dense per-ray bins of the level for the kernels (plain attributes, see the module docstring)
+    s_bins = None
+    e_bins = None
+
+    def dense_bins(self) -> Tensor:
+        """[N, S+1] euclidean bin edges of a [N, S] batch of contiguous frustums (end of sample i = start of sample i+1)."""
+        if self.e_bins is None:
+            if self.ndim != 2:
+                raise ValueError("the kernels take ray samples as a [num_rays, num_samples] batch")
+            self.e_bins = torch.cat([self.frustums.starts[..., 0], self.frustums.ends[..., -1:, 0]], dim=-1).contiguous()
+        return self.e_bins
+
+    def dense_spacing_bins(self) -> Tensor:
+        """[N, S+1] bin edges in normalised (spacing) coordinates, from spacing_starts / spacing_ends."""
+        if self.s_bins is None:
+            if self.ndim != 2 or self.spacing_starts is None or self.spacing_ends is None:
+                raise ValueError("PDF resampling needs [num_rays, num_samples] ray samples that carry spacing_starts / spacing_ends")
+            self.s_bins = torch.cat([self.spacing_starts[..., 0], self.spacing_ends[..., -1:, 0]], dim=-1).contiguous()
+        return self.s_bins
 
     def get_weights(self, densities: Tensor) -> Tensor:
         """RaySamples.get_weights (cameras/rays.py:128-150) -> tn_weights_fwd.  densities [N,S,1] -> weights [N,S,1]."""
-        if self.e_bins is None:
-            self.e_bins = torch.cat([self.frustums.starts[..., 0], self.frustums.ends[..., -1:, 0]], dim=-1).contiguous()
-        w, _ = ops.weights_fwd(self.e_bins, densities[..., 0].contiguous())
+        w, _ = ops.weights_fwd(self.dense_bins(), densities[..., 0].contiguous())
         return w.unsqueeze(-1)
 
 
 @dataclass
-class RayBundle:
-    origins: Tensor
-    directions: Tensor
-    pixel_area: Tensor
-    camera_indices: Optional[Tensor] = None
+class RayBundle(TensorDataclass):
+    origins: Tensor  # [*batch, 3]
+    directions: Tensor  # [*batch, 3]
+    pixel_area: Tensor  # [*batch, 1]
+    camera_indices: Optional[Tensor] = None  # [*batch, 1]
     nears: Optional[Tensor] = None
     fars: Optional[Tensor] = None
     metadata: Dict[str, Tensor] = field(default_factory=dict)
     times: Optional[Tensor] = None
 
-    @property
-    def shape(self):
-        return self.origins.shape[:-1]
-
-    def __len__(self) -> int:
-        return self.origins.numel() // self.origins.shape[-1]
-
     def set_camera_indices(self, camera_index: int) -> None:
         self.camera_indices = torch.ones_like(self.origins[..., 0:1]).long() * camera_index
 
-    def to(self, device) -> "RayBundle":
-        return _map(self, lambda t: t.to(device))
+    def __len__(self) -> int:
+        return torch.numel(self.origins) // self.origins.shape[-1]
 
-    def flatten(self) -> "RayBundle":
-        n = len(self)
-        return _map(self, lambda t: t.reshape(n, t.shape[-1]) if t.dim() >= 2 and t.numel() // max(t.shape[-1], 1) == n else t)
-
-    def __getitem__(self, idx) -> "RayBundle":
-        return _map(self, lambda t: t[idx])
+    def sample(self, num_rays: int) -> "RayBundle":
+        """cameras/rays.py:217-229: a random subset of the rays."""
+        assert num_rays <= len(self)
+        return self[random.sample(range(len(self)), k=num_rays)]
 
     def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
         """cameras/rays.py:238-249."""
@@ -115,13 +106,15 @@ class RayBundle:
 
     def get_ray_samples(self, bin_starts: Tensor, bin_ends: Tensor, spacing_starts: Optional[Tensor] = None, spacing_ends: Optional[Tensor] = None,
                         spacing_to_euclidean_fn: Optional[Callable] = None) -> RaySamples:
-        """cameras/rays.py:251-295: [N,S] frustums with the bundle's origins/directions/pixel_area broadcast as [N,1,.] views."""
-        fr = Frustums(origins=self.origins[..., None, :], directions=self.directions[..., None, :], starts=bin_starts, ends=bin_ends,
-                      pixel_area=self.pixel_area[..., None, :])
-        cam = self.camera_indices[..., None] if self.camera_indices is not None else None
-        return RaySamples(frustums=fr, camera_indices=cam, deltas=bin_ends - bin_starts, spacing_starts=spacing_starts, spacing_ends=spacing_ends,
-                          spacing_to_euclidean_fn=spacing_to_euclidean_fn, metadata={k: v[..., None, :] for k, v in self.metadata.items()},
-                          times=None if self.times is None else self.times[..., None])
+        """cameras/rays.py:251-295: [*batch, S] frustums; the bundle's origins / directions / pixel_area enter as [*batch, 1, .] and are
+        broadcast (views) along the samples."""
+        deltas = bin_ends - bin_starts
+        cam = self.camera_indices[..., None, :] if self.camera_indices is not None else None
+        shaped = self[..., None]
+        fr = Frustums(origins=shaped.origins, directions=shaped.directions, starts=bin_starts, ends=bin_ends, pixel_area=shaped.pixel_area)
+        return RaySamples(frustums=fr, camera_indices=cam, deltas=deltas, spacing_starts=spacing_starts, spacing_ends=spacing_ends,
+                          spacing_to_euclidean_fn=spacing_to_euclidean_fn, metadata=shaped.metadata,
+                          times=None if self.times is None else self.times[..., None, :])
 
 
 def ray_samples_from_level(bundle: RayBundle, s_bins: Tensor, e_bins: Tensor, nears: Tensor, fars: Tensor) -> RaySamples:

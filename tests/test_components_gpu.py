@@ -59,7 +59,8 @@ def test_spaced_and_pdf_samplers_standalone(training):
     hs, he = bins(rs0)
     assert md(hs, ref_s0) == 0.0
     assert md(he, orc.s_to_euclidean(ref_s0, nears, fars)) <= 1e-6 * 1000.0
-    assert rs0.frustums.origins.shape == (N, 1, 3) and rs0.frustums.starts.shape == (N, 256, 1) and rs0.camera_indices.shape == (N, 1, 1)
+    assert rs0.shape == (N, 256) and rs0.frustums.origins.shape == (N, 256, 3) and rs0.frustums.origins.stride(1) == 0  # broadcast view along the samples
+    assert rs0.frustums.starts.shape == (N, 256, 1) and rs0.camera_indices.shape == (N, 256, 1)
     # RaySamples.get_weights + PDFSampler on synthetic densities
     dens = torch.from_numpy(synth.uniform("cmp_dens", (N, 256, 1), 0.0, 40.0, SEED))
     w = rs0.get_weights(dens.to(DEV))

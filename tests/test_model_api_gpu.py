@@ -239,7 +239,7 @@ def test_parameters_without_gradient_get_none(golden_dir, mode):
     for step in range(14):
         before = {n: p.detach().clone() for n, p in model._params.items()}
         _trainer_step(model, opt, rb, batch, step)
-        updated = model._last_branches[""].prop_grad
+        updated = model.engine.last_updated
         for n, p in model._params.items():
             is_prop = n.startswith("proposal_networks.")
             thermal_twin = "_thermal" in n
