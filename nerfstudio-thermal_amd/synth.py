@@ -178,3 +178,29 @@ def synth_rays_simple(num_rays: int, seed: int = 11) -> Dict[str, np.ndarray]:
     d = d / np.linalg.norm(d, axis=1, keepdims=True)
     cam = (splitmix64(np.arange(num_rays, dtype=np.uint64) + np.uint64(seed)) % np.uint64(8)).astype(np.int64)
     return {"origins": o.astype(np.float32), "directions": d.astype(np.float32), "camera_indices": np.sort(cam)}
+
+
+def cube_scene_images(origins: np.ndarray, directions: np.ndarray, is_thermal: bool, half: float = 0.35) -> np.ndarray:
+    """Analytic RGB / thermal image of a textured cube [-half, half]^3 in front of a direction-dependent background, for rays [P,3]: a
+    multi-view CONSISTENT scene ('analytic unit cube with per-face colour / temperature'), unlike synth_images.  -> [P,3] fp32
+    (thermal: the temperature repeated three times, as ThermalDataset stores it)."""
+    o, d = origins.astype(np.float64), directions.astype(np.float64)
+    inv = 1.0 / np.where(np.abs(d) < 1e-12, 1e-12, d)
+    t0, t1 = (-half - o) * inv, (half - o) * inv
+    tn, tf = np.minimum(t0, t1), np.maximum(t0, t1)
+    t_in, t_out = tn.max(axis=1), tf.min(axis=1)
+    hit = (t_out >= np.maximum(t_in, 0.0)) & (t_in > 0.0)
+    axis = tn.argmax(axis=1)
+    p = o + d * t_in[:, None]
+    sign = (np.take_along_axis(p, axis[:, None], axis=1)[:, 0] > 0).astype(np.int64)
+    face = 2 * axis + sign
+    uv = np.stack([np.take_along_axis(p, ((axis + 1) % 3)[:, None], 1)[:, 0], np.take_along_axis(p, ((axis + 2) % 3)[:, None], 1)[:, 0]], 1) / half
+    tex = 0.8 + 0.2 * np.sin(5.0 * uv[:, 0]) * np.sin(5.0 * uv[:, 1])
+    face_rgb = np.array([[0.9, 0.2, 0.2], [0.2, 0.8, 0.3], [0.2, 0.3, 0.9], [0.9, 0.8, 0.2], [0.8, 0.3, 0.8], [0.2, 0.8, 0.8]])
+    face_temp = np.array([0.9, 0.3, 0.7, 0.5, 0.8, 0.4])
+    if is_thermal:
+        bg = 0.25 + 0.1 * d[:, 2]
+        val = np.where(hit, face_temp[face] * tex, bg)
+        return np.repeat(val[:, None], 3, axis=1).astype(np.float32)
+    bg = 0.5 + 0.35 * d
+    return np.where(hit[:, None], face_rgb[face] * tex[:, None], bg).astype(np.float32)
