@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libthermal_nerf_hip.so")
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
-TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN = 1, 2, 4
+TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD = 1, 2, 4, 8, 16
 
 _p = C.c_void_p
 _i32 = C.c_int32

@@ -288,5 +288,11 @@ struct ReplicaK {
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum = nullptr);
+// The binned scatter in two steps, for a backward that hands level ranges to a gradient exchange as they complete: the bin pass covers the
+// whole grid once, the fold runs per level range.  Only valid when tn_grid_scatter_is_binned(grid, P, scratch).
+bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratch);
+int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
+                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream);
+int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream);
 int64_t tn_grid_dense_count(const TnGrid& grid, int64_t P);
 int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream);

@@ -759,8 +759,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   const bool dens_only = d_rgb == nullptr;  // backward of tn_field_density_fwd(training): no colour path at all
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
-  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN)) == 0 && phases != 0, "tn_field_bwd: bad phase set %d", phases);
-  if (phases & TN_BWD_SCATTER)
+  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) == 0 && phases != 0,
+             "tn_field_bwd: bad phase set %d", phases);
+  TN_REQUIRE(!((phases & TN_BWD_SCATTER) && (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD))), "tn_field_bwd: TN_BWD_SCATTER and its two halves exclude each other");
+  if (phases & (TN_BWD_SCATTER | TN_BWD_SCATTER_FOLD))
     TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd: bad level range [%d, %d)", level_begin,
                level_end);
   int64_t P = N * (int64_t)S;
@@ -807,6 +809,12 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, d_origins, d_directions, ws.scatter, st);
+  }
+  if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
+    TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");
+    if (phases & TN_BWD_SCATTER_BIN)
+      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, ws.scatter, st);
+    if (rc == TN_OK && (phases & TN_BWD_SCATTER_FOLD)) rc = tn_grid_scatter_fold(field->grid, P, ws.scatter, level_begin, level_end, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);
   return rcw ? rcw : rc;

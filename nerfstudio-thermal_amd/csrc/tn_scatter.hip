@@ -502,22 +502,23 @@ __device__ __forceinline__ void fold_add_release(float2* acc, uint32_t* lock, ui
   acc[id] = a;
   (void)__hip_atomic_fetch_and(&lock[id >> 5], ~(1u << (id & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk) {
+__global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, uint32_t first_block) {
   extern __shared__ float s_mem[];  // [2 << slice_log2] sums, then [(1 << slice_log2) / 32] lock words
+  const uint32_t blk = first_block + blockIdx.x;  // a launch may cover the blocks of a level range only
   uint32_t l = 0;
 #pragma unroll 1
   for (int i = 1; i < g.L; ++i)
-    if (blockIdx.x >= bk.blk0[i]) l = i;
+    if (blk >= bk.blk0[i]) l = i;
   const uint32_t chunk = bk.chunk[l], chunks_per_bucket = (bk.cap + chunk - 1) / chunk;
   // chunk-major inside a level: consecutive blocks = the same chunk of consecutive buckets.  Blocks go to the 8 XCDs round-robin by index, and
   // only the first chunk or two of a bucket hold records: bucket-major order put every live block of the sparse levels on XCDs 0 and 4
   // (4 chunks per bucket), which then ran twice as long as the other six.
-  const uint32_t ch = (blockIdx.x - bk.blk0[l]) / bk.nslices, sl = (blockIdx.x - bk.blk0[l]) % bk.nslices;
+  const uint32_t ch = (blk - bk.blk0[l]) / bk.nslices, sl = (blk - bk.blk0[l]) % bk.nslices;
   (void)chunks_per_bucket;
   const uint32_t count = min(bk.count[l * bk.nslices + sl], bk.cap);
   const uint32_t begin = ch * chunk;
   if (begin >= count) return;  // whole block leaves together
-  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x] = wall_clock64();
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk] = wall_clock64();
   const uint32_t end = min(count, begin + chunk);
   const bool split = count > chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk) {
     for (uint32_t t = 4 * n4 + tid; t < nf; t += FOLD_THREADS) s_mem[t] = 0.0f;
   }
   __syncthreads();
-  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x + 1] = wall_clock64();
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk + 1] = wall_clock64();
   const bool sparse = (bk.sparse_mask >> l) & 1u;
   float* acc2 = s_mem + 2 * slots + words;  // second image: float atomics only (a float atomic racing a plain read-modify-write would be lost)
   for (uint32_t blk = begin + wave * 512; blk < end; blk += FOLD_THREADS * 8) {  // per wave: no barrier inside
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk) {
     cur = nxt;
   }
   __syncthreads();
-  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blockIdx.x + 2] = wall_clock64();
+  if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk + 2] = wall_clock64();
   float2* dst = g.grad + (size_t)l * g.tsize + ((size_t)sl << bk.slice_log2);
   for (uint32_t t0 = 0; t0 < slots; t0 += FOLD_THREADS * 8) {
     float2 v[8], cv[8];
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk) {
   }
   if (bk.trace) {
     __syncthreads();
-    if (threadIdx.x == 0) bk.trace[16 * blockIdx.x + 3] = wall_clock64();
+    if (threadIdx.x == 0) bk.trace[16 * blk + 3] = wall_clock64();
   }
 }
 
@@ -643,11 +644,11 @@ static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); 
 static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 8192, 1024, 32768) & ~1023; return r; }
 static int merge_res() { static int r = env_int("TN_SCATTER_MERGE_RES", 256, 0, 1 << 20); return r; }
 
-static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
-  const int64_t P = N * (int64_t)S;
+// Layout of the binned scatter for (grid, P, scratch): a pure function of its arguments, so the bin pass and the fold launches of a phased
+// backward (tn_grid_scatter_bin / tn_grid_scatter_fold) agree on it without any state.
+static int bin_plan(const TnGrid& grid, int64_t P, void* scratch, BinK& bk, uint32_t& nblk) {
   const int L = grid.num_levels;
-  BinK bk{};
+  bk = BinK{};
   bk.slice_log2 = std::min(TN_BIN_SLICE_LOG2, grid.log2_hashmap_size);
   bk.nslices = 1 << (grid.log2_hashmap_size - bk.slice_log2);
   TN_REQUIRE(bk.nslices <= TN_BIN_MAX_SLICES, "tn_grid_scatter: table too large for the binned path");
@@ -661,7 +662,7 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
   const int64_t cnt_bytes = 256 + (int64_t)L * TN_BIN_MAX_SLICES * 4;
   bk.val = reinterpret_cast<float2*>(base + cnt_bytes);
   bk.idx = reinterpret_cast<uint16_t*>(base + cnt_bytes + (int64_t)L * tn_bin_level_records(P) * 8);
-  uint32_t nblk = 0;
+  nblk = 0;
   for (int l = 0; l < L; ++l) {
     if (grid.res[l] <= (float)merge_res()) bk.merge_mask |= 1u << l;
     // live slots of the level: (res+1)^3 cells hashed into 2^log2T slots; below half of the table the buckets are sparse and hot
@@ -675,6 +676,17 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
     nblk += (uint32_t)(bk.nslices * tn_cdiv(bk.cap, bk.chunk[l]));
   }
   bk.blk0[L] = nblk;
+  return TN_OK;
+}
+
+int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
+                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
+  const int64_t P = N * (int64_t)S;
+  const int L = grid.num_levels;
+  BinK bk;
+  uint32_t nblk;
+  int rc = bin_plan(grid, P, scratch, bk, nblk);
+  if (rc) return rc;
   hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4, stream);
   TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
   GridK gk = make_gridk(grid);
@@ -690,6 +702,19 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
     hipLaunchKernelGGL(k_grid_bin<false>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S,
                        d_origins, d_directions, level_groups, bk);
   TN_CHECK_LAUNCH("tn_grid_scatter(bin)");
+  return TN_OK;
+}
+
+// fold of levels [level_begin, level_end) of a grid whose records tn_grid_scatter_bin has written (same grid, P and scratch)
+int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream) {
+  const int L = grid.num_levels;
+  TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= L, "tn_grid_scatter_fold: bad level range");
+  BinK bk;
+  uint32_t nblk_all;
+  int rc = bin_plan(grid, P, scratch, bk, nblk_all);
+  if (rc) return rc;
+  GridK gk = make_gridk(grid);
+  const uint32_t first_block = bk.blk0[level_begin], nblk = bk.blk0[level_end] - bk.blk0[level_begin];
   const size_t shmem = ((size_t)(4u << bk.slice_log2) + (((1u << bk.slice_log2) + 31) / 32) + 1) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -700,16 +725,16 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
   static unsigned long long* trace_buf = nullptr;
   if (trace_on) {  // diagnostics only: synchronises and prints
     if (!trace_buf) (void)hipMalloc(&trace_buf, (size_t)1 << 22);
-    (void)hipMemsetAsync(trace_buf, 0, (size_t)nblk * 128, stream);
+    (void)hipMemsetAsync(trace_buf, 0, (size_t)nblk_all * 128, stream);
     bk.trace = trace_buf;
   }
-  hipLaunchKernelGGL(k_grid_fold, dim3(nblk), dim3(FOLD_THREADS), shmem, stream, gk, bk);
+  hipLaunchKernelGGL(k_grid_fold, dim3(nblk), dim3(FOLD_THREADS), shmem, stream, gk, bk, first_block);
   if (trace_on) {
-    std::vector<unsigned long long> h((size_t)nblk * 16);
+    std::vector<unsigned long long> h((size_t)nblk_all * 16);
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h.data(), trace_buf, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull, t1 = 0;
-    for (uint32_t b = 0; b < nblk; ++b)
+    for (uint32_t b = 0; b < nblk_all; ++b)
       if (h[16 * b]) { t0 = std::min(t0, h[16 * b]); t1 = std::max(t1, h[16 * b + 3]); }
     fprintf(stderr, "[fold trace] %u blocks, span %.1f us (wall clock 100 MHz)\n", nblk, (t1 - t0) / 100.0);
     if (const char* dump = getenv("TN_FOLD_TRACE_FILE")) {
@@ -734,14 +759,24 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
   return TN_OK;
 }
 
+bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratch) {
+  return scratch != nullptr && scatter_mode() == 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 && P * 8 < (1ll << 31);
+}
+
+static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
+                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
+  int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream);
+  if (rc) return rc;
+  return tn_grid_scatter_fold(grid, N * (int64_t)S, scratch, 0, grid.num_levels, stream);
+}
+
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
-  if (scratch != nullptr && dense_sum == nullptr && scatter_mode() == 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 &&
-      P * 8 < (1ll << 31))
+  if (dense_sum == nullptr && tn_grid_scatter_is_binned(grid, P, scratch))
     return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream);
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
   // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups

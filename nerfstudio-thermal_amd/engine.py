@@ -311,10 +311,10 @@ class RenderEngine:
             # streams, the number of hardware queues ROCm multiplexes streams onto by default -- a fifth stream shares a queue with another
             # and serialises behind it (measured: one side stream per proposal level made the step 1.7x slower).
             side = None
-            # Without the overlapped exchange only the level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the side
-            # stream; the level-1 network follows the main field on the main stream.  Both on the side stream left the main stream idle
-            # for the last ~250 us of every proposal-update step (rocprofv3 timeline of the step).
-            on_side = (0, 1) if pipelined else (0,)
+            # Only the level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the side stream; the level-1 network follows
+            # the main field on the main stream.  Both on the side stream left the main stream idle for the last ~250 us of every
+            # proposal-update step (rocprofv3 timeline of the step).
+            on_side = (0,)
             if br.prop_grad:
                 side = self._side_stream()
                 main = torch.cuda.current_stream()
@@ -326,7 +326,7 @@ class RenderEngine:
                         if pipelined:  # this network's gradients are final: exchange them while the next one / the main field is still at work
                             glo, ghi = self.arena.group_range["proposal_networks"]
                             first = [self.arena.layout[f"proposal_networks.{k}.mlp_base.0.hash_table"][0] for k in range(2)]
-                            dp.reduce_range(first[i] if i else glo, first[i + 1] if i + 1 < 2 else ghi)
+                            dp.reduce_range(first[i] if i else glo, first[i + 1] if i + 1 < 2 else ghi, side=True)
             if pipelined:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
@@ -337,18 +337,29 @@ class RenderEngine:
                 # the coarse levels first, exchanged as dense per-cell sums (their table slice is almost all zeros): the longest prefix of levels
                 # that are all dense-replica levels at this batch size
                 nd = 0
-                while nd < fld.num_levels and ops.field_dense_count(fld, P, 0, nd + 1) > 0:
+                while getattr(dp, "dense_exchange", False) and nd < fld.num_levels and ops.field_dense_count(fld, P, 0, nd + 1) > 0:
                     nd += 1
                 if nd > 0:
                     cells = ops.field_dense_count(fld, P, 0, nd)
                     dense = torch.empty((cells, 2), device=dev)
                     ops.field_bwd_scatter_dense(fld, br.origins, br.directions, lv[2].e_bins, d_o, d_d, 0, nd, dense)
                     dp.reduce_tensor(dense, (t0, t0 + nd * T2), lambda fld=fld, P=P, nd=nd, dense=dense: ops.field_dense_fold(fld, P, 0, nd, dense))
+                # one bin pass over every level, then one fold per exchanged level range (with the dense exchange of the coarse levels the
+                # remaining levels go range by range through the whole scatter instead: bin + fold per range)
+                two_step = nd == 0
+                if two_step:
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER_BIN)
                 for lb, le in dp.level_ranges(fld.num_levels - nd):
                     lb, le = lb + nd, le + nd
-                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, lb, le)
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
+                                        ph.TN_BWD_SCATTER_FOLD if two_step else ph.TN_BWD_SCATTER, lb, le)
                     dp.reduce_range(t0 + lb * T2, t0 + le * T2)
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
+                if br.prop_grad:  # the level-1 proposal network, behind the table ranges on the main stream and the main communicator
+                    dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, dws[1])
+                    ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="main1")
+                    glo, ghi = self.arena.group_range["proposal_networks"]
+                    dp.reduce_range(self.arena.layout["proposal_networks.1.mlp_base.0.hash_table"][0], ghi)
             else:
                 ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
                 if br.prop_grad:

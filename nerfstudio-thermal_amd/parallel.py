@@ -81,13 +81,21 @@ class OverlappedGradReducer:
 
     pipelined = True
 
-    def __init__(self, world_size: int, group=None, level_chunks=(2, 4, 4, 3, 2, 1)):
-        """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The first exchange can only
-        start after the first scatter and the last one cannot hide behind any, so the ranges are small at both ends: when the ring is the
-        slower side (few GPUs, one xGMI link each way) it starts after 2 levels instead of 6, and the exposed tail is one level (4 MB)."""
+    def __init__(self, world_size: int, group=None, level_chunks=(6, 4, 3, 2, 1), dense_exchange: bool = False, side_group="auto"):
+        """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The last range cannot hide
+        behind any scatter, so the ranges shrink towards the end: the exposed tail is one level (4 MB).  The first range takes the six
+        coarsest levels: their scatter is the cheapest part of the backward and nothing can be exchanged before it anyway.
+        dense_exchange: exchange the coarse levels as dense per-cell sums (2.65 MB instead of 20 MB; tn_field_bwd_scatter_dense + dense fold).
+        It needs the round-1 atomic scatter for those levels and two extra launches; with the binned scatter the plain level ranges are
+        faster on one rank (bench.py --force-dp), so it is off by default.
+        side_group: process group for the proposal networks' exchange, which is issued from the side stream.  A communicator runs its
+        collectives in issue order on ONE stream: in the same group as the table ranges, the first table range would queue behind the
+        proposal exchange, which in turn waits for the whole level-0 proposal backward.  "auto" creates a second group over the same ranks."""
         self.world = world_size
         self.group = group
         self.level_chunks = level_chunks
+        self.dense_exchange = dense_exchange
+        self._side_group = side_group
         self._works: List = []
         self._ranges: List[Tuple[int, int]] = []
         self._arena = None
@@ -121,18 +129,24 @@ class OverlappedGradReducer:
         self._ranges = []
         self._after = {}
 
-    def _issue(self, tensor) -> None:
+    def side_group(self):
+        if isinstance(self._side_group, str):  # "auto": every rank reaches this at the same point of the same schedule (collective call)
+            self._side_group = dist.new_group() if dist.is_initialized() else None
+        return self._side_group
+
+    def _issue(self, tensor, group=None) -> None:
         if dist.is_initialized():  # a 1-process group still goes through the backend (GPU tests drive RCCL that way)
-            self._works.append(dist.all_reduce(tensor, op=self._op(), group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(tensor, op=self._op(), group=group if group is not None else self.group, async_op=True))
         else:
             self._works.append(None)
 
-    def reduce_range(self, lo: int, hi: int) -> None:
-        """Asynchronous mean all-reduce of arena.grads[lo:hi]; ordered after everything already enqueued on the current stream."""
+    def reduce_range(self, lo: int, hi: int, side: bool = False) -> None:
+        """Asynchronous mean all-reduce of arena.grads[lo:hi]; ordered after everything already enqueued on the current stream.
+        side=True: on the second communicator (the proposal networks, issued from their side stream)."""
         if hi <= lo:
             return
         self._ranges.append((lo, hi))
-        self._issue(self._arena.grads[lo:hi])
+        self._issue(self._arena.grads[lo:hi], self.side_group() if side else None)
 
     def reduce_tensor(self, tensor, covers: Tuple[int, int], after) -> None:
         """Asynchronous mean all-reduce of a side tensor that STANDS FOR arena.grads[covers[0]:covers[1]] (the dense per-cell sums of the coarse

@@ -76,19 +76,23 @@ def test_field_bwd_phases_equal_whole(golden_dir):
     gd = torch.rand_like(lv.density)
     gc = torch.rand_like(b.rgb_samples)
     res = []
-    for ranges in (None, [(0, 16)], [(0, 5), (5, 6), (6, 16)]):
+    # whole / SCATTER per level range (bin + fold each) / one SCATTER_BIN over all levels + SCATTER_FOLD per level range
+    for ranges, two_step in ((None, False), ([(0, 16)], False), ([(0, 5), (5, 6), (6, 16)], False), ([(0, 6), (6, 10), (10, 13), (13, 15), (15, 16)], True)):
         arena.zero_grad()
         d_o, d_d = torch.zeros_like(o), torch.zeros_like(d)
         if ranges is None:
             ops.field_bwd(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d)
         else:
             ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d, _lib.TN_BWD_MLP)
+            if two_step:
+                ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d, _lib.TN_BWD_SCATTER_BIN)
             for lb, le in ranges:
-                ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d, _lib.TN_BWD_SCATTER, lb, le)
+                ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d,
+                                    _lib.TN_BWD_SCATTER_FOLD if two_step else _lib.TN_BWD_SCATTER, lb, le)
             ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv.e_bins, gd, gc, d_o, d_d, _lib.TN_BWD_JOIN)
         torch.cuda.synchronize()
         res.append((arena.grads.clone(), d_o.clone(), d_d.clone()))
-    for k in (1, 2):
+    for k in (1, 2, 3):
         for a, bb in zip(res[0], res[k]):
             assert float((a - bb).abs().max()) <= 2e-6 * float(a.abs().max()), k
     with pytest.raises(RuntimeError):
@@ -107,7 +111,7 @@ def test_dense_exchange_of_coarse_levels_full_size(rccl_group):
     cam = idx[:, 0].contiguous()
     jit = [torch.from_numpy(j).to(dev).reshape(-1).contiguous() for j in synth.synth_jitters(4096, seed=5)]
     grads = []
-    for hook in (None, OverlappedGradReducer(1)):
+    for hook in (None, OverlappedGradReducer(1), OverlappedGradReducer(1, dense_exchange=True)):  # plain level ranges (default) / dense coarse levels
         cfg, arena, eng = bench.build_engine(dev)
         assert ops.field_dense_count(eng.field, 4096 * 48, 0, 5) == 4913 + 12167 + 29791 + 79507 + 205379
         assert ops.field_dense_count(eng.field, 4096 * 48, 0, 6) == 0  # level 5 (res 80) has more cells than the table has slots
@@ -123,7 +127,8 @@ def test_dense_exchange_of_coarse_levels_full_size(rccl_group):
             assert sorted(covered)[0][0] == lo and sorted(covered)[-1][1] == hi
         torch.cuda.synchronize()
         grads.append(arena.grads.clone())
-    g0, g1 = grads
+    g0 = grads[0]
     scale = float(g0.abs().max())
-    assert float((g0 - g1).abs().max()) <= 2e-6 * scale, float((g0 - g1).abs().max()) / scale
-    assert torch.equal(g0 == 0, g1 == 0)
+    for g1 in grads[1:]:
+        assert float((g0 - g1).abs().max()) <= 2e-6 * scale, float((g0 - g1).abs().max()) / scale
+        assert int(((g0 == 0) != (g1 == 0)).sum()) <= 4  # exact cancellations may leave a residue in another summation order

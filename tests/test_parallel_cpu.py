@@ -95,11 +95,11 @@ def _worker_overlapped(rank, world, port, q):
     for skip_prop in (False, True):
         arena.grads.copy_(base * (rank + 1))
         red = OverlappedGradReducer(world)
-        assert red.level_ranges(16) == [(0, 2), (2, 6), (6, 10), (10, 13), (13, 15), (15, 16)]
+        assert red.level_ranges(16) == [(0, 6), (6, 10), (10, 13), (13, 15), (15, 16)] and not red.dense_exchange
         assert OverlappedGradReducer(world, level_chunks=4).level_ranges(16) == [(0, 4), (4, 8), (8, 12), (12, 16)]
         red.begin(arena)
         if not skip_prop:
-            red.reduce_range(plo, phi)                      # proposal networks, early
+            red.reduce_range(plo, phi, side=True)           # proposal networks, early, on the second communicator
         for lb, le in red.level_ranges(16):                # the main table in shrinking level ranges
             red.reduce_range(t0 + lb * per_level, t0 + le * per_level)
         # the rest of the live range (embedding, MLPs, pose) is issued by finish_iter, split at the optimiser-group boundaries
