@@ -238,6 +238,11 @@ int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred
  * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
 int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
                tn_stream_t stream);
+/* per-iteration metrics in one launch (models/thermal_nerfacto.py:262-270 PSNR per spectrum from the tn_pixel_losses sums losses[0,1,4,5];
+ * cameras/camera_optimizers.py:197-202 pose norms): metrics_out[0] psnr_rgb, [1] psnr_thermal, [2],[3] |pose0[:, :3]|, |pose0[:, 3:]|,
+ * [4],[5] the same for pose1; either pose may be NULL. */
+int tn_train_metrics(const float* losses, int64_t N, float thermal_mult, const float* pose0, int32_t num_cameras0, const float* pose1,
+                     int32_t num_cameras1, float* metrics_out, tn_stream_t stream);
 /* camera regulariser (cameras/camera_optimizers.py:189-195). */
 int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans_pen, float rot_pen, float scale, float* loss_out,
                   float* grad_pose, tn_stream_t stream);

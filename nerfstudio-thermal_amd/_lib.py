@@ -80,6 +80,7 @@ SIGNATURES = {
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),
+    "tn_train_metrics": (C.c_int, [_p, _i64, _f, _p, _i32, _p, _i32, _p, _p]),
     "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
     "tn_adam_step_ranges": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _d, _d, _d, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),

@@ -23,7 +23,9 @@ def _scalar_grads_equal(gs) -> Optional[Tensor]:
         return None
     g0 = gs[0]
     for g in gs[1:]:
-        if g is not g0 and not bool(torch.equal(g, g0)):
+        if g is g0 or (g.data_ptr() == g0.data_ptr() and g.shape == g0.shape):
+            continue  # one tensor handed down a chain of additions: no device round trip
+        if not bool(torch.equal(g, g0)):
             return None
     return g0
 
@@ -131,3 +133,98 @@ class CameraRegularizer(torch.autograd.Function):
     def backward(ctx, g):
         (gp,) = ctx.saved_tensors
         return gp * g, None, None, None
+
+
+class LossSpec:
+    """What TrainLosses needs besides tensors: the loss multipliers of the config and, per branch, the (non-differentiable) s-space bins of
+    the three levels and whether the proposal networks take a gradient this iteration."""
+
+    def __init__(self, separate: bool, thermal_mult: float, tv_mult: float, cross_mult: float, distortion_mult: float, interlevel_mult: float,
+                 branches, density_weights=None, camera_regs=()):
+        self.separate = separate
+        self.thermal_mult, self.tv_mult, self.cross_mult = thermal_mult, tv_mult, cross_mult
+        self.distortion_mult, self.interlevel_mult = distortion_mult, interlevel_mult
+        self.branches = branches  # [(suffix, [s_bins0, s_bins1, s_bins2], prop_grad)]
+        self.density_weights = density_weights  # (a, b) of the density loss or None
+        self.camera_regs = camera_regs  # [(trans_pen, rot_pen, scale)] per pose parameter passed
+
+
+class TrainLosses(torch.autograd.Function):
+    """EVERY loss term of a training iteration (models/thermal_nerfacto.py:253-388) as one autograd node, through the same launches as the
+    fused step (engine.RenderEngine.loss_and_backward): tn_pixel_losses, tn_proposal_losses per branch (distortion + both interlevel
+    terms), tn_l1_loss x2 (density cross terms), tn_camera_reg.  Every kernel yields value AND gradient; all gradient buffers come out of
+    one zero-filled allocation, and backward scales that allocation once by the incoming gradient -- the Trainer sums the loss dict
+    (engine/trainer.py:483), so all terms arrive with the same weight; anything else is refused (use the *_loss_mult settings).
+
+    inputs : spec, image [N,3], is_thermal [N], then per branch (comp, w0, w1, w2), then (density2, density_thermal, density,
+             density2_thermal) when the density loss is on, then one pose parameter per entry of spec.camera_regs.
+    outputs: L[0..31] unbound: 0 rgb 1 thermal 2 tv 3 cross 4 #rgb rays 5 #thermal rays 8 interlevel 9 distortion 10 density 11/12 camera
+             regularisers; metrics (not differentiable, tn_train_metrics): 16 psnr_rgb 17 psnr_thermal 18/19 |pose[:, :3]|, |pose[:, 3:]| of the
+             first pose parameter, 20/21 of the second."""
+
+    @staticmethod
+    def forward(ctx, spec: LossSpec, image: Tensor, is_thermal: Tensor, *ts: Tensor):
+        dev = image.device
+        it = iter(ts)
+        per = [(sfx, sb, pg, next(it), [next(it), next(it), next(it)]) for sfx, sb, pg in spec.branches]
+        dens = [next(it) for _ in range(4)] if spec.density_weights is not None else []
+        poses = [next(it) for _ in spec.camera_regs]
+        # one zero-filled allocation for the loss vector and every gradient buffer (order = input order)
+        shapes = [(32,)]
+        for _, _, pg, comp, ws in per:
+            shapes.append(tuple(comp.shape))
+            shapes += [tuple(w.shape[:2]) for w in ws]
+        shapes += [tuple(d.shape) for d in dens] + [tuple(p.shape) for p in poses]
+        sizes = [int(torch.Size(s).numel()) for s in shapes]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64
+        flat = torch.zeros(tot, device=dev)
+        bufs = [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
+        L, grads = bufs[0], bufs[1:]
+        gi = iter(grads)
+        g_per = [(next(gi), [next(gi), next(gi), next(gi)]) for _ in per]
+        # ---- pixel terms
+        if spec.separate:
+            (_, _, _, comp, _), (_, _, _, comp_t, _) = per
+            ops.pixel_losses(comp, comp_t, image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], g_per[0][0], g_per[1][0])
+        else:
+            comp, d_comp = per[0][3], g_per[0][0]
+            ops.pixel_losses(comp[:, :3], comp[:, 3:], image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], d_comp[:, :3], d_comp[:, 3:])
+        # ---- proposal terms (metrics_dict["distortion"] is the sum over suffixes and enters once per suffix: x nsfx, :363-368)
+        nsfx = len(per)
+        for (sfx, sb, pg, comp, ws), (_, dws) in zip(per, g_per):
+            w = [x[..., 0] for x in ws]
+            ops.proposal_losses(sb[2], w[2], [(sb[i], w[i], dws[i] if pg else None) for i in range(2)], spec.distortion_mult * nsfx, spec.interlevel_mult,
+                                L[9:10], L[8:9], dws[2])
+        # ---- density cross terms  a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|
+        if dens:
+            a, b = spec.density_weights
+            gd = [next(gi) for _ in range(4)]
+            ops.l1_loss(dens[0], dens[1], b, a, L[10:11], gd[0], gd[1])
+            ops.l1_loss(dens[2], dens[3], b, a, L[10:11], gd[2], gd[3])
+        for k, (pose, (tp, rp, sc)) in enumerate(zip(poses, spec.camera_regs)):
+            ops.camera_reg(pose.detach(), tp, rp, sc, L[11 + k:12 + k], next(gi))
+        ctx.set_materialize_grads(False)  # unused terms arrive as None, not as zeros
+        ctx.flat, ctx.layout, ctx.nper = flat, (offs[1:], sizes[1:], shapes[1:]), [pg for _, _, pg, _, _ in per]
+        ops.train_metrics(L, image.shape[0], spec.thermal_mult, [p.detach() for p in poses], L[16:24])
+        outs = L.unbind(0)
+        ctx.mark_non_differentiable(*(outs[i] for i in range(32) if i not in (0, 1, 2, 3, 8, 9, 10, 11, 12)))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        g = _scalar_grads_equal([gs[i] for i in (0, 1, 2, 3, 8, 9, 10, 11, 12)])
+        if g is None:
+            raise RuntimeError("TrainLosses: the loss terms must enter the total with one common weight (the Trainer sums the loss dict); "
+                               "scale a term through its *_loss_mult instead")
+        scaled = ctx.flat * g  # every gradient buffer at once (out of place: the loss values the caller holds live in the same allocation)
+        out = [None, None, None]
+        gi = iter([scaled[o:o + n].view(*s) for o, n, s in zip(*ctx.layout)])
+        for pg in ctx.nper:
+            out.append(next(gi))
+            dws = [next(gi), next(gi), next(gi)]
+            out += [dws[0].unsqueeze(-1) if pg else None, dws[1].unsqueeze(-1) if pg else None, dws[2].unsqueeze(-1)]
+        out += list(gi)
+        return tuple(out)

@@ -560,23 +560,31 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ dY, int ldy
   }
   // Epilogue.  Same-line global atomics serialise at ~25 ns each (measured: 4096 waves adding into one 64-B line = 100 us), so the block's
   // waves are first summed in LDS and then ONE coalesced burst per block goes out (16 consecutive floats per 64-B request).
-  for (int t = threadIdx.x; t < MO * MI * 1024 + MO * 32; t += blockDim.x) red[t] = 0.0f;
-  __syncthreads();
-  if (p_begin < p_end) {
+  // The LDS sum takes turns, one wave per barrier interval, with plain read-add-write: ds_add_f32 is executed lane by lane on gfx950
+  // (~195 cycles per wave instruction, scripts/microbench/lds_atomic_rate.hip) -- the 16 x tiles float atomics per wave used to cost
+  // as much as the K loop and kept the LDS pipe busy that the concurrent table scatter (k_grid_bin / k_grid_fold) is bound by.
+  const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  for (int w = 0; w < nwv; ++w) {
+    if (wv == w) {
 #pragma unroll
-    for (int a = 0; a < MO; ++a) {
+      for (int a = 0; a < MO; ++a) {
 #pragma unroll
-      for (int b = 0; b < MI; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[a][b][r];
-          if (v != 0.0f) atomicAdd(&red[((a * 32 + RROW(r, h)) * MI + b) * 32 + j], v);
+          for (int r = 0; r < 16; ++r) {
+            float* dst = &red[((a * 32 + RROW(r, h)) * MI + b) * 32 + j];
+            float v = acc[a][b][r];
+            *dst = (w == 0) ? v : *dst + v;
+          }
+        float sb = bsum[a] + __shfl_xor(bsum[a], 32, 64);
+        if (h == 0) {
+          float* dst = &red[MO * MI * 1024 + 32 * a + j];
+          *dst = (w == 0) ? sb : *dst + sb;
         }
-      float sb = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-      if (h == 0 && sb != 0.0f) atomicAdd(&red[MO * MI * 1024 + 32 * a + j], sb);
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   for (int t = threadIdx.x; t < MO * MI * 1024; t += blockDim.x) {
     int i = t % (32 * MI), o = t / (32 * MI);  // row-major over the padded [32*MO][32*MI] tile: consecutive threads = consecutive columns
     float v = red[t];

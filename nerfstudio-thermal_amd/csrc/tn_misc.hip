@@ -387,6 +387,41 @@ extern "C" int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, 
   return TN_OK;
 }
 
+// Per-iteration metrics of ThermalNerfactoModel.get_metrics_dict (models/thermal_nerfacto.py:253-282) that are pure functions of the loss
+// sums and the pose parameters, in ONE single-block launch instead of ~10 tiny tensor operations:
+//   metrics[0] = psnr_rgb     = -10 log10(rgb_loss * N / #rgb rays)                        (losses[0], losses[4] of tn_pixel_losses)
+//   metrics[1] = psnr_thermal = -10 log10(thermal_loss * (N / thermal_mult) / #thermal rays) (losses[1], losses[5])
+//   metrics[2 + 2k], metrics[3 + 2k] = |pose_k[:, :3]|, |pose_k[:, 3:]| (Frobenius; cameras/camera_optimizers.py:197-202), k < num_poses
+__global__ void k_train_metrics(const float* __restrict__ losses, int64_t N, float thermal_mult, const float* __restrict__ pose0, int C0,
+                                const float* __restrict__ pose1, int C1, float* __restrict__ metrics) {
+  if (threadIdx.x == 0) {
+    metrics[0] = -10.0f * log10f(losses[0] * (float)N / losses[4]);
+    metrics[1] = -10.0f * log10f(losses[1] * ((float)N / thermal_mult) / losses[5]);
+  }
+  for (int k = 0; k < 2; ++k) {
+    const float* pose = k ? pose1 : pose0;
+    const int C = k ? C1 : C0;
+    if (pose == nullptr) continue;
+    float st = 0.0f, sr = 0.0f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const float* p = pose + c * 6;
+      st += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+      sr += p[3] * p[3] + p[4] * p[4] + p[5] * p[5];
+    }
+    st = tn_wave_sum(st); sr = tn_wave_sum(sr);
+    if (threadIdx.x == 0) { metrics[2 + 2 * k] = sqrtf(st); metrics[3 + 2 * k] = sqrtf(sr); }
+  }
+}
+
+extern "C" int tn_train_metrics(const float* losses, int64_t N, float thermal_mult, const float* pose0, int32_t num_cameras0, const float* pose1,
+                                int32_t num_cameras1, float* metrics_out, tn_stream_t stream) {
+  TN_REQUIRE(losses && metrics_out && N >= 1 && thermal_mult > 0.0f, "tn_train_metrics: bad argument");
+  TN_REQUIRE((pose0 == nullptr || num_cameras0 >= 1) && (pose1 == nullptr || num_cameras1 >= 1), "tn_train_metrics: bad camera count");
+  hipLaunchKernelGGL(k_train_metrics, dim3(1), dim3(64), 0, tn_s(stream), losses, N, thermal_mult, pose0, num_cameras0, pose1, num_cameras1, metrics_out);
+  TN_CHECK_LAUNCH("tn_train_metrics");
+  return TN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ pixel losses
 // losses_out[0..3] += {rgb_loss, thermal_loss, tv_pixel_loss, cross_channel_loss}; losses_out[4] (scratch) = number of RGB rays.
 // Every block counts the RGB rays itself (N floats, a few KB): no separate count kernel / memset in front of the loss kernel.
@@ -406,7 +441,7 @@ __global__ void k_pixel_losses(const float* __restrict__ pred_rgb, int rs, const
     __syncthreads();
   }
   float n_rgb_rays = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) losses[4] = n_rgb_rays;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { losses[4] = n_rgb_rays; losses[5] = (float)N - n_rgb_rays; }  // ray counts per spectrum (PSNR metrics)
   float n_patches = n_rgb_rays / 4.0f;
   int64_t Q = N / 4;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {

@@ -128,7 +128,9 @@ class _RenderFn(torch.autograd.Function):
         if ctx.has_cross:
             tensors += [out["density2"], out["density2_thermal"]]
         holder.append((out, branches))
-        return tuple(tensors)
+        # hand out ALIASES: autograd makes the returned tensor objects point at this node, and `branches` (kept by the node) holds br.comp
+        # itself -- returning that object would close the cycle node -> branches -> comp -> node again
+        return tuple(t.detach() for t in tensors)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -173,13 +175,22 @@ class _RenderFn(torch.autograd.Function):
             d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dw2)
             if g_dens is not None:
                 d_dens += g_dens[..., 0]
+            # same schedule as the fused step (engine.loss_and_backward): the level-0 proposal network (2/3 of the proposal work) on the side
+            # stream beside the main field's backward, the level-1 network behind the field on the main stream
+            side = None
+            if br.prop_grad and g_w[0] is not None:
+                g0 = g_w[0][..., 0].contiguous()
+                side = eng._side_stream()
+                side.wait_stream(torch.cuda.current_stream())  # g0, d_o, d_d are produced / zeroed on the main stream
+                with torch.cuda.stream(side):
+                    dd = ops.weights_bwd(lv[0].e_bins, lv[0].density, lv[0].weights, g0)
+                    ops.prop_density_bwd(props[0], br.origins, br.directions, lv[0].e_bins, dd, d_o, d_d, tag="side0")
             ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
-            if br.prop_grad:
-                for i in range(2):
-                    if g_w[i] is None:
-                        continue
-                    dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, g_w[i][..., 0].contiguous())
-                    ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d)
+            if br.prop_grad and g_w[1] is not None:
+                dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, g_w[1][..., 0].contiguous())
+                ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="main1")
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             d_od[sfx] = (d_o, d_d)
         if g_d2 is not None or g_d2t is not None:
             b, bt = branches[""], branches["_thermal"]
@@ -403,6 +414,7 @@ class ThermalNerfactoModel(nn.Module):
         if self.training:
             nears, fars = eng._nears_fars(o.shape[0], True)
             for sfx, br in branches.items():
+                out[f"_prop_grad{sfx}"] = br.prop_grad  # the sampler ran this iteration's proposal networks with gradients (ray_samplers.py:591)
                 bundle = RayBundle(origins=br.origins, directions=br.directions, pixel_area=ray_bundle.pixel_area, camera_indices=ray_bundle.camera_indices,
                                    nears=nears[:, None], fars=fars[:, None])
                 out[f"ray_samples_list{sfx}"] = [LazyRaySamples(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
@@ -415,8 +427,79 @@ class ThermalNerfactoModel(nn.Module):
                 return True
         return False
 
+    def _loss_terms(self, outputs, batch):
+        """Every loss term of the iteration as ONE autograd node (autograd_ops.TrainLosses: the fused step's launches), shared by
+        get_metrics_dict (PSNRs, distortion) and get_loss_dict.  Returns the unbound loss vector (see TrainLosses)."""
+        key = (id(outputs), id(batch))
+        cached = self.__dict__.get("_loss_cache")
+        if cached is not None and cached[0] == key and cached[1] is outputs:
+            return cached[2]
+        c = self.config
+        sep = c.density_mode == "separate"
+        is_th = batch["is_thermal"].to(self.device).float().contiguous()
+        img = batch["image"].to(self.device)
+        img = (img if img.shape[-1] == 3 else img[..., :3]).contiguous()
+        branches, ts = [], []
+        for s_ in self.output_suffixes:
+            ws = outputs[f"weights_list{s_}"]
+            pg = bool(outputs.get(f"_prop_grad{s_}", self.training and ws[0].requires_grad))
+            branches.append((s_, [r.s_bins for r in outputs[f"ray_samples_list{s_}"]], pg))
+            if sep:
+                comp = outputs["rgb_thermal"] if s_ else outputs["rgb"]
+            else:
+                comp = outputs["rgbt"] if "rgbt" in outputs else torch.cat([outputs["rgb"], outputs["rgb_thermal"]], -1)
+            ts += [comp, *ws]
+        dw = None
+        if sep and c.density_loss_mult > 0 and "density2" in outputs:
+            dw = (c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult)
+            ts += [outputs["density2"], outputs["density_thermal"], outputs["density"], outputs["density2_thermal"]]
+        regs = []
+        for co in ((self.camera_optimizer, self.camera_optimizer_thermal) if sep else (self.camera_optimizer,)):
+            if co.config.mode != "off":
+                regs.append((co.config.trans_l2_penalty, co.config.rot_l2_penalty, co.config.penalty_scale))
+                ts.append(co.pose_adjustment)
+        spec = F.LossSpec(sep, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, c.distortion_loss_mult, c.interlevel_loss_mult,
+                          branches, dw, regs)
+        terms = F.TrainLosses.apply(spec, img, is_th, *ts)
+        self._loss_cache = (key, outputs, terms)
+        return terms
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
+        """models/thermal_nerfacto.py:253-282.  In training the PSNRs come out of the pixel-loss kernel's sums (mean squared error over the RGB
+        rays / the thermal rays = the masked-mean losses rescaled by the ray counts): no boolean indexing, which would synchronise the device
+        every iteration; the distortion metric is the distortion term of the loss node divided by its multiplier."""
+        m: Dict[str, Any] = {}
+        c = self.config
+        if self.training:
+            L = self._loss_terms(outputs, batch)
+            m["psnr_rgb"], m["psnr_thermal"] = L[16], L[17]
+            nsfx = len(self.output_suffixes)
+            if c.distortion_loss_mult > 0:
+                m["distortion"] = L[9] / (c.distortion_loss_mult * nsfx)
+            else:
+                m["distortion"] = 0
+                for s in self.output_suffixes:
+                    m["distortion"] = m["distortion"] + F.DistortionLoss.apply(outputs[f"weights_list{s}"][-1], outputs[f"ray_samples_list{s}"][-1].s_bins)
+        else:
+            rgb_l, th_l, _, _, n_rgb = self._pixel_terms(outputs, batch)
+            with torch.no_grad():
+                n = float(outputs["rgb"].shape[0])
+                m["psnr_rgb"] = -10.0 * torch.log10(rgb_l.detach() * n / n_rgb)
+                m["psnr_thermal"] = -10.0 * torch.log10(th_l.detach() * (n / c.thermal_loss_mult) / (n - n_rgb))
+        if self.training:  # the pose norms come out of the loss node's metrics launch (same order as the pose parameters it was given)
+            k = 18
+            for co in ((self.camera_optimizer, self.camera_optimizer_thermal) if c.density_mode == "separate" else (self.camera_optimizer,)):
+                if co.config.mode != "off":
+                    m[f"camera_opt_translation{co.suffix}"], m[f"camera_opt_rotation{co.suffix}"] = L[k], L[k + 1]
+                    k += 2
+        else:
+            self.camera_optimizer.get_metrics_dict(m)
+            if c.density_mode == "separate":
+                self.camera_optimizer_thermal.get_metrics_dict(m)
+        return m
+
     def _pixel_terms(self, outputs, batch):
-        """The four pixel losses + the RGB-ray count, ONE kernel launch shared by get_metrics_dict (PSNRs) and get_loss_dict."""
+        """Eval mode: the four pixel losses + the RGB-ray count, one launch shared by get_metrics_dict (PSNRs) and get_loss_dict."""
         key = (id(outputs), id(batch))
         cached = self.__dict__.get("_pixel_cache")
         if cached is not None and cached[0] == key and cached[1] is outputs:
@@ -428,55 +511,40 @@ class ThermalNerfactoModel(nn.Module):
         self._pixel_cache = (key, outputs, terms)
         return terms
 
-    def get_metrics_dict(self, outputs, batch) -> Dict[str, Any]:
-        """models/thermal_nerfacto.py:253-282.  The PSNRs come out of the pixel-loss kernel's sums (mean squared error over the RGB rays /
-        the thermal rays = the masked-mean losses rescaled by the ray counts): no boolean indexing, which would synchronise the device every
-        iteration.  The distortion loss is the kernel (value + gradient in one pass, no [N,S,S] tape)."""
-        m: Dict[str, Any] = {}
-        rgb_l, th_l, _, _, n_rgb = self._pixel_terms(outputs, batch)
-        with torch.no_grad():
-            n = float(outputs["rgb"].shape[0])
-            # rgb_loss = sum over RGB rays of |gt - pred|^2 / (3 n); thermal_loss = thermal_mult * sum over thermal rays / n
-            m["psnr_rgb"] = -10.0 * torch.log10(rgb_l.detach() * n / n_rgb)
-            m["psnr_thermal"] = -10.0 * torch.log10(th_l.detach() * (n / self.config.thermal_loss_mult) / (n - n_rgb))
-        if self.training:
-            m["distortion"] = 0
-            for s in self.output_suffixes:
-                m["distortion"] = m["distortion"] + F.DistortionLoss.apply(outputs[f"weights_list{s}"][-1], outputs[f"ray_samples_list{s}"][-1].s_bins)
-        self.camera_optimizer.get_metrics_dict(m)
-        if self.config.density_mode == "separate":
-            self.camera_optimizer_thermal.get_metrics_dict(m)
-        return m
-
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
-        """models/thermal_nerfacto.py:284-388, every term through its loss kernel (autograd_ops): the pixel terms in one launch, the density
-        cross terms with the reference's detach asymmetry, interlevel per proposal level, the camera regularisers."""
+        """models/thermal_nerfacto.py:284-388.  Training: every term is an output of the one loss node (multipliers folded into the kernels,
+        the density cross terms with the reference's detach asymmetry).  Eval: the pixel terms (+ the density loss) through their own kernels."""
         c = self.config
         ld: Dict[str, Any] = {}
+        sep_loss = c.density_mode == "separate" and c.density_loss_mult > 0
+        if self.training:
+            assert metrics_dict is not None and "distortion" in metrics_dict
+            L = self._loss_terms(outputs, batch)
+            ld["rgb_loss"], ld["thermal_loss"] = L[0], L[1]
+            if sep_loss and "density2" in outputs:
+                ld["density_loss"] = L[10]
+            if c.tv_pixel_loss_mult > 0:
+                ld["tv_pixel_loss"] = L[2]
+            if c.cross_channel_loss_mult > 0:
+                ld["cross_channel_loss"] = L[3]
+            ld["interlevel_loss"] = L[8]
+            ld["distortion_loss"] = L[9]
+            k = 11
+            for co in ((self.camera_optimizer, self.camera_optimizer_thermal) if c.density_mode == "separate" else (self.camera_optimizer,)):
+                if co.config.mode != "off":
+                    ld[f"camera_opt_regularizer{co.suffix}"] = L[k]
+                    k += 1
+            return ld
         rgb_l, th_l, tv_l, cross_l, _ = self._pixel_terms(outputs, batch)
         ld["rgb_loss"], ld["thermal_loss"] = rgb_l, th_l
-        if c.density_mode == "separate" and c.density_loss_mult > 0:
+        if sep_loss and "density2" in outputs:
             a, b = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
-            # a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|   (:336-344)
             ld["density_loss"] = (F.AsymmetricL1.apply(outputs["density2"], outputs["density_thermal"], b, a)
                                   + F.AsymmetricL1.apply(outputs["density"], outputs["density2_thermal"], b, a))
         if c.tv_pixel_loss_mult > 0:
             ld["tv_pixel_loss"] = tv_l
         if c.cross_channel_loss_mult > 0:
             ld["cross_channel_loss"] = cross_l
-        if self.training:
-            ld["interlevel_loss"] = 0
-            ld["distortion_loss"] = 0
-            assert metrics_dict is not None and "distortion" in metrics_dict
-            for s in self.output_suffixes:
-                ws, rs = outputs[f"weights_list{s}"], outputs[f"ray_samples_list{s}"]
-                for i in range(len(ws) - 1):
-                    ld["interlevel_loss"] = ld["interlevel_loss"] + c.interlevel_loss_mult * F.InterlevelLoss.apply(ws[i], rs[i].s_bins, ws[-1].detach(),
-                                                                                                                  rs[-1].s_bins)
-                ld["distortion_loss"] = ld["distortion_loss"] + c.distortion_loss_mult * metrics_dict["distortion"]
-            self.camera_optimizer.get_loss_dict(ld)
-            if c.density_mode == "separate":
-                self.camera_optimizer_thermal.get_loss_dict(ld)
         return ld
 
     # ------------------------------------------------------------------------------------------------ fused fast path

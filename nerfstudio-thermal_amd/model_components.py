@@ -176,8 +176,9 @@ class CameraOptimizer(nn.Module):
 
     def get_metrics_dict(self, metrics_dict: dict) -> None:
         if self.config.mode != "off":
-            metrics_dict[f"camera_opt_translation{self.suffix}"] = self.pose_adjustment[:, :3].norm()
-            metrics_dict[f"camera_opt_rotation{self.suffix}"] = self.pose_adjustment[:, 3:].norm()
+            pa = self.pose_adjustment.detach()  # metrics only: no autograd nodes for two norms per iteration
+            metrics_dict[f"camera_opt_translation{self.suffix}"] = pa[:, :3].norm()
+            metrics_dict[f"camera_opt_rotation{self.suffix}"] = pa[:, 3:].norm()
 
     def get_param_groups(self, param_groups: dict, name: str = "camera_opt") -> None:
         if self.config.mode != "off":

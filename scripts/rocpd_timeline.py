@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Kernel timeline of ONE training step from a rocprofv3 --kernel-trace run (rocpd sqlite): which stream / queue every kernel ran on, when it
+started relative to the step's first kernel and how long it took.  Used to show the order of the RCCL all-reduce kernels relative to the
+scatter launches of the data-parallel schedule (bench.py --force-dp).
+
+    python scripts/rocpd_timeline.py gpurun_out/prof_dp/x_results.db [out.md] [--step-from-end 3]
+
+A step is delimited by consecutive launches of k_sample_pixels (the first kernel of every bench step).
+"""
+import re
+import sqlite3
+import sys
+
+
+def main():
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--step-from-end"]
+    back = int(sys.argv[sys.argv.index("--step-from-end") + 1]) if "--step-from-end" in sys.argv else 3
+    con = sqlite3.connect(args[0])
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    lane = [c for c in ("stream_id", "queue_id", "stream", "queue", "tid") if c in cols]
+    sel = ", ".join(["name", "start", "end"] + lane)
+    rows = con.execute(f"select {sel} from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if r[0].startswith("k_sample_pixels")]
+    if len(marks) < back + 1:
+        print("not enough steps in the trace", len(marks))
+        return
+    a, b = marks[-back - 1], marks[-back]
+    step = rows[a:b]
+    t0 = step[0][1]
+    lines = [f"step of {len(step)} kernels, {(max(r[2] for r in step) - t0) / 1e3:.1f} us from first start to last end; columns: start_us, dur_us, "
+             + "/".join(lane) + ", kernel", ""]
+    lines.append("| start us | dur us | " + " | ".join(lane) + " | kernel |")
+    lines.append("|---|---|" + "---|" * len(lane) + "---|")
+    for r in step:
+        nm = re.sub(r"\(anonymous namespace\)::", "", r[0])
+        nm = (nm.split("(")[0] if len(nm.split("(")[0]) > 8 else nm)[:70]
+        lines.append(f"| {(r[1] - t0) / 1e3:8.1f} | {(r[2] - r[1]) / 1e3:7.1f} | " + " | ".join(str(x) for x in r[3:]) + f" | `{nm}` |")
+    text = "\n".join(lines)
+    print(text)
+    if len(args) > 1:
+        with open(args[1], "w") as f:
+            f.write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -48,10 +48,11 @@ for step in range(120, 170):
     o, d, cam, im, th = dm.next_train(step)
     opt.zero_grad_all()
     rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
-    pr.enable(); out = model(rb); pr.disable()
+    out = model(rb)
     batch = {"image": im, "is_thermal": th}
-    ld = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+    pr.enable(); md = model.get_metrics_dict(out, batch); pr.disable()
+    ld = model.get_loss_dict(out, batch, md)
     functools.reduce(torch.add, ld.values()).backward()
     opt.optimizer_step_all(step)
 torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime"); st.print_stats(18)
+st = pstats.Stats(pr); st.sort_stats("cumulative"); st.print_stats(30)

@@ -257,28 +257,45 @@ def test_parameters_without_gradient_get_none(golden_dir, mode):
 
 
 def test_hip_fused_adam_matches_torch_adam(golden_dir):
-    """HipFusedAdam (one kernel launch per group over the arena) against torch.optim.Adam on the same model, same rays, 6 iterations."""
+    """HipFusedAdam (one kernel launch per group over the arena) against torch.optim.Adam: the same gradients for 5 steps, then one real iteration."""
     from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
 
     gi, rb = bundle(golden_dir)
     jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
     batch = {"image": gi["image"].to(DEV), "is_thermal": gi["is_thermal"].to(DEV)}
-    finals = []
-    for cls in (HipFusedAdam, HipFusedAdam, torch.optim.Adam):
+    # (1) the update rule, deterministically: the same synthetic gradients through both optimisers for 5 steps -- the proposal networks
+    # without a gradient on steps 2 and 3 (skipped by both, their step counts fall behind the field's) -- must give the same parameters.
+    # (Comparing whole training runs instead is ill-posed: the float-atomic sums of the backward differ in the last bits from run to run and
+    # Adam with eps = 1e-15 turns a sign flip of a ~1e-12 gradient into a 2 lr difference.)
+    frac = lambda a, b: float(((a - b).abs() > 1e-5).float().mean())  # noqa: E731
+    models, opts = [], []
+    for cls in (HipFusedAdam, torch.optim.Adam):
         ocfg, cfg, model = build_model("shared")
         model.arena.load(make_params(ocfg))
         model.train()
-        opt = Optimizers(model.get_param_groups(), optimizer_cls=cls)
-        for step in range(6):
-            _trainer_step(model, opt, rb, batch, step, jit)
-        finals.append({n: p.detach().clone() for n, p in model._params.items()})
-    frac = lambda a, b: float(((a - b).abs() > 1e-5).float().mean())  # noqa: E731
-    for n in finals[0]:
-        # Both optimisers see gradients from the same kernels, whose float-atomic sums differ in the last bits from run to run; Adam
-        # (eps = 1e-15) turns a sign flip of a ~1e-12 gradient into 2 lr, so two runs of the SAME optimiser already differ on a few percent of
-        # the table entries after 6 iterations.  The fused optimiser must not differ from torch's by more than that run-to-run noise.
-        noise = frac(finals[0][n], finals[1][n])
-        assert frac(finals[0][n], finals[2][n]) <= 2.0 * noise + 0.01, (n, frac(finals[0][n], finals[2][n]), noise)
+        models.append(model)
+        opts.append(Optimizers(model.get_param_groups(), optimizer_cls=cls))
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    for step in range(5):
+        grads = {}
+        for n, p in models[0]._params.items():
+            idle = "_thermal" in n or (n.startswith("proposal_networks.") and step in (2, 3))
+            # a sparse gradient with a wide dynamic range (exact zeros included, as the hash tables have)
+            g = torch.randn(p.shape, device=DEV, generator=gen) * torch.pow(10.0, torch.randint(-8, 1, p.shape, device=DEV, generator=gen).float())
+            grads[n] = None if idle else g * (torch.rand(p.shape, device=DEV, generator=gen) < 0.5)
+        for model, opt in zip(models, opts):
+            opt.zero_grad_all()
+            for n, p in model._params.items():
+                if grads[n] is not None:
+                    view = model.arena.grad_view(n)
+                    view.copy_(grads[n])
+                    p.grad = view
+            opt.optimizer_step_all(step)
+            opt.scheduler_step_all(step)
+    for n, p in models[0]._params.items():
+        q = models[1]._params[n]
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-6, (n, float((p.detach() - q.detach()).abs().max()))
+    del models, opts
     # and on a single iteration from identical state the two are the same update (up to the same noise on near-zero gradients)
     one = []
     for cls in (HipFusedAdam, torch.optim.Adam):
