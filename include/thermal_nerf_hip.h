@@ -259,6 +259,42 @@ int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float
                         tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * N4: forward Gaussian-splat render, RGB + thermal colour per Gaussian.  Replaces the gsplat calls of
+ * SplatfactoModel.get_outputs (nerfstudio/models/splatfacto.py:739-807): project_gaussians, spherical_harmonics, rasterize_gaussians
+ * (colour and depth).  gsplat is a third-party package outside the reference tree: parity is UNPINNED (oracle/splat_oracle.py restates
+ * its published algorithm).  16x16 tiles (splatfacto.py:738). */
+typedef struct TnSplatCamera {
+  float viewmat[12];  /* world -> camera, rows of the 3x4 matrix in gsplat's convention (x right, y down, z forward): splatfacto.py:700-712 */
+  float projmat[16];  /* projection_matrix(0.001, 1000, fovx, fovy) @ viewmat, row-major 4x4: splatfacto.py:718,745 */
+  float fx, fy, cx, cy;
+  float position[3];  /* camera centre in world space (view directions of the SH colours, splatfacto.py:770) */
+  float clip_thresh;  /* near clip in view space (gsplat default 0.01) */
+  int32_t width, height;
+} TnSplatCamera;
+/* scratch for num_gaussians Gaussians and up to max_intersections (Gaussian, tile) pairs; num_tiles = ceil(W/16) * ceil(H/16) */
+int64_t tn_splat_workspace_bytes(int64_t num_gaussians, int64_t max_intersections, int32_t num_tiles);
+/* project_gaussians + spherical_harmonics (splatfacto.py:739-777).  means [N,3], log_scales [N,3] (exponentiated inside), quats [N,4]
+ * (w,x,y,z; normalised inside), opacities [N] (logits), features_dc [N,3], features_rest [N,K,3], thermal_dc [N,1], thermal_rest [N,K,1]
+ * (K = num_rest_coeffs).  sh_degree 0..3 = degree evaluated this step (min(step // interval, sh_degree)); -1 = sigmoid(features_dc)
+ * (config.sh_degree == 0).  antialiased != 0: opacity x compensation (rasterize_mode "antialiased").  Outputs as gsplat returns them:
+ * xys [N,2], depths [N], radii [N] int32, conics [N,3], compensation [N], num_tiles_hit [N] int32, plus tile_box [N,4] int32
+ * (x0, y0, x1, y1 in tiles).  Colours and opacities go into the workspace for tn_splat_raster. */
+int tn_splat_project(const TnSplatCamera* camera, const float* means, const float* log_scales, const float* quats, const float* opacities,
+                     const float* features_dc, const float* features_rest, const float* thermal_dc, const float* thermal_rest,
+                     int64_t num_gaussians, int32_t num_rest_coeffs, int32_t sh_degree, int32_t antialiased, float* xys, float* depths,
+                     int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit, int32_t* tile_box, void* workspace,
+                     int64_t max_intersections, tn_stream_t stream);
+/* tile binning of rasterize_gaussians: scan, (tile, depth) keys, radix sort, tile ranges.  Reads the intersection count back to the host
+ * (*num_intersections_out, a HOST pointer; one stream synchronisation, as gsplat's binning does); returns TN_EINVAL with the needed count
+ * in *num_intersections_out when it exceeds max_intersections. */
+int tn_splat_bin(const TnSplatCamera* camera, const float* depths, const int32_t* num_tiles_hit, const int32_t* tile_box, int64_t num_gaussians,
+                 void* workspace, int64_t max_intersections, int64_t* num_intersections_out, tn_stream_t stream);
+/* rasterize_gaussians, colour (RGB + thermal over background4) and depth in one pass (splatfacto.py:789-809): out_rgbt [H,W,4] clamped to
+ * <= 1, out_depth [H,W] = depth / alpha where alpha > 0, else the maximum of the un-normalised depth image, out_alpha [H,W]. */
+int tn_splat_raster(const TnSplatCamera* camera, int64_t num_gaussians, void* workspace, int64_t max_intersections, const float* background4,
+                    int32_t antialiased, float* out_rgbt, float* out_depth, float* out_alpha, tn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,11 @@ class TnField(C.Structure):
     _fields_ = [("grid", TnGrid)] + [(n, _p) for n in _FIELD_PTRS] + [("num_channels", _i32), ("num_images", _i32)]
 
 
+class TnSplatCamera(C.Structure):
+    _fields_ = [("viewmat", _f * 12), ("projmat", _f * 16), ("fx", _f), ("fy", _f), ("cx", _f), ("cy", _f), ("position", _f * 3),
+                ("clip_thresh", _f), ("width", _i32), ("height", _i32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/thermal_nerf_hip.h declares
 SIGNATURES = {
     "tn_last_error": (C.c_char_p, []),
@@ -84,6 +89,10 @@ SIGNATURES = {
     "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
     "tn_adam_step_ranges": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _d, _d, _d, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
+    "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
+    "tn_splat_bin": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    "tn_splat_raster": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

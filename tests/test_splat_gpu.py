@@ -1,0 +1,134 @@
+"""N4: the HIP splat path (tn_splat_project / tn_splat_bin / tn_splat_raster behind ThermalSplatfactoModel.get_outputs) against the oracle
+on identical Gaussians and cameras, plus size-independent properties at BASELINE config 4's 1080p.  Parity UNPINNED (see the oracle's
+header): the oracle restates gsplat's published algorithm; tolerances: projection 1e-4 relative, images 2e-3 absolute (fp32 exp and
+accumulation order inside a pixel are the same; the differences are the last bits of exp / sigmoid)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build(params, cfg=None, step=10**6):
+    import nerfstudio_thermal_amd  # noqa: F401
+    from nerfstudio_thermal_amd.splat import ThermalSplatfactoModel, ThermalSplatfactoModelConfig
+
+    m = ThermalSplatfactoModel(cfg or ThermalSplatfactoModelConfig(), num_points=4, device=DEV)
+    m.load_gaussians(params)
+    m.step = step
+    return m
+
+
+def camera(c2w, fx, fy, cx, cy, W, H):
+    from nerfstudio_thermal_amd.splat import PinholeCamera
+
+    return PinholeCamera(c2w, fx, fy, cx, cy, W, H)
+
+
+@pytest.mark.parametrize("mode,deg", [("classic", 3), ("antialiased", 3), ("classic", 1), ("classic", 0)])
+def test_render_matches_oracle(mode, deg):
+    import splat_oracle as so
+    from nerfstudio_thermal_amd.splat import ThermalSplatfactoModelConfig
+
+    p = so.synth_gaussians(3000, seed=3, extent=1.0)
+    c2w = so.look_at_camera((2.6, 0.4, 0.9))
+    fx, fy, cx, cy, W, H = 170.0, 165.0, 81.0, 58.5, 160, 120  # principal point off-centre, W and H not multiples of... 160 = 10 tiles, 120 = 7.5 tiles
+    ref = so.render(p, c2w, fx, fy, cx, cy, W, H, sh_degree_to_use=deg, rasterize_mode=mode, background=torch.zeros(3), background_thermal=0.0)
+    cfg = ThermalSplatfactoModelConfig(rasterize_mode=mode, sh_degree_interval=1)
+    m = build(p, cfg, step=deg)  # min(step // 1, 3) = deg
+    out = m.get_outputs(camera(c2w, fx, fy, cx, cy, W, H))
+    pj, rp = m.last_projection, ref["projection"]
+    vis = rp["radii"] > 0
+    # radii / tile counts are integers of ceil(): identical except on knife edges
+    assert int((pj["radii"].cpu() != rp["radii"]).sum()) <= 2
+    assert int((pj["num_tiles_hit"].cpu() != rp["num_tiles_hit"]).sum()) <= 2
+    same = vis & (pj["radii"].cpu() == rp["radii"])
+    for k, tol in (("xys", 2e-4), ("depths", 1e-5), ("conics", 1e-4), ("compensation", 1e-4)):
+        a, b = pj[k].cpu()[same], rp[k][same]
+        assert float(((a - b).abs() / (b.abs() + 1.0)).max()) <= tol, k
+    assert m.last_num_intersections == int(rp["num_tiles_hit"].sum()) or abs(m.last_num_intersections - int(rp["num_tiles_hit"].sum())) <= 8
+    for k in ("rgb", "thermal", "accumulation"):
+        err = (out[k].cpu() - ref[k]).abs()
+        assert float(err.max()) <= 2e-3, (k, float(err.max()))
+        assert float(err.mean()) <= 2e-5, (k, float(err.mean()))
+    # depth: normalised by alpha -- compare where something was hit; the fill value is the max of the un-normalised image
+    hitpix = ref["accumulation"][..., 0] > 1e-3
+    derr = (out["depth"].cpu() - ref["depth"])[..., 0][hitpix].abs()
+    assert float(derr.max()) <= 5e-3, float(derr.max())
+    empty = ref["accumulation"][..., 0] == 0
+    if bool(empty.any()):
+        assert torch.allclose(out["depth"].cpu()[..., 0][empty], ref["depth"][..., 0][empty], rtol=1e-4)
+
+
+def test_sigmoid_colours_when_sh_degree_is_zero():
+    import splat_oracle as so
+    from nerfstudio_thermal_amd.splat import ThermalSplatfactoModelConfig
+
+    p = so.synth_gaussians(500, seed=5)
+    p["features_rest"], p["features_rest_thermal"] = p["features_rest"][:, :0], p["features_rest_thermal"][:, :0]
+    c2w = so.look_at_camera((2.2, -0.5, 0.4))
+    ref = so.render(p, c2w, 90.0, 90.0, 32.0, 24.0, 64, 48, sh_degree_to_use=-1)
+    out = build(p, ThermalSplatfactoModelConfig(sh_degree=0)).get_outputs(camera(c2w, 90.0, 90.0, 32.0, 24.0, 64, 48))
+    for k in ("rgb", "thermal", "accumulation"):
+        assert float((out[k].cpu() - ref[k]).abs().max()) <= 2e-3, k
+
+
+def test_empty_and_offscreen_inputs():
+    import splat_oracle as so
+
+    p = so.synth_gaussians(64, seed=1)
+    p["means"] = p["means"] + torch.tensor([50.0, 0.0, 0.0])  # everything behind the camera
+    out = build(p).get_outputs(camera(so.look_at_camera((3.0, 0.0, 0.0)), 100.0, 100.0, 32.0, 24.0, 64, 48))
+    assert float(out["accumulation"].abs().max()) == 0.0 and float(out["depth"].min()) == 10.0 and tuple(out["rgb"].shape) == (48, 64, 3)
+    # a single Gaussian partly outside the image: clamped tile box, no out-of-bounds writes (neighbouring memory would show up as garbage)
+    one = {k: v[:1].clone() for k, v in so.synth_gaussians(4, seed=2).items()}
+    one["means"][0] = torch.tensor([0.0, 1.15, 0.0])
+    one["scales"][:] = -1.5
+    ref = so.render(one, so.look_at_camera((3.0, 0.0, 0.0)), 100.0, 100.0, 32.0, 24.0, 64, 48)
+    out = build(one).get_outputs(camera(so.look_at_camera((3.0, 0.0, 0.0)), 100.0, 100.0, 32.0, 24.0, 64, 48))
+    assert float((out["rgb"].cpu() - ref["rgb"]).abs().max()) <= 2e-3 and float(out["accumulation"].max()) > 0.01
+
+
+def test_workspace_grows_when_the_scene_has_more_intersections_than_expected():
+    import splat_oracle as so
+
+    p = so.synth_gaussians(20000, seed=7, scale_range=(-2.5, -1.5))  # big splats: > 2^16 (Gaussian, tile) pairs at 320x240
+    m = build(p)
+    cam = camera(so.look_at_camera((2.4, 0.2, 0.5)), 300.0, 300.0, 160.0, 120.0, 320, 240)
+    a = m.get_outputs(cam)
+    assert m.last_num_intersections > (1 << 16)
+    b = m.get_outputs(cam)  # second frame reuses the grown workspace; the render is deterministic
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"])
+
+
+def test_full_hd_properties():
+    """BASELINE config 4: 1080p, 16x16 tiles (120 x 68 = 8160 tiles, the last row half empty).  Size-independent properties: values in range,
+    determinism, invariance to the order of the Gaussians (the depth sort decides), linearity of the colour image in the colours."""
+    import splat_oracle as so
+
+    N = 200_000
+    p = so.synth_gaussians(N, seed=11, extent=1.5, scale_range=(-5.0, -3.5))
+    cam = camera(so.look_at_camera((3.2, 0.5, 0.8)), 1400.0, 1400.0, 960.0, 540.0, 1920, 1080)
+    m = build(p)
+    a = m.get_outputs(cam)
+    assert tuple(a["rgb"].shape) == (1080, 1920, 3) and tuple(a["thermal"].shape) == (1080, 1920, 1)
+    acc = a["accumulation"]
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 - 1e-4 + 1e-6  # transmittance never drops below 1e-4
+    assert float(a["rgb"].min()) >= 0.0 and float(a["rgb"].max()) <= 1.0 and bool(torch.isfinite(a["depth"]).all())
+    b = m.get_outputs(cam)
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["accumulation"], b["accumulation"])
+    # permuting the Gaussians changes nothing but the order of equal-depth ties (none in a random scene)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(0))
+    c = build({k: v[perm] for k, v in p.items()}).get_outputs(cam)
+    assert float((a["rgb"] - c["rgb"]).abs().max()) <= 1e-5 and float((a["depth"] - c["depth"]).abs().max()) <= 1e-3
+    # accumulation and depth do not depend on the colours; the un-clamped thermal image is linear in the thermal colours
+    q = dict(p)
+    q["features_dc_thermal"] = p["features_dc_thermal"] * 0.0 - 10.0  # colour clamp(SH + 0.5, 0) = 0 everywhere
+    q["features_rest_thermal"] = p["features_rest_thermal"] * 0.0
+    d = build(q).get_outputs(cam)
+    assert torch.equal(d["accumulation"], a["accumulation"]) and torch.equal(d["rgb"], a["rgb"]) and float(d["thermal"].abs().max()) == 0.0
