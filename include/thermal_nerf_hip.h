@@ -285,11 +285,13 @@ int tn_splat_project(const TnSplatCamera* camera, const float* means, const floa
                      int64_t num_gaussians, int32_t num_rest_coeffs, int32_t sh_degree, int32_t antialiased, float* xys, float* depths,
                      int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit, int32_t* tile_box, void* workspace,
                      int64_t max_intersections, tn_stream_t stream);
-/* tile binning of rasterize_gaussians: scan, (tile, depth) keys, radix sort, tile ranges.  Reads the intersection count back to the host
+/* tile binning of rasterize_gaussians: depth sort of the Gaussians, scan, (tile, Gaussian) pairs in depth order, stable radix sort by
+ * tile, tile ranges.  The pairs come from the TIGHT tile boxes tn_splat_project left in the workspace (gsplat's 3-sigma box cut down to
+ * the tiles where alpha >= 1/255 is reachable: exact, fewer pairs than sum(num_tiles_hit)).  Reads the pair count back to the host
  * (*num_intersections_out, a HOST pointer; one stream synchronisation, as gsplat's binning does); returns TN_EINVAL with the needed count
  * in *num_intersections_out when it exceeds max_intersections. */
-int tn_splat_bin(const TnSplatCamera* camera, const float* depths, const int32_t* num_tiles_hit, const int32_t* tile_box, int64_t num_gaussians,
-                 void* workspace, int64_t max_intersections, int64_t* num_intersections_out, tn_stream_t stream);
+int tn_splat_bin(const TnSplatCamera* camera, const float* depths, int64_t num_gaussians, void* workspace, int64_t max_intersections,
+                 int64_t* num_intersections_out, tn_stream_t stream);
 /* rasterize_gaussians, colour (RGB + thermal over background4) and depth in one pass (splatfacto.py:789-809): out_rgbt [H,W,4] clamped to
  * <= 1, out_depth [H,W] = depth / alpha where alpha > 0, else the maximum of the un-normalised depth image, out_alpha [H,W]. */
 int tn_splat_raster(const TnSplatCamera* camera, int64_t num_gaussians, void* workspace, int64_t max_intersections, const float* background4,

@@ -91,7 +91,7 @@ SIGNATURES = {
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
-    "tn_splat_bin": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _p, _p]),
+    "tn_splat_bin": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p]),
     "tn_splat_raster": (C.c_int, [_p, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
 }
 

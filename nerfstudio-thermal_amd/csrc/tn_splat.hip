@@ -8,9 +8,14 @@
 //   k_splat_project    thread = Gaussian: view transform, 3D covariance, EWA projection (+0.3 px blur), conic, 3-sigma radius, tile bounding
 //                      box; for visible Gaussians also the view-dependent colour (degree <= 3 SH, RGB and thermal) and the opacity -> one
 //                      packed 48-byte record the rasteriser reads with three 16-byte loads
-//   rocprim scan       inclusive scan of tiles-per-Gaussian
-//   k_splat_intersect  (tile id << 32 | depth bits) keys + Gaussian ids, one per (Gaussian, tile) pair
-//   rocprim radix sort on 32 + log2(#tiles) bits
+//   depth sort         rocprim radix sort of the N Gaussians by depth bits (32-bit keys, N elements)
+//   rocprim scan       inclusive scan of tiles-per-Gaussian in depth order
+//   k_splat_intersect  one (tile id, Gaussian id) pair per (Gaussian, tile), emitted in depth order; a wave owns 64 Gaussians and writes
+//                      their pairs as ONE contiguous, coalesced range (lane = output position, owner found by binary search in LDS)
+//   rocprim radix sort of the pairs on log2(#tiles) bits only (13 bits at 1080p = 2 passes over 8-byte pairs).  gsplat sorts
+//                      (tile << 32 | depth) 64-bit keys: 6 passes over 12-byte pairs, 46 % of the frame in the first version of this
+//                      file.  A stable sort by tile of a depth-ordered list gives the same order, ties included (equal depths keep the
+//                      Gaussian order in both).
 //   k_splat_tile_edges start / end of every tile's run
 //   k_splat_raster     block = one 16x16 tile = 4 waves, lane = pixel.  256 records at a time are staged through LDS (each thread fetches
 //                      one); every lane then walks the batch front to back.  The LDS reads are wave-uniform broadcasts (conflict-free);
@@ -26,30 +31,49 @@
 #define SPLAT_BLOCK 16
 #define SPLAT_BATCH 256
 
-struct SplatRec {  // 48 bytes per Gaussian
-  float4 a;        // x, y, conic.x, conic.y
-  float4 b;        // conic.z, opacity (compensated in antialiased mode), depth, plain opacity
+// alpha = opacity exp(-sigma), sigma = 0.5 (cx dx^2 + cz dy^2) + cy dx dy, is evaluated as exp2(l2op - (A dx^2 + B dx dy + C dy^2)) with
+// A = 0.5 cx log2(e), B = cy log2(e), C = 0.5 cz log2(e), l2op = log2(opacity): 5 FMAs + one v_exp_f32 per pixel instead of 9 multiply/adds,
+// two scalings and a multiply by the opacity (the rasteriser is VALU-bound: rocprofv3 SQ_ACTIVE_INST_VALU = 70 % of its duration).
+struct SplatRec {  // 64 bytes per Gaussian
+  float4 a;        // x, y, A, B
+  float4 b;        // C, l2op (compensated opacity in antialiased mode), hx, hy: half extents of the box around {alpha >= 1/255}
   float4 c;        // r, g, b, thermal
+  float4 d;        // depth, l2op of the plain opacity, -, -
 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct SplatWs {
   SplatRec* recs;
-  int32_t* cum;        // inclusive scan of num_tiles_hit
+  int32_t* cum;        // inclusive scan of the tight tile counts in depth order
+  int32_t* tbox;       // [N][4] tight tile box (x0, y0, x1, y1): gsplat's 3-sigma box cut down to the tiles alpha >= 1/255 can reach
+  int32_t* thits;      // [N] tiles in the tight box
   int32_t* tile_bins;  // [num_tiles][2]
+  uint32_t* lkeys[2];  // ~run length per tile (sort key: longest first)
+  int32_t* lvals[2];   // tile ids; lvals[1] = the order the rasteriser takes the tiles in
   uint32_t* depth_max; // float bits (depths are positive)
-  uint64_t* keys[2];
-  int32_t* vals[2];
+  uint32_t* dkeys;     // sorted depth bits [N]
+  int32_t* order;      // Gaussian ids in depth order [N]
+  uint32_t* keys[2];   // tile id per intersection
+  int32_t* vals[2];    // Gaussian id per intersection
   void* tmp;
   size_t tmp_bytes;
+};
+
+struct HitsInOrder {  // tiles-per-Gaussian read through the depth order (input of the scan)
+  const int32_t* hits;
+  __host__ __device__ int32_t operator()(int32_t id) const { return hits[id]; }
 };
 
 static size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 
 static size_t sort_tmp_bytes(int64_t capacity, int64_t N) {
-  size_t a = 0, b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)std::max<int64_t>(capacity, 1), 0, 64);
-  (void)rocprim::inclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)std::max<int64_t>(N, 1), rocprim::plus<int32_t>());
-  return al256(std::max(a, b)) + 4096;
+  size_t a = 0, b = 0, c = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)std::max<int64_t>(capacity, 1 << 20), 0, 32);  // also covers the sort of the tile order (<= 2^20 tiles)
+  (void)rocprim::radix_sort_pairs(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<int32_t>(0), (int32_t*)nullptr,
+                                  (size_t)std::max<int64_t>(N, 1), 0, 32);
+  (void)rocprim::inclusive_scan(nullptr, b, rocprim::make_transform_iterator((const int32_t*)nullptr, HitsInOrder{nullptr}), (int32_t*)nullptr,
+                                (size_t)std::max<int64_t>(N, 1), rocprim::plus<int32_t>());
+  return al256(std::max(std::max(a, b), c)) + 4096;
 }
 
 static SplatWs splat_layout(void* base, int64_t N, int64_t capacity, int32_t num_tiles, size_t* total) {
@@ -59,9 +83,15 @@ static SplatWs splat_layout(void* base, int64_t N, int64_t capacity, int32_t num
   auto take = [&](size_t bytes) { size_t o = off; off += al256(bytes); return base ? (void*)(p + o) : (void*)nullptr; };
   w.recs = (SplatRec*)take(sizeof(SplatRec) * (size_t)N);
   w.cum = (int32_t*)take(4 * (size_t)N);
+  w.tbox = (int32_t*)take(16 * (size_t)N);
+  w.thits = (int32_t*)take(4 * (size_t)N);
   w.tile_bins = (int32_t*)take(8 * (size_t)num_tiles);
   w.depth_max = (uint32_t*)take(256);
-  for (int i = 0; i < 2; ++i) w.keys[i] = (uint64_t*)take(8 * (size_t)capacity);
+  for (int i = 0; i < 2; ++i) w.lkeys[i] = (uint32_t*)take(4 * (size_t)num_tiles);
+  for (int i = 0; i < 2; ++i) w.lvals[i] = (int32_t*)take(4 * (size_t)num_tiles);
+  w.dkeys = (uint32_t*)take(4 * (size_t)N);
+  w.order = (int32_t*)take(4 * (size_t)N);
+  for (int i = 0; i < 2; ++i) w.keys[i] = (uint32_t*)take(4 * (size_t)capacity);
   for (int i = 0; i < 2; ++i) w.vals[i] = (int32_t*)take(4 * (size_t)capacity);
   w.tmp_bytes = sort_tmp_bytes(capacity, N);
   w.tmp = take(w.tmp_bytes);
@@ -109,7 +139,30 @@ __global__ void __launch_bounds__(256) k_splat_project(SplatCamK cam, const floa
                                                        const float* __restrict__ t_dc, const float* __restrict__ t_rest, int64_t N, int sh_degree,
                                                        int rest_coeffs, int antialiased, float2* __restrict__ xys, float* __restrict__ depths,
                                                        int32_t* __restrict__ radii, float* __restrict__ conics, float* __restrict__ comp_out,
-                                                       int32_t* __restrict__ tiles_hit, int32_t* __restrict__ tile_box, SplatRec* __restrict__ recs) {
+                                                       int32_t* __restrict__ tiles_hit, int32_t* __restrict__ tile_box, SplatRec* __restrict__ recs,
+                                                       int32_t* __restrict__ tbox, int32_t* __restrict__ thits) {
+  // The higher-order SH coefficients of the block's 256 Gaussians (45 + 15 floats each) go through LDS: the block copies its contiguous
+  // 46 KB + 15 KB slab with coalesced 16-byte loads, and each thread then reads its own coefficients at stride 45 / 15 floats -- odd strides,
+  // so the 64 lanes of a wave hit 64 different banks.  Reading them straight from global memory (each lane its own 180-byte run) cost
+  // 3.6x the requests the data needs (TCC_REQ 17 M x 64 B for 300 MB) and made the kernel latency-bound (150 us per 1 M Gaussians; 124 us with the staging at 128 Gaussians per block).
+  extern __shared__ float sh_lds[];
+  float* s_rest = sh_lds;
+  float* s_trest = sh_lds + (int)blockDim.x * rest_coeffs * 3;
+  {
+    const int64_t g0 = blockIdx.x * (int64_t)blockDim.x;
+    const int cnt = (int)min((int64_t)blockDim.x, N - g0);
+    if (rest_coeffs > 0 && sh_degree >= 1) {
+      const int n3 = cnt * rest_coeffs * 3, n1 = cnt * rest_coeffs;
+      const float* src3 = f_rest + g0 * rest_coeffs * 3;
+      const float* src1 = t_rest + g0 * rest_coeffs;
+      // both slabs start 16-byte aligned: blockDim * K * 3 * 4 and blockDim * K * 4 bytes per block are multiples of 16
+      for (int t = threadIdx.x * 4; t + 3 < n3; t += blockDim.x * 4) *reinterpret_cast<float4*>(s_rest + t) = *reinterpret_cast<const float4*>(src3 + t);
+      for (int t = (n3 & ~3) + threadIdx.x; t < n3; t += blockDim.x) s_rest[t] = src3[t];
+      for (int t = threadIdx.x * 4; t + 3 < n1; t += blockDim.x * 4) *reinterpret_cast<float4*>(s_trest + t) = *reinterpret_cast<const float4*>(src1 + t);
+      for (int t = (n1 & ~3) + threadIdx.x; t < n1; t += blockDim.x) s_trest[t] = src1[t];
+    }
+    __syncthreads();
+  }
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= N) return;
   float2 xy = make_float2(0.f, 0.f);
@@ -203,14 +256,18 @@ __global__ void __launch_bounds__(256) k_splat_project(SplatCamK cam, const floa
   comp_out[i] = cmp;
   tiles_hit[i] = area;
   tile_box[4 * i] = x0; tile_box[4 * i + 1] = y0; tile_box[4 * i + 2] = x1; tile_box[4 * i + 3] = y1;
-  if (!ok) return;
+  if (!ok) {
+    tbox[4 * i] = tbox[4 * i + 1] = tbox[4 * i + 2] = tbox[4 * i + 3] = 0;
+    thits[i] = 0;
+    return;
+  }
   // view-dependent colour (splatfacto.py:769-777): clamp(SH + 0.5, min 0); degree < 0 means "no SH": sigmoid of the DC term
   float dx = mx - cam.pos[0], dy = my - cam.pos[1], dz = mz - cam.pos[2];
   float dn = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
   dx *= dn; dy *= dn; dz *= dn;
   float col[4];
-  const float* rest = f_rest + (int64_t)i * rest_coeffs * 3;
-  const float* trest = t_rest + (int64_t)i * rest_coeffs;
+  const float* rest = s_rest + (int)threadIdx.x * rest_coeffs * 3;
+  const float* trest = s_trest + (int)threadIdx.x * rest_coeffs;
   if (sh_degree >= 0) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) col[ch] = fmaxf(sh_eval(sh_degree, dx, dy, dz, f_dc + 3 * i, rest, 3, ch) + 0.5f, 0.0f);
@@ -221,103 +278,200 @@ __global__ void __launch_bounds__(256) k_splat_project(SplatCamK cam, const floa
     col[3] = 1.0f / (1.0f + expf(-t_dc[i]));
   }
   float op = 1.0f / (1.0f + expf(-opac_logit[i]));
+  // Where can this Gaussian reach alpha >= 1/255 at all?  alpha = opacity exp(-sigma) >= 1/255  <=>  sigma <= ln(255 opacity) =: s_max, and
+  // {sigma <= s_max} is the ellipse d^T cov2d^-1 d <= 2 s_max, whose bounding box has half extents sqrt(2 s_max cov_xx), sqrt(2 s_max cov_yy).
+  // Tiles (and, in the rasteriser, 8x8 pixel quadrants) outside that box see nothing of the Gaussian: dropping them is EXACT.  The box is
+  // intersected with gsplat's 3-sigma tile box (pixels outside THAT never see the Gaussian in the reference even where alpha >= 1/255).
+  // In antialiased mode the depth pass uses the plain opacity (>= the compensated one): the bound uses the larger.
+  float smax = logf(255.0f * op);
+  float hx = -1.0f, hy = -1.0f;
+  int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0;
+  if (smax > 0.0f) {
+    float inv_cd = 1.0f / (conic.x * conic.z - conic.y * conic.y);  // cov2d = conic^-1: cov_xx = conic.z / det, cov_yy = conic.x / det
+    hx = sqrtf(2.0f * smax * conic.z * inv_cd) * 1.0005f + 1e-3f;
+    hy = sqrtf(2.0f * smax * conic.x * inv_cd) * 1.0005f + 1e-3f;
+    // tile t holds the pixel centres 16 t + 0.5 .. 16 t + 15.5
+    bx0 = max(x0, (int)ceilf((xy.x - hx - 15.5f) / (float)SPLAT_BLOCK));
+    bx1 = min(x1, (int)floorf((xy.x + hx - 0.5f) / (float)SPLAT_BLOCK) + 1);
+    by0 = max(y0, (int)ceilf((xy.y - hy - 15.5f) / (float)SPLAT_BLOCK));
+    by1 = min(y1, (int)floorf((xy.y + hy - 0.5f) / (float)SPLAT_BLOCK) + 1);
+    if (bx1 <= bx0 || by1 <= by0) bx0 = bx1 = by0 = by1 = 0;
+  }
+  tbox[4 * i] = bx0; tbox[4 * i + 1] = by0; tbox[4 * i + 2] = bx1; tbox[4 * i + 3] = by1;
+  thits[i] = (bx1 - bx0) * (by1 - by0);
+  const float LOG2E = 1.4426950408889634f;
   SplatRec r;
-  r.a = make_float4(xy.x, xy.y, conic.x, conic.y);
-  r.b = make_float4(conic.z, antialiased ? op * cmp : op, depth, op);
+  r.a = make_float4(xy.x, xy.y, 0.5f * conic.x * LOG2E, conic.y * LOG2E);
+  r.b = make_float4(0.5f * conic.z * LOG2E, log2f(antialiased ? op * cmp : op), hx, hy);
   r.c = make_float4(col[0], col[1], col[2], col[3]);
+  r.d = make_float4(depth, log2f(op), 0.f, 0.f);
   recs[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------------ tile binning
-__global__ void k_splat_intersect(const int32_t* __restrict__ tile_box, const float* __restrict__ depths, const int32_t* __restrict__ cum, int64_t N,
-                                  int tbx, uint64_t* __restrict__ keys, int32_t* __restrict__ vals, int64_t capacity) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  int x0 = tile_box[4 * i], y0 = tile_box[4 * i + 1], x1 = tile_box[4 * i + 2], y1 = tile_box[4 * i + 3];
-  if (x1 <= x0 || y1 <= y0) return;
-  int64_t at = i == 0 ? 0 : cum[i - 1];
-  uint64_t dbits = (uint64_t)__float_as_uint(depths[i]);
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      if (at < capacity) {
-        keys[at] = ((uint64_t)(uint32_t)(y * tbx + x) << 32) | dbits;
-        vals[at] = (int32_t)i;
-      }
-      ++at;
+// One wave = 64 consecutive Gaussians of the depth order.  Their pairs occupy ONE contiguous range of the output (cum is the inclusive scan
+// in the same order), so the lanes walk that range position by position -- coalesced 4-byte stores -- and find the owning Gaussian of a
+// position by binary search over the wave's 64 range ends in LDS (a thread-per-Gaussian loop writes 64 scattered streams and serialises
+// on the Gaussians that cover hundreds of tiles).
+__global__ void __launch_bounds__(256) k_splat_intersect(const int32_t* __restrict__ order, const int32_t* __restrict__ tile_box,
+                                                         const int32_t* __restrict__ cum, int64_t N, int tbx, uint32_t* __restrict__ keys,
+                                                         int32_t* __restrict__ vals, int64_t capacity) {
+  __shared__ int32_t s_end[4][64], s_x0[4][64], s_y0[4][64], s_w[4][64], s_id[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t j0 = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64;
+  if (j0 >= N) return;  // whole wave
+  const int64_t j = j0 + lane;
+  int32_t end = 0, g = 0, x0 = 0, y0 = 0, w = 1;
+  if (j < N) {
+    end = cum[j];
+    g = order[j];
+    x0 = tile_box[4 * g]; y0 = tile_box[4 * g + 1];
+    w = max(tile_box[4 * g + 2] - x0, 1);
+  } else {
+    end = cum[N - 1];
+  }
+  s_end[wv][lane] = end; s_x0[wv][lane] = x0; s_y0[wv][lane] = y0; s_w[wv][lane] = w; s_id[wv][lane] = g;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its other lanes
+  const int64_t begin = j0 == 0 ? 0 : cum[j0 - 1];
+  const int64_t stop = s_end[wv][63];
+  for (int64_t pos = begin + lane; pos < stop; pos += 64) {
+    // first lane o with end_o > pos
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if ((int64_t)s_end[wv][mid] > pos) hi = mid; else lo = mid + 1;
     }
+    int64_t first = lo == 0 ? begin : (int64_t)s_end[wv][lo - 1];
+    int local = (int)(pos - first);
+    int ww = s_w[wv][lo];
+    int ty = local / ww, tx = local - ty * ww;
+    if (pos < capacity) {
+      keys[pos] = (uint32_t)((s_y0[wv][lo] + ty) * tbx + s_x0[wv][lo] + tx);
+      vals[pos] = s_id[wv][lo];
+    }
+  }
 }
 
-__global__ void k_splat_tile_edges(const uint64_t* __restrict__ keys, int64_t M, int32_t* __restrict__ tile_bins) {
+__global__ void k_splat_tile_edges(const uint32_t* __restrict__ keys, int64_t M, int32_t* __restrict__ tile_bins) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= M) return;
-  int32_t t = (int32_t)(keys[i] >> 32);
+  int32_t t = (int32_t)keys[i];
   if (i == 0) tile_bins[2 * t] = 0;
   else {
-    int32_t tp = (int32_t)(keys[i - 1] >> 32);
+    int32_t tp = (int32_t)keys[i - 1];
     if (tp != t) { tile_bins[2 * tp + 1] = (int32_t)i; tile_bins[2 * t] = (int32_t)i; }
   }
   if (i == M - 1) tile_bins[2 * t + 1] = (int32_t)M;
 }
 
+// longest tiles first: a tile is a sequential front-to-back walk, so the frame ends when the deepest tile ends -- started last (row-major
+// order puts the deep centre of the image in the middle of the launch) it runs alone at the end with the rest of the chip idle
+__global__ void k_splat_tile_len(const int32_t* __restrict__ tile_bins, int num_tiles, uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= num_tiles) return;
+  keys[t] = 0xffffffffu - (uint32_t)(tile_bins[2 * t + 1] - tile_bins[2 * t]);
+  vals[t] = t;
+}
+
 // ------------------------------------------------------------------------------------------------ rasteriser
 template <bool AA>
 __global__ void __launch_bounds__(256) k_splat_raster(const SplatRec* __restrict__ recs, const int32_t* __restrict__ sorted_ids,
-                                                      const int32_t* __restrict__ tile_bins, int W, int H, int tbx, float4 background,
-                                                      float* __restrict__ out_rgbt, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                                                      uint32_t* __restrict__ depth_max) {
-  __shared__ float4 sa[SPLAT_BATCH], sb[SPLAT_BATCH], sc[SPLAT_BATCH];
+                                                      const int32_t* __restrict__ tile_bins, const int32_t* __restrict__ tile_order, int W, int H,
+                                                      int tbx, float4 background, float* __restrict__ out_rgbt, float* __restrict__ out_depth,
+                                                      float* __restrict__ out_alpha, uint32_t* __restrict__ depth_max) {
+  __shared__ float4 sa[SPLAT_BATCH], sb[SPLAT_BATCH], sc[SPLAT_BATCH], sd[SPLAT_BATCH];
   __shared__ float smax[4];
-  const int tile = blockIdx.y * tbx + blockIdx.x;
-  // lane -> pixel: a wave covers a 16x4 strip of the tile (rows 4w .. 4w+3): 64-byte rows of the output per 16 lanes
-  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-  const int ix = blockIdx.x * SPLAT_BLOCK + lx, iy = blockIdx.y * SPLAT_BLOCK + ly;
+  const int tile = tile_order[blockIdx.x];
+  const int tile_x = tile % tbx, tile_y = tile / tbx;
+  // lane -> pixel: a wave covers one 8x8 QUADRANT of the tile (the squarest 64-pixel footprint: the per-wave culling below rejects the most
+  // Gaussians for it); 8 lanes = one 128-byte row segment of the RGBT output
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int qx0 = tile_x * SPLAT_BLOCK + 8 * (wv & 1), qy0 = tile_y * SPLAT_BLOCK + 8 * (wv >> 1);
+  const int ix = qx0 + (lane & 7), iy = qy0 + (lane >> 3);
   const bool inside = ix < W && iy < H;
   const float pxf = (float)ix + 0.5f, pyf = (float)iy + 0.5f;
+  const float qcx = (float)qx0 + 4.0f, qcy = (float)qy0 + 4.0f;  // centre of the quadrant's pixel centres (they span +-3.5 around it)
   const int begin = tile_bins[2 * tile], end = tile_bins[2 * tile + 1];
   float T = 1.0f, Td = 1.0f;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
   float dacc = 0.f;
   bool done = !inside, done_d = !inside;
+  // software pipeline: the records of batch i+1 are fetched (two dependent gathers: id, then the 64-byte record) while batch i is blended
+  float4 ra, rb, rc, rd;
+  ra = rb = rc = rd = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (begin + (int)threadIdx.x < end) {
+    const SplatRec* r = recs + sorted_ids[begin + (int)threadIdx.x];
+    ra = r->a; rb = r->b; rc = r->c; rd = r->d;
+  }
   for (int base = begin; base < end; base += SPLAT_BATCH) {
     // all 256 pixels finished -> nothing left to blend in this tile
     if (__syncthreads_count((AA ? (done && done_d) : done) ? 1 : 0) == 256) break;
-    int idx = base + (int)threadIdx.x;
-    if (idx < end) {
-      const SplatRec* r = recs + sorted_ids[idx];
-      sa[threadIdx.x] = r->a; sb[threadIdx.x] = r->b; sc[threadIdx.x] = r->c;
-    }
+    sa[threadIdx.x] = ra; sb[threadIdx.x] = rb; sc[threadIdx.x] = rc; sd[threadIdx.x] = rd;
     __syncthreads();
+    {
+      int nidx = base + SPLAT_BATCH + (int)threadIdx.x;
+      if (nidx < end) {
+        const SplatRec* r = recs + sorted_ids[nidx];
+        ra = r->a; rb = r->b; rc = r->c; rd = r->d;
+      }
+    }
     const int n = min(SPLAT_BATCH, end - base);
     // the whole wave is done: skip the arithmetic of this batch (wave-uniform branch)
     if (__all((AA ? (done && done_d) : done) ? 1 : 0)) continue;
-    for (int k = 0; k < n; ++k) {
-      float4 a = sa[k], b = sb[k];
-      float dx = a.x - pxf, dy = a.y - pyf;
-      float sigma = 0.5f * (a.z * dx * dx + b.x * dy * dy) + a.w * dx * dy;
-      if (sigma < 0.f) continue;
-      float e = __expf(-sigma);
-      float alpha = fminf(0.999f, b.y * e);
-      if (!done && alpha >= (1.0f / 255.0f)) {
-        float nT = T * (1.0f - alpha);
-        if (nT <= 1e-4f) done = true;
-        else {
-          float vis = alpha * T;
-          float4 c = sc[k];
-          acc[0] += vis * c.x; acc[1] += vis * c.y; acc[2] += vis * c.z; acc[3] += vis * c.w;
-          if (!AA) dacc += vis * b.z;
-          T = nT;
-        }
+    // Per-wave culling, 64 Gaussians per step: lane l tests Gaussian 64 q + l against this wave's quadrant (box around {alpha >= 1/255},
+    // see k_splat_project); the ballot is the list of Gaussians that can touch the quadrant, walked with scalar bit operations.  A
+    // Gaussian that misses the quadrant costs 1/64 of a test instead of a full evaluation on all 64 lanes.
+#pragma unroll 1
+    for (int q = 0; q < SPLAT_BATCH / 64; ++q) {
+      if (q * 64 >= n) break;
+      const int kk = q * 64 + lane;
+      bool keep = false;
+      if (kk < n) {
+        float4 a = sa[kk], b = sb[kk];
+        keep = fabsf(a.x - qcx) <= b.z + 3.5f && fabsf(a.y - qcy) <= b.w + 3.5f;
       }
-      if (AA) {
-        float alpha_d = fminf(0.999f, b.w * e);
-        if (!done_d && alpha_d >= (1.0f / 255.0f)) {
-          float nT = Td * (1.0f - alpha_d);
-          if (nT <= 1e-4f) done_d = true;
-          else { dacc += alpha_d * Td * b.z; Td = nT; }
+      uint64_t live = __ballot(keep);
+      while (live) {
+        const int k = q * 64 + __builtin_ctzll(live);
+        live &= live - 1;
+        // wave-uniform (broadcast) LDS reads.  Holding the records in registers and broadcasting the fields with v_readlane instead was
+        // measured slower (403 vs 360 us: +11 VALU instructions per Gaussian in a kernel that is VALU-issue bound).
+        float4 a = sa[k], b = sb[k];
+        float dx = a.x - pxf, dy = a.y - pyf;
+        float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), b.x * dy * dy);  // sigma log2(e)
+        float ex = b.y - power;
+        // nobody in the wave can reach alpha >= 1/255 = 2^-7.994 (or the form is negative): skip the exponential and the blend
+        // (antialiased: the depth pass blends with the plain opacity, which is the larger one)
+        if (!__any((power >= 0.f && (AA ? sd[k].y - power : ex) >= -8.0f) ? 1 : 0)) continue;
+        if (power < 0.f) continue;
+        float alpha = fminf(0.999f, __builtin_amdgcn_exp2f(ex));
+        if (!done && alpha >= (1.0f / 255.0f)) {
+          float nT = fmaf(-alpha, T, T);
+          if (nT <= 1e-4f) done = true;
+          else {
+            float vis = alpha * T;
+            float4 c = sc[k];
+            f32x2 v2 = {vis, vis};
+            acc01 = __builtin_elementwise_fma(v2, (f32x2){c.x, c.y}, acc01);
+            acc23 = __builtin_elementwise_fma(v2, (f32x2){c.z, c.w}, acc23);
+            if (!AA) dacc = fmaf(vis, sd[k].x, dacc);
+            T = nT;
+          }
+        }
+        if (AA) {
+          float4 d = sd[k];
+          float alpha_d = fminf(0.999f, __builtin_amdgcn_exp2f(d.y - power));
+          if (!done_d && alpha_d >= (1.0f / 255.0f)) {
+            float nT = fmaf(-alpha_d, Td, Td);
+            if (nT <= 1e-4f) done_d = true;
+            else { dacc = fmaf(alpha_d * Td, d.x, dacc); Td = nT; }
+          }
         }
       }
     }
   }
+  const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
   float dmax = 0.f;
   if (inside) {
     int64_t p = (int64_t)iy * W + ix;
@@ -383,15 +537,18 @@ extern "C" int tn_splat_project(const TnSplatCamera* camera, const float* means,
   TN_REQUIRE(num_rest_coeffs == 0 || (features_rest && thermal_rest), "tn_splat_project: null SH coefficients");
   SplatCamK k = make_camk(camera);
   SplatWs ws = splat_layout(workspace, num_gaussians, max_intersections, k.tbx * k.tby, nullptr);
-  hipLaunchKernelGGL(k_splat_project, dim3((unsigned)tn_cdiv(num_gaussians, 256)), dim3(256), 0, tn_s(stream), k, means, log_scales, quats, opacities,
+  const int PB = 128;  // Gaussians per block: 30 KB of LDS at degree 3 -> 5 blocks per CU (256 per block = 61 KB = 2 blocks: 136 vs 1xx us)
+  const size_t lds = (size_t)PB * num_rest_coeffs * 4 * sizeof(float);
+  TN_REQUIRE(lds <= 65536, "tn_splat_project: %d higher-order coefficients do not fit the LDS staging", num_rest_coeffs);
+  hipLaunchKernelGGL(k_splat_project, dim3((unsigned)tn_cdiv(num_gaussians, PB)), dim3(PB), lds, tn_s(stream), k, means, log_scales, quats, opacities,
                      features_dc, features_rest, thermal_dc, thermal_rest, num_gaussians, sh_degree, num_rest_coeffs, antialiased, (float2*)xys, depths, radii,
-                     conics, compensation, num_tiles_hit, tile_box, ws.recs);
+                     conics, compensation, num_tiles_hit, tile_box, ws.recs, ws.tbox, ws.thits);
   TN_CHECK_LAUNCH("tn_splat_project");
   return TN_OK;
 }
 
-extern "C" int tn_splat_bin(const TnSplatCamera* camera, const float* depths, const int32_t* num_tiles_hit, const int32_t* tile_box, int64_t num_gaussians,
-                            void* workspace, int64_t max_intersections, int64_t* num_intersections_out, tn_stream_t stream) {
+extern "C" int tn_splat_bin(const TnSplatCamera* camera, const float* depths, int64_t num_gaussians, void* workspace, int64_t max_intersections,
+                            int64_t* num_intersections_out, tn_stream_t stream) {
   int rc = check_cam(camera, "tn_splat_bin");
   if (rc) return rc;
   TN_REQUIRE(num_intersections_out != nullptr, "tn_splat_bin: null output");
@@ -405,10 +562,21 @@ extern "C" int tn_splat_bin(const TnSplatCamera* camera, const float* depths, co
     tn_set_error("tn_splat_bin: memset failed");
     return TN_ELAUNCH;
   }
+  // default tile order = identity (every run empty); replaced by longest-first once the runs are known
+  hipLaunchKernelGGL(k_splat_tile_len, dim3((unsigned)tn_cdiv(num_tiles, 256)), dim3(256), 0, st, ws.tile_bins, num_tiles, ws.lkeys[1], ws.lvals[1]);
+  TN_CHECK_LAUNCH("tn_splat_bin(order)");
   if (num_gaussians == 0) return TN_OK;
-  TN_REQUIRE(depths && num_tiles_hit && tile_box, "tn_splat_bin: null pointer");
+  TN_REQUIRE(depths != nullptr, "tn_splat_bin: null pointer");
+  // depth order of the Gaussians (stable: equal depths keep their index order; culled Gaussians have depth 0 and no tiles)
   size_t tb = ws.tmp_bytes;
-  if (rocprim::inclusive_scan(ws.tmp, tb, num_tiles_hit, ws.cum, (size_t)num_gaussians, rocprim::plus<int32_t>(), st) != hipSuccess) {
+  if (rocprim::radix_sort_pairs(ws.tmp, tb, reinterpret_cast<const uint32_t*>(depths), ws.dkeys, rocprim::counting_iterator<int32_t>(0), ws.order,
+                                (size_t)num_gaussians, 0, 32, st) != hipSuccess) {
+    tn_set_error("tn_splat_bin: depth sort failed");
+    return TN_ELAUNCH;
+  }
+  tb = ws.tmp_bytes;
+  if (rocprim::inclusive_scan(ws.tmp, tb, rocprim::make_transform_iterator((const int32_t*)ws.order, HitsInOrder{ws.thits}), ws.cum,
+                              (size_t)num_gaussians, rocprim::plus<int32_t>(), st) != hipSuccess) {
     tn_set_error("tn_splat_bin: scan failed");
     return TN_ELAUNCH;
   }
@@ -425,18 +593,25 @@ extern "C" int tn_splat_bin(const TnSplatCamera* camera, const float* depths, co
     return TN_EINVAL;
   }
   if (total == 0) return TN_OK;
-  hipLaunchKernelGGL(k_splat_intersect, dim3((unsigned)tn_cdiv(num_gaussians, 256)), dim3(256), 0, st, tile_box, depths, ws.cum, num_gaussians, k.tbx,
+  hipLaunchKernelGGL(k_splat_intersect, dim3((unsigned)tn_cdiv(num_gaussians, 256)), dim3(256), 0, st, ws.order, ws.tbox, ws.cum, num_gaussians, k.tbx,
                      ws.keys[0], ws.vals[0], max_intersections);
   TN_CHECK_LAUNCH("tn_splat_bin(intersect)");
   int tile_bits = 1;
   while ((1 << tile_bits) < num_tiles) ++tile_bits;
   tb = ws.tmp_bytes;
-  if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], (size_t)total, 0, 32 + tile_bits, st) != hipSuccess) {
+  if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.keys[0], ws.keys[1], ws.vals[0], ws.vals[1], (size_t)total, 0, tile_bits, st) != hipSuccess) {
     tn_set_error("tn_splat_bin: radix sort failed");
     return TN_ELAUNCH;
   }
   hipLaunchKernelGGL(k_splat_tile_edges, dim3((unsigned)tn_cdiv(total, 256)), dim3(256), 0, st, ws.keys[1], (int64_t)total, ws.tile_bins);
   TN_CHECK_LAUNCH("tn_splat_bin(edges)");
+  hipLaunchKernelGGL(k_splat_tile_len, dim3((unsigned)tn_cdiv(num_tiles, 256)), dim3(256), 0, st, ws.tile_bins, num_tiles, ws.lkeys[0], ws.lvals[0]);
+  TN_CHECK_LAUNCH("tn_splat_bin(lengths)");
+  tb = ws.tmp_bytes;
+  if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.lkeys[0], ws.lkeys[1], ws.lvals[0], ws.lvals[1], (size_t)num_tiles, 0, 32, st) != hipSuccess) {
+    tn_set_error("tn_splat_bin: tile order sort failed");
+    return TN_ELAUNCH;
+  }
   return TN_OK;
 }
 
@@ -450,10 +625,10 @@ extern "C" int tn_splat_raster(const TnSplatCamera* camera, int64_t num_gaussian
   float4 bg = make_float4(background4[0], background4[1], background4[2], background4[3]);
   hipStream_t st = tn_s(stream);
   if (antialiased)
-    hipLaunchKernelGGL(k_splat_raster<true>, dim3(k.tbx, k.tby), dim3(256), 0, st, ws.recs, ws.vals[1], ws.tile_bins, k.W, k.H, k.tbx, bg, out_rgbt, out_depth,
+    hipLaunchKernelGGL(k_splat_raster<true>, dim3(k.tbx * k.tby), dim3(256), 0, st, ws.recs, ws.vals[1], ws.tile_bins, ws.lvals[1], k.W, k.H, k.tbx, bg, out_rgbt, out_depth,
                        out_alpha, ws.depth_max);
   else
-    hipLaunchKernelGGL(k_splat_raster<false>, dim3(k.tbx, k.tby), dim3(256), 0, st, ws.recs, ws.vals[1], ws.tile_bins, k.W, k.H, k.tbx, bg, out_rgbt, out_depth,
+    hipLaunchKernelGGL(k_splat_raster<false>, dim3(k.tbx * k.tby), dim3(256), 0, st, ws.recs, ws.vals[1], ws.tile_bins, ws.lvals[1], k.W, k.H, k.tbx, bg, out_rgbt, out_depth,
                        out_alpha, ws.depth_max);
   TN_CHECK_LAUNCH("tn_splat_raster");
   int64_t n = (int64_t)k.W * k.H;

@@ -189,8 +189,7 @@ class ThermalSplatfactoModel(nn.Module):
                                             _ptr(xys, f32, "xys"), _ptr(depths, f32, "depths"), _ptr(radii, i32, "radii"), _ptr(conics, f32, "conics"),
                                             _ptr(comp, f32, "compensation"), _ptr(hit, i32, "num_tiles_hit"), _ptr(box, i32, "tile_box"), wsp, cap, _stream()),
                        "tn_splat_project")
-            rc = lib.tn_splat_bin(C.byref(cam), _ptr(depths, f32, "depths"), _ptr(hit, i32, "num_tiles_hit"), _ptr(box, i32, "tile_box"), N, wsp, cap,
-                                  C.byref(total), _stream())
+            rc = lib.tn_splat_bin(C.byref(cam), _ptr(depths, f32, "depths"), N, wsp, cap, C.byref(total), _stream())
             if rc == 0:
                 break
             if attempt == 0 and total.value > cap:  # the workspace was sized for fewer (Gaussian, tile) pairs: grow once and redo the frame

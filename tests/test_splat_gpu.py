@@ -51,7 +51,8 @@ def test_render_matches_oracle(mode, deg):
     for k, tol in (("xys", 2e-4), ("depths", 1e-5), ("conics", 1e-4), ("compensation", 1e-4)):
         a, b = pj[k].cpu()[same], rp[k][same]
         assert float(((a - b).abs() / (b.abs() + 1.0)).max()) <= tol, k
-    assert m.last_num_intersections == int(rp["num_tiles_hit"].sum()) or abs(m.last_num_intersections - int(rp["num_tiles_hit"].sum())) <= 8
+    # the binning works on tight tile boxes (tiles where alpha >= 1/255 is reachable): never more pairs than gsplat's 3-sigma boxes
+    assert 0 < m.last_num_intersections <= int(rp["num_tiles_hit"].sum()) + 8
     for k in ("rgb", "thermal", "accumulation"):
         err = (out[k].cpu() - ref[k]).abs()
         assert float(err.max()) <= 2e-3, (k, float(err.max()))
