@@ -250,8 +250,88 @@ def cpu_baseline(num_rays, steps, threads, mode="shared"):
     return num_rays / t, t
 
 
+def bench_splat(args):
+    """BASELINE configs[4]: thermal-splatfacto forward render at 1080p (N4, parity unpinned).  One step = one frame: project + SH colours,
+    tile binning (depth sort, pair emission, tile sort), raster of RGB + thermal + depth + accumulation; Gaussians resident in HBM.
+    Replicas only across GPUs (every rank renders its own frames: a frame does not shard in the reference either)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerfstudio_thermal_amd  # noqa: F401
+    import splat_oracle as so  # synthetic scene generator + the CPU baseline (checker only)
+    from nerfstudio_thermal_amd.parallel import init_distributed
+    from nerfstudio_thermal_amd.splat import PinholeCamera, ThermalSplatfactoModel, ThermalSplatfactoModelConfig
+
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    N, W, H = args.gaussians, 1920, 1080
+    p = so.synth_gaussians(N, seed=11 + rank, extent=1.5, scale_range=(-5.5, -3.5))
+    m = ThermalSplatfactoModel(ThermalSplatfactoModelConfig(), num_points=4, device=f"cuda:{local}")
+    m.load_gaussians(p)
+    m.step = 10**6  # all SH degrees active
+    cam = PinholeCamera(so.look_at_camera((3.2, 0.5, 0.8)), 1400.0, 1400.0, 960.0, 540.0, W, H)
+    for _ in range(args.warmup):
+        m.get_outputs(cam)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = m.get_outputs(cam)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    # raster alone, HIP events on torch's current stream (the stream the library launches on)
+    import ctypes as C
+
+    from nerfstudio_thermal_amd import _lib
+    from nerfstudio_thermal_amd.ops import _stream
+    from nerfstudio_thermal_amd.splat import camera_struct
+
+    cs = camera_struct(cam)
+    rgbt, dep, alp = (torch.empty((H, W, c), device=f"cuda:{local}") for c in (4, 1, 1))
+    bg4 = (C.c_float * 4)(0, 0, 0, 0)
+    lib = _lib.load()
+
+    def raster():
+        # (depth_max is only reset by tn_splat_bin: re-running the raster alone re-derives the same images)
+        _lib.check(lib.tn_splat_raster(C.byref(cs), N, C.c_void_p(m._ws.data_ptr()), m._cap, bg4, 0, C.c_void_p(rgbt.data_ptr()), C.c_void_p(dep.data_ptr()),
+                                       C.c_void_p(alp.data_ptr()), _stream()), "tn_splat_raster")
+
+    t_r = time_ms(raster, iters=10, warmup=2)
+    line = {
+        "metric": "thermal-splatfacto forward render, frames/s at 1080p", "value": world * 1e3 / ms, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"thermal-splatfacto (RGB+T Gaussians) forward render, 1920x1080, 16x16 tiles, {N} synthetic Gaussians, degree-3 SH, classic mode",
+                   "visible": int((m.last_projection["radii"] > 0).sum()), "tile_pairs": m.last_num_intersections, "parallelism": f"replicas x{world}",
+                   "parity": "unpinned (gsplat outside the reference tree; oracle = published algorithm)"},
+        "roofline": {"bound": "valu", "kernel": "k_splat_raster", "avg_launch_ms": t_r, "achieved": None, "peak": None, "unit": "VALU issue", "frac": None,
+                     "traffic": None, "note": "VALU-issue bound (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration) in profiles/r02_splat_pmc.md); neither HBM- nor MFMA-bound"},
+        "Mpix_per_s": W * H / ms / 1e3, "mean_accumulation": float(out["accumulation"].mean()),
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle (port) on a BOUNDED sample: 1/64 of the frame (240x135, intrinsics scaled) with 1/64 of the Gaussians, host cores
+        n_s, Ws, Hs = max(N // 64, 1000), W // 8, H // 8
+        ps = {k: v[:n_s] for k, v in p.items()}
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        t0 = time.perf_counter()
+        so.render(ps, so.look_at_camera((3.2, 0.5, 0.8)), 1400.0 / 8, 1400.0 / 8, 960.0 / 8, 540.0 / 8, Ws, Hs)
+        tc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": 1.0 / (tc * 64.0), "unit": "frames/s (extrapolated x64 from the sample)", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": f"{Ws}x{Hs} pixels, {n_s} Gaussians by oracle/splat_oracle.py in {tc:.1f} s"}
+    if rank == 0:
+        print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="nerfacto", choices=["nerfacto", "splat"], help="nerfacto: the thermal-nerfacto train step (BASELINE metric); "
+                    "splat: thermal-splatfacto forward render at 1080p (BASELINE configs[4], N4)")
+    ap.add_argument("--gaussians", type=int, default=1_000_000, help="--workload splat: number of synthetic Gaussians")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -272,6 +352,8 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
     args = ap.parse_args()
+    if args.workload == "splat":
+        return bench_splat(args)
 
     import nerfstudio_thermal_amd  # noqa: F401
     from nerfstudio_thermal_amd import _lib
