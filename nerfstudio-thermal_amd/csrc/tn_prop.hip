@@ -10,9 +10,6 @@
 #define PH 16    // hidden width
 #define PROP_NW (PH * PF + PH + PH + 1)  // 193 weights: w0[16][10], b0[16], w1[16], b1
 
-int tn_wgrad_launch2(const float* dY0, int ldy0, int out0, const float* X0, int ldx0, int in0, float* dW0, int ldw0, float* db0, const float* dY1,
-                     int ldy1, int out1, const float* X1, int ldx1, int in1, float* dW1, int ldw1, float* db1, int64_t P, hipStream_t stream);  // tn_field.hip
-
 struct PropK {
   GridK g;
   const float *w0, *b0, *w1, *b1;
@@ -68,17 +65,32 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
 
 // ------------------------------------------------------------------------------------------------ backward
 // k_prop_bwd_mlp (1 lane = 1 sample): recompute the forward, then  d_out = g * exp(clamp(out,-15,15)) * sel  (trunc_exp backward),
-//   d a_j = d_out*w1_j*[a_j>0],  d enc_k = sum_j d a_j w0_jk.  It writes the operands of the two weight-gradient GEMMs
-//   (dW0 = dA^T ENC, dW1 = dOUT^T H; K = all points; reduced by the shared fp32-MFMA kernel tn_wgrad_launch) and d enc.
-// The table scatter-add (+ d position) is the shared request-coalescing kernel in tn_scatter.hip.
+//   d a_j = d_out*w1_j*[a_j>0],  d enc_k = sum_j d a_j w0_jk  -> ws_denc for the table scatter (tn_scatter.hip), and the WEIGHT GRADIENTS
+//   dW0 = dA^T ENC, db0 = sum dA, dW1 = dOUT^T H, db1 = sum dOUT in the same kernel:
+//   a wave transposes its 64 samples' dA [64][16] and ENC [64][16: cols 0-9 enc, col 10 = 1 -> the bias column] through LDS and feeds them
+//   to v_mfma_f32_16x16x4_f32 (K = samples): written sample-major, the operand of k-step t is the LINEAR read lds[64 t + lane] (lane l holds
+//   row/col l % 16 of sample 4 t + l / 16), so the transpose costs 8 ds_write_b128 + 32 ds_read_b32 per 64 samples.  The accumulators
+//   (2 x 4 registers) persist over the wave's grid-stride loop; one block-level sum in LDS and one atomic burst per block close the kernel.
+//   Before: 65 floats per sample written to HBM (273 MB at level 0) and read back by a separate batched GEMM launch on a companion stream.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 __global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
-                                                      float* __restrict__ ws_da, float* __restrict__ ws_dout, float* __restrict__ ws_enc,
-                                                      float* __restrict__ ws_h, float* __restrict__ ws_denc) {
+                                                      float* __restrict__ ws_denc) {
+  __shared__ float lds[4][2][64 * 16];  // per wave: operand A, operand B (8 KB)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* bufA = lds[wv][0];
+  float* bufB = lds[wv][1];
   int64_t P = N * (int64_t)S;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t ray = i / S;
-    int s = (int)(i - ray * S);
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float sum_dout = 0.0f;
+  // every wave of the grid makes the same number of trips (inactive lanes contribute zeros): the wave-level LDS hand-over below needs all lanes
+  for (int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64; base < P; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = base + lane;
+    const bool live = i < P;
+    const int64_t ic = live ? i : P - 1;
+    int64_t ray = ic / S;
+    int s = (int)(ic - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
@@ -100,7 +112,7 @@ __global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __
       a[j] = t;
       out = fmaf(net.w1[j], fmaxf(t, 0.0f), out);
     }
-    float d_out = c.sel ? d_density[i] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
+    float d_out = (live && c.sel) ? d_density[ic] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
     float denc[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) denc[k] = 0.0f;
@@ -112,23 +124,79 @@ __global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __
 #pragma unroll
       for (int k = 0; k < PF; ++k) denc[k] = fmaf(da[j], net.w0[j * PF + k], denc[k]);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      *reinterpret_cast<float4*>(ws_da + i * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-      *reinterpret_cast<float4*>(ws_h + i * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
+    if (live) {
+      *reinterpret_cast<float4*>(ws_denc + i * 16 + 0) = make_float4(denc[0], denc[1], denc[2], denc[3]);
+      *reinterpret_cast<float4*>(ws_denc + i * 16 + 4) = make_float4(denc[4], denc[5], denc[6], denc[7]);
+      *reinterpret_cast<float4*>(ws_denc + i * 16 + 8) = make_float4(denc[8], denc[9], 0.0f, 0.0f);
     }
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
-    *reinterpret_cast<float4*>(ws_enc + i * 16 + 8) = make_float4(enc[8], enc[9], 0.0f, 0.0f);
-    *reinterpret_cast<float4*>(ws_denc + i * 16 + 0) = make_float4(denc[0], denc[1], denc[2], denc[3]);
-    *reinterpret_cast<float4*>(ws_denc + i * 16 + 4) = make_float4(denc[4], denc[5], denc[6], denc[7]);
-    *reinterpret_cast<float4*>(ws_denc + i * 16 + 8) = make_float4(denc[8], denc[9], 0.0f, 0.0f);
-    ws_dout[i] = d_out;
+    sum_dout += d_out;
+    // ---- dW0 | db0: A = dA [sample][16], B = [enc(10) | 1 | 0...] [sample][16]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bufA + lane * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+    *reinterpret_cast<float4*>(bufB + lane * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
+    *reinterpret_cast<float4*>(bufB + lane * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
+    *reinterpret_cast<float4*>(bufB + lane * 16 + 8) = make_float4(enc[8], enc[9], 1.0f, 0.0f);
+    *reinterpret_cast<float4*>(bufB + lane * 16 + 12) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[64 * t + lane], bufB[64 * t + lane], acc0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- dW1: A = [d_out | 0 ...] (row 0 of a 16-row operand), B = H [sample][16]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bufB + lane * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
+    bufA[lane] = d_out;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float av = (lane & 15) == 0 ? bufA[4 * t + (lane >> 4)] : 0.0f;
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bufB[64 * t + lane], acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- block-level sum (plain LDS adds, one wave per turn: ds_add_f32 is lane-serialised on gfx950), then one atomic burst per block.
+  // accumulator register r of lane l = entry [4 (l / 16) + r][l % 16] of the 16x16 result
+  __syncthreads();
+  float* red = &lds[0][0][0];  // [0..255] dW0|db0 tile, [256..271] dW1 (row 0 of its tile), [272] db1
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum_dout += __shfl_xor(sum_dout, o, 64);
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int idx = (4 * (lane >> 4) + r) * 16 + (lane & 15);
+        red[idx] = (w == 0 ? 0.0f : red[idx]) + acc0[r];
+      }
+      if (lane < 16) red[256 + lane] = (w == 0 ? 0.0f : red[256 + lane]) + acc1[0];  // row 0 = register 0 of lanes 0..15
+      if (lane == 0) red[272] = (w == 0 ? 0.0f : red[272]) + sum_dout;
+    }
+    __syncthreads();
+  }
+  {
+    int j = threadIdx.x >> 4, k = threadIdx.x & 15;
+    float v = red[threadIdx.x];
+    if (v != 0.0f) {
+      if (k < PF) atomicAdd(net.gw0 + j * PF + k, v);
+      else if (k == PF) atomicAdd(net.gb0 + j, v);
+    }
+    if (threadIdx.x < 16) {
+      float u = red[256 + threadIdx.x];
+      if (u != 0.0f) atomicAdd(net.gw1 + threadIdx.x, u);
+    }
+    if (threadIdx.x == 16) {
+      float u = red[272];
+      if (u != 0.0f) atomicAdd(net.gb1, u);
+    }
   }
 }
 
-// [P][16] x4 GEMM operands + [P] d_out, then the scatter's replica scratch (256-B aligned)
-static inline int64_t prop_scratch_offset(int64_t P) { return ((P * (16 + 16 + 16 + 16 + 1) * (int64_t)sizeof(float) + 1024 + 255) / 256) * 256; }
+// d enc [P][16], then the scatter's scratch (256-B aligned)
+static inline int64_t prop_scratch_offset(int64_t P) { return ((P * 16 * (int64_t)sizeof(float) + 1024 + 255) / 256) * 256; }
 
 extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
   if (num_points < 0) return TN_EINVAL;
@@ -150,17 +218,13 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   if (N == 0) return TN_OK;
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, net->gw0, net->gb0, net->gw1, net->gb1};
   int64_t P = N * (int64_t)S;
-  float* ws = reinterpret_cast<float*>(workspace);
-  float *ws_da = ws, *ws_h = ws + P * 16, *ws_enc = ws + P * 32, *ws_denc = ws + P * 48, *ws_dout = ws + P * 64;
-  int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
-  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, d_density, N, S, ws_da, ws_dout, ws_enc,
-                     ws_h, ws_denc);
+  float* ws_denc = reinterpret_cast<float*>(workspace);
+  // 1024 blocks: every wave makes ~4 trips at level 0 (1 M samples), so the weight-gradient accumulators are flushed 1024 times, not 16 384
+  // (same-line global atomics serialise at ~25 ns each)
+  int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 1024);
+  hipStream_t st = tn_s(stream);
+  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
-  // the two weight-gradient GEMMs run beside the (atomic-bound) table scatter on the companion stream
-  hipStream_t st = tn_s(stream), side = tn_fork(st);
-  int rcw = tn_wgrad_launch2(ws_da, 16, 16, ws_enc, 16, PF, net->gw0, PF, net->gb0, ws_dout, 1, 1, ws_h, 16, 16, net->gw1, 16, net->gb1, P, side ? side : st);
-  int rcs = tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions,
-                                   reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), st);
-  if (side) tn_join(st, side);
-  return rcw ? rcw : rcs;
+  return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions,
+                                reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), st);
 }

@@ -81,10 +81,13 @@ class OverlappedGradReducer:
 
     pipelined = True
 
-    def __init__(self, world_size: int, group=None, level_chunks=(6, 4, 3, 2, 1), dense_exchange: bool = False, side_group="auto"):
+    def __init__(self, world_size: int, group=None, level_chunks=(6, 6, 4), dense_exchange: bool = False, side_group="auto"):
         """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The last range cannot hide
-        behind any scatter, so the ranges shrink towards the end: the exposed tail is one level (4 MB).  The first range takes the six
-        coarsest levels: their scatter is the cheapest part of the backward and nothing can be exchanged before it anyway.
+        behind any fold, so it is the smallest (4 levels = 16 MB, ~50 us on 8 GPUs); the first takes the six coarsest levels: their fold is
+        the cheapest part of the backward and nothing can be exchanged before it anyway.  Three ranges, not more: every range costs a fold
+        launch, a collective and an Adam launch on the HOST (a torch.distributed collective is ~10x a kernel launch), and the schedule is
+        host-bound on a loaded host (bench.py --force-dp: 1.59 ms with 3 ranges / 1.63 ms with 6-4-3-2-1 on a quiet host, far apart on a
+        busy one); finer ranges only shave the exposed tail.
         dense_exchange: exchange the coarse levels as dense per-cell sums (2.65 MB instead of 20 MB; tn_field_bwd_scatter_dense + dense fold).
         It needs the round-1 atomic scatter for those levels and two extra launches; with the binned scatter the plain level ranges are
         faster on one rank (bench.py --force-dp), so it is off by default.

@@ -95,7 +95,7 @@ def _worker_overlapped(rank, world, port, q):
     for skip_prop in (False, True):
         arena.grads.copy_(base * (rank + 1))
         red = OverlappedGradReducer(world)
-        assert red.level_ranges(16) == [(0, 6), (6, 10), (10, 13), (13, 15), (15, 16)] and not red.dense_exchange
+        assert red.level_ranges(16) == [(0, 6), (6, 12), (12, 16)] and not red.dense_exchange
         assert OverlappedGradReducer(world, level_chunks=4).level_ranges(16) == [(0, 4), (4, 8), (8, 12), (12, 16)]
         red.begin(arena)
         if not skip_prop:
