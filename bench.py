@@ -40,14 +40,14 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def build_engine(device, mode="shared", seed=0):
+def build_engine(device, mode="shared", seed=0, nerf_samples=48):
     import nerfstudio_thermal_amd  # noqa: F401
     from nerfstudio_thermal_amd import synth
     from nerfstudio_thermal_amd.arena import ParamArena
     from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
     from nerfstudio_thermal_amd.engine import RenderEngine
 
-    cfg = ThermalNerfactoModelConfig(density_mode=mode)
+    cfg = ThermalNerfactoModelConfig(density_mode=mode, num_nerf_samples_per_ray=nerf_samples)
     arena = ParamArena(cfg, 8, device)
     shapes = {n: s for n, (_, s) in arena.layout.items()}
     arena.load({k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=seed).items()})
@@ -55,14 +55,14 @@ def build_engine(device, mode="shared", seed=0):
     return cfg, arena, eng
 
 
-def build_model(device, mode="shared", seed=0):
+def build_model(device, mode="shared", seed=0, nerf_samples=48):
     """The drop-in object: ThermalNerfactoModel behind the reference's Model API, same synthetic weights as build_engine."""
     import nerfstudio_thermal_amd  # noqa: F401
     from nerfstudio_thermal_amd import synth
     from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
     from nerfstudio_thermal_amd.model import SceneBox
 
-    cfg = ThermalNerfactoModelConfig(density_mode=mode)
+    cfg = ThermalNerfactoModelConfig(density_mode=mode, num_nerf_samples_per_ray=nerf_samples)
     model = cfg.setup(scene_box=SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), num_train_data=8, metadata={"is_thermal": [0, 0, 0, 0, 1, 1, 1, 1]},
                       device=device)
     shapes = {n: s for n, (_, s) in model.arena.layout.items()}
@@ -198,13 +198,15 @@ def kernel_roofline(eng, cam_t, idx):
     return rows
 
 
-def step_algorithmic_bytes(arena, mode, rays, update_frac):
+def step_algorithmic_bytes(arena, mode, rays, update_frac, nerf_samples=48):
     """(N x bytes_ray + bytes_step) of one train step, no cache credit.  Per ray: forward gathers 161 792 B (separate: 421 888 B
     incl. the two cross-evaluated densities); backward scatter-add 98 304 B per main-grid backward (shared 1, separate 4: two branches + two
     cross terms) and 225 280 B per proposal-network backward (shared: on update steps; separate: the thermal sampler updates every step).
     Per step: Adam 28 B per optimised parameter (proposal groups only when they are stepped)."""
-    fwd = 161792 if mode == "shared" else 421888
-    main_bwd = 98304 * (1 if mode == "shared" else 4)
+    field = nerf_samples * 16 * 8 * 8  # one main-grid gather per ray (48 samples: 49 152 B)
+    prop = (256 + 96) * 5 * 8 * 8  # both proposal levels
+    fwd = prop + field if mode == "shared" else 2 * prop + 4 * field  # separate: two branches + two cross-evaluated densities
+    main_bwd = 2 * field * (1 if mode == "shared" else 4)
     prop_bwd = 225280 * (update_frac + (1.0 if mode == "separate" else 0.0))
     n_prop = sum(int(np.prod(arena.layout[k][1])) for k in arena.group_keys["proposal_networks"])
     n_all = arena.num_optimised()
@@ -337,6 +339,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="shared", choices=["shared", "separate"], help="density_mode (default = BASELINE configs[1]; separate = configs[2])")
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU, help="rays per GPU per step (configs[2] uses 8192)")
+    ap.add_argument("--nerf-samples", type=int, default=48, help="field samples per ray (num_nerf_samples_per_ray: 48 = the method's default; "
+                    "96 = the variant SURVEY.md section 8 quotes the metric on)")
     ap.add_argument("--path", default="fused", choices=["fused", "model-api"], help="fused: RenderEngine.train_step (no autograd tape); model-api: the "
                     "reference Trainer's sequence forward -> get_metrics_dict -> get_loss_dict -> backward -> optimisers on ThermalNerfactoModel")
     ap.add_argument("--api-optimizer", default="hip", choices=["hip", "torch"], help="--path model-api: HipFusedAdam (one launch per group over the arena) or "
@@ -370,11 +374,11 @@ def main():
     if api:
         from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
 
-        cfg, arena, model = build_model(device, mode=args.mode)
+        cfg, arena, model = build_model(device, mode=args.mode, nerf_samples=args.nerf_samples)
         eng = model.engine
         optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam if args.api_optimizer == "hip" else torch.optim.Adam)
     else:
-        cfg, arena, eng = build_engine(device, mode=args.mode)
+        cfg, arena, eng = build_engine(device, mode=args.mode, nerf_samples=args.nerf_samples)
     rays = args.rays
     broadcast_params(arena)
     torch.manual_seed(rank_seed(42, rank))  # every rank draws its own pixels (scripts/train.py:97)
@@ -437,7 +441,7 @@ def main():
         if pmc is not None and all(k in pmc for k in PMC_KEYS.get(name, ["?"])):
             traffic = sum(pmc[k]["traffic_bytes"] for k in PMC_KEYS[name])
         upd = updates / max(args.steps, 1)
-        step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd)
+        step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
         step_gbs = step_bytes / (dt / args.steps) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
@@ -466,7 +470,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (pixel sampling+raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
-                                   "256/96 proposal + 48 field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
+                                   f"256/96 proposal + {args.nerf_samples} field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
                        "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam)" if api else ""),
                        "final_loss": final_loss},
             "roofline": roofline,
