@@ -12,6 +12,7 @@ backward, gradient all-reduce (N>1) and Adam over all parameter groups.  Inputs 
 region.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import glob
 import hashlib
 import json
@@ -20,6 +21,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: see nerfstudio-thermal_amd/__init__.py
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
@@ -272,6 +274,8 @@ def bench_splat(args):
     cam = PinholeCamera(so.look_at_camera((3.2, 0.5, 0.8)), 1400.0, 1400.0, 960.0, 540.0, W, H)
     for _ in range(args.warmup):
         m.get_outputs(cam)
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -353,6 +357,7 @@ def main():
     ap.add_argument("--ops", action="store_true", help="print the per-kernel timing table to stderr")
     ap.add_argument("--dp-chunks", type=int, default=-1, help="N>1: level ranges of the main table exchanged separately (-1 = the default "
                     "schedule, n = n equal ranges, 0 = one all-reduce after the backward)")
+    ap.add_argument("--dp-adam-per-range", action="store_true", help="N>1 / --force-dp: one Adam launch per exchanged range instead of one after the exchange")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
     args = ap.parse_args()
@@ -388,6 +393,8 @@ def main():
     make_hook = lambda w: (OverlappedGradReducer(w) if args.dp_chunks < 0 else OverlappedGradReducer(w, level_chunks=args.dp_chunks)  # noqa: E731
                            if args.dp_chunks > 0 else GradAllReducer(w))
     hook = make_hook(world) if world > 1 else None
+    if hook is not None and args.dp_adam_per_range:
+        hook.adam_per_range = True
     if args.force_dp and world == 1:
         from nerfstudio_thermal_amd.parallel import free_port
 
@@ -395,6 +402,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(free_port()))
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         hook = make_hook(1)
+        if args.dp_adam_per_range:
+            hook.adam_per_range = True
         if args.dp_chunks == 0:
             hook.world = 2  # GradAllReducer returns early at world 1: make it issue the collective (the 1/2 scale does not matter here)
 
@@ -411,6 +420,12 @@ def main():
     for _ in range(args.warmup):
         run(step)
         step += 1
+    # Everything built so far (torch, the model, the arena views, ctypes structs: ~10^6 tracked objects) moves to the permanent generation:
+    # a full pass of Python's cyclic collector over them costs 35-40 ms and used to land inside the timed loop every 50-150 steps
+    # (+0.25 ms/step on the fused step, +0.7 ms/step on the data-parallel and drop-in paths, which allocate more containers per step).
+    # The collector stays ENABLED: garbage created from here on is still found, the passes just stop re-scanning the long-lived heap.
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     barrier()
     updates = 0

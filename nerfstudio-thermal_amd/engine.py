@@ -311,9 +311,9 @@ class RenderEngine:
             # streams, the number of hardware queues ROCm multiplexes streams onto by default -- a fifth stream shares a queue with another
             # and serialises behind it (measured: one side stream per proposal level made the step 1.7x slower).
             side = None
-            # Only the level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the side stream; the level-1 network follows
-            # the main field on the main stream.  Both on the side stream left the main stream idle for the last ~250 us of every
-            # proposal-update step (rocprofv3 timeline of the step).
+            # The level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the first side stream.  Both levels on ONE side
+            # stream left the main stream idle for the last ~250 us of every proposal-update step (rocprofv3 timeline of the step); the
+            # level-1 network gets a side stream of its own below (data-parallel schedule: behind the table ranges on the main stream).
             on_side = (0,)
             if br.prop_grad:
                 side = self._side_stream()
@@ -361,11 +361,18 @@ class RenderEngine:
                     glo, ghi = self.arena.group_range["proposal_networks"]
                     dp.reduce_range(self.arena.layout["proposal_networks.1.mlp_base.0.hash_table"][0], ghi)
             else:
-                ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+                # the level-1 network on a second side stream (the package asks the runtime for 8 hardware queues, see __init__.py; with
+                # the default 4 a fifth busy stream shares a queue and serialises).  Measured: 1.249 -> 1.216 ms per step.
+                side1 = None
                 if br.prop_grad:
-                    for i in (1,):
-                        dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
-                        ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d, tag="main1")
+                    side1 = self._side_stream(1)
+                    side1.wait_stream(main)
+                    with torch.cuda.stream(side1):
+                        dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, dws[1])
+                        ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="side1")
+                ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+                if side1 is not None:
+                    torch.cuda.current_stream().wait_stream(side1)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
@@ -484,9 +491,13 @@ class RenderEngine:
             # proposal networks that got no gradient this step are not stepped either: nothing to exchange for them
             skip = () if branches[""].prop_grad else ("proposal_networks",)
             idle = [self.arena.group_range[g] for g in skip]
-            # Adam range by range, each as soon as its exchange has landed: the update of the first table levels runs while the last ones
-            # are still on the wire
-            self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
+            if getattr(grad_hook, "adam_per_range", False):
+                # Adam range by range, each as soon as its exchange has landed: the update of the first table levels runs while the last
+                # ones are still on the wire (one more launch per range on the host)
+                self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
+            else:
+                grad_hook.finish(skip=idle)
+                self.optimizer_step(scheduled=scheduled, skip_groups=skip)
         else:
             losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
             if grad_hook is not None:

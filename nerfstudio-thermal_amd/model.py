@@ -176,7 +176,7 @@ class _RenderFn(torch.autograd.Function):
             if g_dens is not None:
                 d_dens += g_dens[..., 0]
             # same schedule as the fused step (engine.loss_and_backward): the level-0 proposal network (2/3 of the proposal work) on the side
-            # stream beside the main field's backward, the level-1 network behind the field on the main stream
+            # stream beside the main field's backward, the level-1 network on a second one
             side = None
             if br.prop_grad and g_w[0] is not None:
                 g0 = g_w[0][..., 0].contiguous()
@@ -185,12 +185,18 @@ class _RenderFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     dd = ops.weights_bwd(lv[0].e_bins, lv[0].density, lv[0].weights, g0)
                     ops.prop_density_bwd(props[0], br.origins, br.directions, lv[0].e_bins, dd, d_o, d_d, tag="side0")
-            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            side1 = None
             if br.prop_grad and g_w[1] is not None:
-                dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, g_w[1][..., 0].contiguous())
-                ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="main1")
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
+                g1 = g_w[1][..., 0].contiguous()
+                side1 = eng._side_stream(1)
+                side1.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side1):
+                    dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, g1)
+                    ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="side1")
+            ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+            for st in (side, side1):
+                if st is not None:
+                    torch.cuda.current_stream().wait_stream(st)
             d_od[sfx] = (d_o, d_d)
         if g_d2 is not None or g_d2t is not None:
             b, bt = branches[""], branches["_thermal"]

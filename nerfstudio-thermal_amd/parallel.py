@@ -80,6 +80,7 @@ class OverlappedGradReducer:
     Every rank runs the same Python schedule, so the collectives are issued in the same order everywhere."""
 
     pipelined = True
+    adam_per_range = False  # True: RenderEngine.train_step launches Adam per exchanged range (finish_iter) instead of once after finish()
 
     def __init__(self, world_size: int, group=None, level_chunks=(6, 6, 4), dense_exchange: bool = False, side_group="auto"):
         """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The last range cannot hide

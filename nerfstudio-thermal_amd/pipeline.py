@@ -44,6 +44,14 @@ class ThermalPipeline:
         """num_steps fused training iterations (callbacks + forward + losses + backward + Adam); returns the last loss dict."""
         self.model.train()
         losses = {}
+        if num_steps > 8 and not getattr(self, "_gc_frozen", False):
+            # the long-lived heap (torch, the model, the arena views) out of the cyclic collector's full passes: 35-40 ms each, every
+            # 50-150 iterations of a 1.3 ms step (the collector stays enabled for what the loop allocates)
+            import gc
+
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
         for _ in range(num_steps):
             o, d, cam, img, is_th = self.datamanager.next_train(self.step)
             rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
