@@ -209,6 +209,19 @@ int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N
 int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
                      float* d_weights, tn_stream_t stream);
 
+/* a11 + a15 + a16 of the last sampling level in ONE launch: RaySamples.get_weights (cameras/rays.py:128-150) followed by every renderer above
+ * (models/nerfacto.py:330-340), the weights handed over in registers; a second, single-block launch applies the batch-global clip of the
+ * expected depth.  Results are bit-identical to tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth (two launches, not four).
+ * state: 16 bytes of device memory, zero-filled ONCE by the caller; every call leaves them zero again (required when depth_expected is given;
+ * one state buffer per stream that may run this concurrently).  accumulation / depth_median / depth_expected may be NULL. */
+int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
+                  float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* state,
+                  tn_stream_t stream);
+/* its backward: tn_composite_bwd followed by tn_weights_bwd in one launch.  d_weights_in [N,S] = gradient that reaches the weights from the
+ * losses (read only: the compositing term is added in registers); d_rgb [N,S,C] and d_density [N,S] are written. */
+int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
+                  const float* d_weights_in, int64_t N, int32_t S, int32_t C, float* d_rgb, float* d_density, tn_stream_t stream);
+
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
 int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
@@ -234,6 +247,15 @@ int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int3
 int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
                     const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
                     float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
+/* The proposal losses of one branch AND the pixel terms above in ONE launch (they are independent, and each alone is a short latency-bound
+ * kernel: get_loss_dict's distortion / interlevel / rgb / thermal / tv / cross-channel terms of models/thermal_nerfacto.py:284-368 side by
+ * side).  Arguments and accumulation semantics are those of tn_proposal_losses followed by those of tn_pixel_losses. */
+int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                    const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                    float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                    float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
+                    int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
+                    float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
 /* density L1 cross loss with the reference's detach asymmetry (models/thermal_nerfacto.py:328-344): loss += a*mean|x-y| with
  * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
 int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,

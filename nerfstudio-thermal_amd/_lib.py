@@ -9,7 +9,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libthermal_nerf_hip.so")
+# TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
+LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD = 1, 2, 4, 8, 16
@@ -79,10 +80,13 @@ SIGNATURES = {
     "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "tn_clip_depth": (C.c_int, [_p, _p, _i64, _p]),
     "tn_composite_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
     "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
     "tn_proposal_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_train_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _f, _f, _f, _p, _p, _p, _p]),
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),
     "tn_train_metrics": (C.c_int, [_p, _i64, _f, _p, _i32, _p, _i32, _p, _p]),

@@ -185,19 +185,20 @@ class TrainLosses(torch.autograd.Function):
         L, grads = bufs[0], bufs[1:]
         gi = iter(grads)
         g_per = [(next(gi), [next(gi), next(gi), next(gi)]) for _ in per]
-        # ---- pixel terms
+        # ---- pixel terms: in the first branch's loss launch (tn_train_losses)
         if spec.separate:
             (_, _, _, comp, _), (_, _, _, comp_t, _) = per
-            ops.pixel_losses(comp, comp_t, image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], g_per[0][0], g_per[1][0])
+            pixel = (comp, comp_t, image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], g_per[0][0], g_per[1][0])
         else:
             comp, d_comp = per[0][3], g_per[0][0]
-            ops.pixel_losses(comp[:, :3], comp[:, 3:], image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], d_comp[:, :3], d_comp[:, 3:])
+            pixel = (comp[:, :3], comp[:, 3:], image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], d_comp[:, :3], d_comp[:, 3:])
         # ---- proposal terms (metrics_dict["distortion"] is the sum over suffixes and enters once per suffix: x nsfx, :363-368)
         nsfx = len(per)
         for (sfx, sb, pg, comp, ws), (_, dws) in zip(per, g_per):
             w = [x[..., 0] for x in ws]
             ops.proposal_losses(sb[2], w[2], [(sb[i], w[i], dws[i] if pg else None) for i in range(2)], spec.distortion_mult * nsfx, spec.interlevel_mult,
-                                L[9:10], L[8:9], dws[2])
+                                L[9:10], L[8:9], dws[2], pixel=pixel)
+            pixel = None
         # ---- density cross terms  a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|
         if dens:
             a, b = spec.density_weights

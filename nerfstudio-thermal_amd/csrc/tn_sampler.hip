@@ -6,6 +6,7 @@
 //   tn_composite_*   - RGB(T)Renderer / Accumulation / Depth renderers   (model_components/renderers.py:118-133,238-245,509,547-576)
 //   tn_distortion_loss / tn_interlevel_loss                              (model_components/losses.py:57-158)
 #include "tn_common.h"
+#include "tn_pixel_loss.h"
 
 #define RAYS_PER_BLOCK 4
 #define BLOCK (RAYS_PER_BLOCK * TN_WAVE)
@@ -327,31 +328,24 @@ extern "C" int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream) {
   return TN_OK;
 }
 
+// one ray of the renderers: w[k] = weight of sample lane*ITEMS + k (0 beyond S); mn / mx take the ray's smallest / largest midpoint
 template <int ITEMS, int C>
-__global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict__ rgb, const float* __restrict__ weights,
-                                                         const float* __restrict__ e_bins, int64_t N, int S, int training,
-                                                         float* __restrict__ comp, float* __restrict__ accumulation,
-                                                         float* __restrict__ depth_median, float* __restrict__ depth_expected,
-                                                         uint32_t* __restrict__ steps_minmax) {
-  int lane = tn_lane();
-  __shared__ float sh_mn[RAYS_PER_BLOCK], sh_mx[RAYS_PER_BLOCK];
-  float blk_mn = INFINITY, blk_mx = 0.0f;
-  // grid-stride over groups of RAYS_PER_BLOCK rays: same-address atomics serialise at ~15-25 ns each, so the batch-global min/max (and the
-  // loss sums of the kernels below) leave the block once, not once per ray
-  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+__device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const float* __restrict__ rgb, const float* __restrict__ e_bins, int S,
+                                              int64_t ray, int training, float* __restrict__ comp, float* __restrict__ accumulation,
+                                              float* __restrict__ depth_median, float* __restrict__ depth_expected, int lane, float& mn, float& mx) {
   const float* eb = e_bins + ray * (S + 1);
   float acc_c[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc_c[c] = 0.0f;
-  float wsum = 0.0f, wmid = 0.0f, mn = INFINITY, mx = 0.0f;
-  float w[ITEMS], mid[ITEMS];
+  float wsum = 0.0f, wmid = 0.0f;
+  mn = INFINITY; mx = 0.0f;
+  float mid[ITEMS];
   double wloc = 0.0;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     int i = lane * ITEMS + k;
-    w[k] = 0.0f; mid[k] = 0.0f;
+    mid[k] = 0.0f;
     if (i < S) {
-      w[k] = weights[ray * S + i];
       mid[k] = (eb[i] + eb[i + 1]) / 2.0f;
       mn = fminf(mn, mid[k]); mx = fmaxf(mx, mid[k]);
 #pragma unroll
@@ -381,10 +375,6 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
     if (accumulation) accumulation[ray] = wsum;
     if (depth_expected) depth_expected[ray] = wmid / (wsum + 1e-10f);
   }
-  if (steps_minmax != nullptr) {
-    blk_mn = fminf(blk_mn, tn_wave_min(mn));
-    blk_mx = fmaxf(blk_mx, tn_wave_max(mx));
-  }
   if (depth_median != nullptr) {
     double wincl = tn_wave_incl_scan_d(wloc, lane);
     double wrun = tn_excl_from_incl_d(wincl, lane);
@@ -405,6 +395,32 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
     v = __shfl(v, owner, 64);
     if (lane == 0) depth_median[ray] = v;
   }
+}
+
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict__ rgb, const float* __restrict__ weights,
+                                                         const float* __restrict__ e_bins, int64_t N, int S, int training,
+                                                         float* __restrict__ comp, float* __restrict__ accumulation,
+                                                         float* __restrict__ depth_median, float* __restrict__ depth_expected,
+                                                         uint32_t* __restrict__ steps_minmax) {
+  int lane = tn_lane();
+  __shared__ float sh_mn[RAYS_PER_BLOCK], sh_mx[RAYS_PER_BLOCK];
+  float blk_mn = INFINITY, blk_mx = 0.0f;
+  // grid-stride over groups of RAYS_PER_BLOCK rays: same-address atomics serialise at ~15-25 ns each, so the batch-global min/max (and the
+  // loss sums of the kernels below) leave the block once, not once per ray
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+    float w[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      int i = lane * ITEMS + k;
+      w[k] = (i < S) ? weights[ray * S + i] : 0.0f;
+    }
+    float mn, mx;
+    composite_ray<ITEMS, C>(w, rgb, e_bins, S, ray, training, comp, accumulation, depth_median, depth_expected, lane, mn, mx);
+    if (steps_minmax != nullptr) {
+      blk_mn = fminf(blk_mn, tn_wave_min(mn));
+      blk_mx = fmaxf(blk_mx, tn_wave_max(mx));
+    }
   }  // ray loop
   if (steps_minmax != nullptr) {
     if (lane == 0) { sh_mn[threadIdx.x >> 6] = blk_mn; sh_mx[threadIdx.x >> 6] = blk_mx; }
@@ -415,6 +431,89 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
       if (a != INFINITY) { atomicMin(&steps_minmax[0], f2ord(a)); atomicMax(&steps_minmax[1], f2ord(b)); }
     }
   }
+}
+
+// ---- get_weights + every renderer of the last level in ONE launch (tn_render_fwd): the weights stay in registers between the two halves.
+// The batch-global clip of the expected depth (renderers.py:574: clip to [steps.min(), steps.max()]) needs every block's min / max first:
+// state[0] = max over blocks of ~bits(min midpoint), state[1] = max of bits(max midpoint) -- both encodings start from ZERO, so no launch
+// initialises them -- and k_clip_depth_state applies the clip and, when it runs as a single block, puts the state back to zero for the next
+// call.  (A last-block-done epilogue inside this kernel was measured: the device-scope fences it needs write the whole L2 back once per block,
+// 55 us against 20 + 5 us for the two launches.)
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_render_fwd(const float* __restrict__ e_bins, const float* __restrict__ density,
+                                                      const float* __restrict__ rgb, int64_t N, int S, int training, float* __restrict__ weights,
+                                                      float* __restrict__ comp, float* __restrict__ accumulation, float* __restrict__ depth_median,
+                                                      float* __restrict__ depth_expected, uint32_t* __restrict__ state) {
+  const int lane = tn_lane();
+  __shared__ float sh_mn[RAYS_PER_BLOCK], sh_mx[RAYS_PER_BLOCK];
+  float blk_mn = INFINITY, blk_mx = 0.0f;
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6); ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+    float w[ITEMS];
+    weights_body<ITEMS>(e_bins, density, S, ray, weights, nullptr, lane, w);
+    float mn, mx;
+    composite_ray<ITEMS, C>(w, rgb, e_bins, S, ray, training, comp, accumulation, depth_median, depth_expected, lane, mn, mx);
+    if (depth_expected != nullptr) {
+      blk_mn = fminf(blk_mn, tn_wave_min(mn));
+      blk_mx = fmaxf(blk_mx, tn_wave_max(mx));
+    }
+  }
+  if (depth_expected == nullptr) return;  // wave-uniform, whole grid
+  if (lane == 0) { sh_mn[threadIdx.x >> 6] = blk_mn; sh_mx[threadIdx.x >> 6] = blk_mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = sh_mn[0], b = sh_mx[0];
+    for (int w = 1; w < RAYS_PER_BLOCK; ++w) { a = fminf(a, sh_mn[w]); b = fmaxf(b, sh_mx[w]); }
+    if (a != INFINITY) { atomicMax(&state[0], ~f2ord(a)); atomicMax(&state[1], f2ord(b)); }
+  }
+}
+// RESET: launched as ONE block, which reads the range, then zeroes the state for the next call, then clips
+template <bool RESET>
+__global__ void __launch_bounds__(1024) k_clip_depth_state(float* __restrict__ d, uint32_t* __restrict__ state, int64_t N) {
+  const float lo = __uint_as_float(~state[0]), hi = __uint_as_float(state[1]);
+  if (RESET) {
+    __syncthreads();
+    if (threadIdx.x < 2) state[threadIdx.x] = 0u;
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = d[i];
+    if (v == v) v = fminf(fmaxf(v, lo), hi);  // torch.clip; NaN propagates
+    d[i] = v;
+  }
+}
+
+extern "C" int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
+                             float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* state,
+                             tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(e_bins && density && rgb && weights && comp, "tn_render_fwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_render_fwd: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_render_fwd: unsupported channel count %d", C);
+  TN_REQUIRE(depth_expected == nullptr || state != nullptr, "tn_render_fwd: depth_expected needs the 16-byte state buffer");
+  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), block(BLOCK);
+  hipStream_t st = tn_s(stream);
+#define LAUNCH_R(I, CC)                                                                                                               \
+  hipLaunchKernelGGL((k_render_fwd<I, CC>), grid, block, 0, st, e_bins, density, rgb, N, S, training, weights, comp, accumulation, \
+                     depth_median, depth_expected, state)
+#define LAUNCH_R_C(I) \
+  do { if (C == 1) LAUNCH_R(I, 1); else if (C == 3) LAUNCH_R(I, 3); else LAUNCH_R(I, 4); } while (0)
+  if (S <= 64) LAUNCH_R_C(1);
+  else if (S <= 128) LAUNCH_R_C(2);
+  else LAUNCH_R_C(4);
+#undef LAUNCH_R_C
+#undef LAUNCH_R
+  TN_CHECK_LAUNCH("tn_render_fwd");
+  if (depth_expected != nullptr) {
+    if (N <= 65536) {
+      hipLaunchKernelGGL(k_clip_depth_state<true>, dim3(1), dim3(1024), 0, st, depth_expected, state, N);
+      TN_CHECK_LAUNCH("tn_render_fwd(clip)");
+    } else {  // one block looping over a huge batch would take longer than a memset node
+      hipLaunchKernelGGL(k_clip_depth_state<false>, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 1024), 1024)), dim3(1024), 0, st, depth_expected, state, N);
+      TN_CHECK_LAUNCH("tn_render_fwd(clip)");
+      hipError_t e = hipMemsetAsync(state, 0, 16, st);  // the state is zero between calls
+      TN_REQUIRE(e == hipSuccess, "tn_render_fwd: memset failed: %s", hipGetErrorString(e));
+    }
+  }
+  return TN_OK;
 }
 
 extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
@@ -514,6 +613,88 @@ extern "C" int tn_composite_bwd(const float* rgb, const float* weights, const fl
 #undef LAUNCH_CB_C
 #undef LAUNCH_CB
   TN_CHECK_LAUNCH("tn_composite_bwd");
+  return TN_OK;
+}
+
+// backward of tn_render_fwd in one launch: composite_bwd, then weights_bwd on d_weights_in + the compositing term (held in registers;
+// d_weights_in is NOT updated).  Same arithmetic, same order as tn_composite_bwd followed by tn_weights_bwd.
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_render_bwd(const float* __restrict__ e_bins, const float* __restrict__ density,
+                                                      const float* __restrict__ rgb, const float* __restrict__ weights,
+                                                      const float* __restrict__ d_comp, const float* __restrict__ d_weights_in, int64_t N, int S,
+                                                      float* __restrict__ d_rgb, float* __restrict__ d_density) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const float* eb = e_bins + ray * (S + 1);
+  float g[C], last[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { g[c] = d_comp[ray * C + c]; last[c] = rgb[(ray * S + (S - 1)) * C + c]; }
+  float dd[ITEMS], delta[ITEMS], gw[ITEMS], wk[ITEMS];
+  float wsum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    wk[k] = (i < S) ? weights[ray * S + i] : 0.0f;
+    if (i < S) wsum += wk[k];
+  }
+  wsum = tn_wave_sum(wsum);
+  double loc = 0.0;
+  float sloc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    dd[k] = delta[k] = gw[k] = 0.0f;
+    if (i < S) {
+      float dw = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float v = rgb[(ray * S + i) * C + c];
+        dw += g[c] * (v - last[c]);
+        float dr = wk[k] * g[c];
+        if (i == S - 1) dr += (1.0f - wsum) * g[c];
+        d_rgb[(ray * S + i) * C + c] = dr;
+      }
+      gw[k] = d_weights_in[ray * S + i] + dw;
+      delta[k] = eb[i + 1] - eb[i];
+      dd[k] = delta[k] * density[ray * S + i];
+    }
+    loc += (double)dd[k];
+    sloc += gw[k] * wk[k];
+  }
+  double incl = tn_wave_incl_scan_d(loc, lane);
+  double run = tn_excl_from_incl_d(incl, lane);
+  float sincl = tn_wave_incl_rscan(sloc, lane);
+  float suffix = tn_rexcl_from_incl(sincl, lane);
+  float T[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) { T[k] = expf(-(float)run); run += (double)dd[k]; }
+#pragma unroll
+  for (int k = ITEMS - 1; k >= 0; --k) {
+    int i = lane * ITEMS + k;
+    float gg = gw[k] * expf(-dd[k]) * T[k] - suffix;
+    if (i < S) d_density[ray * S + i] = gg * delta[k];
+    suffix += gw[k] * wk[k];
+  }
+}
+
+extern "C" int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
+                             const float* d_weights_in, int64_t N, int32_t S, int32_t C, float* d_rgb, float* d_density, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(e_bins && density && rgb && weights && d_comp && d_weights_in && d_rgb && d_density, "tn_render_bwd: null pointer");
+  TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_render_bwd: bad N=%lld S=%d", (long long)N, S);
+  TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_render_bwd: unsupported channel count %d", C);
+  dim3 grid((unsigned)tn_cdiv(N, RAYS_PER_BLOCK)), block(BLOCK);
+#define LAUNCH_RB(I, CC) \
+  hipLaunchKernelGGL((k_render_bwd<I, CC>), grid, block, 0, tn_s(stream), e_bins, density, rgb, weights, d_comp, d_weights_in, N, S, d_rgb, d_density)
+#define LAUNCH_RB_C(I) \
+  do { if (C == 1) LAUNCH_RB(I, 1); else if (C == 3) LAUNCH_RB(I, 3); else LAUNCH_RB(I, 4); } while (0)
+  if (S <= 64) LAUNCH_RB_C(1);
+  else if (S <= 128) LAUNCH_RB_C(2);
+  else LAUNCH_RB_C(4);
+#undef LAUNCH_RB_C
+#undef LAUNCH_RB
+  TN_CHECK_LAUNCH("tn_render_bwd");
   return TN_OK;
 }
 
@@ -647,7 +828,28 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
   if (d_w_prop != nullptr) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    // most fine intervals have no excess (g_i == 0): walk only the others (wave-uniform bit masks, 64 intervals per word)
+    // lo_i and hi_i do not decrease with i (the fine bins are sorted), so the fine intervals that cover proposal bin k are ONE run
+    // [B, A): A = #{i : lo_i <= k}, B = #{i : hi_i < k}; should B exceed A, [A, B) is the run of inverted intervals (hi_i < k < lo_i) that the
+    // reference's formula subtracts.  Two binary searches and a short in-order sum per lane -- the same additions in the same order as a walk
+    // over every interval (48 dependent LDS round trips per 64 bins before).
+    bool mono = true;
+    for (int i = lane; i < Sf; i += 64)
+      if (i > 0 && (sh_lo[wv][i] < sh_lo[wv][i - 1] || sh_hi[wv][i] < sh_hi[wv][i - 1])) mono = false;
+    if (__all(mono)) {
+      for (int k = lane; k < Sp; k += 64) {
+        int l = 0, h = Sf;
+        while (l < h) { int m = (l + h) >> 1; if (sh_lo[wv][m] <= k) l = m + 1; else h = m; }
+        const int A = l;
+        l = 0; h = Sf;
+        while (l < h) { int m = (l + h) >> 1; if (sh_hi[wv][m] < k) l = m + 1; else h = m; }
+        const int B = l;
+        float acc = 0.0f;
+        if (B < A) { for (int i = B; i < A; ++i) acc += sh_g[wv][i]; }
+        else { for (int i = A; i < B; ++i) acc -= sh_g[wv][i]; }
+        if (acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
+      }
+    } else {
+    // unsorted fine bins (never from the samplers): walk every interval with a non-zero g_i (wave-uniform bit masks, 64 intervals per word)
     for (int k0 = 0; k0 < Sp; k0 += 64) {
       int k = k0 + lane;
       float acc = 0.0f;
@@ -664,6 +866,7 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
         }
       }
       if (k < Sp && acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
+    }
     }
   }
   }  // ray loop
@@ -699,10 +902,19 @@ struct PropLossArgs {
   float* distortion_out;
   float* interlevel_out;
   float* d_w_fine;
+  // optional last slice (blockIdx.y = 1 + num_props): the pixel terms of the same iteration (tn_train_losses); pred_rgb == NULL: none
+  const float* pred_rgb; const float* pred_th; const float* image; const float* is_thermal;
+  int rs, ts, pixel_blocks;
+  float thermal_mult, tv_mult, cross_mult;
+  float* pixel_losses; float* d_pred_rgb; float* d_pred_th;
 };
 __global__ void __launch_bounds__(BLOCK) k_proposal_losses(PropLossArgs a) {
   if (blockIdx.y == 0) {
     distortion_body(a.s_bins_fine, a.w_fine, a.N, a.Sf, a.distortion_mult, a.distortion_out, a.d_w_fine);
+  } else if ((int)blockIdx.y == 1 + a.num_props) {
+    if ((int)blockIdx.x >= a.pixel_blocks) return;  // whole block leaves together
+    pixel_losses_body(a.pred_rgb, a.rs, a.pred_th, a.ts, a.image, a.is_thermal, a.N, a.thermal_mult, a.tv_mult, a.cross_mult, a.pixel_losses,
+                      a.d_pred_rgb, a.d_pred_th, blockIdx.x, a.pixel_blocks);
   } else {
     int i = blockIdx.y - 1;
     interlevel_body(a.s_bins_fine, a.w_fine, a.Sf, a.s_bins_prop[i], a.w_prop[i], a.Sp[i], a.N, a.interlevel_mult, a.interlevel_out, a.d_w_prop[i]);
@@ -723,27 +935,61 @@ extern "C" int tn_interlevel_loss(const float* s_bins_fine, const float* weights
   return TN_OK;
 }
 
-extern "C" int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
-                                  const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
-                                  float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
-                                  float* interlevel_out, float* d_weights_fine, tn_stream_t stream) {
+static int launch_train_losses(const char* who, const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                               const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                               float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                               float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
+                               int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
+                               float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
-  TN_REQUIRE(s_bins_fine && weights_fine && distortion_out && interlevel_out, "tn_proposal_losses: null pointer");
-  TN_REQUIRE(N > 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES, "tn_proposal_losses: bad N=%lld S_fine=%d", (long long)N, S_fine);
+  TN_REQUIRE(s_bins_fine && weights_fine && distortion_out && interlevel_out, "%s: null pointer", who);
+  TN_REQUIRE(N > 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES, "%s: bad N=%lld S_fine=%d", who, (long long)N, S_fine);
   TN_REQUIRE(num_props >= 0 && num_props <= TN_MAX_PROP_LEVELS && (num_props == 0 || (s_bins_prop && weights_prop && S_prop && d_weights_prop)),
-             "tn_proposal_losses: bad proposal level list (num_props=%d, at most %d)", num_props, TN_MAX_PROP_LEVELS);
+             "%s: bad proposal level list (num_props=%d, at most %d)", who, num_props, TN_MAX_PROP_LEVELS);
   PropLossArgs a{};
   a.s_bins_fine = s_bins_fine; a.w_fine = weights_fine; a.Sf = S_fine; a.num_props = num_props; a.N = N;
   a.distortion_mult = distortion_mult; a.interlevel_mult = interlevel_mult;
   a.distortion_out = distortion_out; a.interlevel_out = interlevel_out; a.d_w_fine = d_weights_fine;
   for (int i = 0; i < num_props; ++i) {
-    TN_REQUIRE(s_bins_prop[i] && weights_prop[i] && S_prop[i] >= 1 && S_prop[i] <= TN_MAX_SAMPLES, "tn_proposal_losses: bad proposal level %d", i);
+    TN_REQUIRE(s_bins_prop[i] && weights_prop[i] && S_prop[i] >= 1 && S_prop[i] <= TN_MAX_SAMPLES, "%s: bad proposal level %d", who, i);
     a.s_bins_prop[i] = s_bins_prop[i]; a.w_prop[i] = weights_prop[i]; a.Sp[i] = S_prop[i]; a.d_w_prop[i] = d_weights_prop[i];
   }
-  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), 1 + num_props);
+  int slices = 1 + num_props;
+  if (pred_rgb != nullptr) {
+    TN_REQUIRE(pred_thermal && image && is_thermal && pixel_losses_out, "%s: null pointer in the pixel terms", who);
+    TN_REQUIRE(N % 4 == 0, "%s: N=%lld must be a multiple of 4 (2x2 patches)", who, (long long)N);
+    TN_REQUIRE(rgb_stride >= 3 && thermal_stride >= 1, "%s: bad strides", who);
+    a.pred_rgb = pred_rgb; a.pred_th = pred_thermal; a.image = image; a.is_thermal = is_thermal; a.rs = rgb_stride; a.ts = thermal_stride;
+    a.thermal_mult = thermal_mult; a.tv_mult = tv_mult; a.cross_mult = cross_mult;
+    a.pixel_losses = pixel_losses_out; a.d_pred_rgb = d_pred_rgb; a.d_pred_th = d_pred_thermal;
+    a.pixel_blocks = pixel_loss_blocks(N);
+    ++slices;
+  }
+  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), slices);
   hipLaunchKernelGGL(k_proposal_losses, grid, dim3(BLOCK), 0, tn_s(stream), a);
-  TN_CHECK_LAUNCH("tn_proposal_losses");
+  TN_CHECK_LAUNCH(who);
   return TN_OK;
+}
+
+extern "C" int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                                  const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                                  float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                                  float* interlevel_out, float* d_weights_fine, tn_stream_t stream) {
+  return launch_train_losses("tn_proposal_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
+                             distortion_mult, interlevel_mult, distortion_out, interlevel_out, d_weights_fine, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                             0.f, 0.f, 0.f, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+                               const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
+                               float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
+                               float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
+                               int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
+                               float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
+  TN_REQUIRE(pred_rgb != nullptr, "tn_train_losses: null pointer (pred_rgb)");
+  return launch_train_losses("tn_train_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
+                             distortion_mult, interlevel_mult, distortion_out, interlevel_out, d_weights_fine, pred_rgb, rgb_stride, pred_thermal,
+                             thermal_stride, image, is_thermal, thermal_mult, tv_mult, cross_mult, pixel_losses_out, d_pred_rgb, d_pred_thermal, stream);
 }
 
 extern "C" int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,

@@ -18,6 +18,9 @@ from .arena import ParamArena
 from .config import ThermalNerfactoModelConfig
 from .netparams import field_params, prop_params
 
+import os as _os
+_FUSE = _os.environ.get("TN_FUSE_SMALL", "1") != "0"  # timing experiments: 0 = one launch per op (weights / composite / clip / pixel losses)
+
 
 @dataclass
 class Level:
@@ -136,8 +139,12 @@ class RenderEngine:
             levels.append(L)
         last = levels[-1]
         last.density, rgb, _ = ops.field_fwd(fld, origins, directions, cam, last.e_bins, training, tag=tag)
-        last.weights, _ = ops.weights_fwd(last.e_bins, last.density)
-        comp, acc, med, exp = ops.composite_fwd(rgb, last.weights, last.e_bins, training)
+        # get_weights + the four renderers (+ the batch-global depth clip) of the last level: one launch
+        if _FUSE:
+            last.weights, comp, acc, med, exp = ops.render_fwd(last.e_bins, last.density, rgb, training)
+        else:
+            last.weights, _ = ops.weights_fwd(last.e_bins, last.density)
+            comp, acc, med, exp = ops.composite_fwd(rgb, last.weights, last.e_bins, training)
         last.median = med
         return Branch(origins=origins, directions=directions, origins_in=o_in, directions_in=d_in, levels=levels, rgb_samples=rgb, comp=comp,
                       accumulation=acc, depth=med, expected_depth=exp, prop_grad=prop_grad)
@@ -255,12 +262,16 @@ class RenderEngine:
         Z = dict(zip(zkeys, self._zeros_many(zshapes)))
         L = Z[("L", "")]
         d_comp = Z[("d_comp", "")]
+        # the pixel terms ride in the first branch's loss launch (ops.proposal_losses(pixel=...)): one launch instead of two back to back
         if self.separate:
             d_comp_t = Z[("d_comp", "_thermal")]
-            ops.pixel_losses(b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8], d_comp, d_comp_t)
+            pixel = (b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8], d_comp, d_comp_t)
         else:
-            ops.pixel_losses(b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8],
-                             d_comp[:, :3], d_comp[:, 3:])
+            pixel = (b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8],
+                     d_comp[:, :3], d_comp[:, 3:])
+        if not _FUSE:
+            ops.pixel_losses(*pixel)
+            pixel = None
         # ---- proposal losses.  NB (models/thermal_nerfacto.py:363-368): metrics_dict["distortion"] is the SUM over suffixes and is added once per
         # suffix, so in separate mode each branch's distortion enters with 2x distortion_loss_mult.
         nsfx = 2 if self.separate else 1
@@ -273,7 +284,8 @@ class RenderEngine:
                     dws[i] = Z[(f"dw{i}", sfx)]
             # distortion + both interlevel terms: one launch (they are independent and ~15 us each)
             ops.proposal_losses(lv[2].s_bins, lv[2].weights, [(lv[i].s_bins, lv[i].weights, dws[i]) for i in range(2)],
-                                c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, L[9:10], L[8:9], dws[2])
+                                c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, L[9:10], L[8:9], dws[2], pixel=pixel)
+            pixel = None
             grads_w[sfx] = dws
         # ---- per-branch backward
         # Overlapped data-parallel exchange only where a slice of the arena is final right after its kernel: in separate mode the
@@ -302,8 +314,11 @@ class RenderEngine:
             d_d = Z[("d_d", sfx)] if want_pos else None
             dws = grads_w[sfx]
             dc = d_comp_t if sfx else d_comp
-            d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, dc, dws[2])
-            d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dws[2])
+            if _FUSE:
+                d_rgb, d_dens = ops.render_bwd(lv[2].e_bins, lv[2].density, br.rgb_samples, lv[2].weights, dc, dws[2])
+            else:
+                d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, dc, dws[2])
+                d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dws[2])
             if d_dens_extra[sfx] is not None:
                 d_dens += d_dens_extra[sfx]
             # The proposal networks' backward (own tables, MLPs and scatter; d origins / d directions are accumulated atomically) is

@@ -170,9 +170,9 @@ class _RenderFn(torch.autograd.Function):
             lv = br.levels
             d_o = torch.zeros((N, 3), device=dev) if pose is not None else None
             d_d = torch.zeros((N, 3), device=dev) if pose is not None else None
-            dw2 = (g_w[2][..., 0].contiguous().clone() if g_w[2] is not None else z(lv[2].weights))
-            d_rgb = ops.composite_bwd(br.rgb_samples, lv[2].weights, (g_comp.contiguous() if g_comp is not None else z(br.comp)), dw2)
-            d_dens = ops.weights_bwd(lv[2].e_bins, lv[2].density, lv[2].weights, dw2)
+            dw2 = (g_w[2][..., 0].contiguous() if g_w[2] is not None else z(lv[2].weights))  # read only (tn_render_bwd)
+            d_rgb, d_dens = ops.render_bwd(lv[2].e_bins, lv[2].density, br.rgb_samples, lv[2].weights,
+                                           (g_comp.contiguous() if g_comp is not None else z(br.comp)), dw2)
             if g_dens is not None:
                 d_dens += g_dens[..., 0]
             # same schedule as the fused step (engine.loss_and_backward): the level-0 proposal network (2/3 of the proposal work) on the side

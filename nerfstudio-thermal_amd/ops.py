@@ -515,6 +515,44 @@ def composite_bwd(rgb: Tensor, weights: Tensor, d_comp: Tensor, d_weights: Tenso
     return d_rgb
 
 
+_RENDER_STATE: dict = {}
+
+
+def render_fwd(e_bins: Tensor, density: Tensor, rgb: Tensor, training: bool, want_depth: bool = True):
+    """weights_fwd + composite_fwd (+ depth clip) of the last level in one launch (tn_render_fwd)
+    -> weights [N,S], comp [N,C], accumulation [N,1], depth_median [N,1] or None, depth_expected [N,1] or None."""
+    N, S, Cc = rgb.shape
+    dev = rgb.device
+    w = torch.empty((N, S), device=dev)
+    comp = torch.empty((N, Cc), device=dev)
+    acc = torch.empty((N, 1), device=dev)
+    med = torch.empty((N, 1), device=dev) if want_depth else None
+    exp = torch.empty((N, 1), device=dev) if want_depth else None
+    st = _stream()
+    state = None
+    if want_depth:
+        # 16 bytes that every call leaves zero again: one buffer per (device, stream), zero-filled when it is created
+        key = (dev.index, st.value)
+        state = _RENDER_STATE.get(key)
+        if state is None:
+            state = _RENDER_STATE[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    check(_lib.load().tn_render_fwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), _f32(rgb, "rgb", (N, S, Cc)), N, S, Cc,
+                                    1 if training else 0, _f32(w, "w"), _f32(comp, "comp"), _f32(acc, "acc"), _f32(med, "med", optional=True),
+                                    _f32(exp, "exp", optional=True), C.c_void_p(state.data_ptr()) if state is not None else None, st), "tn_render_fwd")
+    return w, comp, acc, med, exp
+
+
+def render_bwd(e_bins: Tensor, density: Tensor, rgb: Tensor, weights: Tensor, d_comp: Tensor, d_weights_in: Tensor):
+    """composite_bwd + weights_bwd in one launch (tn_render_bwd) -> d_rgb [N,S,C], d_density [N,S]; d_weights_in is left as it is."""
+    N, S, Cc = rgb.shape
+    d_rgb = torch.empty_like(rgb)
+    dd = torch.empty((N, S), device=rgb.device)
+    check(_lib.load().tn_render_bwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), _f32(rgb, "rgb", (N, S, Cc)),
+                                    _f32(weights, "weights", (N, S)), _f32(d_comp, "d_comp", (N, Cc)), _f32(d_weights_in, "d_weights", (N, S)), N, S, Cc,
+                                    _f32(d_rgb, "d_rgb"), _f32(dd, "d_density"), _stream()), "tn_render_bwd")
+    return d_rgb, dd
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def distortion_loss(s_bins: Tensor, weights: Tensor, mult: float, loss_out: Tensor, d_weights: Optional[Tensor]) -> None:
     N, S = weights.shape
@@ -531,9 +569,10 @@ def interlevel_loss(s_fine: Tensor, w_fine: Tensor, s_prop: Tensor, w_prop: Tens
 
 
 def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, interlevel_mult: float, distortion_out: Tensor,
-                    interlevel_out: Tensor, d_w_fine: Optional[Tensor]) -> None:
+                    interlevel_out: Tensor, d_w_fine: Optional[Tensor], pixel=None) -> None:
     """distortion_loss on the fine level + interlevel_loss against every proposal level, one launch (tn_proposal_losses).
-    props: list of (s_bins [N,Sp+1], weights [N,Sp], d_weights [N,Sp] or None)."""
+    props: list of (s_bins [N,Sp+1], weights [N,Sp], d_weights [N,Sp] or None).
+    pixel: None, or the arguments of pixel_losses() as a tuple -- the pixel terms then run in the same launch (tn_train_losses)."""
     N, Sf = w_fine.shape
     n = len(props)
     sb = (C.c_void_p * max(n, 1))()
@@ -547,29 +586,41 @@ def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: floa
         v = _f32(d_p, "d_w_prop", (N, Sp), True)
         dw[i] = v.value if v is not None else None
         sp[i] = Sp
-    check(_lib.load().tn_proposal_losses(_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N,
-                                         float(distortion_mult), float(interlevel_mult), _f32(distortion_out, "distortion"),
-                                         _f32(interlevel_out, "interlevel"), _f32(d_w_fine, "d_w_fine", (N, Sf), True), _stream()),
-          "tn_proposal_losses")
+    head = (_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N, float(distortion_mult), float(interlevel_mult),
+            _f32(distortion_out, "distortion"), _f32(interlevel_out, "interlevel"), _f32(d_w_fine, "d_w_fine", (N, Sf), True))
+    if pixel is None:
+        check(_lib.load().tn_proposal_losses(*head, _stream()), "tn_proposal_losses")
+    else:
+        check(_lib.load().tn_train_losses(*head, *_pixel_args(*pixel, N=N), _stream()), "tn_train_losses")
 
 
-def pixel_losses(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
-                 losses_out: Tensor, d_pred_rgb: Optional[Tensor], d_pred_thermal: Optional[Tensor]) -> None:
-    """pred_rgb [N,3] / pred_thermal [N,1] may be strided views of one [N,4] buffer (shared mode)."""
-    N = pred_rgb.shape[0]
+def _pixel_args(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
+                losses_out: Tensor, d_pred_rgb: Optional[Tensor], d_pred_thermal: Optional[Tensor], N: Optional[int] = None):
+    """Validated argument tail shared by tn_pixel_losses and tn_train_losses (without N and the stream)."""
+    n = pred_rgb.shape[0]
+    if N is not None and n != N:
+        raise ValueError("pixel terms and proposal terms must cover the same rays")
     if pred_rgb.dtype != torch.float32 or pred_thermal.dtype != torch.float32 or not pred_rgb.is_cuda:
         raise ValueError("predictions must be CUDA float32")
-    if pred_rgb.stride(1) != 1 or pred_thermal.stride(1) != 1 or pred_rgb.shape != (N, 3) or pred_thermal.shape != (N, 1):
+    if pred_rgb.stride(1) != 1 or pred_thermal.stride(1) != 1 or pred_rgb.shape != (n, 3) or pred_thermal.shape != (n, 1):
         raise ValueError("bad prediction views")
     if losses_out.numel() < 8:
         raise ValueError("losses_out needs 8 floats")
     for g, p in ((d_pred_rgb, pred_rgb), (d_pred_thermal, pred_thermal)):
         if g is not None and (g.stride() != p.stride() or g.shape != p.shape or g.dtype != torch.float32):
             raise ValueError("gradient views must mirror the prediction views")
-    check(_lib.load().tn_pixel_losses(C.c_void_p(pred_rgb.data_ptr()), pred_rgb.stride(0), C.c_void_p(pred_thermal.data_ptr()), pred_thermal.stride(0),
-                                      _f32(image, "image", (N, 3)), _f32(is_thermal, "is_thermal", (N,)), N, float(thermal_mult), float(tv_mult),
-                                      float(cross_mult), _f32(losses_out, "losses"), C.c_void_p(d_pred_rgb.data_ptr()) if d_pred_rgb is not None else None,
-                                      C.c_void_p(d_pred_thermal.data_ptr()) if d_pred_thermal is not None else None, _stream()), "tn_pixel_losses")
+    return (C.c_void_p(pred_rgb.data_ptr()), pred_rgb.stride(0), C.c_void_p(pred_thermal.data_ptr()), pred_thermal.stride(0),
+            _f32(image, "image", (n, 3)), _f32(is_thermal, "is_thermal", (n,)), float(thermal_mult), float(tv_mult), float(cross_mult),
+            _f32(losses_out, "losses"), C.c_void_p(d_pred_rgb.data_ptr()) if d_pred_rgb is not None else None,
+            C.c_void_p(d_pred_thermal.data_ptr()) if d_pred_thermal is not None else None)
+
+
+def pixel_losses(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
+                 losses_out: Tensor, d_pred_rgb: Optional[Tensor], d_pred_thermal: Optional[Tensor]) -> None:
+    """pred_rgb [N,3] / pred_thermal [N,1] may be strided views of one [N,4] buffer (shared mode)."""
+    a = _pixel_args(pred_rgb, pred_thermal, image, is_thermal, thermal_mult, tv_mult, cross_mult, losses_out, d_pred_rgb, d_pred_thermal)
+    # C order: ..., image, is_thermal, N, thermal_mult, ...
+    check(_lib.load().tn_pixel_losses(*a[:6], pred_rgb.shape[0], *a[6:], _stream()), "tn_pixel_losses")
 
 
 def l1_loss(x: Tensor, y: Tensor, gx: float, gy: float, loss_out: Tensor, d_x: Optional[Tensor], d_y: Optional[Tensor]) -> None:

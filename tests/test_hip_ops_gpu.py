@@ -423,6 +423,116 @@ def test_proposal_losses():
     assert abs(float(loss_h[1]) - float(loss[1])) <= 1e-5 * abs(float(loss[1]))
 
 
+@pytest.mark.parametrize("C,S,N,training", [(4, 48, 4096, True), (4, 48, 257, False), (3, 96, 130, True), (1, 256, 66, True), (4, 48, 70001, True)])
+def test_render_fwd_bwd_is_the_separate_launches(C, S, N, training):
+    """tn_render_fwd / tn_render_bwd (one launch each) against tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth and
+    tn_composite_bwd + tn_weights_bwd: bit-identical, including the batch-global depth clip done by the last block (N <= 65536) or by the
+    follow-up launch (larger batches), and the state buffer left zero for the next call."""
+    gen = torch.Generator().manual_seed(5 + S)
+    nears = torch.full((N, 1), 0.05) + 0.3 * torch.rand((N, 1), generator=gen)
+    fars = torch.full((N, 1), 50.0) + 900.0 * torch.rand((N, 1), generator=gen)
+    s, e = sample_level(N, S, nears, fars)
+    dens = (6.0 * torch.rand((N, S), generator=gen)) ** 2
+    rgb = torch.rand((N, S, C), generator=gen)
+    if not training:
+        rgb[3, 5, 0] = float("nan")
+    he, hd, hr = g(e), g(dens), g(rgb)
+    w_ref, _ = ops.weights_fwd(he, hd)
+    c_ref, a_ref, m_ref, x_ref = ops.composite_fwd(hr, w_ref, he, training)
+    for rep in range(2):  # the second call finds the state as the first one left it
+        w, c, a, m, x = ops.render_fwd(he, hd, hr, training)
+        for got, ref in ((w, w_ref), (c, c_ref), (a, a_ref), (m, m_ref), (x, x_ref)):
+            assert torch.equal(got.nan_to_num(nan=-7.0), ref.nan_to_num(nan=-7.0))
+        assert all(int(v) == 0 for st in ops._RENDER_STATE.values() for v in st.cpu())
+    # the clip really is batch-global: expected depths lie inside [min midpoint, max midpoint] of the whole batch
+    mid = (e[:, 1:] + e[:, :-1]) / 2
+    assert float(x.min()) >= float(mid.min()) and float(x.max()) <= float(mid.max())
+    w2, c2, a2, _, _ = ops.render_fwd(he, hd, hr, training, want_depth=False)
+    assert torch.equal(w2, w_ref) and torch.equal(c2.nan_to_num(nan=-7.0), c_ref.nan_to_num(nan=-7.0)) and torch.equal(a2, a_ref)
+    if not training:
+        return
+    gc = g(torch.rand((N, C), generator=gen) - 0.5)
+    dw_loss = g(1e-3 * (torch.rand((N, S), generator=gen) - 0.5))
+    dw = dw_loss.clone()
+    drgb_ref = ops.composite_bwd(hr, w_ref, gc, dw)
+    dd_ref = ops.weights_bwd(he, hd, w_ref, dw)
+    keep = dw_loss.clone()
+    drgb, dd = ops.render_bwd(he, hd, hr, w_ref, gc, dw_loss)
+    assert torch.equal(drgb, drgb_ref) and torch.equal(dd, dd_ref)
+    assert torch.equal(dw_loss, keep)  # read only
+
+
+def test_train_losses_one_launch_equals_two():
+    """tn_train_losses = tn_proposal_losses + tn_pixel_losses in one launch: same gradients bit for bit, same sums up to atomic order."""
+    N = 512
+    gen = torch.Generator().manual_seed(11)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    j0, j1, j2 = (torch.from_numpy(j) for j in synth.synth_jitters(N))
+    sb, ws = [], []
+    s_prev, w_prev = None, None
+    for i, S in enumerate((256, 96, 48)):
+        s = orc.spaced_bins(N, S, j0) if i == 0 else orc.pdf_resample(s_prev, w_prev, S, (j1, j2)[i - 1])
+        e = orc.s_to_euclidean(s, nears, fars)
+        smp = orc.Samples(s_bins=s, e_bins=e)
+        w = orc.get_weights(smp.deltas, (5.0 * torch.rand((N, S, 1), generator=gen)) ** 3)
+        sb.append(g(s)); ws.append(g(w[..., 0]))
+        s_prev, w_prev = s, w
+    cams = synth.synth_cameras()
+    idx = synth.synth_ray_indices(cams, N)
+    img, is_th = synth.synth_gt(idx, cams)
+    img, is_th = g(torch.from_numpy(img)), g(torch.from_numpy(is_th))
+    pred = g(torch.rand((N, 4), generator=gen))
+
+    def run(fused: bool):
+        L = torch.zeros(16, device=DEV)
+        d0, d1, d2, dp = torch.zeros_like(ws[0]), torch.zeros_like(ws[1]), torch.zeros_like(ws[2]), torch.zeros_like(pred)
+        pixel = (pred[:, :3], pred[:, 3:], img, is_th, 100.0, 1e-3, 1e-3, L[0:8], dp[:, :3], dp[:, 3:])
+        if not fused:
+            ops.pixel_losses(*pixel)
+        ops.proposal_losses(sb[2], ws[2], [(sb[0], ws[0], d0), (sb[1], ws[1], d1)], 0.002, 1.0, L[9:10], L[8:9], d2, pixel=pixel if fused else None)
+        return L, (d0, d1, d2, dp)
+
+    La, ga = run(False)
+    Lb, gb = run(True)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+    assert float((La - Lb).abs().max()) <= 1e-6 * float(La.abs().max())
+    assert float(Lb[4]) + float(Lb[5]) == N
+
+
+def test_interlevel_gradient_on_unsorted_bins_falls_back_to_the_full_walk():
+    """The fast gradient path relies on sorted fine bins (lo_i, hi_i monotone); anything else takes the walk over every interval.  Checked
+    against a direct evaluation of d wp_k = sum_i ([lo_i <= k <= hi_i] - [hi_i < k < lo_i]) g_i (csrc/tn_sampler.hip, interlevel_body)."""
+    N, Sf, Sp = 6, 48, 96
+    gen = torch.Generator().manual_seed(3)
+    cp = torch.sort(torch.rand((N, Sp + 1), generator=gen), dim=1).values
+    c = torch.sort(torch.rand((N, Sf + 1), generator=gen), dim=1).values
+    c[1::2] = c[1::2][:, torch.randperm(Sf + 1, generator=gen)]  # every other ray: unsorted fine bins
+    wf = torch.rand((N, Sf), generator=gen) * 0.05
+    wp = torch.rand((N, Sp), generator=gen) * 0.01
+    cy = torch.cat([torch.zeros(N, 1), torch.cumsum(wp.double(), 1).float()], 1).numpy()
+    cpn, cn, wfn = cp.numpy(), c.numpy(), wf.numpy()
+    ref = np.zeros((N, Sp), np.float64)
+    total = 0.0
+    scale = np.float32(1.0) / (np.float32(N) * np.float32(Sf))
+    for r in range(N):
+        for i in range(Sf):
+            lo = int(np.clip(np.searchsorted(cpn[r, :-1], cn[r, i], side="right") - 1, 0, Sp - 1))
+            hi = int(np.clip(np.searchsorted(cpn[r, 1:], cn[r, i + 1], side="right"), 0, Sp - 1))
+            d = max(np.float32(wfn[r, i]) - (np.float32(cy[r, hi + 1]) - np.float32(cy[r, lo])), np.float32(0))
+            total += float(d * d / (wfn[r, i] + np.float32(1e-7)))
+            gi = float(np.float32(-2.0) * d / (wfn[r, i] + np.float32(1e-7)) * scale)
+            if lo <= hi:
+                ref[r, lo:hi + 1] += gi
+            else:
+                ref[r, hi + 1:lo] -= gi
+    loss = torch.zeros(1, device=DEV)
+    dw = torch.zeros((N, Sp), device=DEV)
+    ops.interlevel_loss(g(c), g(wf), g(cp), g(wp), 1.0, loss, dw)
+    assert abs(float(loss) - total * float(scale)) <= 1e-5 * total * float(scale)
+    assert float((dw.cpu().double() - torch.from_numpy(ref)).abs().max()) <= 1e-5 * float(np.abs(ref).max())
+
+
 def test_pixel_losses_l1_camera_reg():
     cams = synth.synth_cameras()
     N = 512
