@@ -87,6 +87,14 @@ int tn_sample_pixels(const float* images, const int64_t* image_offsets, const in
 int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx,
               const float* cy, const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions,
               float* pixel_area, float* directions_norm, tn_stream_t stream);
+/* N2 + a1 in ONE launch (VanillaDataManager.next_train, data/datamanagers/base_datamanager.py:538-547: pixel sampler -> ground truth ->
+ * RayGenerator): arguments of tn_sample_pixels followed by those of tn_raygen without ray_indices (the sampled pixel is handed over in
+ * registers; ray_indices is still written).  Same results as the two calls. */
+int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+                   const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
+                   int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
+                   const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy, const float* distortion,
+                   int32_t num_cameras, float* origins, float* directions, float* pixel_area, float* directions_norm, tn_stream_t stream);
 
 /* ---- a4  CameraOptimizer(SO3xR3).apply_to_raybundle (cameras/camera_optimizers.py:130-176, cameras/lie_groups.py:24-58).
  * pose_adjustment [C,6]; frozen [C] uint8 (1 = non-trainable camera -> identity); camera_indices [N] int64. */
@@ -102,6 +110,12 @@ int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const
  * lin_bins [S+1] = torch.linspace(0,1,S+1) supplied by the host; jitter [N] or NULL (eval). Outputs s_bins,e_bins [N,S+1]. */
 int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
                    float* s_bins, float* e_bins, tn_stream_t stream);
+/* tn_pose_apply_fwd and tn_spaced_bins (the two independent first steps of a training render) in one launch; arguments of the former, then of
+ * the latter without N. */
+int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+                        const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
+                        const float* lin_bins, const float* jitter, const float* nears, const float* fars, int32_t S, float* s_bins,
+                        float* e_bins, tn_stream_t stream);
 
 /* ---- a8/a9/a10  Field.density_fn -> HashMLPDensityField.get_density (fields/base_field.py:48-68, fields/density_fields.py:95-118,
  *          field_components/encodings.py:401-461, field_components/mlp.py:159-178, field_components/activations.py:28-41).
@@ -210,12 +224,13 @@ int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp
                      float* d_weights, tn_stream_t stream);
 
 /* a11 + a15 + a16 of the last sampling level in ONE launch: RaySamples.get_weights (cameras/rays.py:128-150) followed by every renderer above
- * (models/nerfacto.py:330-340), the weights handed over in registers; a second, single-block launch applies the batch-global clip of the
- * expected depth.  Results are bit-identical to tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth (two launches, not four).
- * state: 16 bytes of device memory, zero-filled ONCE by the caller; every call leaves them zero again (required when depth_expected is given;
- * one state buffer per stream that may run this concurrently).  accumulation / depth_median / depth_expected may be NULL. */
+ * (models/nerfacto.py:330-340), the weights handed over in registers; a second small launch applies the batch-global clip of the expected
+ * depth.  Results are bit-identical to tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth (two launches, not four, and no
+ * atomics).  scratch: TN_RENDER_SCRATCH_FLOATS floats of device memory, contents irrelevant (required when depth_expected is given; one
+ * buffer per stream that may run this concurrently).  accumulation / depth_median / depth_expected may be NULL. */
+#define TN_RENDER_SCRATCH_FLOATS 1024
 int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
-                  float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* state,
+                  float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
                   tn_stream_t stream);
 /* its backward: tn_composite_bwd followed by tn_weights_bwd in one launch.  d_weights_in [N,S] = gradient that reaches the weights from the
  * losses (read only: the compositing term is added in registers); d_rgb [N,S,C] and d_density [N,S] are written. */
@@ -247,15 +262,30 @@ int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int3
 int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
                     const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
                     float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
-/* The proposal losses of one branch AND the pixel terms above in ONE launch (they are independent, and each alone is a short latency-bound
- * kernel: get_loss_dict's distortion / interlevel / rgb / thermal / tv / cross-channel terms of models/thermal_nerfacto.py:284-368 side by
- * side).  Arguments and accumulation semantics are those of tn_proposal_losses followed by those of tn_pixel_losses. */
+/* The proposal losses of one branch AND (pred_rgb != NULL) the pixel terms above in ONE launch: they are independent, and each alone is a
+ * short latency-bound kernel (get_loss_dict's distortion / interlevel / rgb / thermal / tv / cross-channel terms of
+ * models/thermal_nerfacto.py:284-368 side by side).  Arguments as tn_proposal_losses and tn_pixel_losses, except for where the sums go:
+ * every block of every term would end with a float atomic into the same 64-byte line, and those execute one after the other (~25 ns each:
+ * 40 us for 1500 blocks), so the sums are spread over loss_lines [TN_LOSS_LINES][16] (zero-filled by the caller; block b adds into line
+ * b % TN_LOSS_LINES; slots 0 rgb, 1 thermal, 2 tv_pixel, 3 cross_channel, 4 / 5 ray counts per spectrum, 8 interlevel, 9 distortion) and
+ * tn_losses_finish adds the lines up: losses16[k] += sum over lines of loss_lines[.][k].  tn_losses_finish also evaluates the camera
+ * regulariser of one pose tensor in the same single-block launch when pose_adjustment != NULL (arguments of tn_camera_reg; reg_out may be
+ * one of the 16 slots). */
+#define TN_LOSS_LINES 64
 int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
                     const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
-                    float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
-                    float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
-                    int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
-                    float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
+                    float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* d_weights_fine,
+                    const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
+                    const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult, float* d_pred_rgb, float* d_pred_thermal,
+                    float* loss_lines, tn_stream_t stream);
+int tn_losses_finish(const float* loss_lines, float* losses16, const float* pose_adjustment, int32_t num_cameras, float trans_pen,
+                     float rot_pen, float scale, float* reg_out, float* grad_pose, tn_stream_t stream);
+/* tn_pose_apply_bwd + tn_losses_finish for the same pose tensor in one launch (the end of an iteration's backward); loss_lines / losses16 may
+ * both be NULL (regulariser only). */
+int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                       const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                       const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
+                       tn_stream_t stream);
 /* density L1 cross loss with the reference's detach asymmetry (models/thermal_nerfacto.py:328-344): loss += a*mean|x-y| with
  * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
 int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,

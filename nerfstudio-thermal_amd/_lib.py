@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
+TN_RENDER_SCRATCH_FLOATS = 1024
+TN_LOSS_LINES = 64
 TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD = 1, 2, 4, 8, 16
 
 _p = C.c_void_p
@@ -57,6 +59,9 @@ SIGNATURES = {
     "tn_prop_workspace_bytes": (_i64, [_i64]),
     "tn_sample_pixels": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "tn_raygen": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),
+    "tn_sample_rays": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "tn_pose_spaced_bins": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
+    "tn_pose_bwd_finish": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _f, _f, _f, _p, _p]),
     "tn_pose_apply_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_pose_apply_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "tn_spaced_bins": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
@@ -86,7 +91,8 @@ SIGNATURES = {
     "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
     "tn_proposal_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
-    "tn_train_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p, _i32, _p, _i32, _p, _p, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_train_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _i32, _p, _i32, _p, _p, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_losses_finish": (C.c_int, [_p, _p, _p, _i32, _f, _f, _f, _p, _p, _p]),
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_camera_reg": (C.c_int, [_p, _i32, _f, _f, _f, _p, _p, _p]),
     "tn_train_metrics": (C.c_int, [_p, _i64, _f, _p, _i32, _p, _i32, _p, _p]),

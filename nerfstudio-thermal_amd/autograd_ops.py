@@ -151,8 +151,8 @@ class LossSpec:
 
 class TrainLosses(torch.autograd.Function):
     """EVERY loss term of a training iteration (models/thermal_nerfacto.py:253-388) as one autograd node, through the same launches as the
-    fused step (engine.RenderEngine.loss_and_backward): tn_pixel_losses, tn_proposal_losses per branch (distortion + both interlevel
-    terms), tn_l1_loss x2 (density cross terms), tn_camera_reg.  Every kernel yields value AND gradient; all gradient buffers come out of
+    fused step (engine.RenderEngine.loss_and_backward): tn_train_losses per branch (distortion + both interlevel terms, the pixel terms in the
+    first one), tn_l1_loss x2 (density cross terms), tn_losses_finish (sums + camera regulariser), tn_camera_reg for a second pose tensor.  Every kernel yields value AND gradient; all gradient buffers come out of
     one zero-filled allocation, and backward scales that allocation once by the incoming gradient -- the Trainer sums the loss dict
     (engine/trainer.py:483), so all terms arrive with the same weight; anything else is refused (use the *_loss_mult settings).
 
@@ -170,7 +170,7 @@ class TrainLosses(torch.autograd.Function):
         dens = [next(it) for _ in range(4)] if spec.density_weights is not None else []
         poses = [next(it) for _ in spec.camera_regs]
         # one zero-filled allocation for the loss vector and every gradient buffer (order = input order)
-        shapes = [(32,)]
+        shapes = [(32,), (ops.LOSS_LINES, 16)]  # the loss vector, then the lines the loss launches spread their sums over (ops.train_losses)
         for _, _, pg, comp, ws in per:
             shapes.append(tuple(comp.shape))
             shapes += [tuple(w.shape[:2]) for w in ws]
@@ -182,22 +182,22 @@ class TrainLosses(torch.autograd.Function):
             tot += (n + 63) // 64 * 64
         flat = torch.zeros(tot, device=dev)
         bufs = [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
-        L, grads = bufs[0], bufs[1:]
+        L, Lp, grads = bufs[0], bufs[1], bufs[2:]
         gi = iter(grads)
         g_per = [(next(gi), [next(gi), next(gi), next(gi)]) for _ in per]
         # ---- pixel terms: in the first branch's loss launch (tn_train_losses)
         if spec.separate:
             (_, _, _, comp, _), (_, _, _, comp_t, _) = per
-            pixel = (comp, comp_t, image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], g_per[0][0], g_per[1][0])
+            pixel = (comp, comp_t, image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, g_per[0][0], g_per[1][0])
         else:
             comp, d_comp = per[0][3], g_per[0][0]
-            pixel = (comp[:, :3], comp[:, 3:], image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, L[0:8], d_comp[:, :3], d_comp[:, 3:])
+            pixel = (comp[:, :3], comp[:, 3:], image, is_thermal, spec.thermal_mult, spec.tv_mult, spec.cross_mult, d_comp[:, :3], d_comp[:, 3:])
         # ---- proposal terms (metrics_dict["distortion"] is the sum over suffixes and enters once per suffix: x nsfx, :363-368)
         nsfx = len(per)
         for (sfx, sb, pg, comp, ws), (_, dws) in zip(per, g_per):
             w = [x[..., 0] for x in ws]
-            ops.proposal_losses(sb[2], w[2], [(sb[i], w[i], dws[i] if pg else None) for i in range(2)], spec.distortion_mult * nsfx, spec.interlevel_mult,
-                                L[9:10], L[8:9], dws[2], pixel=pixel)
+            ops.train_losses(sb[2], w[2], [(sb[i], w[i], dws[i] if pg else None) for i in range(2)], spec.distortion_mult * nsfx, spec.interlevel_mult,
+                             dws[2], Lp, pixel=pixel)
             pixel = None
         # ---- density cross terms  a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|
         if dens:
@@ -206,9 +206,14 @@ class TrainLosses(torch.autograd.Function):
             ops.l1_loss(dens[0], dens[1], b, a, L[10:11], gd[0], gd[1])
             ops.l1_loss(dens[2], dens[3], b, a, L[10:11], gd[2], gd[3])
         for k, (pose, (tp, rp, sc)) in enumerate(zip(poses, spec.camera_regs)):
-            ops.camera_reg(pose.detach(), tp, rp, sc, L[11 + k:12 + k], next(gi))
+            if k == 0:  # the loss lines are added up in the first regulariser's launch
+                ops.losses_finish(Lp, L, pose.detach(), tp, rp, sc, L[11:12], next(gi))
+            else:
+                ops.camera_reg(pose.detach(), tp, rp, sc, L[11 + k:12 + k], next(gi))
+        if not poses:
+            ops.losses_finish(Lp, L)
         ctx.set_materialize_grads(False)  # unused terms arrive as None, not as zeros
-        ctx.flat, ctx.layout, ctx.nper = flat, (offs[1:], sizes[1:], shapes[1:]), [pg for _, _, pg, _, _ in per]
+        ctx.flat, ctx.layout, ctx.nper = flat, (offs[2:], sizes[2:], shapes[2:]), [pg for _, _, pg, _, _ in per]
         ops.train_metrics(L, image.shape[0], spec.thermal_mult, [p.detach() for p in poses], L[16:24])
         outs = L.unbind(0)
         ctx.mark_non_differentiable(*(outs[i] for i in range(32) if i not in (0, 1, 2, 3, 8, 9, 10, 11, 12)))

@@ -78,6 +78,28 @@ __device__ __forceinline__ float tn_s_to_euclid(float x, float s_near, float s_f
   return tn_spacing_inv(x * s_far + (1.0f - x) * s_near);
 }
 
+// SpacedSampler / UniformLinDispPiecewiseSampler bins of every ray (model_components/ray_samplers.py:78-128,225-248) as a grid-stride body
+// (bid / nblk stand in for blockIdx.x / gridDim.x: tn_spaced_bins launches it alone, tn_pose_spaced_bins as one slice of a launch)
+__device__ __forceinline__ void tn_spaced_bins_body(const float* __restrict__ lin_bins, const float* __restrict__ jitter,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
+                                                    float* __restrict__ s_bins, float* __restrict__ e_bins, int bid, int nblk) {
+  int64_t total = N * (int64_t)(S + 1);
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
+    int64_t ray = i / (S + 1);
+    int j = (int)(i - ray * (S + 1));
+    float b = lin_bins[j];
+    if (jitter != nullptr) {
+      // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
+      float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
+      float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
+      b = lower + (upper - lower) * jitter[ray];
+    }
+    float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
+    s_bins[i] = b;
+    e_bins[i] = tn_s_to_euclid(b, s_near, s_far);
+  }
+}
+
 // Frustums.get_positions + SceneContraction(L_inf) + (x+2)/4 + selector (cameras/rays.py:49-58,
 // field_components/spatial_distortions.py:66-69, fields/density_fields.py:96-103).
 // Returns the selector; p = masked unit-cube position; if jac != nullptr also d(p_unmasked)/d(world) facts for backward.

@@ -111,34 +111,60 @@ __device__ __forceinline__ void undistort(float xd, float yd, const float* __res
 }
 
 // ---- N2: patch pixel sampler + ground-truth gather (one thread per ray) ---------------------------------------------------------
-__global__ void k_sample_pixels(const float* __restrict__ images, const int64_t* __restrict__ image_offsets, const int32_t* __restrict__ heights,
-                                const int32_t* __restrict__ widths, const float* __restrict__ is_thermal, const int64_t* __restrict__ image_idx,
-                                int num_images, const float* __restrict__ u, int64_t N, int ps, int64_t rays_per_image,
-                                int64_t* __restrict__ ray_indices, float* __restrict__ image, float* __restrict__ is_thermal_out,
-                                int64_t* __restrict__ camera_indices) {
-  const int pp = ps * ps;
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
-    int64_t i = rays_per_image > 0 ? r / rays_per_image : num_images - 1;  // every image holds rays_per_image rays, the last one the rest
-    if (i > num_images - 1) i = num_images - 1;
-    int64_t local = r - i * rays_per_image;
-    int64_t patch = local / pp;
-    int k = (int)(local - patch * pp);
-    int dy = k / ps, dx = k - dy * ps;
-    const float* up = u + (i * (rays_per_image / pp) + patch) * 3;
-    int H = heights[i], W = widths[i];
-    // torch: floor(rand * [1, H - ps, W - ps]) in fp32 (float32 x int64 promotes to float32), then + patch offsets
-    int64_t y = (int64_t)floorf(up[1] * (float)(H - ps) + (float)dy);
-    int64_t x = (int64_t)floorf(up[2] * (float)(W - ps) + (float)dx);
-    ray_indices[r * 3 + 0] = image_idx[i];
-    if (camera_indices != nullptr) camera_indices[r] = image_idx[i];
-    ray_indices[r * 3 + 1] = y;
-    ray_indices[r * 3 + 2] = x;
-    const float* px = images + image_offsets[i] + (y * W + x) * 3;
-    image[r * 3 + 0] = px[0];
-    image[r * 3 + 1] = px[1];
-    image[r * 3 + 2] = px[2];
-    is_thermal_out[r] = is_thermal[i];
+struct SamplePixelsArgs {
+  const float* images; const int64_t* image_offsets; const int32_t* heights; const int32_t* widths; const float* is_thermal;
+  const int64_t* image_idx; int num_images; const float* u; int64_t N; int ps; int64_t rays_per_image;
+  int64_t* ray_indices; float* image; float* is_thermal_out; int64_t* camera_indices;
+};
+// one ray: which image / patch / pixel, its ground truth; returns (camera, y, x)
+__device__ __forceinline__ void sample_pixel_ray(const SamplePixelsArgs& a, int64_t r, int64_t& cam_out, int64_t& y_out, int64_t& x_out) {
+  const int pp = a.ps * a.ps;
+  int64_t i = a.rays_per_image > 0 ? r / a.rays_per_image : a.num_images - 1;  // every image holds rays_per_image rays, the last one the rest
+  if (i > a.num_images - 1) i = a.num_images - 1;
+  int64_t local = r - i * a.rays_per_image;
+  int64_t patch = local / pp;
+  int k = (int)(local - patch * pp);
+  int dy = k / a.ps, dx = k - dy * a.ps;
+  const float* up = a.u + (i * (a.rays_per_image / pp) + patch) * 3;
+  int H = a.heights[i], W = a.widths[i];
+  // torch: floor(rand * [1, H - ps, W - ps]) in fp32 (float32 x int64 promotes to float32), then + patch offsets
+  int64_t y = (int64_t)floorf(up[1] * (float)(H - a.ps) + (float)dy);
+  int64_t x = (int64_t)floorf(up[2] * (float)(W - a.ps) + (float)dx);
+  const int64_t cam = a.image_idx[i];
+  a.ray_indices[r * 3 + 0] = cam;
+  if (a.camera_indices != nullptr) a.camera_indices[r] = cam;
+  a.ray_indices[r * 3 + 1] = y;
+  a.ray_indices[r * 3 + 2] = x;
+  const float* px = a.images + a.image_offsets[i] + (y * W + x) * 3;
+  a.image[r * 3 + 0] = px[0];
+  a.image[r * 3 + 1] = px[1];
+  a.image[r * 3 + 2] = px[2];
+  a.is_thermal_out[r] = a.is_thermal[i];
+  cam_out = cam; y_out = y; x_out = x;
+}
+__global__ void k_sample_pixels(SamplePixelsArgs a) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cam, y, x;
+    sample_pixel_ray(a, r, cam, y, x);
   }
+}
+
+static int sample_pixels_args(const char* who, const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+                              const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
+                              int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
+                              SamplePixelsArgs& a) {
+  TN_REQUIRE(images && image_offsets && heights && widths && is_thermal && image_idx && u && ray_indices && image && is_thermal_out,
+             "%s: null pointer", who);
+  TN_REQUIRE(num_rays > 0 && num_images >= 1 && patch_size >= 1 && patch_size <= 8, "%s: bad num_rays=%lld num_images=%d patch_size=%d", who,
+             (long long)num_rays, num_images, patch_size);
+  const int64_t pp = (int64_t)patch_size * patch_size;
+  const int64_t per = ((num_rays / num_images) / pp) * pp;  // rays of every image but the last
+  const int64_t last = num_rays - (int64_t)(num_images - 1) * per;
+  TN_REQUIRE(last > 0 && last % pp == 0, "%s: %lld rays over %d images do not split into whole %dx%d patches", who, (long long)num_rays,
+             num_images, patch_size, patch_size);
+  a = SamplePixelsArgs{images, image_offsets, heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size, per,
+                       ray_indices, image, is_thermal_out, camera_indices};
+  return TN_OK;
 }
 
 extern "C" int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
@@ -146,62 +172,68 @@ extern "C" int tn_sample_pixels(const float* images, const int64_t* image_offset
                                 int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
                                 tn_stream_t stream) {
   if (num_rays == 0) return TN_OK;  // empty batches are valid and touch nothing
-  TN_REQUIRE(images && image_offsets && heights && widths && is_thermal && image_idx && u && ray_indices && image && is_thermal_out,
-             "tn_sample_pixels: null pointer");
-  TN_REQUIRE(num_rays > 0 && num_images >= 1 && patch_size >= 1 && patch_size <= 8, "tn_sample_pixels: bad num_rays=%lld num_images=%d patch_size=%d",
-             (long long)num_rays, num_images, patch_size);
-  const int64_t pp = (int64_t)patch_size * patch_size;
-  const int64_t per = ((num_rays / num_images) / pp) * pp;  // rays of every image but the last
-  const int64_t last = num_rays - (int64_t)(num_images - 1) * per;
-  TN_REQUIRE(last > 0 && last % pp == 0, "tn_sample_pixels: %lld rays over %d images do not split into whole %dx%d patches", (long long)num_rays,
-             num_images, patch_size, patch_size);
-  hipLaunchKernelGGL(k_sample_pixels, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), images, image_offsets,
-                     heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size, per, ray_indices, image, is_thermal_out, camera_indices);
+  SamplePixelsArgs a;
+  int rc = sample_pixels_args("tn_sample_pixels", images, image_offsets, heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size,
+                              ray_indices, image, is_thermal_out, camera_indices, a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sample_pixels, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), a);
   TN_CHECK_LAUNCH("tn_sample_pixels");
   return TN_OK;
 }
 
-__global__ void k_raygen(const int64_t* __restrict__ ray_indices, const float* __restrict__ c2w, const float* __restrict__ fx,
-                         const float* __restrict__ fy, const float* __restrict__ cx, const float* __restrict__ cy,
-                         const float* __restrict__ distortion, int any_distortion, int num_cameras, int64_t N, float* __restrict__ origins,
-                         float* __restrict__ directions, float* __restrict__ pixel_area, float* __restrict__ directions_norm) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t cam = ray_indices[i * 3];
-    if (cam < 0 || cam >= num_cameras) cam = 0;  // host validates; keep the access in bounds regardless
-    float y = (float)ray_indices[i * 3 + 1] + 0.5f;  // get_image_coords(pixel_offset=0.5)
-    float x = (float)ray_indices[i * 3 + 2] + 0.5f;
-    float fxc = fx[cam], fyc = fy[cam], cxc = cx[cam], cyc = cy[cam];
-    // coord, coord_x_offset, coord_y_offset
-    float u[3] = {(x - cxc) / fxc, (x - cxc + 1.0f) / fxc, (x - cxc) / fxc};
-    float v[3] = {(y - cyc) / fyc, (y - cyc) / fyc, (y - cyc + 1.0f) / fyc};
-    const float* R = c2w + cam * 12;
-    float dir[3][3];
-    float nrm0 = 0.0f;
+struct RaygenArgs {
+  const float* c2w; const float* fx; const float* fy; const float* cx; const float* cy; const float* distortion;
+  int any_distortion, num_cameras;
+  float* origins; float* directions; float* pixel_area; float* directions_norm;
+};
+// one ray from (camera, pixel row, pixel column)
+__device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64_t cam, int64_t yi, int64_t xi) {
+  if (cam < 0 || cam >= g.num_cameras) cam = 0;  // host validates; keep the access in bounds regardless
+  float y = (float)yi + 0.5f;  // get_image_coords(pixel_offset=0.5)
+  float x = (float)xi + 0.5f;
+  float fxc = g.fx[cam], fyc = g.fy[cam], cxc = g.cx[cam], cyc = g.cy[cam];
+  // coord, coord_x_offset, coord_y_offset
+  float u[3] = {(x - cxc) / fxc, (x - cxc + 1.0f) / fxc, (x - cxc) / fxc};
+  float v[3] = {(y - cyc) / fyc, (y - cyc) / fyc, (y - cyc + 1.0f) / fyc};
+  const float* R = g.c2w + cam * 12;
+  float dir[3][3];
+  float nrm0 = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      float a = u[q], b = v[q];
-      if (any_distortion) undistort(a, b, distortion + cam * 6, a, b);
-      b = -b;  // OpenCV -> OpenGL
-      float dz = -1.0f;
-      // sum(d[None,:] * R, dim=-1): row r of R dotted with d
-      float w0 = a * R[0] + b * R[1] + dz * R[2];
-      float w1 = a * R[4] + b * R[5] + dz * R[6];
-      float w2 = a * R[8] + b * R[9] + dz * R[10];
-      float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-      n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
-      dir[q][0] = w0 / n; dir[q][1] = w1 / n; dir[q][2] = w2 / n;
-      if (q == 0) nrm0 = n;
-    }
-    float ddx = 0.0f, ddy = 0.0f;
+  for (int q = 0; q < 3; ++q) {
+    float a = u[q], b = v[q];
+    if (g.any_distortion) undistort(a, b, g.distortion + cam * 6, a, b);
+    b = -b;  // OpenCV -> OpenGL
+    float dz = -1.0f;
+    // sum(d[None,:] * R, dim=-1): row r of R dotted with d
+    float w0 = a * R[0] + b * R[1] + dz * R[2];
+    float w1 = a * R[4] + b * R[5] + dz * R[6];
+    float w2 = a * R[8] + b * R[9] + dz * R[10];
+    float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+    n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
+    dir[q][0] = w0 / n; dir[q][1] = w1 / n; dir[q][2] = w2 / n;
+    if (q == 0) nrm0 = n;
+  }
+  float ddx = 0.0f, ddy = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float a = dir[0][c] - dir[1][c], b = dir[0][c] - dir[2][c];
-      ddx += a * a; ddy += b * b;
-    }
-    origins[i * 3 + 0] = R[3]; origins[i * 3 + 1] = R[7]; origins[i * 3 + 2] = R[11];
-    directions[i * 3 + 0] = dir[0][0]; directions[i * 3 + 1] = dir[0][1]; directions[i * 3 + 2] = dir[0][2];
-    pixel_area[i] = sqrtf(ddx) * sqrtf(ddy);
-    if (directions_norm) directions_norm[i] = nrm0;
+  for (int c = 0; c < 3; ++c) {
+    float a = dir[0][c] - dir[1][c], b = dir[0][c] - dir[2][c];
+    ddx += a * a; ddy += b * b;
+  }
+  g.origins[i * 3 + 0] = R[3]; g.origins[i * 3 + 1] = R[7]; g.origins[i * 3 + 2] = R[11];
+  g.directions[i * 3 + 0] = dir[0][0]; g.directions[i * 3 + 1] = dir[0][1]; g.directions[i * 3 + 2] = dir[0][2];
+  g.pixel_area[i] = sqrtf(ddx) * sqrtf(ddy);
+  if (g.directions_norm) g.directions_norm[i] = nrm0;
+}
+__global__ void k_raygen(const int64_t* __restrict__ ray_indices, RaygenArgs g, int64_t N) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    raygen_ray(g, i, ray_indices[i * 3], ray_indices[i * 3 + 1], ray_indices[i * 3 + 2]);
+}
+// datamanager.next_train in one launch: pixel sampling + ground-truth gather + ray generation (the pixel goes from one to the other in registers)
+__global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cam, y, x;
+    sample_pixel_ray(a, r, cam, y, x);
+    raygen_ray(g, r, cam, y, x);
   }
 }
 
@@ -211,10 +243,27 @@ extern "C" int tn_raygen(const int64_t* ray_indices, const float* c2w, const flo
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(ray_indices && c2w && fx && fy && cx && cy && origins && directions && pixel_area, "tn_raygen: null pointer");
   TN_REQUIRE(N >= 0 && num_cameras >= 1, "tn_raygen: bad N=%lld num_cameras=%d", (long long)N, num_cameras);
-  if (N == 0) return TN_OK;
-  hipLaunchKernelGGL(k_raygen, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 2048)), dim3(256), 0, tn_s(stream), ray_indices, c2w, fx, fy, cx,
-                     cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, N, origins, directions, pixel_area, directions_norm);
+  RaygenArgs g{c2w, fx, fy, cx, cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, origins, directions, pixel_area, directions_norm};
+  hipLaunchKernelGGL(k_raygen, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 2048)), dim3(256), 0, tn_s(stream), ray_indices, g, N);
   TN_CHECK_LAUNCH("tn_raygen");
+  return TN_OK;
+}
+
+extern "C" int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+                              const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
+                              int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
+                              const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy, const float* distortion,
+                              int32_t num_cameras, float* origins, float* directions, float* pixel_area, float* directions_norm,
+                              tn_stream_t stream) {
+  if (num_rays == 0) return TN_OK;  // empty batches are valid and touch nothing
+  SamplePixelsArgs a;
+  int rc = sample_pixels_args("tn_sample_rays", images, image_offsets, heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size,
+                              ray_indices, image, is_thermal_out, camera_indices, a);
+  if (rc) return rc;
+  TN_REQUIRE(c2w && fx && fy && cx && cy && origins && directions && pixel_area && num_cameras >= 1, "tn_sample_rays: bad camera arguments");
+  RaygenArgs g{c2w, fx, fy, cx, cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, origins, directions, pixel_area, directions_norm};
+  hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), a, g);
+  TN_CHECK_LAUNCH("tn_sample_rays");
   return TN_OK;
 }
 
@@ -244,10 +293,10 @@ __device__ __forceinline__ Pose pose_exp(const float* __restrict__ p) {
   return o;
 }
 
-__global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
-                           const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C, float* __restrict__ o_out,
-                           float* __restrict__ d_out) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pose_fwd_body(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                                              const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C,
+                                              float* __restrict__ o_out, float* __restrict__ d_out, int bid, int nblk) {
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)nblk * blockDim.x) {
     int64_t cam = cam_idx[i];
     if (cam < 0 || cam >= C) cam = 0;
     float ox = o_in[i * 3], oy = o_in[i * 3 + 1], oz = o_in[i * 3 + 2];
@@ -265,6 +314,24 @@ __global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __rest
     d_out[i * 3 + 2] = p.R[6] * dx + p.R[7] * dy + p.R[8] * dz;
   }
 }
+__global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                           const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C, float* __restrict__ o_out,
+                           float* __restrict__ d_out) {
+  pose_fwd_body(pose, frozen, cam_idx, o_in, d_in, N, C, o_out, d_out, blockIdx.x, gridDim.x);
+}
+// the two independent first steps of a training render in one launch: blockIdx.y = 0 the level-0 bins, 1 the pose correction of the rays
+__global__ void k_pose_spaced_bins(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                                   const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C, float* __restrict__ o_out,
+                                   float* __restrict__ d_out, int pose_blocks, const float* __restrict__ lin_bins,
+                                   const float* __restrict__ jitter, const float* __restrict__ nears, const float* __restrict__ fars, int S,
+                                   float* __restrict__ s_bins, float* __restrict__ e_bins) {
+  if (blockIdx.y == 0) {
+    tn_spaced_bins_body(lin_bins, jitter, nears, fars, N, S, s_bins, e_bins, blockIdx.x, gridDim.x);
+  } else {
+    if ((int)blockIdx.x >= pose_blocks) return;
+    pose_fwd_body(pose, frozen, cam_idx, o_in, d_in, N, C, o_out, d_out, blockIdx.x, pose_blocks);
+  }
+}
 
 extern "C" int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
                                  const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
@@ -279,17 +346,33 @@ extern "C" int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* fr
   return TN_OK;
 }
 
+extern "C" int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+                                   const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
+                                   const float* lin_bins, const float* jitter, const float* nears, const float* fars, int32_t S, float* s_bins,
+                                   float* e_bins, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(pose_adjustment && camera_indices && origins_in && directions_in && origins_out && directions_out, "tn_pose_spaced_bins: null pointer");
+  TN_REQUIRE(lin_bins && nears && fars && s_bins && e_bins, "tn_pose_spaced_bins: null pointer");
+  TN_REQUIRE(N >= 0 && num_cameras >= 1 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_pose_spaced_bins: bad N=%lld C=%d S=%d", (long long)N, num_cameras, S);
+  const int bins_blocks = (int)std::min<int64_t>(tn_cdiv(N * (int64_t)(S + 1), 256), 4096);
+  const int pose_blocks = (int)std::min<int64_t>(tn_cdiv(N, 256), (int64_t)bins_blocks);
+  hipLaunchKernelGGL(k_pose_spaced_bins, dim3((unsigned)bins_blocks, 2), dim3(256), 0, tn_s(stream), pose_adjustment, frozen, camera_indices, origins_in,
+                     directions_in, N, num_cameras, origins_out, directions_out, pose_blocks, lin_bins, jitter, nears, fars, S, s_bins, e_bins);
+  TN_CHECK_LAUNCH("tn_pose_spaced_bins");
+  return TN_OK;
+}
+
 // backward:  R = I + f1 K + f2 K^2, K = skew(v), K^2 = v v^T - |v|^2 I, theta = sqrt(clamp(|v|^2, 1e-4))
 //   G = g_d (outer) d_in ;  dL/dt = g_o
 //   dL/dv_m = f1 * skewpart(G)_m + f2 * ((G + G^T) v - 2 v tr G)_m + (<G,K> f1' + <G,K^2> f2') * dtheta/dn * 2 v_m
-__global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
-                           const float* __restrict__ d_in, const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N, int C,
-                           float* __restrict__ grad_pose) {
+__device__ __forceinline__ void pose_bwd_body(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                                              const float* __restrict__ d_in, const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N,
+                                              int C, float* __restrict__ grad_pose, int bid, int nblk) {
   int lane = tn_lane();
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t stride = (int64_t)nblk * blockDim.x;
   int64_t iters = tn_cdiv(N, stride);
   for (int64_t it = 0; it < iters; ++it) {
-    int64_t i = it * stride + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t i = it * stride + bid * (int64_t)blockDim.x + threadIdx.x;
     bool live = i < N;
     int64_t ii = live ? i : N - 1;
     int64_t cam = cam_idx[ii];
@@ -346,6 +429,69 @@ __global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __rest
   }
 }
 
+__global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
+                           const float* __restrict__ d_in, const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N, int C,
+                           float* __restrict__ grad_pose) {
+  pose_bwd_body(pose, frozen, cam_idx, d_in, g_o, g_d, N, C, grad_pose, blockIdx.x, gridDim.x);
+}
+
+// Column sums of the loss lines of tn_train_losses into the loss vector + (pose != NULL) the camera regulariser: one block's work.
+// ATOMIC_GRAD: other blocks of the same launch add into grad_pose at the same time (k_pose_bwd_finish).
+template <bool ATOMIC_GRAD>
+__device__ __forceinline__ void losses_finish_body(const float* __restrict__ lines, float* __restrict__ losses, const float* __restrict__ pose, int C,
+                                                   float trans_pen, float rot_pen, float scale, float* __restrict__ reg_out,
+                                                   float* __restrict__ grad_pose) {
+  __shared__ float sh[16][17];
+  const int t = threadIdx.x, k = t & 15, g = t >> 4;  // 16 groups of 16 slots; group g sums lines g, g + 16, ...
+  if (lines != nullptr) {
+    float acc = 0.0f;
+    for (int l = g; l < TN_LOSS_LINES; l += 16) acc += lines[l * 16 + k];
+    sh[g][k] = acc;
+    __syncthreads();
+    if (t < 16) {
+      float v = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += sh[q][t];
+      if (v != 0.0f) losses[t] += v;
+    }
+    __syncthreads();  // reg_out may be one of the 16 slots
+  }
+  if (pose != nullptr) {
+    float r = 0.0f;
+    for (int c = t; c < C; c += blockDim.x) {
+      const float* p = pose + c * 6;
+      float nt = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+      float nr = sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5]);
+      r += (nt * trans_pen + nr * rot_pen) * scale / (float)C;
+      if (grad_pose != nullptr) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          // torch.norm backward: x / |x| (0 at the origin)
+          if (nt > 0.0f) { float v = p[m] / nt * trans_pen * scale / (float)C; if (ATOMIC_GRAD) atomicAdd(&grad_pose[c * 6 + m], v); else grad_pose[c * 6 + m] += v; }
+          if (nr > 0.0f) { float v = p[3 + m] / nr * rot_pen * scale / (float)C; if (ATOMIC_GRAD) atomicAdd(&grad_pose[c * 6 + 3 + m], v); else grad_pose[c * 6 + 3 + m] += v; }
+        }
+      }
+    }
+    r = tn_wave_sum(r);
+    if ((t & 63) == 0) atomicAdd(reg_out, r);
+  }
+}
+__global__ void __launch_bounds__(256) k_losses_finish(const float* __restrict__ lines, float* __restrict__ losses, const float* __restrict__ pose,
+                                                       int C, float trans_pen, float rot_pen, float scale, float* __restrict__ reg_out,
+                                                       float* __restrict__ grad_pose) {
+  losses_finish_body<false>(lines, losses, pose, C, trans_pen, rot_pen, scale, reg_out, grad_pose);
+}
+// the end of a training iteration's backward in one launch: pose gradient from d origins / d directions (blocks 0 .. n-1) and, in the last
+// block, the loss sums + the camera regulariser of the same pose tensor
+__global__ void __launch_bounds__(256) k_pose_bwd_finish(const float* __restrict__ pose, const uint8_t* __restrict__ frozen,
+                                                         const int64_t* __restrict__ cam_idx, const float* __restrict__ d_in,
+                                                         const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N, int C,
+                                                         float* __restrict__ grad_pose, const float* __restrict__ lines, float* __restrict__ losses,
+                                                         float trans_pen, float rot_pen, float scale, float* __restrict__ reg_out) {
+  if (blockIdx.x + 1 == gridDim.x) losses_finish_body<true>(lines, losses, pose, C, trans_pen, rot_pen, scale, reg_out, grad_pose);
+  else pose_bwd_body(pose, frozen, cam_idx, d_in, g_o, g_d, N, C, grad_pose, blockIdx.x, gridDim.x - 1);
+}
+
 extern "C" int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
                                  const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                                  tn_stream_t stream) {
@@ -356,6 +502,30 @@ extern "C" int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* fr
   hipLaunchKernelGGL(k_pose_bwd, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024)), dim3(256), 0, tn_s(stream), pose_adjustment, frozen,
                      camera_indices, directions_in, d_origins, d_directions, N, num_cameras, grad_pose);
   TN_CHECK_LAUNCH("tn_pose_apply_bwd");
+  return TN_OK;
+}
+
+extern "C" int tn_losses_finish(const float* loss_lines, float* losses16, const float* pose_adjustment, int32_t num_cameras, float trans_pen,
+                                float rot_pen, float scale, float* reg_out, float* grad_pose, tn_stream_t stream) {
+  TN_REQUIRE(loss_lines && losses16, "tn_losses_finish: null pointer");
+  TN_REQUIRE(pose_adjustment == nullptr || (num_cameras >= 1 && reg_out != nullptr), "tn_losses_finish: bad camera regulariser arguments");
+  hipLaunchKernelGGL(k_losses_finish, dim3(1), dim3(256), 0, tn_s(stream), loss_lines, losses16, pose_adjustment, num_cameras, trans_pen, rot_pen, scale,
+                     reg_out, grad_pose);
+  TN_CHECK_LAUNCH("tn_losses_finish");
+  return TN_OK;
+}
+
+extern "C" int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                                  const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                                  const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
+                                  tn_stream_t stream) {
+  TN_REQUIRE(pose_adjustment && camera_indices && directions_in && d_origins && d_directions && grad_pose && reg_out, "tn_pose_bwd_finish: null pointer");
+  TN_REQUIRE((loss_lines == nullptr) == (losses16 == nullptr), "tn_pose_bwd_finish: loss_lines and losses16 go together");
+  TN_REQUIRE(N >= 1 && num_cameras >= 1, "tn_pose_bwd_finish: bad N=%lld C=%d", (long long)N, num_cameras);
+  const unsigned nb = (unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024);
+  hipLaunchKernelGGL(k_pose_bwd_finish, dim3(nb + 1), dim3(256), 0, tn_s(stream), pose_adjustment, frozen, camera_indices, directions_in, d_origins,
+                     d_directions, N, num_cameras, grad_pose, loss_lines, losses16, trans_pen, rot_pen, scale, reg_out);
+  TN_CHECK_LAUNCH("tn_pose_bwd_finish");
   return TN_OK;
 }
 
@@ -458,15 +628,19 @@ __global__ void k_l1(const float* __restrict__ x, const float* __restrict__ y, i
     if (d_x) d_x[i] += gx * s;
     if (d_y) d_y[i] -= gy * s;
   }
+  // one atomic per BLOCK: same-address float atomics execute one after the other (~25 ns each); one per wave of a 2048-block grid was 0.2 ms
+  __shared__ float sh[4];
   acc = tn_wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, (gx + gy) * acc / (float)n);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (gx + gy) * (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n);
 }
 extern "C" int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
                           tn_stream_t stream) {
   if (count == 0) return TN_OK;
   TN_REQUIRE(x && y && loss_out && count >= 0, "tn_l1_loss: bad argument");
   if (count == 0) return TN_OK;
-  hipLaunchKernelGGL(k_l1, dim3((unsigned)std::min<int64_t>(tn_cdiv(count, 256), 2048)), dim3(256), 0, tn_s(stream), x, y, count, gx, gy, loss_out,
+  hipLaunchKernelGGL(k_l1, dim3((unsigned)std::min<int64_t>(tn_cdiv(count, 256), 256)), dim3(256), 0, tn_s(stream), x, y, count, gx, gy, loss_out,
                      d_x, d_y);
   TN_CHECK_LAUNCH("tn_l1_loss");
   return TN_OK;

@@ -14,21 +14,7 @@
 // ------------------------------------------------------------------------------------------------ spaced bins
 __global__ void k_spaced_bins(const float* __restrict__ lin_bins, const float* __restrict__ jitter, const float* __restrict__ nears,
                               const float* __restrict__ fars, int64_t N, int S, float* __restrict__ s_bins, float* __restrict__ e_bins) {
-  int64_t total = N * (int64_t)(S + 1);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t ray = i / (S + 1);
-    int j = (int)(i - ray * (S + 1));
-    float b = lin_bins[j];
-    if (jitter != nullptr) {
-      // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
-      float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
-      float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
-      b = lower + (upper - lower) * jitter[ray];
-    }
-    float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
-    s_bins[i] = b;
-    e_bins[i] = tn_s_to_euclid(b, s_near, s_far);
-  }
+  tn_spaced_bins_body(lin_bins, jitter, nears, fars, N, S, s_bins, e_bins, blockIdx.x, gridDim.x);
 }
 
 extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
@@ -435,15 +421,16 @@ __global__ void __launch_bounds__(BLOCK) k_composite_fwd(const float* __restrict
 
 // ---- get_weights + every renderer of the last level in ONE launch (tn_render_fwd): the weights stay in registers between the two halves.
 // The batch-global clip of the expected depth (renderers.py:574: clip to [steps.min(), steps.max()]) needs every block's min / max first:
-// state[0] = max over blocks of ~bits(min midpoint), state[1] = max of bits(max midpoint) -- both encodings start from ZERO, so no launch
-// initialises them -- and k_clip_depth_state applies the clip and, when it runs as a single block, puts the state back to zero for the next
-// call.  (A last-block-done epilogue inside this kernel was measured: the device-scope fences it needs write the whole L2 back once per block,
-// 55 us against 20 + 5 us for the two launches.)
+// block b STORES its pair into scratch[b], scratch[RENDER_MAX_BLOCKS + b] (no atomics: same-address atomics execute one after the other at
+// ~25 ns each, a 512-block grid would spend more time on them than on the rendering; and nothing to initialise), and k_clip_depth_blocks
+// reduces the pairs and applies the clip.  (A last-block-done epilogue inside this kernel was measured too: the device-scope fences it needs
+// write the whole L2 back once per block, 55 us against 20 + 5 us for the two launches.)
+#define RENDER_MAX_BLOCKS 512
 template <int ITEMS, int C>
 __global__ void __launch_bounds__(BLOCK) k_render_fwd(const float* __restrict__ e_bins, const float* __restrict__ density,
                                                       const float* __restrict__ rgb, int64_t N, int S, int training, float* __restrict__ weights,
                                                       float* __restrict__ comp, float* __restrict__ accumulation, float* __restrict__ depth_median,
-                                                      float* __restrict__ depth_expected, uint32_t* __restrict__ state) {
+                                                      float* __restrict__ depth_expected, float* __restrict__ scratch) {
   const int lane = tn_lane();
   __shared__ float sh_mn[RAYS_PER_BLOCK], sh_mx[RAYS_PER_BLOCK];
   float blk_mn = INFINITY, blk_mx = 0.0f;
@@ -463,18 +450,22 @@ __global__ void __launch_bounds__(BLOCK) k_render_fwd(const float* __restrict__ 
   if (threadIdx.x == 0) {
     float a = sh_mn[0], b = sh_mx[0];
     for (int w = 1; w < RAYS_PER_BLOCK; ++w) { a = fminf(a, sh_mn[w]); b = fmaxf(b, sh_mx[w]); }
-    if (a != INFINITY) { atomicMax(&state[0], ~f2ord(a)); atomicMax(&state[1], f2ord(b)); }
+    scratch[blockIdx.x] = a;  // +inf / 0 from a block without rays: neutral
+    scratch[RENDER_MAX_BLOCKS + blockIdx.x] = b;
   }
 }
-// RESET: launched as ONE block, which reads the range, then zeroes the state for the next call, then clips
-template <bool RESET>
-__global__ void __launch_bounds__(1024) k_clip_depth_state(float* __restrict__ d, uint32_t* __restrict__ state, int64_t N) {
-  const float lo = __uint_as_float(~state[0]), hi = __uint_as_float(state[1]);
-  if (RESET) {
-    __syncthreads();
-    if (threadIdx.x < 2) state[threadIdx.x] = 0u;
-  }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+// every block reduces the nblk (<= 512) pairs itself (4 KB out of L2), then clips its share of the rays
+__global__ void __launch_bounds__(512) k_clip_depth_blocks(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int64_t N) {
+  __shared__ float sh_lo[8], sh_hi[8];
+  const int t = threadIdx.x;
+  float lo = t < nblk ? scratch[t] : INFINITY, hi = t < nblk ? scratch[RENDER_MAX_BLOCKS + t] : 0.0f;
+  lo = tn_wave_min(lo); hi = tn_wave_max(hi);
+  if ((t & 63) == 0) { sh_lo[t >> 6] = lo; sh_hi[t >> 6] = hi; }
+  __syncthreads();
+  lo = sh_lo[0]; hi = sh_hi[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) { lo = fminf(lo, sh_lo[w]); hi = fmaxf(hi, sh_hi[w]); }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + t; i < N; i += (int64_t)gridDim.x * blockDim.x) {
     float v = d[i];
     if (v == v) v = fminf(fmaxf(v, lo), hi);  // torch.clip; NaN propagates
     d[i] = v;
@@ -482,18 +473,20 @@ __global__ void __launch_bounds__(1024) k_clip_depth_state(float* __restrict__ d
 }
 
 extern "C" int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
-                             float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* state,
+                             float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
                              tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(e_bins && density && rgb && weights && comp, "tn_render_fwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_render_fwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(C == 1 || C == 3 || C == 4, "tn_render_fwd: unsupported channel count %d", C);
-  TN_REQUIRE(depth_expected == nullptr || state != nullptr, "tn_render_fwd: depth_expected needs the 16-byte state buffer");
-  dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512)), block(BLOCK);
+  TN_REQUIRE(depth_expected == nullptr || scratch != nullptr, "tn_render_fwd: depth_expected needs the scratch buffer (TN_RENDER_SCRATCH_FLOATS)");
+  static_assert(TN_RENDER_SCRATCH_FLOATS >= 2 * RENDER_MAX_BLOCKS, "render scratch");
+  const int nblk = (int)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), RENDER_MAX_BLOCKS);
+  dim3 grid((unsigned)nblk), block(BLOCK);
   hipStream_t st = tn_s(stream);
 #define LAUNCH_R(I, CC)                                                                                                               \
   hipLaunchKernelGGL((k_render_fwd<I, CC>), grid, block, 0, st, e_bins, density, rgb, N, S, training, weights, comp, accumulation, \
-                     depth_median, depth_expected, state)
+                     depth_median, depth_expected, scratch)
 #define LAUNCH_R_C(I) \
   do { if (C == 1) LAUNCH_R(I, 1); else if (C == 3) LAUNCH_R(I, 3); else LAUNCH_R(I, 4); } while (0)
   if (S <= 64) LAUNCH_R_C(1);
@@ -503,15 +496,8 @@ extern "C" int tn_render_fwd(const float* e_bins, const float* density, const fl
 #undef LAUNCH_R
   TN_CHECK_LAUNCH("tn_render_fwd");
   if (depth_expected != nullptr) {
-    if (N <= 65536) {
-      hipLaunchKernelGGL(k_clip_depth_state<true>, dim3(1), dim3(1024), 0, st, depth_expected, state, N);
-      TN_CHECK_LAUNCH("tn_render_fwd(clip)");
-    } else {  // one block looping over a huge batch would take longer than a memset node
-      hipLaunchKernelGGL(k_clip_depth_state<false>, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 1024), 1024)), dim3(1024), 0, st, depth_expected, state, N);
-      TN_CHECK_LAUNCH("tn_render_fwd(clip)");
-      hipError_t e = hipMemsetAsync(state, 0, 16, st);  // the state is zero between calls
-      TN_REQUIRE(e == hipSuccess, "tn_render_fwd: memset failed: %s", hipGetErrorString(e));
-    }
+    hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, st, depth_expected, scratch, nblk, N);
+    TN_CHECK_LAUNCH("tn_render_fwd(clip)");
   }
   return TN_OK;
 }
@@ -702,13 +688,17 @@ extern "C" int tn_render_bwd(const float* e_bins, const float* density, const fl
 // per ray: L = sum_ij w_i w_j |m_i - m_j| + (1/3) sum_i w_i^2 (t_{i+1}-t_i),  m = bin centres in s-space
 //   dL/dw_i = 2 sum_j w_j |m_i - m_j| + (2/3) w_i (t_{i+1}-t_i)      (s-space bins carry no gradient)
 // loss_out += mult * mean_over_rays(L)
+// LDS of the loss bodies: ONE buffer per block, carved up by whichever body the block runs (a block of the fused launch runs exactly one),
+// small enough for 8 blocks per CU -- the whole grid of tn_train_losses is resident at once.
+#define LOSS_SMEM_BYTES (RAYS_PER_BLOCK * 3600 + 16)
 __device__ __forceinline__ void distortion_body(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S, float mult,
-                                                float* __restrict__ loss_out, float* __restrict__ d_weights) {
-  __shared__ float sh_w[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
-  __shared__ float sh_m[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+                                                float* __restrict__ loss_out, float* __restrict__ d_weights, unsigned char* smem) {
+  float (*sh_w)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem);
+  float (*sh_m)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem + RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4);
+  float* sh_part = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600);
+  static_assert(2 * TN_MAX_SAMPLES * 4 <= 3600, "loss smem");
   int lane = tn_lane();
   int wv = threadIdx.x >> 6;
-  __shared__ float sh_part[RAYS_PER_BLOCK];
   float wave_total = 0.0f;
   float scale = mult / (float)N;
   for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
@@ -743,7 +733,8 @@ __device__ __forceinline__ void distortion_body(const float* __restrict__ s_bins
 
 __global__ void __launch_bounds__(BLOCK) k_distortion(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S,
                                                       float mult, float* __restrict__ loss_out, float* __restrict__ d_weights) {
-  distortion_body(s_bins, weights, N, S, mult, loss_out, d_weights);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LOSS_SMEM_BYTES];
+  distortion_body(s_bins, weights, N, S, mult, loss_out, d_weights, smem);
 }
 
 extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
@@ -768,15 +759,14 @@ extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int
 // cancellation residue (1e-16) would become full-size Adam steps on table entries whose true gradient is exactly 0.
 __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
                                                 const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N, float mult,
-                                                float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
-  __shared__ float sh_cp[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
-  __shared__ float sh_cy[RAYS_PER_BLOCK][TN_MAX_SAMPLES + 1];
-  __shared__ float sh_g[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
-  __shared__ int sh_lo[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
-  __shared__ int sh_hi[RAYS_PER_BLOCK][TN_MAX_SAMPLES];
+                                                float* __restrict__ loss_out, float* __restrict__ d_w_prop, unsigned char* smem) {
+  // per wave: cp[257] cy[257] g[256] floats, lo[256] hi[256] bytes (proposal-bin indices < 256) = 3592 bytes
+  struct WaveLds { float cp[TN_MAX_SAMPLES + 1]; float cy[TN_MAX_SAMPLES + 1]; float g[TN_MAX_SAMPLES]; uint8_t lo[TN_MAX_SAMPLES]; uint8_t hi[TN_MAX_SAMPLES]; };
+  static_assert(sizeof(WaveLds) <= 3600 && TN_MAX_SAMPLES <= 256, "loss smem");
   int lane = tn_lane();
   int wv = threadIdx.x >> 6;
-  __shared__ float sh_part[RAYS_PER_BLOCK];
+  WaveLds& wl = *reinterpret_cast<WaveLds*>(smem + wv * 3600);
+  float* sh_part = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600);
   float wave_total = 0.0f;
   float scale = mult / ((float)N * (float)Sf);
   for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
@@ -796,33 +786,33 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
   }
   double incl = tn_wave_incl_scan_d(loc, lane);
   double run = tn_excl_from_incl_d(incl, lane);
-  if (lane == 0) sh_cy[wv][0] = 0.0f;
+  if (lane == 0) wl.cy[0] = 0.0f;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     int i = lane * ITEMS + k;
     run += (double)v[k];
-    if (i < Sp) sh_cy[wv][i + 1] = (float)run;
+    if (i < Sp) wl.cy[i + 1] = (float)run;
   }
-  for (int i = lane; i <= Sp; i += 64) sh_cp[wv][i] = cp[i];
+  for (int i = lane; i <= Sp; i += 64) wl.cp[i] = cp[i];
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float total = 0.0f;
   for (int i = lane; i < Sf; i += 64) {
     float t0 = c[i], t1 = c[i + 1];
     int lo = 0, hi = Sp;  // searchsorted right over the starts cp[0..Sp-1]
-    while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m] <= t0) lo = m + 1; else hi = m; }
+    while (lo < hi) { int m = (lo + hi) >> 1; if (wl.cp[m] <= t0) lo = m + 1; else hi = m; }
     int ilo = lo - 1; ilo = ilo < 0 ? 0 : (ilo > Sp - 1 ? Sp - 1 : ilo);
     lo = 0; hi = Sp;      // searchsorted right over the ends cp[1..Sp]
-    while (lo < hi) { int m = (lo + hi) >> 1; if (sh_cp[wv][m + 1] <= t1) lo = m + 1; else hi = m; }
+    while (lo < hi) { int m = (lo + hi) >> 1; if (wl.cp[m + 1] <= t1) lo = m + 1; else hi = m; }
     int ihi = lo > Sp - 1 ? Sp - 1 : lo;
-    float w_outer = sh_cy[wv][ihi + 1] - sh_cy[wv][ilo];
+    float w_outer = wl.cy[ihi + 1] - wl.cy[ilo];
     float w = w_fine[ray * Sf + i];
     float d = w - w_outer;
     if (d < 0.0f) d = 0.0f;
     total += d * d / (w + 1.0e-7f);
-    sh_g[wv][i] = -2.0f * d / (w + 1.0e-7f) * scale;
-    sh_lo[wv][i] = ilo;
-    sh_hi[wv][i] = ihi;
+    wl.g[i] = -2.0f * d / (w + 1.0e-7f) * scale;
+    wl.lo[i] = (uint8_t)ilo;
+    wl.hi[i] = (uint8_t)ihi;
   }
   wave_total += tn_wave_sum(total);
   if (d_w_prop != nullptr) {
@@ -834,18 +824,18 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
     // over every interval (48 dependent LDS round trips per 64 bins before).
     bool mono = true;
     for (int i = lane; i < Sf; i += 64)
-      if (i > 0 && (sh_lo[wv][i] < sh_lo[wv][i - 1] || sh_hi[wv][i] < sh_hi[wv][i - 1])) mono = false;
+      if (i > 0 && (wl.lo[i] < wl.lo[i - 1] || wl.hi[i] < wl.hi[i - 1])) mono = false;
     if (__all(mono)) {
       for (int k = lane; k < Sp; k += 64) {
         int l = 0, h = Sf;
-        while (l < h) { int m = (l + h) >> 1; if (sh_lo[wv][m] <= k) l = m + 1; else h = m; }
+        while (l < h) { int m = (l + h) >> 1; if (wl.lo[m] <= k) l = m + 1; else h = m; }
         const int A = l;
         l = 0; h = Sf;
-        while (l < h) { int m = (l + h) >> 1; if (sh_hi[wv][m] < k) l = m + 1; else h = m; }
+        while (l < h) { int m = (l + h) >> 1; if (wl.hi[m] < k) l = m + 1; else h = m; }
         const int B = l;
         float acc = 0.0f;
-        if (B < A) { for (int i = B; i < A; ++i) acc += sh_g[wv][i]; }
-        else { for (int i = A; i < B; ++i) acc -= sh_g[wv][i]; }
+        if (B < A) { for (int i = B; i < A; ++i) acc += wl.g[i]; }
+        else { for (int i = A; i < B; ++i) acc -= wl.g[i]; }
         if (acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
       }
     } else {
@@ -855,12 +845,12 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
       float acc = 0.0f;
       for (int i0 = 0; i0 < Sf; i0 += 64) {
         int ii = i0 + lane;
-        unsigned long long m = __ballot(ii < Sf && sh_g[wv][ii < Sf ? ii : 0] != 0.0f);
+        unsigned long long m = __ballot(ii < Sf && wl.g[ii < Sf ? ii : 0] != 0.0f);
         while (m) {
           int i = i0 + __builtin_ctzll(m);
           m &= m - 1;
-          int a = sh_lo[wv][i], b = sh_hi[wv][i];
-          float gi = sh_g[wv][i];
+          int a = wl.lo[i], b = wl.hi[i];
+          float gi = wl.g[i];
           if (a <= k && k <= b) acc += gi;
           else if (b < k && k < a) acc -= gi;
         }
@@ -882,7 +872,8 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
 __global__ void __launch_bounds__(BLOCK) k_interlevel(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
                                                       const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N,
                                                       float mult, float* __restrict__ loss_out, float* __restrict__ d_w_prop) {
-  interlevel_body(c_bins, w_fine, Sf, p_bins, w_prop, Sp, N, mult, loss_out, d_w_prop);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LOSS_SMEM_BYTES];
+  interlevel_body(c_bins, w_fine, Sf, p_bins, w_prop, Sp, N, mult, loss_out, d_w_prop, smem);
 }
 
 // K7: distortion + every interlevel term of one branch in ONE launch -- blockIdx.y = 0 is the distortion loss of the fine level,
@@ -902,22 +893,37 @@ struct PropLossArgs {
   float* distortion_out;
   float* interlevel_out;
   float* d_w_fine;
-  // optional last slice (blockIdx.y = 1 + num_props): the pixel terms of the same iteration (tn_train_losses); pred_rgb == NULL: none
+  // optional first slice (blockIdx.y = 0): the pixel terms of the same iteration (tn_train_losses); pred_rgb == NULL: none
   const float* pred_rgb; const float* pred_th; const float* image; const float* is_thermal;
   int rs, ts, pixel_blocks;
   float thermal_mult, tv_mult, cross_mult;
   float* pixel_losses; float* d_pred_rgb; float* d_pred_th;
+  float* loss_lines;  // NULL: every term adds into its own output; else [TN_LOSS_LINES][16], see k_proposal_losses
 };
-__global__ void __launch_bounds__(BLOCK) k_proposal_losses(PropLossArgs a) {
-  if (blockIdx.y == 0) {
-    distortion_body(a.s_bins_fine, a.w_fine, a.N, a.Sf, a.distortion_mult, a.distortion_out, a.d_w_fine);
-  } else if ((int)blockIdx.y == 1 + a.num_props) {
-    if ((int)blockIdx.x >= a.pixel_blocks) return;  // whole block leaves together
-    pixel_losses_body(a.pred_rgb, a.rs, a.pred_th, a.ts, a.image, a.is_thermal, a.N, a.thermal_mult, a.tv_mult, a.cross_mult, a.pixel_losses,
-                      a.d_pred_rgb, a.d_pred_th, blockIdx.x, a.pixel_blocks);
+__global__ void __launch_bounds__(BLOCK, 6) k_proposal_losses(PropLossArgs a) {
+  // Every block ends with one float atomic per loss term, and atomics into ONE 64-byte line execute one after the other (~25 ns each):
+  // 512 blocks x 3 slices into the same line is ~40 us, more than the losses themselves take.  With loss_lines the sums are spread over
+  // TN_LOSS_LINES lines (block b adds into line b % TN_LOSS_LINES, slot = the term's index) and tn_losses_finish adds the lines up.
+  float* line = a.loss_lines ? a.loss_lines + 16 * (blockIdx.x & (TN_LOSS_LINES - 1)) : nullptr;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LOSS_SMEM_BYTES];
+  // slice order = dispatch order: the pixel terms first (a handful of blocks with the longest dependent chain: they must not wait for a
+  // second round of blocks), then distortion, then the interlevel terms
+  int slice = blockIdx.y;
+  if (a.pred_rgb != nullptr) {
+    if (slice == 0) {
+      if ((int)blockIdx.x >= a.pixel_blocks) return;  // whole block leaves together
+      pixel_losses_body(a.pred_rgb, a.rs, a.pred_th, a.ts, a.image, a.is_thermal, a.N, a.thermal_mult, a.tv_mult, a.cross_mult,
+                        line ? line : a.pixel_losses, a.d_pred_rgb, a.d_pred_th, blockIdx.x, a.pixel_blocks);
+      return;
+    }
+    --slice;
+  }
+  if (slice == 0) {
+    distortion_body(a.s_bins_fine, a.w_fine, a.N, a.Sf, a.distortion_mult, line ? line + 9 : a.distortion_out, a.d_w_fine, smem);
   } else {
-    int i = blockIdx.y - 1;
-    interlevel_body(a.s_bins_fine, a.w_fine, a.Sf, a.s_bins_prop[i], a.w_prop[i], a.Sp[i], a.N, a.interlevel_mult, a.interlevel_out, a.d_w_prop[i]);
+    int i = slice - 1;
+    interlevel_body(a.s_bins_fine, a.w_fine, a.Sf, a.s_bins_prop[i], a.w_prop[i], a.Sp[i], a.N, a.interlevel_mult, line ? line + 8 : a.interlevel_out,
+                    a.d_w_prop[i], smem);
   }
 }
 
@@ -940,9 +946,10 @@ static int launch_train_losses(const char* who, const float* s_bins_fine, const 
                                float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
                                float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
                                int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
-                               float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
+                               float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, float* loss_lines,
+                               tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
-  TN_REQUIRE(s_bins_fine && weights_fine && distortion_out && interlevel_out, "%s: null pointer", who);
+  TN_REQUIRE(s_bins_fine && weights_fine && ((distortion_out && interlevel_out) || loss_lines), "%s: null pointer", who);
   TN_REQUIRE(N > 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES, "%s: bad N=%lld S_fine=%d", who, (long long)N, S_fine);
   TN_REQUIRE(num_props >= 0 && num_props <= TN_MAX_PROP_LEVELS && (num_props == 0 || (s_bins_prop && weights_prop && S_prop && d_weights_prop)),
              "%s: bad proposal level list (num_props=%d, at most %d)", who, num_props, TN_MAX_PROP_LEVELS);
@@ -956,7 +963,7 @@ static int launch_train_losses(const char* who, const float* s_bins_fine, const 
   }
   int slices = 1 + num_props;
   if (pred_rgb != nullptr) {
-    TN_REQUIRE(pred_thermal && image && is_thermal && pixel_losses_out, "%s: null pointer in the pixel terms", who);
+    TN_REQUIRE(pred_thermal && image && is_thermal && (pixel_losses_out || loss_lines), "%s: null pointer in the pixel terms", who);
     TN_REQUIRE(N % 4 == 0, "%s: N=%lld must be a multiple of 4 (2x2 patches)", who, (long long)N);
     TN_REQUIRE(rgb_stride >= 3 && thermal_stride >= 1, "%s: bad strides", who);
     a.pred_rgb = pred_rgb; a.pred_th = pred_thermal; a.image = image; a.is_thermal = is_thermal; a.rs = rgb_stride; a.ts = thermal_stride;
@@ -965,6 +972,7 @@ static int launch_train_losses(const char* who, const float* s_bins_fine, const 
     a.pixel_blocks = pixel_loss_blocks(N);
     ++slices;
   }
+  a.loss_lines = loss_lines;
   dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), slices);
   hipLaunchKernelGGL(k_proposal_losses, grid, dim3(BLOCK), 0, tn_s(stream), a);
   TN_CHECK_LAUNCH(who);
@@ -977,19 +985,19 @@ extern "C" int tn_proposal_losses(const float* s_bins_fine, const float* weights
                                   float* interlevel_out, float* d_weights_fine, tn_stream_t stream) {
   return launch_train_losses("tn_proposal_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
                              distortion_mult, interlevel_mult, distortion_out, interlevel_out, d_weights_fine, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                             0.f, 0.f, 0.f, nullptr, nullptr, nullptr, stream);
+                             0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
                                const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
-                               float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
-                               float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
-                               int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
-                               float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream) {
-  TN_REQUIRE(pred_rgb != nullptr, "tn_train_losses: null pointer (pred_rgb)");
+                               float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* d_weights_fine,
+                               const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
+                               const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult, float* d_pred_rgb,
+                               float* d_pred_thermal, float* loss_lines, tn_stream_t stream) {
+  TN_REQUIRE(loss_lines != nullptr, "tn_train_losses: null pointer (loss_lines)");
   return launch_train_losses("tn_train_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
-                             distortion_mult, interlevel_mult, distortion_out, interlevel_out, d_weights_fine, pred_rgb, rgb_stride, pred_thermal,
-                             thermal_stride, image, is_thermal, thermal_mult, tv_mult, cross_mult, pixel_losses_out, d_pred_rgb, d_pred_thermal, stream);
+                             distortion_mult, interlevel_mult, nullptr, nullptr, d_weights_fine, pred_rgb, rgb_stride, pred_thermal, thermal_stride,
+                             image, is_thermal, thermal_mult, tv_mult, cross_mult, nullptr, d_pred_rgb, d_pred_thermal, loss_lines, stream);
 }
 
 extern "C" int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,

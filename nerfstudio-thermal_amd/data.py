@@ -25,9 +25,7 @@ class DeviceDataManager:
     def _make(self) -> Tuple[Tensor, ...]:
         n = self.num_rays
         u = torch.rand((n // (self.patch * self.patch), 3), device=self.device)  # what PatchPixelSampler draws with torch.rand
-        idx, img, is_th, cam = ops.sample_pixels(self.cache, n, u, self.patch, want_camera_indices=True)
-        c = self.cam
-        o, d, _, _ = ops.raygen(idx, c["c2w"], c["fx"], c["fy"], c["cx"], c["cy"], c.get("distortion"))
+        o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch)  # pixel sampler + GT gather + raygen: one launch
         return o, d, cam, img, is_th
 
     def _launch_prefetch(self) -> None:

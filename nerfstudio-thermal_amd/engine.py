@@ -122,13 +122,19 @@ class RenderEngine:
     def render_branch(self, props, fld, pose, frozen, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
                       training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main") -> Branch:
         o_in, d_in = origins, directions
+        first = None
         if training and pose is not None:
-            origins, directions = ops.pose_apply_fwd(pose, frozen, cam, origins, directions)
+            if _FUSE:  # pose correction and the level-0 bins are independent: one launch
+                origins, directions, s0, e0 = ops.pose_spaced_bins(pose, frozen, cam, origins, directions, nears, fars, self.counts[0],
+                                                                   None if jitters is None else jitters[0])
+                first = (s0, e0)
+            else:
+                origins, directions = ops.pose_apply_fwd(pose, frozen, cam, origins, directions)
         levels: List[Level] = []
         for lvl, S in enumerate(self.counts):
             jit = None if jitters is None else jitters[lvl]
             if lvl == 0:
-                s, e = ops.spaced_bins(nears, fars, S, jit)
+                s, e = first if first is not None else ops.spaced_bins(nears, fars, S, jit)
             else:
                 # weights of the previous level + this level's bins in one launch (get_weights -> PDFSampler, ray_samplers.py:593-611)
                 prev = levels[-1]
@@ -249,7 +255,8 @@ class RenderEngine:
         # ---- pixel losses -> d comp
         # every zero-initialised accumulator of the step comes out of one allocation / one fill (see _zeros_many)
         # L: 0 rgb 1 thermal 2 tv 3 cross 4 (scratch) 8 interlevel 9 distortion 10 density 11 camreg 12 camreg_thermal
-        zshapes, zkeys = [(16,)], [("L", "")]
+        # Lp: the loss sums spread over LOSS_LINES 64-byte lines (ops.train_losses), added up into L by ops.losses_finish at the end
+        zshapes, zkeys = [(16,), (ops.LOSS_LINES, 16)], [("L", ""), ("Lp", "")]
         for sfx, br in branches.items():
             zkeys.append(("d_comp", sfx)); zshapes.append(tuple(br.comp.shape))
             zkeys.append(("dw2", sfx)); zshapes.append(tuple(br.levels[2].weights.shape))
@@ -260,17 +267,17 @@ class RenderEngine:
                 zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
                 zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
         Z = dict(zip(zkeys, self._zeros_many(zshapes)))
-        L = Z[("L", "")]
+        L, Lp = Z[("L", "")], Z[("Lp", "")]
         d_comp = Z[("d_comp", "")]
-        # the pixel terms ride in the first branch's loss launch (ops.proposal_losses(pixel=...)): one launch instead of two back to back
+        # the pixel terms ride in the first branch's loss launch (ops.train_losses(pixel=...)): one launch instead of two back to back
         if self.separate:
             d_comp_t = Z[("d_comp", "_thermal")]
-            pixel = (b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8], d_comp, d_comp_t)
+            pixel = (b.comp, bt.comp, image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, d_comp, d_comp_t)
         else:
-            pixel = (b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, L[0:8],
+            pixel = (b.comp[:, :3], b.comp[:, 3:], image, is_thermal, c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult,
                      d_comp[:, :3], d_comp[:, 3:])
         if not _FUSE:
-            ops.pixel_losses(*pixel)
+            ops.pixel_losses(*pixel[:7], L[0:8], *pixel[7:])
             pixel = None
         # ---- proposal losses.  NB (models/thermal_nerfacto.py:363-368): metrics_dict["distortion"] is the SUM over suffixes and is added once per
         # suffix, so in separate mode each branch's distortion enters with 2x distortion_loss_mult.
@@ -282,9 +289,12 @@ class RenderEngine:
             for i in range(2):
                 if br.prop_grad:
                     dws[i] = Z[(f"dw{i}", sfx)]
-            # distortion + both interlevel terms: one launch (they are independent and ~15 us each)
-            ops.proposal_losses(lv[2].s_bins, lv[2].weights, [(lv[i].s_bins, lv[i].weights, dws[i]) for i in range(2)],
-                                c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, L[9:10], L[8:9], dws[2], pixel=pixel)
+            # distortion + both interlevel terms (+ the pixel terms): one launch
+            props_l = [(lv[i].s_bins, lv[i].weights, dws[i]) for i in range(2)]
+            if _FUSE:
+                ops.train_losses(lv[2].s_bins, lv[2].weights, props_l, c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, dws[2], Lp, pixel=pixel)
+            else:
+                ops.proposal_losses(lv[2].s_bins, lv[2].weights, props_l, c.distortion_loss_mult * nsfx, c.interlevel_loss_mult, L[9:10], L[8:9], dws[2])
             pixel = None
             grads_w[sfx] = dws
         # ---- per-branch backward
@@ -397,6 +407,7 @@ class RenderEngine:
             # get_density only), so its backward, its three weight-gradient GEMMs and the embedding rows are skipped
             ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, None, bt._d_o, bt._d_d, tag="cross")
             ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, None, b._d_o, b._d_d, tag="cross")
+        finished = not _FUSE
         for sfx, br in branches.items():
             pose = self.pose_thermal if sfx else self.pose
             if pose is None:
@@ -404,8 +415,16 @@ class RenderEngine:
             pose_grad = self.pose_thermal_grad if sfx else self.pose_grad
             frozen = self.frozen_thermal if sfx else self.frozen_rgb
             co = c.camera_optimizer_thermal if sfx else c.camera_optimizer
-            ops.pose_apply_bwd(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad)
-            ops.camera_reg(pose, co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale, L[12:13] if sfx else L[11:12], pose_grad)
+            reg = L[12:13] if sfx else L[11:12]
+            if _FUSE:  # pose gradient + regulariser (+ the loss sums, once) in one launch
+                ops.pose_bwd_finish(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad, co.trans_l2_penalty, co.rot_l2_penalty,
+                                    co.penalty_scale, reg, None if finished else Lp, None if finished else L)
+                finished = True
+            else:
+                ops.pose_apply_bwd(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad)
+                ops.camera_reg(pose, co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale, reg, pose_grad)
+        if not finished:
+            ops.losses_finish(Lp, L)
         losses = {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
                   "distortion_loss": L[9]}
         if self.separate and c.density_loss_mult > 0:

@@ -226,6 +226,29 @@ def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int =
     return (idx, img, is_th, cam) if want_camera_indices else (idx, img, is_th)
 
 
+def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2):
+    """sample_pixels + raygen in one launch (tn_sample_rays) -> origins [N,3], directions [N,3], camera_indices [N] int64, image [N,3],
+    is_thermal [N], ray_indices [N,3].  cameras: c2w [C,3,4], fx, fy, cx, cy [C], optional distortion [C,6]."""
+    n_img = cache.offsets.shape[0]
+    dev = cache.buffer.device
+    if u.device != dev or u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (num_rays // (patch_size * patch_size), 3):
+        raise ValueError(f"u must be a contiguous fp32 [{num_rays // (patch_size * patch_size)}, 3] tensor on {dev}")
+    idx = torch.empty((num_rays, 3), dtype=torch.int64, device=dev)
+    cam = torch.empty((num_rays,), dtype=torch.int64, device=dev)
+    img, is_th, o, d, area, nrm = (torch.empty((num_rays, 3), device=dev), torch.empty((num_rays,), device=dev), torch.empty((num_rays, 3), device=dev),
+                                   torch.empty((num_rays, 3), device=dev), torch.empty((num_rays, 1), device=dev), torch.empty((num_rays, 1), device=dev))
+    c2w = cameras["c2w"]
+    Cn = c2w.shape[0]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    check(_lib.load().tn_sample_rays(p(cache.buffer), p(cache.offsets), p(cache.heights), p(cache.widths), p(cache.is_thermal), p(cache.image_idx),
+                                     n_img, p(u), num_rays, patch_size, p(idx), p(img), p(is_th), p(cam),
+                                     _f32(c2w, "c2w", (Cn, 3, 4)), _f32(cameras["fx"], "fx", (Cn,)), _f32(cameras["fy"], "fy", (Cn,)),
+                                     _f32(cameras["cx"], "cx", (Cn,)), _f32(cameras["cy"], "cy", (Cn,)),
+                                     _f32(cameras.get("distortion"), "distortion", (Cn, 6), optional=True), Cn, p(o), p(d), p(area), p(nrm), _stream()),
+          "tn_sample_rays")
+    return o, d, cam, img, is_th, idx
+
+
 # ------------------------------------------------------------------------------------------------ a1 / a4
 def raygen(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, distortion: Optional[Tensor]):
     N, Cn = ray_indices.shape[0], c2w.shape[0]
@@ -255,6 +278,33 @@ def pose_apply_fwd(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, origins:
     check(_lib.load().tn_pose_apply_fwd(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)), _f32(origins, "origins", (N, 3)),
                                         _f32(directions, "directions", (N, 3)), N, Cn, _f32(o, "o"), _f32(d, "d"), _stream()), "tn_pose_apply_fwd")
     return o, d
+
+
+def pose_spaced_bins(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, origins: Tensor, directions: Tensor, nears: Tensor, fars: Tensor, S: int,
+                     jitter: Optional[Tensor] = None):
+    """pose_apply_fwd + spaced_bins in one launch (tn_pose_spaced_bins) -> origins', directions', s_bins [N,S+1], e_bins [N,S+1]."""
+    N, Cn = origins.shape[0], pose.shape[0]
+    o, d = torch.empty_like(origins), torch.empty_like(directions)
+    s = torch.empty((N, S + 1), device=origins.device)
+    e = torch.empty((N, S + 1), device=origins.device)
+    check(_lib.load().tn_pose_spaced_bins(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)), _f32(origins, "origins", (N, 3)),
+                                          _f32(directions, "directions", (N, 3)), N, Cn, _f32(o, "o"), _f32(d, "d"),
+                                          _f32(_lin_table("spaced", S, origins.device), "lin"), _ray_scalar(jitter, "jitter", N, True),
+                                          _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), S, _f32(s, "s"), _f32(e, "e"), _stream()),
+          "tn_pose_spaced_bins")
+    return o, d, s, e
+
+
+def pose_bwd_finish(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, directions_in: Tensor, d_o: Tensor, d_d: Tensor, grad_pose: Tensor,
+                    trans_pen: float, rot_pen: float, scale: float, reg_out: Tensor, loss_lines: Optional[Tensor] = None,
+                    losses16: Optional[Tensor] = None) -> None:
+    """pose_apply_bwd + camera_reg (+ losses_finish when loss_lines / losses16 are given) in one launch (tn_pose_bwd_finish)."""
+    N, Cn = directions_in.shape[0], pose.shape[0]
+    check(_lib.load().tn_pose_bwd_finish(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)),
+                                         _f32(directions_in, "directions", (N, 3)), _f32(d_o, "d_origins", (N, 3)), _f32(d_d, "d_directions", (N, 3)),
+                                         N, Cn, _f32(grad_pose, "grad_pose", (Cn, 6)),
+                                         _f32(loss_lines, "loss_lines", (_lib.TN_LOSS_LINES, 16), optional=True), _f32(losses16, "losses16", optional=True),
+                                         float(trans_pen), float(rot_pen), float(scale), _f32(reg_out, "reg_out"), _stream()), "tn_pose_bwd_finish")
 
 
 def pose_apply_bwd(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, directions_in: Tensor, d_o: Tensor, d_d: Tensor, grad_pose: Tensor):
@@ -515,7 +565,7 @@ def composite_bwd(rgb: Tensor, weights: Tensor, d_comp: Tensor, d_weights: Tenso
     return d_rgb
 
 
-_RENDER_STATE: dict = {}
+_RENDER_SCRATCH: dict = {}
 
 
 def render_fwd(e_bins: Tensor, density: Tensor, rgb: Tensor, training: bool, want_depth: bool = True):
@@ -529,16 +579,16 @@ def render_fwd(e_bins: Tensor, density: Tensor, rgb: Tensor, training: bool, wan
     med = torch.empty((N, 1), device=dev) if want_depth else None
     exp = torch.empty((N, 1), device=dev) if want_depth else None
     st = _stream()
-    state = None
+    scratch = None
     if want_depth:
-        # 16 bytes that every call leaves zero again: one buffer per (device, stream), zero-filled when it is created
+        # per-block min / max of the sample midpoints (contents irrelevant between calls): one buffer per (device, stream)
         key = (dev.index, st.value)
-        state = _RENDER_STATE.get(key)
-        if state is None:
-            state = _RENDER_STATE[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+        scratch = _RENDER_SCRATCH.get(key)
+        if scratch is None:
+            scratch = _RENDER_SCRATCH[key] = torch.empty(_lib.TN_RENDER_SCRATCH_FLOATS, device=dev)
     check(_lib.load().tn_render_fwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), _f32(rgb, "rgb", (N, S, Cc)), N, S, Cc,
                                     1 if training else 0, _f32(w, "w"), _f32(comp, "comp"), _f32(acc, "acc"), _f32(med, "med", optional=True),
-                                    _f32(exp, "exp", optional=True), C.c_void_p(state.data_ptr()) if state is not None else None, st), "tn_render_fwd")
+                                    _f32(exp, "exp", optional=True), _f32(scratch, "scratch", optional=True), st), "tn_render_fwd")
     return w, comp, acc, med, exp
 
 
@@ -568,12 +618,7 @@ def interlevel_loss(s_fine: Tensor, w_fine: Tensor, s_prop: Tensor, w_prop: Tens
                                          _stream()), "tn_interlevel_loss")
 
 
-def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, interlevel_mult: float, distortion_out: Tensor,
-                    interlevel_out: Tensor, d_w_fine: Optional[Tensor], pixel=None) -> None:
-    """distortion_loss on the fine level + interlevel_loss against every proposal level, one launch (tn_proposal_losses).
-    props: list of (s_bins [N,Sp+1], weights [N,Sp], d_weights [N,Sp] or None).
-    pixel: None, or the arguments of pixel_losses() as a tuple -- the pixel terms then run in the same launch (tn_train_losses)."""
-    N, Sf = w_fine.shape
+def _prop_level_arrays(props, N: int):
     n = len(props)
     sb = (C.c_void_p * max(n, 1))()
     wp = (C.c_void_p * max(n, 1))()
@@ -586,12 +631,52 @@ def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: floa
         v = _f32(d_p, "d_w_prop", (N, Sp), True)
         dw[i] = v.value if v is not None else None
         sp[i] = Sp
-    head = (_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N, float(distortion_mult), float(interlevel_mult),
-            _f32(distortion_out, "distortion"), _f32(interlevel_out, "interlevel"), _f32(d_w_fine, "d_w_fine", (N, Sf), True))
+    return n, sb, wp, sp, dw
+
+
+def proposal_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, interlevel_mult: float, distortion_out: Tensor,
+                    interlevel_out: Tensor, d_w_fine: Optional[Tensor]) -> None:
+    """distortion_loss on the fine level + interlevel_loss against every proposal level, one launch (tn_proposal_losses).
+    props: list of (s_bins [N,Sp+1], weights [N,Sp], d_weights [N,Sp] or None)."""
+    N, Sf = w_fine.shape
+    n, sb, wp, sp, dw = _prop_level_arrays(props, N)
+    check(_lib.load().tn_proposal_losses(_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N,
+                                         float(distortion_mult), float(interlevel_mult), _f32(distortion_out, "distortion"),
+                                         _f32(interlevel_out, "interlevel"), _f32(d_w_fine, "d_w_fine", (N, Sf), True), _stream()),
+          "tn_proposal_losses")
+
+
+LOSS_LINES = _lib.TN_LOSS_LINES
+
+
+def train_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, interlevel_mult: float, d_w_fine: Optional[Tensor],
+                 loss_lines: Tensor, pixel=None) -> None:
+    """proposal_losses and (pixel != None: the arguments of pixel_losses() without losses_out) the pixel terms in ONE launch, the sums spread
+    over loss_lines [LOSS_LINES,16] (zero-filled by the caller; slots: 0 rgb 1 thermal 2 tv 3 cross 4/5 ray counts 8 interlevel 9 distortion);
+    losses_finish() adds the lines up (tn_train_losses / tn_losses_finish)."""
+    N, Sf = w_fine.shape
+    n, sb, wp, sp, dw = _prop_level_arrays(props, N)
     if pixel is None:
-        check(_lib.load().tn_proposal_losses(*head, _stream()), "tn_proposal_losses")
+        tail = (None, 0, None, 0, None, None, 0.0, 0.0, 0.0, None, None)
     else:
-        check(_lib.load().tn_train_losses(*head, *_pixel_args(*pixel, N=N), _stream()), "tn_train_losses")
+        pr, pt, image, is_th, tm, tvm, cm, d_pr, d_pt = pixel
+        a = _pixel_args(pr, pt, image, is_th, tm, tvm, cm, None, d_pr, d_pt, N=N)
+        tail = a[:9] + a[10:]
+    check(_lib.load().tn_train_losses(_f32(s_fine, "s_fine", (N, Sf + 1)), _f32(w_fine, "w_fine", (N, Sf)), Sf, n, sb, wp, sp, dw, N,
+                                      float(distortion_mult), float(interlevel_mult), _f32(d_w_fine, "d_w_fine", (N, Sf), True), *tail,
+                                      _f32(loss_lines, "loss_lines", (LOSS_LINES, 16)), _stream()), "tn_train_losses")
+
+
+def losses_finish(loss_lines: Tensor, losses16: Tensor, pose: Optional[Tensor] = None, trans_pen: float = 0.0, rot_pen: float = 0.0,
+                  scale: float = 0.0, reg_out: Optional[Tensor] = None, grad_pose: Optional[Tensor] = None) -> None:
+    """losses16[k] += column sums of loss_lines; with `pose` also camera_reg(pose, ...) -> reg_out / grad_pose, same single-block launch."""
+    if losses16.numel() < 16:
+        raise ValueError("losses16 needs 16 floats")
+    Cn = pose.shape[0] if pose is not None else 0
+    check(_lib.load().tn_losses_finish(_f32(loss_lines, "loss_lines", (LOSS_LINES, 16)), _f32(losses16, "losses16"),
+                                       _f32(pose, "pose", (Cn, 6), optional=True), Cn, float(trans_pen), float(rot_pen), float(scale),
+                                       _f32(reg_out, "reg_out", optional=True), _f32(grad_pose, "grad_pose", (Cn, 6), True), _stream()),
+          "tn_losses_finish")
 
 
 def _pixel_args(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float,
@@ -604,14 +689,14 @@ def _pixel_args(pred_rgb: Tensor, pred_thermal: Tensor, image: Tensor, is_therma
         raise ValueError("predictions must be CUDA float32")
     if pred_rgb.stride(1) != 1 or pred_thermal.stride(1) != 1 or pred_rgb.shape != (n, 3) or pred_thermal.shape != (n, 1):
         raise ValueError("bad prediction views")
-    if losses_out.numel() < 8:
+    if losses_out is not None and losses_out.numel() < 8:
         raise ValueError("losses_out needs 8 floats")
     for g, p in ((d_pred_rgb, pred_rgb), (d_pred_thermal, pred_thermal)):
         if g is not None and (g.stride() != p.stride() or g.shape != p.shape or g.dtype != torch.float32):
             raise ValueError("gradient views must mirror the prediction views")
     return (C.c_void_p(pred_rgb.data_ptr()), pred_rgb.stride(0), C.c_void_p(pred_thermal.data_ptr()), pred_thermal.stride(0),
             _f32(image, "image", (n, 3)), _f32(is_thermal, "is_thermal", (n,)), float(thermal_mult), float(tv_mult), float(cross_mult),
-            _f32(losses_out, "losses"), C.c_void_p(d_pred_rgb.data_ptr()) if d_pred_rgb is not None else None,
+            _f32(losses_out, "losses", optional=True), C.c_void_p(d_pred_rgb.data_ptr()) if d_pred_rgb is not None else None,
             C.c_void_p(d_pred_thermal.data_ptr()) if d_pred_thermal is not None else None)
 
 

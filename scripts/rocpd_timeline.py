@@ -20,7 +20,7 @@ def main():
     lane = [c for c in ("stream_id", "queue_id", "stream", "queue", "tid") if c in cols]
     sel = ", ".join(["name", "start", "end"] + lane)
     rows = con.execute(f"select {sel} from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if r[0].startswith("k_sample_pixels")]
+    marks = [i for i, r in enumerate(rows) if r[0].startswith(("k_sample_pixels", "k_sample_rays"))]
     if len(marks) < back + 1:
         print("not enough steps in the trace", len(marks))
         return

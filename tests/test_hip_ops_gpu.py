@@ -426,8 +426,8 @@ def test_proposal_losses():
 @pytest.mark.parametrize("C,S,N,training", [(4, 48, 4096, True), (4, 48, 257, False), (3, 96, 130, True), (1, 256, 66, True), (4, 48, 70001, True)])
 def test_render_fwd_bwd_is_the_separate_launches(C, S, N, training):
     """tn_render_fwd / tn_render_bwd (one launch each) against tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth and
-    tn_composite_bwd + tn_weights_bwd: bit-identical, including the batch-global depth clip done by the last block (N <= 65536) or by the
-    follow-up launch (larger batches), and the state buffer left zero for the next call."""
+    tn_composite_bwd + tn_weights_bwd: bit-identical, including the batch-global depth clip (per-block min / max pairs reduced by the
+    follow-up launch), for batches below and above one round of blocks."""
     gen = torch.Generator().manual_seed(5 + S)
     nears = torch.full((N, 1), 0.05) + 0.3 * torch.rand((N, 1), generator=gen)
     fars = torch.full((N, 1), 50.0) + 900.0 * torch.rand((N, 1), generator=gen)
@@ -439,11 +439,10 @@ def test_render_fwd_bwd_is_the_separate_launches(C, S, N, training):
     he, hd, hr = g(e), g(dens), g(rgb)
     w_ref, _ = ops.weights_fwd(he, hd)
     c_ref, a_ref, m_ref, x_ref = ops.composite_fwd(hr, w_ref, he, training)
-    for rep in range(2):  # the second call finds the state as the first one left it
+    for rep in range(2):  # the second call finds the scratch as the first one left it
         w, c, a, m, x = ops.render_fwd(he, hd, hr, training)
         for got, ref in ((w, w_ref), (c, c_ref), (a, a_ref), (m, m_ref), (x, x_ref)):
             assert torch.equal(got.nan_to_num(nan=-7.0), ref.nan_to_num(nan=-7.0))
-        assert all(int(v) == 0 for st in ops._RENDER_STATE.values() for v in st.cpu())
     # the clip really is batch-global: expected depths lie inside [min midpoint, max midpoint] of the whole batch
     mid = (e[:, 1:] + e[:, :-1]) / 2
     assert float(x.min()) >= float(mid.min()) and float(x.max()) <= float(mid.max())
@@ -463,7 +462,8 @@ def test_render_fwd_bwd_is_the_separate_launches(C, S, N, training):
 
 
 def test_train_losses_one_launch_equals_two():
-    """tn_train_losses = tn_proposal_losses + tn_pixel_losses in one launch: same gradients bit for bit, same sums up to atomic order."""
+    """tn_train_losses (+ tn_losses_finish) = tn_proposal_losses + tn_pixel_losses in one launch: same gradients bit for bit, same sums up to
+    the order of the additions."""
     N = 512
     gen = torch.Generator().manual_seed(11)
     nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
@@ -485,19 +485,32 @@ def test_train_losses_one_launch_equals_two():
 
     def run(fused: bool):
         L = torch.zeros(16, device=DEV)
+        Lp = torch.zeros((ops.LOSS_LINES, 16), device=DEV)
         d0, d1, d2, dp = torch.zeros_like(ws[0]), torch.zeros_like(ws[1]), torch.zeros_like(ws[2]), torch.zeros_like(pred)
-        pixel = (pred[:, :3], pred[:, 3:], img, is_th, 100.0, 1e-3, 1e-3, L[0:8], dp[:, :3], dp[:, 3:])
-        if not fused:
-            ops.pixel_losses(*pixel)
-        ops.proposal_losses(sb[2], ws[2], [(sb[0], ws[0], d0), (sb[1], ws[1], d1)], 0.002, 1.0, L[9:10], L[8:9], d2, pixel=pixel if fused else None)
+        props = [(sb[0], ws[0], d0), (sb[1], ws[1], d1)]
+        if fused:
+            ops.train_losses(sb[2], ws[2], props, 0.002, 1.0, d2, Lp, pixel=(pred[:, :3], pred[:, 3:], img, is_th, 100.0, 1e-3, 1e-3, dp[:, :3], dp[:, 3:]))
+            ops.losses_finish(Lp, L)
+        else:
+            ops.pixel_losses(pred[:, :3], pred[:, 3:], img, is_th, 100.0, 1e-3, 1e-3, L[0:8], dp[:, :3], dp[:, 3:])
+            ops.proposal_losses(sb[2], ws[2], props, 0.002, 1.0, L[9:10], L[8:9], d2)
         return L, (d0, d1, d2, dp)
 
     La, ga = run(False)
     Lb, gb = run(True)
     for a, b in zip(ga, gb):
         assert torch.equal(a, b)
-    assert float((La - Lb).abs().max()) <= 1e-6 * float(La.abs().max())
+    assert float((La - Lb).abs().max()) <= 2e-6 * float(La.abs().max())
     assert float(Lb[4]) + float(Lb[5]) == N
+    # the finisher also evaluates the camera regulariser (same arithmetic as tn_camera_reg) and ACCUMULATES into the loss vector
+    pose = g(torch.from_numpy(synth.uniform("pose_f", (8, 6), -0.01, 0.01, SEED)))
+    r1, g1 = torch.zeros(1, device=DEV), torch.zeros((8, 6), device=DEV)
+    ops.camera_reg(pose, 1e-2, 1e-3, 1.0, r1, g1)
+    L2, g2 = Lb.clone(), torch.zeros((8, 6), device=DEV)
+    Lp = torch.zeros((ops.LOSS_LINES, 16), device=DEV)
+    Lp[5, 9] = 0.25
+    ops.losses_finish(Lp, L2, pose, 1e-2, 1e-3, 1.0, L2[11:12], g2)
+    assert torch.equal(g1, g2) and float(L2[11]) == float(r1) and abs(float(L2[9]) - float(Lb[9]) - 0.25) <= 1e-7
 
 
 def test_interlevel_gradient_on_unsorted_bins_falls_back_to_the_full_walk():
@@ -531,6 +544,49 @@ def test_interlevel_gradient_on_unsorted_bins_falls_back_to_the_full_walk():
     ops.interlevel_loss(g(c), g(wf), g(cp), g(wp), 1.0, loss, dw)
     assert abs(float(loss) - total * float(scale)) <= 1e-5 * total * float(scale)
     assert float((dw.cpu().double() - torch.from_numpy(ref)).abs().max()) <= 1e-5 * float(np.abs(ref).max())
+
+
+def test_fused_first_and_last_launches_equal_the_separate_ones(golden_dir):
+    """tn_sample_rays = tn_sample_pixels + tn_raygen, tn_pose_spaced_bins = tn_pose_apply_fwd + tn_spaced_bins (bit-identical);
+    tn_pose_bwd_finish = tn_pose_apply_bwd + tn_camera_reg + tn_losses_finish (same sums up to the order of the atomic additions)."""
+    gen = torch.Generator().manual_seed(21)
+    cams = synth.synth_cameras()
+    cam_t = {k: g(torch.from_numpy(np.ascontiguousarray(v))) for k, v in cams.items() if k in ("c2w", "fx", "fy", "cx", "cy", "distortion")}
+    Cn = cam_t["c2w"].shape[0]
+    H, W = 20, 28
+    images = [torch.rand((H + i, W + 2 * i, 3), generator=gen) for i in range(Cn)]
+    cache = ops.ImageCache.build(images, torch.tensor([i % 2 for i in range(Cn)], dtype=torch.float32), torch.arange(Cn), DEV)
+    N = 8 * 36
+    u = g(torch.rand((N // 4, 3), generator=gen))
+    idx, img, is_th, cam = ops.sample_pixels(cache, N, u, 2, want_camera_indices=True)
+    o, d, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t.get("distortion"))
+    o2, d2, cam2, img2, is_th2, idx2 = ops.sample_rays(cache, N, u, cam_t, 2)
+    for a, b in ((o, o2), (d, d2), (cam, cam2), (img, img2), (is_th, is_th2), (idx, idx2)):
+        assert torch.equal(a, b)
+    pose = g(torch.from_numpy(synth.uniform("pose_fl", (Cn, 6), -0.02, 0.02, SEED)))
+    frozen = g(torch.tensor([0, 1] * (Cn // 2), dtype=torch.uint8))
+    nears, fars, jit = g(torch.full((N,), 0.05)), g(torch.full((N,), 1000.0)), g(torch.rand(N, generator=gen))
+    po, pd = ops.pose_apply_fwd(pose, frozen, cam, o, d)
+    s, e = ops.spaced_bins(nears, fars, 256, jit)
+    po2, pd2, s2, e2 = ops.pose_spaced_bins(pose, frozen, cam, o, d, nears, fars, 256, jit)
+    for a, b in ((po, po2), (pd, pd2), (s, s2), (e, e2)):
+        assert torch.equal(a, b)
+    g_o, g_d = g(torch.rand((N, 3), generator=gen) - 0.5), g(torch.rand((N, 3), generator=gen) - 0.5)
+    gp1, L1 = torch.zeros((Cn, 6), device=DEV), torch.zeros(16, device=DEV)
+    Lp = g(torch.rand((ops.LOSS_LINES, 16), generator=gen))
+    ops.pose_apply_bwd(pose, frozen, cam, d, g_o, g_d, gp1)
+    ops.camera_reg(pose, 1e-2, 1e-3, 1.0, L1[11:12], gp1)
+    ops.losses_finish(Lp, L1)
+    gp2, L2 = torch.zeros((Cn, 6), device=DEV), torch.zeros(16, device=DEV)
+    ops.pose_bwd_finish(pose, frozen, cam, d, g_o, g_d, gp2, 1e-2, 1e-3, 1.0, L2[11:12], Lp, L2)
+    assert float((gp1 - gp2).abs().max()) <= 1e-6 * float(gp1.abs().max())
+    assert float((L1 - L2).abs().max()) <= 1e-6 * float(L1.abs().max())
+    assert float((L1[:11].cpu() - Lp.cpu().sum(0)[:11]).abs().max()) <= 1e-5
+    gp3, L3 = torch.zeros((Cn, 6), device=DEV), torch.zeros(16, device=DEV)
+    ops.pose_bwd_finish(pose, frozen, cam, d, g_o, g_d, gp3, 1e-2, 1e-3, 1.0, L3[12:13])  # second pose tensor of separate mode: no loss lines
+    reg_only = torch.zeros(1, device=DEV)
+    ops.camera_reg(pose, 1e-2, 1e-3, 1.0, reg_only, None)
+    assert float((gp1 - gp3).abs().max()) <= 1e-6 * float(gp1.abs().max()) and float(L3[12]) == float(reg_only) and float(L3[:11].abs().max()) == 0.0
 
 
 def test_pixel_losses_l1_camera_reg():
