@@ -21,10 +21,11 @@ class DeviceDataManager:
         self.prefetch = prefetch
         self._side = side_stream
         self._pending: Optional[Tuple[Tuple[Tensor, ...], torch.cuda.Event]] = None
+        self._rand = ops.UniformPool(self.device)
 
     def _make(self) -> Tuple[Tensor, ...]:
         n = self.num_rays
-        u = torch.rand((n // (self.patch * self.patch), 3), device=self.device)  # what PatchPixelSampler draws with torch.rand
+        u = self._rand.take((n // (self.patch * self.patch), 3))  # what PatchPixelSampler draws with torch.rand (drawn 32 steps at a time)
         o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch)  # pixel sampler + GT gather + raygen: one launch
         return o, d, cam, img, is_th
 

@@ -100,6 +100,13 @@ class RenderEngine:
             side[i] = torch.cuda.Stream(device=self.device)
         return side[i]
 
+    def _uniforms(self) -> "ops.UniformPool":
+        """The samplers' per-ray jitter (ray_samplers.py:104-110, 322-330: torch.rand per call), drawn for 32 requests at a time."""
+        pool = self.__dict__.get("_rand")
+        if pool is None:
+            pool = self.__dict__["_rand"] = ops.UniformPool(self.device)
+        return pool
+
     # ---------------------------------------------------------------- sampler schedule
     def update_schedule(self, step: int) -> float:
         c = self.cfg
@@ -197,7 +204,7 @@ class RenderEngine:
         N = origins.shape[0]
         nears, fars = self._nears_fars(N, training)
         if training and jitters is None:
-            jitters = list(torch.rand((3, N), device=self.device).unbind(0))
+            jitters = list(self._uniforms().take((3, N)).unbind(0))
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
         b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
                                jitters, prop_grad=updated)
@@ -213,7 +220,7 @@ class RenderEngine:
             out["rgb_thermal"] = rgbt[..., 3:]
             return out, branches
         if training and jitters_thermal is None:
-            jitters_thermal = list(torch.rand((3, N), device=self.device).unbind(0))
+            jitters_thermal = list(self._uniforms().take((3, N)).unbind(0))
         # thermal sampler: never receives step_cb -> anneal stays 1.0 and always "updated" (models/thermal_nerfacto.py:222-250)
         bt = self.render_branch(self.props_thermal, self.field_thermal, self.pose_thermal, self.frozen_thermal, origins, directions, cam, nears, fars,
                                 training, 1.0, jitters_thermal, prop_grad=True)

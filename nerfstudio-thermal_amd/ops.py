@@ -178,6 +178,29 @@ class FieldParams:
         return cur
 
 
+class UniformPool:
+    """torch.rand in bulk: the per-step uniforms of the training loop (pixel sampler: [N/4,3]; sampler jitter: [3,N]) are a few KB each, and a
+    launch for a few KB costs what a launch costs (~5 us on the step's serial chain).  take(shape) hands out fresh, never-reused slices of a
+    buffer drawn `steps` requests at a time by ONE torch.rand call; every refill is a new allocation, so earlier slices stay valid."""
+
+    def __init__(self, device, steps: int = 32):
+        self.device, self.steps = device, int(steps)
+        self._buf: Optional[Tensor] = None
+        self._pos = 0
+
+    def take(self, shape) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        span = (n + 63) // 64 * 64  # 256-byte aligned slices
+        if self._buf is None or self._pos + span > self._buf.numel():
+            self._buf = torch.rand(max(span * self.steps, span), device=self.device)
+            self._pos = 0
+        out = self._buf[self._pos:self._pos + n].view(*shape)
+        self._pos += span
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ N2 pixel sampling
 @dataclass
 class ImageCache:

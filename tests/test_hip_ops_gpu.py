@@ -799,8 +799,9 @@ def test_device_data_manager_batches(golden_dir):
         got = [dm.next_train(i) for i in range(3)]
         torch.cuda.synchronize()
         torch.manual_seed(11)
+        pool = ops.UniformPool(DEV)  # the manager draws its uniforms through one of these (one torch.rand per 32 batches)
         for o, d, cam, img, is_th in got:
-            u = torch.rand((64, 3), device=DEV)
+            u = pool.take((64, 3))
             idx, img_r, th_r, cam_r = ops.sample_pixels(cache, 256, u, 2, want_camera_indices=True)
             o_r, d_r, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
             for a, r in ((o, o_r), (d, d_r), (cam, cam_r), (img, img_r), (is_th, th_r)):
