@@ -152,8 +152,8 @@ class LossSpec:
 class TrainLosses(torch.autograd.Function):
     """EVERY loss term of a training iteration (models/thermal_nerfacto.py:253-388) as one autograd node, through the same launches as the
     fused step (engine.RenderEngine.loss_and_backward): tn_train_losses per branch (distortion + both interlevel terms, the pixel terms in the
-    first one), tn_l1_loss x2 (density cross terms), tn_losses_finish (sums + camera regulariser), tn_camera_reg for a second pose tensor.  Every kernel yields value AND gradient; all gradient buffers come out of
-    one zero-filled allocation, and backward scales that allocation once by the incoming gradient -- the Trainer sums the loss dict
+    first one), tn_l1_loss x2 (density cross terms), tn_losses_finish (sums + camera regulariser), tn_camera_reg for a second pose tensor.
+    Every kernel yields value AND gradient; all gradient buffers come out of one zero-filled allocation, and backward scales that allocation once by the incoming gradient -- the Trainer sums the loss dict
     (engine/trainer.py:483), so all terms arrive with the same weight; anything else is refused (use the *_loss_mult settings).
 
     inputs : spec, image [N,3], is_thermal [N], then per branch (comp, w0, w1, w2), then (density2, density_thermal, density,

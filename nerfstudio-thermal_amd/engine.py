@@ -6,6 +6,7 @@ Everything here is launch plumbing; the arithmetic lives in libthermal_nerf_hip.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -18,8 +19,9 @@ from .arena import ParamArena
 from .config import ThermalNerfactoModelConfig
 from .netparams import field_params, prop_params
 
-import os as _os
-_FUSE = _os.environ.get("TN_FUSE_SMALL", "1") != "0"  # timing experiments: 0 = one launch per op (weights / composite / clip / pixel losses)
+# timing experiments: TN_FUSE_SMALL=0 runs the small operators through one entry point per reference seam (tn_weights_fwd, tn_composite_fwd,
+# tn_clip_depth, tn_pixel_losses, tn_proposal_losses, tn_pose_apply_fwd/bwd, tn_camera_reg) instead of the fused launches
+_FUSE = os.environ.get("TN_FUSE_SMALL", "1") != "0"
 
 
 @dataclass
