@@ -237,6 +237,23 @@ int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, i
 int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
                   const float* d_weights_in, int64_t N, int32_t S, int32_t C, float* d_rgb, float* d_density, tn_stream_t stream);
 
+/* ---- a5..a17 in ONE call: the no-grad render of one branch (a sampler with two proposal networks + a field), i.e.
+ * ThermalNerfactoModel.get_outputs at inference (models/nerfacto.py:299-353 via models/thermal_nerfacto.py:403-445; ProposalNetworkSampler
+ * model_components/ray_samplers.py:577-618 without jitter; mean appearance embedding; "last_sample" background; depth clip).  The library
+ * enqueues tn_spaced_bins -> tn_prop_density_fwd -> tn_weights_resample -> tn_prop_density_fwd -> tn_weights_resample ->
+ * tn_field_pack_weights + tn_field_fwd -> tn_render_fwd itself: same kernels, same results as those calls made one by one.
+ * nears / fars [N]; lin_spaced0 [S0+1] = linspace(0,1,S0+1), lin_pdf_k [S_k+1] = linspace(0, 1 - 1/(S_k+1), S_k+1) as the reference builds
+ * them on the host; anneal = the sampler's current histogram-padding exponent.  Outputs: rgb [N,C], density [N,S2] (required);
+ * accumulation, depth_median, depth_expected, prop_depth0/1 [N], e_bins_out [N,S2+1], rgb_samples_out [N,S2,C] (each may be NULL).
+ * workspace: tn_render_rays_eval_workspace_bytes(N, S0, S1, S2, C) bytes, 256-byte aligned. */
+int64_t tn_render_rays_eval_workspace_bytes(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
+int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+                        const float* directions, const int64_t* camera_indices, const float* nears, const float* fars, int64_t N,
+                        int32_t S0, int32_t S1, int32_t S2, float anneal, const float* lin_spaced0, const float* lin_pdf1,
+                        const float* lin_pdf2, void* workspace, float* rgb, float* accumulation, float* depth_median,
+                        float* depth_expected, float* prop_depth0, float* prop_depth1, float* density, float* e_bins_out,
+                        float* rgb_samples_out, tn_stream_t stream);
+
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
 int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,

@@ -85,6 +85,9 @@ SIGNATURES = {
     "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "tn_clip_depth": (C.c_int, [_p, _p, _i64, _p]),
     "tn_composite_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "tn_render_rays_eval_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32]),
+    "tn_render_rays_eval": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f,
+                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),

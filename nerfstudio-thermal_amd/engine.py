@@ -164,6 +164,16 @@ class RenderEngine:
         return Branch(origins=origins, directions=directions, origins_in=o_in, directions_in=d_in, levels=levels, rgb_samples=rgb, comp=comp,
                       accumulation=acc, depth=med, expected_depth=exp, prop_grad=prop_grad)
 
+    def render_branch_eval(self, props, fld, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor, anneal: float) -> Branch:
+        """render_branch at inference as ONE call of the C ABI (tn_render_rays_eval: the library enqueues the launches back to back)."""
+        r = ops.render_rays_eval(props, fld, origins, directions, cam, nears, fars, self.counts, anneal)
+        med = [r["prop_depth_0"], r["prop_depth_1"], r["depth"]]
+        levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=med[i])
+                  for i, (S, lv) in enumerate(zip(self.counts, r["levels"]))]
+        return Branch(origins=origins, directions=directions, origins_in=origins, directions_in=directions, levels=levels,
+                      rgb_samples=r["rgb_samples"], comp=r["rgb"], accumulation=r["accumulation"], depth=r["depth"],
+                      expected_depth=r["expected_depth"], prop_grad=False)
+
     def _nears_fars(self, N: int, training: bool):
         near = self.cfg.near_plane if training else 0.0  # NearFarCollider resets the near plane at inference (scene_colliders.py:186-191)
         key = (N, bool(training))
@@ -208,8 +218,11 @@ class RenderEngine:
         if training and jitters is None:
             jitters = list(self._uniforms().take((3, N)).unbind(0))
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
-        b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
-                               jitters, prop_grad=updated)
+        if not training and _FUSE:
+            b = self.render_branch_eval(self.props, self.field, origins, directions, cam, nears, fars, self.anneal)
+        else:
+            b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
+                                   jitters, prop_grad=updated)
         self.last_updated = bool(updated)  # did the proposal networks of the RGB sampler get gradients in this forward?
         if updated:  # eval renders included, as ProposalNetworkSampler.generate_ray_samples does (ray_samplers.py:612-613)
             self.steps_since_update = 0
@@ -224,8 +237,11 @@ class RenderEngine:
         if training and jitters_thermal is None:
             jitters_thermal = list(self._uniforms().take((3, N)).unbind(0))
         # thermal sampler: never receives step_cb -> anneal stays 1.0 and always "updated" (models/thermal_nerfacto.py:222-250)
-        bt = self.render_branch(self.props_thermal, self.field_thermal, self.pose_thermal, self.frozen_thermal, origins, directions, cam, nears, fars,
-                                training, 1.0, jitters_thermal, prop_grad=True)
+        if not training and _FUSE:
+            bt = self.render_branch_eval(self.props_thermal, self.field_thermal, origins, directions, cam, nears, fars, 1.0)
+        else:
+            bt = self.render_branch(self.props_thermal, self.field_thermal, self.pose_thermal, self.frozen_thermal, origins, directions, cam, nears,
+                                    fars, training, 1.0, jitters_thermal, prop_grad=True)
         out.update(self._branch_outputs(bt, "_thermal", training))
         branches["_thermal"] = bt
         if self.cfg.density_loss_mult > 0 or not training:

@@ -588,6 +588,55 @@ def composite_bwd(rgb: Tensor, weights: Tensor, d_comp: Tensor, d_weights: Tenso
     return d_rgb
 
 
+def render_rays_eval(props: Sequence[PropNetParams], fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
+                     counts: Sequence[int], anneal: float):
+    """The inference render of one branch in ONE library call (tn_render_rays_eval): proposal sampling, field, weights, renderers.
+    -> dict(rgb [N,C], accumulation [N,1], depth [N,1], expected_depth [N,1], prop_depth_0/1 [N,1], density [N,S2], e_bins [N,S2+1],
+    rgb_samples [N,S2,C])."""
+    N = origins.shape[0]
+    S0, S1, S2 = (int(c) for c in counts)
+    Cc = fld.num_channels
+    dev = origins.device
+    lib = _lib.load()
+    need = int(lib.tn_render_rays_eval_workspace_bytes(N, S0, S1, S2, Cc))
+    if need < 0:
+        raise ValueError("render_rays_eval: unsupported sample counts / channels")
+    # a fresh buffer per call (the caching allocator recycles it): the per-level tensors returned below are views of it
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = {"rgb": torch.empty((N, Cc), device=dev), "accumulation": torch.empty((N, 1), device=dev), "depth": torch.empty((N, 1), device=dev),
+           "expected_depth": torch.empty((N, 1), device=dev), "prop_depth_0": torch.empty((N, 1), device=dev),
+           "prop_depth_1": torch.empty((N, 1), device=dev), "density": torch.empty((N, S2), device=dev),
+           "e_bins": torch.empty((N, S2 + 1), device=dev), "rgb_samples": torch.empty((N, S2, Cc), device=dev)}
+    p0, p1, f = props[0].cstruct(), props[1].cstruct(), fld.cstruct()
+    check(lib.tn_render_rays_eval(C.byref(p0), C.byref(p1), C.byref(f), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
+                                  _i64(cam, "camera_indices", (N,)), _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S0, S1, S2,
+                                  float(anneal), _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"),
+                                  _f32(_lin_table("pdf", S2, dev), "u2"), C.c_void_p(ws.data_ptr()), _f32(out["rgb"], "rgb"), _f32(out["accumulation"], "acc"),
+                                  _f32(out["depth"], "depth"), _f32(out["expected_depth"], "exp"), _f32(out["prop_depth_0"], "pd0"),
+                                  _f32(out["prop_depth_1"], "pd1"), _f32(out["density"], "density"), _f32(out["e_bins"], "e_bins"),
+                                  _f32(out["rgb_samples"], "rgb_samples"), _stream()), "tn_render_rays_eval")
+    # the sampler's intermediate levels live in the workspace, in the order tn_render_rays_eval lays them out (csrc/tn_pipeline.hip,
+    # eval_layout: every region rounded up to 256 bytes): s_bins, e_bins, density, weights of level 0, the same of level 1, s_bins of level 2,
+    # (its e_bins: returned above), weights of level 2
+    off = 0
+
+    def view(rows, cols):
+        nonlocal off
+        n = rows * cols
+        t = ws[off:off + 4 * n].view(torch.float32).view(rows, cols)
+        off += (4 * n + 255) // 256 * 256
+        return t
+
+    lv = []
+    for S in (S0, S1):
+        lv.append({"s_bins": view(N, S + 1), "e_bins": view(N, S + 1), "density": view(N, S), "weights": view(N, S)})
+    s2 = view(N, S2 + 1)
+    view(N, S2 + 1)  # e_bins of level 2 inside the workspace: unused, the caller's tensor received them
+    lv.append({"s_bins": s2, "e_bins": out["e_bins"], "density": out["density"], "weights": view(N, S2)})
+    out["levels"] = lv
+    return out
+
+
 _RENDER_SCRATCH: dict = {}
 
 

@@ -347,6 +347,31 @@ def test_render_psnr_vs_oracle():
         assert md(out[key], refv) <= 1e-3
 
 
+@pytest.mark.parametrize("mode,N", [("shared", 512), ("separate", 130)])
+def test_render_rays_eval_is_the_launch_sequence(mode, N):
+    """tn_render_rays_eval (one library call: bins -> proposal nets -> resampling -> field -> weights -> renderers) gives bit for bit what the
+    same entry points give when the engine calls them one by one, for every output key of the inference render, in both density modes."""
+    from nerfstudio_thermal_amd.engine import RenderEngine
+
+    ocfg, params, cfg, arena = setup_pair(mode)
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    r = rays(N)
+    o, d = g(r["origins"]), g(r["directions"])
+    cam = g(torch.arange(N, dtype=torch.int64) % ocfg.num_images)
+    nears, fars = eng._nears_fars(N, False)
+    for props, fld, anneal in ((eng.props, eng.field, 0.37),) + (((eng.props_thermal, eng.field_thermal, 1.0),) if mode == "separate" else ()):
+        a = eng.render_branch(props, fld, None, None, o, d, cam, nears, fars, False, anneal, None, prop_grad=False)
+        b = eng.render_branch_eval(props, fld, o, d, cam, nears, fars, anneal)
+        for name in ("comp", "accumulation", "depth", "expected_depth", "rgb_samples"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x.nan_to_num(nan=-7.0), y.nan_to_num(nan=-7.0)), name
+        for la, lb in zip(a.levels, b.levels):
+            for name in ("s_bins", "e_bins", "density", "weights", "median"):
+                assert torch.equal(getattr(la, name), getattr(lb, name)), name
+    out, _ = eng.get_outputs(o, d, cam, training=False)  # the engine's inference path goes through the single call
+    assert out["rgb"].shape == (N, 3) and out["density"].shape == (N, 48, 1) and torch.isfinite(out["expected_depth"]).all()
+
+
 # ------------------------------------------------------------------------------------------------ renderers and losses
 @pytest.mark.parametrize("C,S,training", [(4, 48, False), (4, 48, True), (3, 48, True), (1, 96, False), (4, 256, True)])
 def test_composite_fwd_bwd(C, S, training):
