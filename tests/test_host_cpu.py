@@ -135,3 +135,23 @@ def test_method_plugin_object():
     cfg = spec.config.pipeline.model if hasattr(spec, "config") else spec.model
     assert isinstance(cfg, ThermalNerfactoModelConfig) and cfg.camera_optimizer.mode == "SO3xR3"
     cfg.validate_for_hip()
+
+
+def test_uniform_pool_hands_out_fresh_disjoint_slices():
+    """ops.UniformPool: one torch.rand per `steps` requests, slices never overlap, never repeat, stay valid across a refill, and the sequence
+    is a function of the seed alone (what lets a test replay the data manager's draws)."""
+    from nerfstudio_thermal_amd.ops import UniformPool
+
+    torch.manual_seed(5)
+    pool = UniformPool("cpu", steps=4)
+    got = [pool.take((3, 50)) for _ in range(9)]  # 9 requests of 150 floats (192-float spans): refills after every 4
+    for t in got:
+        assert t.shape == (3, 50) and t.is_contiguous() and float(t.min()) >= 0.0 and float(t.max()) < 1.0
+    ptrs = sorted((t.data_ptr(), t.data_ptr() + 4 * t.numel()) for t in got)
+    assert all(a_end <= b for (_, a_end), (b, _) in zip(ptrs, ptrs[1:]))  # disjoint storage, also across refills (new allocations)
+    keep = got[0].clone()
+    pool.take((1000,))  # larger than a span: forces a refill of its own size
+    assert torch.equal(got[0], keep)
+    torch.manual_seed(5)
+    again = UniformPool("cpu", steps=4)
+    assert all(torch.equal(a, again.take((3, 50))) for a in got)
