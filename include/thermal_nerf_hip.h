@@ -254,6 +254,23 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
                         float* depth_expected, float* prop_depth0, float* prop_depth1, float* density, float* e_bins_out,
                         float* rgb_samples_out, tn_stream_t stream);
 
+/* The same for TRAINING: one call = CameraOptimizer.apply_to_raybundle (pose_adjustment may be NULL) + ProposalNetworkSampler with jitter
+ * (jitter_k [N] or NULL per level) + Field.forward with the activations kept in field_workspace (tn_field_workspace_bytes(N*S2, 1)) for
+ * tn_field_bwd + get_weights + renderers.  Launches: tn_pose_spaced_bins, tn_prop_density_fwd, tn_weights_resample, tn_prop_density_fwd,
+ * tn_weights_resample, tn_field_pack_weights, tn_field_fwd(training), tn_render_fwd(training): results identical to those calls.
+ * Everything later stages need goes into ONE buffer `out` (256-byte aligned); tn_render_rays_train_layout fills offsets[] (floats) with the
+ * position of: 0 origins 1 directions (pose-corrected; unused when pose_adjustment is NULL) | 2 s_bins0 3 e_bins0 4 density0 5 weights0
+ * 6 median0 | 7..11 the same for level 1 | 12 s_bins2 13 e_bins2 14 density2 15 weights2 | 16 rgb_samples [N,S2,C] 17 comp [N,C]
+ * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS. */
+#define TN_RENDER_TRAIN_OFFSETS 23
+int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
+int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
+                         const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
+                         const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
+                         int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
+                         const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace, float* out,
+                         tn_stream_t stream);
+
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
 int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,

@@ -15,6 +15,7 @@ TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
 TN_LOSS_LINES = 64
+TN_RENDER_TRAIN_OFFSETS = 23
 TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD = 1, 2, 4, 8, 16
 
 _p = C.c_void_p
@@ -88,6 +89,9 @@ SIGNATURES = {
     "tn_render_rays_eval_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "tn_render_rays_eval": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f,
                                       _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "tn_render_rays_train_layout": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _i32]),
+    "tn_render_rays_train": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32,
+                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),

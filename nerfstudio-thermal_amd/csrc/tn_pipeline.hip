@@ -65,3 +65,79 @@ extern "C" int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop
   if ((rc = tn_field_fwd(field, origins, directions, camera_indices, e2, N, S2, 0, w.field_ws, density, rgb_s, nullptr, stream))) return rc;
   return tn_render_fwd(e2, density, rgb_s, N, S2, C, 0, w.w2, rgb, accumulation, depth_median, depth_expected, w.scratch, stream);
 }
+
+// ---- the TRAINING forward of one branch as one call: pose correction + level-0 bins, the two proposal levels (density -> weights + PDF
+// resampling with jitter), the field with its activations kept for tn_field_bwd, get_weights + renderers.  Everything a backward pass or a
+// loss needs later is written into ONE caller-provided buffer; tn_render_rays_train_layout gives the float offset of every tensor in it.
+// Slots of the offsets array:
+enum {
+  TRO_ORIGINS = 0, TRO_DIRECTIONS,                       // [N,3] pose-corrected rays (the inputs themselves when pose_adjustment == NULL)
+  TRO_S0, TRO_E0, TRO_D0, TRO_W0, TRO_M0,                // level 0: s_bins, e_bins [N,S0+1], density, weights [N,S0], median depth [N]
+  TRO_S1, TRO_E1, TRO_D1, TRO_W1, TRO_M1,                // level 1
+  TRO_S2, TRO_E2, TRO_D2, TRO_W2,                        // level 2 (field)
+  TRO_RGB_SAMPLES, TRO_COMP, TRO_ACC, TRO_DEPTH, TRO_EXPECTED, TRO_SCRATCH, TRO_END,
+  TRO_COUNT
+};
+static void train_layout(int64_t N, int S0, int S1, int S2, int C, int64_t* off) {
+  int64_t o = 0;
+  auto take = [&](int slot, int64_t floats) { off[slot] = o; o += (floats + 63) / 64 * 64; };  // 256-byte aligned regions
+  take(TRO_ORIGINS, N * 3); take(TRO_DIRECTIONS, N * 3);
+  take(TRO_S0, N * (S0 + 1)); take(TRO_E0, N * (S0 + 1)); take(TRO_D0, N * S0); take(TRO_W0, N * S0); take(TRO_M0, N);
+  take(TRO_S1, N * (S1 + 1)); take(TRO_E1, N * (S1 + 1)); take(TRO_D1, N * S1); take(TRO_W1, N * S1); take(TRO_M1, N);
+  take(TRO_S2, N * (S2 + 1)); take(TRO_E2, N * (S2 + 1)); take(TRO_D2, N * S2); take(TRO_W2, N * S2);
+  take(TRO_RGB_SAMPLES, N * (int64_t)S2 * C); take(TRO_COMP, N * C); take(TRO_ACC, N); take(TRO_DEPTH, N); take(TRO_EXPECTED, N);
+  take(TRO_SCRATCH, TN_RENDER_SCRATCH_FLOATS);
+  off[TRO_END] = o;
+}
+
+extern "C" int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets) {
+  TN_REQUIRE(offsets != nullptr && num_offsets >= TRO_COUNT, "tn_render_rays_train_layout: offsets needs %d entries", (int)TRO_COUNT);
+  TN_REQUIRE(num_rays >= 0 && S0 >= 1 && S1 >= 1 && S2 >= 1 && S0 <= TN_MAX_SAMPLES && S1 <= TN_MAX_SAMPLES && S2 <= TN_MAX_SAMPLES && C >= 1 && C <= 4,
+             "tn_render_rays_train_layout: bad argument");
+  train_layout(num_rays, S0, S1, S2, C, offsets);
+  return TN_OK;
+}
+
+extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
+                                    const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
+                                    const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
+                                    int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
+                                    const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
+                                    float* out, tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
+                 field_workspace && out,
+             "tn_render_rays_train: null pointer");
+  TN_REQUIRE(N > 0 && S0 >= 1 && S1 >= 1 && S2 >= 1 && S0 <= TN_MAX_SAMPLES && S1 <= TN_MAX_SAMPLES && S2 <= TN_MAX_SAMPLES,
+             "tn_render_rays_train: bad N=%lld S=(%d, %d, %d)", (long long)N, S0, S1, S2);
+  TN_REQUIRE(((uintptr_t)out % 256) == 0, "tn_render_rays_train: the output buffer must be 256-byte aligned");
+  const int C = field->num_channels;
+  int64_t off[TRO_COUNT];
+  train_layout(N, S0, S1, S2, C, off);
+  auto at = [&](int slot) { return out + off[slot]; };
+  const float* o = origins_in;
+  const float* d = directions_in;
+  int rc;
+  if (pose_adjustment != nullptr) {  // CameraOptimizer.apply_to_raybundle and the first sampler level: independent, one launch
+    TN_REQUIRE(num_cameras >= 1, "tn_render_rays_train: bad num_cameras=%d", num_cameras);
+    if ((rc = tn_pose_spaced_bins(pose_adjustment, frozen, camera_indices, origins_in, directions_in, N, num_cameras, at(TRO_ORIGINS), at(TRO_DIRECTIONS),
+                                  lin_spaced0, jitter0, nears, fars, S0, at(TRO_S0), at(TRO_E0), stream)))
+      return rc;
+    o = at(TRO_ORIGINS);
+    d = at(TRO_DIRECTIONS);
+  } else if ((rc = tn_spaced_bins(lin_spaced0, jitter0, nears, fars, N, S0, at(TRO_S0), at(TRO_E0), stream))) {
+    return rc;
+  }
+  if ((rc = tn_prop_density_fwd(prop0, o, d, at(TRO_E0), N, S0, at(TRO_D0), stream))) return rc;
+  if ((rc = tn_weights_resample(at(TRO_E0), at(TRO_D0), at(TRO_S0), S0, anneal, lin_pdf1, jitter1, nears, fars, N, S1, at(TRO_W0), at(TRO_M0), at(TRO_S1),
+                                at(TRO_E1), stream)))
+    return rc;
+  if ((rc = tn_prop_density_fwd(prop1, o, d, at(TRO_E1), N, S1, at(TRO_D1), stream))) return rc;
+  if ((rc = tn_weights_resample(at(TRO_E1), at(TRO_D1), at(TRO_S1), S1, anneal, lin_pdf2, jitter2, nears, fars, N, S2, at(TRO_W1), at(TRO_M1), at(TRO_S2),
+                                at(TRO_E2), stream)))
+    return rc;
+  if ((rc = tn_field_pack_weights(field, field_workspace, stream))) return rc;
+  if ((rc = tn_field_fwd(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, stream))) return rc;
+  return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
+                       at(TRO_SCRATCH), stream);
+}

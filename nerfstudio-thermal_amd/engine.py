@@ -131,6 +131,16 @@ class RenderEngine:
     def render_branch(self, props, fld, pose, frozen, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
                       training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main") -> Branch:
         o_in, d_in = origins, directions
+        if training and _FUSE:
+            # the whole training forward of the branch as ONE call of the C ABI (tn_render_rays_train): the library enqueues the eight
+            # launches itself and every result is a view of one allocation -- the host side of a step is what bounds small batches and the
+            # drop-in path
+            r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag)
+            levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=lv["median"])
+                      for S, lv in zip(self.counts, r["levels"])]
+            return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
+                          rgb_samples=r["rgb_samples"], comp=r["rgb"], accumulation=r["accumulation"], depth=r["depth"],
+                          expected_depth=r["expected_depth"], prop_grad=prop_grad)
         first = None
         if training and pose is not None:
             if _FUSE:  # pose correction and the level-0 bins are independent: one launch

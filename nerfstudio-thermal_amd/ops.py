@@ -637,6 +637,54 @@ def render_rays_eval(props: Sequence[PropNetParams], fld: FieldParams, origins: 
     return out
 
 
+_TRAIN_LAYOUTS: dict = {}
+
+
+def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Optional[Tensor], frozen: Optional[Tensor], origins: Tensor,
+                      directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor, counts: Sequence[int], anneal: float,
+                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main"):
+    """The training forward of one branch in ONE library call (tn_render_rays_train): pose correction, proposal sampling with jitter, field
+    (activations kept in the field's workspace `tag`), weights, renderers.  Every result is a view of one allocation.
+    -> dict(origins, directions [N,3]; levels: 3 x dict(s_bins, e_bins, density, weights, median); rgb_samples [N,S2,C]; rgb [N,C];
+    accumulation, depth, expected_depth [N,1])."""
+    N = origins.shape[0]
+    S0, S1, S2 = (int(c) for c in counts)
+    Cc = fld.num_channels
+    dev = origins.device
+    lib = _lib.load()
+    key = (N, S0, S1, S2, Cc)
+    off = _TRAIN_LAYOUTS.get(key)
+    if off is None:
+        arr = (C.c_int64 * _lib.TN_RENDER_TRAIN_OFFSETS)()
+        check(lib.tn_render_rays_train_layout(N, S0, S1, S2, Cc, arr, _lib.TN_RENDER_TRAIN_OFFSETS), "tn_render_rays_train_layout")
+        off = _TRAIN_LAYOUTS[key] = [int(v) for v in arr]
+    buf = torch.empty(off[22], device=dev)
+    ws = fld.workspace(N * S2, True, tag)
+    jit = list(jitters) if jitters is not None else [None, None, None]
+    Cn = pose.shape[0] if pose is not None else 0
+    p0, p1, f = props[0].cstruct(), props[1].cstruct(), fld.cstruct()
+    check(lib.tn_render_rays_train(C.byref(p0), C.byref(p1), C.byref(f), _f32(pose, "pose", (Cn, 6), optional=True), _u8(frozen, Cn) if pose is not None else None,
+                                   Cn, _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
+                                   _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S0, S1, S2, float(anneal),
+                                   _ray_scalar(jit[0], "jitter", N, True), _ray_scalar(jit[1], "jitter", N, True), _ray_scalar(jit[2], "jitter", N, True),
+                                   _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"), _f32(_lin_table("pdf", S2, dev), "u2"),
+                                   C.c_void_p(ws.data_ptr()), C.c_void_p(buf.data_ptr()), _stream()), "tn_render_rays_train")
+
+    def v(slot, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return buf[off[slot]:off[slot] + n].view(*shape)
+
+    levels = []
+    for i, S in enumerate((S0, S1)):
+        b = 2 + 5 * i
+        levels.append({"s_bins": v(b, N, S + 1), "e_bins": v(b + 1, N, S + 1), "density": v(b + 2, N, S), "weights": v(b + 3, N, S), "median": v(b + 4, N, 1)})
+    levels.append({"s_bins": v(12, N, S2 + 1), "e_bins": v(13, N, S2 + 1), "density": v(14, N, S2), "weights": v(15, N, S2), "median": v(19, N, 1)})
+    return {"origins": v(0, N, 3) if pose is not None else origins, "directions": v(1, N, 3) if pose is not None else directions, "levels": levels,
+            "rgb_samples": v(16, N, S2, Cc), "rgb": v(17, N, Cc), "accumulation": v(18, N, 1), "depth": v(19, N, 1), "expected_depth": v(20, N, 1)}
+
+
 _RENDER_SCRATCH: dict = {}
 
 

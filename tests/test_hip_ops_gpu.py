@@ -372,6 +372,40 @@ def test_render_rays_eval_is_the_launch_sequence(mode, N):
     assert out["rgb"].shape == (N, 3) and out["density"].shape == (N, 48, 1) and torch.isfinite(out["expected_depth"]).all()
 
 
+@pytest.mark.parametrize("with_pose", [True, False])
+def test_render_rays_train_is_the_launch_sequence(with_pose, monkeypatch):
+    """tn_render_rays_train (the training forward of a branch as one library call, all results in one buffer) against the same entry points
+    called one by one by the engine: every tensor a loss or the backward reads is bit-identical, with and without pose correction."""
+    from nerfstudio_thermal_amd import engine as engine_mod
+    from nerfstudio_thermal_amd.engine import RenderEngine
+
+    ocfg, params, cfg, arena = setup_pair("shared")
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    N = 260
+    r = rays(N)
+    o, d = g(r["origins"]), g(r["directions"])
+    cam = g(torch.arange(N, dtype=torch.int64) % ocfg.num_images)
+    nears, fars = eng._nears_fars(N, True)
+    gen = torch.Generator().manual_seed(9)
+    jit = [g(torch.rand(N, generator=gen)) for _ in range(3)]
+    pose = eng.pose if with_pose else None
+    if with_pose:
+        eng.pose.copy_(g(torch.from_numpy(synth.uniform("pose_rt", tuple(eng.pose.shape), -0.02, 0.02, SEED))))
+    monkeypatch.setattr(engine_mod, "_FUSE", True)
+    a = eng.render_branch(eng.props, eng.field, pose, eng.frozen_rgb, o, d, cam, nears, fars, True, 0.37, jit, prop_grad=True)
+    act_a = eng.field.workspace(N * 48, True, "main").clone()
+    monkeypatch.setattr(engine_mod, "_FUSE", False)
+    b = eng.render_branch(eng.props, eng.field, pose, eng.frozen_rgb, o, d, cam, nears, fars, True, 0.37, jit, prop_grad=True)
+    act_b = eng.field.workspace(N * 48, True, "main")
+    for name in ("origins", "directions", "rgb_samples", "comp", "accumulation", "depth", "expected_depth"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for la, lb in zip(a.levels, b.levels):
+        for name in ("s_bins", "e_bins", "density", "weights", "median"):
+            assert torch.equal(getattr(la, name), getattr(lb, name)), name
+    nb = int(ops._lib.load().tn_field_workspace_bytes(N * 48, 1)) - int(ops._lib.load().tn_hash_scatter_workspace_bytes(N * 48, 16))
+    assert torch.equal(act_a[:nb], act_b[:nb])  # the activations kept for the backward (everything before the scatter scratch)
+
+
 # ------------------------------------------------------------------------------------------------ renderers and losses
 @pytest.mark.parametrize("C,S,training", [(4, 48, False), (4, 48, True), (3, 48, True), (1, 96, False), (4, 256, True)])
 def test_composite_fwd_bwd(C, S, training):
