@@ -131,6 +131,39 @@ def test_train_step_matches_reference_golden(golden_dir, mode, size):
         assert float(diff.max()) <= 2.1e-2, (name, float(diff.max()))
 
 
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_fused_launches_equal_one_launch_per_seam(golden_dir, mode, monkeypatch):
+    """The engine's hot path (tn_render_rays_train, tn_train_losses + tn_losses_finish, tn_render_bwd, tn_pose_bwd_finish) against the same
+    step made of one entry point per reference seam (TN_FUSE_SMALL=0: tn_pose_apply_fwd, tn_spaced_bins, ..., tn_weights_fwd, tn_composite_fwd,
+    tn_clip_depth, tn_pixel_losses, tn_proposal_losses, tn_composite_bwd, tn_weights_bwd, tn_pose_apply_bwd, tn_camera_reg): forward tensors
+    bit for bit, loss terms and every parameter gradient up to the order of float additions."""
+    from nerfstudio_thermal_amd import engine as engine_mod
+
+    gi, o, d, cam = dev_inputs(golden_dir, "tiny")
+    jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(engine_mod, "_FUSE", fuse)
+        ocfg, cfg, arena, eng = build(mode, "tiny")
+        eng.set_anneal_for_step(500)
+        arena.zero_grad()
+        out, branches = eng.get_outputs(o, d, cam, True, jit, jit_t)
+        losses = eng.loss_and_backward(out, branches, cam, gi["image"].to(DEV), gi["is_thermal"].to(DEV))
+        torch.cuda.synchronize()
+        res[fuse] = ({k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, {k: float(v) for k, v in losses.items()}, arena.grads.clone())
+    (out_a, loss_a, grad_a), (out_b, loss_b, grad_b) = res[True], res[False]
+    assert sorted(out_a) == sorted(out_b)
+    for k in out_a:
+        assert torch.equal(out_a[k].nan_to_num(nan=-7.0), out_b[k].nan_to_num(nan=-7.0)), k
+    assert sorted(loss_a) == sorted(loss_b)
+    for k in loss_a:
+        assert abs(loss_a[k] - loss_b[k]) <= 2e-6 * abs(loss_b[k]) + 1e-12, (k, loss_a[k], loss_b[k])
+    scale = float(grad_b.abs().max())
+    assert float((grad_a - grad_b).abs().max()) <= 1e-5 * scale  # atomically accumulated sums (table scatter, weight gradients) in another order
+    assert torch.equal(grad_a == 0, grad_b == 0)  # the same parameters receive a gradient
+
+
 @pytest.mark.parametrize("size", ["tiny", "default"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_density_on_identical_samples(golden_dir, mode, size):
