@@ -727,6 +727,20 @@ def test_empty_single_and_eval_chunk_sizes():
     assert d.shape == (0, 256)
     w, _ = ops.weights_fwd(e, d)
     assert w.shape == (0, 256)
+    # the fused entry points accept an empty batch too: whole-branch renders (inference and training), renderers, loss launch
+    zc = torch.zeros(0, dtype=torch.int64, device=DEV)
+    ze = torch.zeros(0, device=DEV)
+    r0 = ops.render_rays_eval(eng.props, eng.field, z3, z3, zc, ze, ze, eng.counts, 1.0)
+    assert r0["rgb"].shape == (0, 4) and r0["levels"][0]["weights"].shape == (0, 256)
+    t0 = ops.render_rays_train(eng.props, eng.field, eng.pose, eng.frozen_rgb, z3, z3, zc, ze, ze, eng.counts, 1.0, None)
+    assert t0["rgb"].shape == (0, 4) and t0["levels"][2]["e_bins"].shape == (0, 49)
+    w0, c0, a0, m0, x0 = ops.render_fwd(torch.zeros((0, 49), device=DEV), torch.zeros((0, 48), device=DEV), torch.zeros((0, 48, 4), device=DEV), True)
+    assert w0.shape == (0, 48) and c0.shape == (0, 4) and x0.shape == (0, 1)
+    Lp = torch.zeros((ops.LOSS_LINES, 16), device=DEV)
+    ops.train_losses(torch.zeros((0, 49), device=DEV), torch.zeros((0, 48), device=DEV), [(torch.zeros((0, 257), device=DEV), torch.zeros((0, 256), device=DEV), None)],
+                     0.002, 1.0, None, Lp)
+    torch.cuda.synchronize()
+    assert float(Lp.abs().max()) == 0.0
     r1 = rays(1)
     out1, _ = eng.get_outputs(g(r1["origins"]), g(r1["directions"]), g(r1["camera_indices"]), training=False)
     with torch.no_grad():
