@@ -333,6 +333,52 @@ def bench_splat(args):
         print(json.dumps(line))
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves, as the reference's launcher does
+    (scripts/train.py:138-151,204-209: mp.spawn of one process per device).  The parent has made NO HIP call at this point (torch is imported,
+    nothing else): it starts `python -m torch.distributed.run` as a fresh child process, which starts one fresh process per GPU, and
+    returns the child's exit code.  No process that has touched the GPU is ever replaced."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    env["TN_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(args):
+    """--rendezvous-only: the launcher logic without the workload (CPU test of `--gpus N`): join the process group (gloo without a GPU), prove
+    the rank count with a real all-reduce, print the same bookkeeping keys as the bench line."""
+    import torch.distributed as dist
+
+    from nerfstudio_thermal_amd.parallel import init_distributed
+
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    ranks = 1
+    if world > 1:
+        t = torch.ones(1)
+        if dist.get_backend() == "nccl":
+            t = t.cuda(local)
+        dist.all_reduce(t)
+        ranks = int(t.item())
+        assert ranks == dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "rccl_ranks": ranks, "backend": dist.get_backend() if world > 1 else None,
+                          "spawned_by_bench": os.environ.get("TN_BENCH_SPAWNED") == "1"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="nerfacto", choices=["nerfacto", "splat"], help="nerfacto: the thermal-nerfacto train step (BASELINE metric); "
@@ -360,7 +406,14 @@ def main():
     ap.add_argument("--dp-adam-per-range", action="store_true", help="N>1 / --force-dp: one Adam launch per exchanged range instead of one after the exchange")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launcher test: spawn / join the ranks, all-reduce once, print the rank count, exit")
+    ap.add_argument("--long-steps", type=int, default=200, help="extra steps after the timed region for the BASELINE.md 3.4 figure (median of >= 200 "
+                    "per-step times, reported as extra keys; `value` always follows --steps).  0 disables")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # before any GPU call of this process
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     if args.workload == "splat":
         return bench_splat(args)
 
@@ -370,7 +423,10 @@ def main():
 
     _lib.load()  # fail loudly if the HIP library is missing
     rank, local, world = init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:  # never degrade silently to fewer ranks than asked for
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a "
+              "torchrun environment (bench.py then spawns the ranks itself)", file=sys.stderr)
+        sys.exit(2)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     api = args.path == "model-api"
@@ -437,12 +493,53 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    rccl_ranks, per_rank_ms = 1, [dt / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(gathered, t)
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        one = torch.ones(1, device=device)
+        torch.distributed.all_reduce(one)  # a real collective: the number of ranks RCCL actually joined
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == torch.distributed.get_world_size() == world, (rccl_ranks, world)
     final_loss = {k: float(v) for k, v in losses.items()}
     assert all(np.isfinite(v) for v in final_loss.values()), final_loss
+
+    # "median of >= 200 steps after skipping 2".  `value` above follows --steps; this is the long-run figure beside it:
+    # every step bracketed by HIP events on the launch stream (no host sync inside the loop), median / mean of the per-step device times.
+    long_run = None
+    if args.long_steps > 0:
+        n_long = args.long_steps
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_long + 1)]
+        upd_flags = []
+        barrier()
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        evs[0].record()
+        for i in range(n_long):
+            run(step)
+            upd_flags.append(int(eng.steps_since_update == 1))
+            step += 1
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        barrier()
+        tl = time.perf_counter() - tl0
+        per = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n_long)])
+        uf = np.array(upd_flags, dtype=bool)
+        med = float(np.median(per[2:]))
+        if world > 1:
+            tm = torch.tensor([med, tl], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            med, tl = float(tm[0].item()), float(tm[1].item())
+        long_run = {"steps": n_long, "median_ms_per_step": med, "median_rays_per_s": world * rays / (med * 1e-3),
+                    "mean_ms_per_step": tl / n_long * 1e3, "mean_rays_per_s": world * rays * n_long / tl,
+                    "proposal_update_fraction": float(uf.mean()),
+                    "median_ms_update_steps": float(np.median(per[uf])) if uf.any() else None,
+                    "median_ms_other_steps": float(np.median(per[~uf])) if (~uf).any() else None,
+                    "note": "BASELINE.md 3.4 figure (median of per-step HIP-event times, first 2 skipped; max over ranks); `value` follows --steps"}
 
     if rank == 0:
         rows = kernel_roofline(eng, cam_t, idx)
@@ -488,6 +585,9 @@ def main():
                                    f"256/96 proposal + {args.nerf_samples} field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
                        "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam)" if api else ""),
                        "final_loss": final_loss},
+            "rccl_ranks": rccl_ranks,
+            "per_rank_ms_per_step": per_rank_ms,
+            "long_run": long_run,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
