@@ -16,17 +16,26 @@ from torch import Tensor
 from . import ops
 
 
-def _scalar_grads_equal(gs) -> Optional[Tensor]:
-    """The common value if all incoming scalar gradients are the same tensor value (the Trainer sums the loss dict: all ones), else None."""
-    gs = [g for g in gs if g is not None]
-    if not gs:
+def _scalar_grads_equal(gs, who: str = "loss node") -> Optional[Tensor]:
+    """The common incoming gradient of the loss terms `gs` (the Trainer sums the loss dict, engine/trainer.py:483: every term arrives with the
+    same tensor).  The kernels accumulate the gradients of ALL terms into shared buffers, so the terms cannot be weighted one by one:
+      * every term None (nothing of this node is being differentiated) -> None;
+      * a term with NO incoming gradient beside terms that have one (e.g. `loss_dict["rgb_loss"].backward()`, or a sum over a subset) has
+        weight 0, which differs from the others' weight -> refused loudly, never answered with the gradient of all terms;
+      * different values -> refused as well."""
+    if all(g is None for g in gs):
         return None
+    if any(g is None for g in gs):
+        raise RuntimeError(f"{who}: backward reached only a subset of the loss terms (the others have no incoming gradient, i.e. weight 0). The HIP loss "
+                           "kernels produce the gradient of the SUM of all terms in one pass; backpropagate the sum of the whole loss dict as the "
+                           "reference Trainer does (engine/trainer.py:483), and switch a term off through its *_loss_mult")
     g0 = gs[0]
     for g in gs[1:]:
         if g is g0 or (g.data_ptr() == g0.data_ptr() and g.shape == g0.shape):
             continue  # one tensor handed down a chain of additions: no device round trip
         if not bool(torch.equal(g, g0)):
-            return None
+            raise RuntimeError(f"{who}: the loss terms must enter the total with one common weight (the Trainer sums the loss dict); scale a term "
+                               "through its *_loss_mult instead")
     return g0
 
 
@@ -56,10 +65,9 @@ class PixelLosses(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1, g2, g3, _g4):
         d_rgb, d_th = ctx.saved_tensors
-        g = _scalar_grads_equal((g0, g1, g2, g3))
+        g = _scalar_grads_equal((g0, g1, g2, g3), "PixelLosses")
         if g is None:
-            raise RuntimeError("PixelLosses: the four pixel-loss terms must enter the total with the same weight (the Trainer sums the loss dict); "
-                               "scale a term through its *_loss_mult instead")
+            return None, None, None, None, None, None, None
         return d_rgb * g, d_th * g, None, None, None, None, None
 
 
@@ -213,6 +221,9 @@ class TrainLosses(torch.autograd.Function):
         if not poses:
             ops.losses_finish(Lp, L)
         ctx.set_materialize_grads(False)  # unused terms arrive as None, not as zeros
+        # the terms this iteration actually produced (a term that does not exist in this mode is never waited for in backward)
+        ctx.live = [0, 1, 2, 3, 8, 9] + ([10] if dens else []) + [11 + k for k in range(len(poses))]
+        ctx.n_inputs = 3 + len(ts)
         ctx.flat, ctx.layout, ctx.nper = flat, (offs[2:], sizes[2:], shapes[2:]), [pg for _, _, pg, _, _ in per]
         ops.train_metrics(L, image.shape[0], spec.thermal_mult, [p.detach() for p in poses], L[16:24])
         outs = L.unbind(0)
@@ -221,10 +232,9 @@ class TrainLosses(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        g = _scalar_grads_equal([gs[i] for i in (0, 1, 2, 3, 8, 9, 10, 11, 12)])
+        g = _scalar_grads_equal([gs[i] for i in ctx.live], "TrainLosses")
         if g is None:
-            raise RuntimeError("TrainLosses: the loss terms must enter the total with one common weight (the Trainer sums the loss dict); "
-                               "scale a term through its *_loss_mult instead")
+            return (None,) * ctx.n_inputs
         scaled = ctx.flat * g  # every gradient buffer at once (out of place: the loss values the caller holds live in the same allocation)
         out = [None, None, None]
         gi = iter([scaled[o:o + n].view(*s) for o, n, s in zip(*ctx.layout)])

@@ -389,3 +389,43 @@ def test_optimizer_state_roundtrip_fused_and_trainer_paths(golden_dir):
         noise = frac(t0.arena.view(n), t1.arena.view(n))
         small = t1.arena.view(n).numel() < 1000 and float((t1.arena.view(n) - t3.arena.view(n)).abs().max()) <= 0.03
         assert small or frac(t1.arena.view(n), t3.arena.view(n)) <= 2.0 * noise + 0.05, (n, noise)
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_backward_of_a_subset_of_loss_terms_is_refused(golden_dir, mode):
+    """The loss kernels produce the gradient of the SUM of all terms (one pass, shared gradient buffers).  `loss_dict["rgb_loss"].backward()` or a
+    sum over a subset gives the other terms weight 0: the reference's per-term autograd handles that, this node cannot -- it must refuse, never
+    answer with the gradient of every term.  The sum over the whole dict, scaled by any common factor (GradScaler), is accepted."""
+    gi, rb = bundle(golden_dir)
+    jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+    batch = {"image": gi["image"].to(DEV), "is_thermal": gi["is_thermal"].to(DEV)}
+    ocfg, cfg, model = build_model(mode)
+    model.arena.load(make_params(ocfg))
+    model.train()
+
+    def losses():
+        out = model.get_outputs(model.collider(rb[...]), jit, jit_t)
+        return model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+
+    with pytest.raises(RuntimeError, match="subset of the loss terms"):
+        losses()["rgb_loss"].backward()
+    with pytest.raises(RuntimeError, match="subset of the loss terms"):
+        L = losses()
+        (L["rgb_loss"] + L["interlevel_loss"]).backward()
+    with pytest.raises(RuntimeError, match="one common weight"):
+        L = losses()
+        (2.0 * L["rgb_loss"] + sum(v for k, v in L.items() if k != "rgb_loss")).backward()
+    # whole dict, common scale 128 (what GradScaler does): gradients = 128 x the unscaled ones
+    model.arena.zero_grad()
+    for p in model.parameters():
+        p.grad = None
+    sum(losses().values()).backward()
+    g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for p in model.parameters():
+        p.grad = None
+    model.arena.zero_grad()
+    (sum(losses().values()) * 128.0).backward()
+    for n, p in model.named_parameters():
+        if n in g1:
+            assert md(p.grad, g1[n] * 128.0) <= 2e-5 * float(g1[n].abs().max()) * 128.0 + 1e-30, n
