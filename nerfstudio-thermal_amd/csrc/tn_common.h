@@ -197,6 +197,40 @@ __device__ __forceinline__ float2 tn_level_interp(const float2 f[8], float ox, f
 #undef TN_LERP3
   return r;
 }
+// Trilinear value AND its derivatives wrt the in-cell offset (o = scaled - floor(scaled); d o / d position = res), feature by feature:
+// what autograd derives from tn_level_interp's operation sequence (field_components/encodings.py:449-459 with offset = scaled - scaled_f).
+// jac[3 f + axis] = res * d enc_f / d o_axis
+__device__ __forceinline__ float2 tn_level_interp_jac(const float2 f[8], float ox, float oy, float oz, float res, float jac[6]) {
+  float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+  float2 r;
+#define TN_LERP3J(C, K)                                                         \
+  {                                                                              \
+    float f03 = f[0].C * ox + f[3].C * ux;                                       \
+    float f12 = f[1].C * ox + f[2].C * ux;                                       \
+    float f56 = f[5].C * ox + f[6].C * ux;                                       \
+    float f47 = f[4].C * ox + f[7].C * ux;                                       \
+    float f0312 = f03 * oy + f12 * uy;                                           \
+    float f4756 = f47 * oy + f56 * uy;                                           \
+    r.C = f0312 * oz + f4756 * uz;                                               \
+    float dx = ((f[0].C - f[3].C) * oy + (f[1].C - f[2].C) * uy) * oz + ((f[4].C - f[7].C) * oy + (f[5].C - f[6].C) * uy) * uz; \
+    float dy = (f03 - f12) * oz + (f47 - f56) * uz;                              \
+    float dz = f0312 - f4756;                                                    \
+    jac[3 * K] = dx * res; jac[3 * K + 1] = dy * res; jac[3 * K + 2] = dz * res; \
+  }
+  TN_LERP3J(x, 0)
+  TN_LERP3J(y, 1)
+#undef TN_LERP3J
+  return r;
+}
+__device__ __forceinline__ float2 tn_encode_level_jac(const float2* __restrict__ table, float px, float py, float pz, float res, uint32_t mask,
+                                                      uint32_t level_off, float jac[6]) {
+  LevelCorners lc;
+  tn_level_corners(px, py, pz, res, mask, level_off, lc);
+  float2 f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
+  return tn_level_interp_jac(f, lc.ox, lc.oy, lc.oz, res, jac);
+}
 __device__ __forceinline__ float2 tn_encode_level(const float2* __restrict__ table, float px, float py, float pz, float res, uint32_t mask,
                                                   uint32_t level_off) {
   LevelCorners lc;
@@ -285,9 +319,10 @@ __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int6
 // 8 corners: the hash spreads the records evenly, coarse levels are merged before they are written) plus slack for small batches.
 #define TN_BIN_SLICE_LOG2 12
 #define TN_BIN_MAX_SLICES 256
+#define TN_BIN_COUNT_STRIDE 16  // words reserved per bucket counter (one 64-B line each)
 static inline int64_t tn_bin_level_records(int64_t P) { return 16 * P + TN_BIN_MAX_SLICES * 1032; }
 static inline int64_t tn_bin_bytes(int64_t P, int num_levels) {
-  return 256 + (int64_t)num_levels * TN_BIN_MAX_SLICES * 4 + (int64_t)num_levels * tn_bin_level_records(P) * (2 + 8);
+  return 256 + (int64_t)num_levels * TN_BIN_MAX_SLICES * 4 * TN_BIN_COUNT_STRIDE + (int64_t)num_levels * tn_bin_level_records(P) * (2 + 8);
 }
 // bytes of scatter scratch a backward workspace carries for P samples on a grid of num_levels levels
 static inline int64_t tn_scatter_scratch_bytes(int64_t P, int num_levels) {

@@ -123,6 +123,8 @@ struct FieldWs {
   float* gy_bo;    // [P][16]
   float* gy_h1;    // [P][64]
   float* g_enc;    // [P][32]
+  float* jac;      // res * d enc / d offset: 16 levels x 2 features x 3 axes per sample, in fragment order [tile of 32][q][k][lane] float4
+                   // (written by the training encode, read by k_field_dpos with the same lane mapping)
   void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
   int64_t bytes;
 };
@@ -142,9 +144,10 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     w.h1 = take(P * 64); w.hin = take(P * 64); w.hh1 = take(P * 64); w.hh2 = take(P * 64); w.y = take(P * 4);
     w.g3 = take(P * 4); w.gy_hh2 = take(P * 64); w.gy_hh1 = take(P * 64); w.g_hin = take(P * 64);
     w.gy_bo = take(P * 16); w.gy_h1 = take(P * 64); w.g_enc = take(P * 32);
+    w.jac = take(tn_cdiv(P, 32) * 32 * 96);  // whole tiles (fragment order)
     w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
   } else {
-    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = nullptr;
+    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = w.jac = nullptr;
     w.scatter = nullptr;
   }
   w.bytes = off;
@@ -157,9 +160,12 @@ extern "C" int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training
 
 // ---- encode ------------------------------------------------------------------------------------------------------------
 // thread = (sample p, half h): levels {4q + 2h, 4q + 2h + 1 : q = 0..3}  <->  features 8g + 4h + {0..3}, g = 0..3
+// JAC (training): also res * d enc / d offset per level and feature (6 floats per level -> jac[P][96]); the backward turns d enc into
+// d position with it (k_field_dpos) instead of gathering the 8 x 16 corners again inside the table-gradient scatter.
+template <bool JAC>
 __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ enc,
-                                                      float* __restrict__ sel) {
+                                                      float* __restrict__ sel, float* __restrict__ jac) {
   int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     // lanes 0-31: h=0 of 32 consecutive samples, lanes 32-63: h=1 of the same samples (matches the MFMA tile layout)
@@ -179,9 +185,81 @@ __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __re
     for (int q = 0; q < 4; ++q) {
       int l0 = 4 * q + 2 * h;
       float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
-      if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
-      if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
+      if (JAC) {
+        float ja[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, jb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (l0 < g.L) a = tn_encode_level_jac(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize, ja);
+        if (l0 + 1 < g.L) b = tn_encode_level_jac(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize, jb);
+        // fragment order [tile][q][k][lane] float4: every store instruction of the wave writes one contiguous KiB (sample-major rows would be
+        // 48-byte pieces 384 B apart: the 75 MB cost 35 us that way)
+        float4* jp = reinterpret_cast<float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;
+        jp[0] = make_float4(ja[0], ja[1], ja[2], ja[3]);
+        jp[64] = make_float4(ja[4], ja[5], jb[0], jb[1]);
+        jp[128] = make_float4(jb[2], jb[3], jb[4], jb[5]);
+      } else {
+        if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
+        if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
+      }
       *reinterpret_cast<float4*>(enc + p * 32 + 8 * q + 4 * h) = make_float4(a.x, a.y, b.x, b.y);
+    }
+  }
+}
+
+// d position of every sample from d enc and the saved derivatives: dp_axis = sum_l sum_f g_enc[2l + f] * jac[l][f][axis]; then the
+// backward of contraction / frustum position and the per-ray sums into d origins / d directions (same arithmetic as the table scatter's
+// own d-position path, which stays for tn_hash_scatter and the proposal grids).  Lane mapping = k_field_encode's.
+__global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ origins, const float* __restrict__ directions,
+                                                    const float* __restrict__ e_bins, const float* __restrict__ g_enc, const float* __restrict__ jac,
+                                                    int64_t N, int S, float* __restrict__ d_origins, float* __restrict__ d_directions) {
+  const int64_t P = N * (int64_t)S;
+  const int64_t ntiles = tn_cdiv(P, 32);
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+    const int64_t p = tile * 32 + j;
+    const bool live = p < P;
+    const int64_t pc = live ? p : P - 1;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 gv = *reinterpret_cast<const float4*>(g_enc + pc * 32 + 8 * q + 4 * h);
+      const float4* jp = reinterpret_cast<const float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order, as k_field_encode wrote it
+      const float4 j0 = jp[0], j1 = jp[64], j2 = jp[128];
+      dx += gv.x * j0.x + gv.y * j0.w + gv.z * j1.z + gv.w * j2.y;
+      dy += gv.x * j0.y + gv.y * j1.x + gv.z * j1.w + gv.w * j2.z;
+      dz += gv.x * j0.z + gv.y * j1.y + gv.z * j2.x + gv.w * j2.w;
+    }
+    dx += __shfl_xor(dx, 32, 64); dy += __shfl_xor(dy, 32, 64); dz += __shfl_xor(dz, 32, 64);
+    const int64_t ray = pc / S;
+    const int s = (int)(pc - ray * S);
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    const float st = eb[0], en = eb[1];
+    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+    float wx, wy, wz;
+    tn_contract_bwd(c, dx, dy, dz, wx, wy, wz);
+    if (!live || h != 0) { wx = wy = wz = 0.0f; }
+    const float tm = (st + en) / 2.0f;
+    float v[6] = {wx, wy, wz, wx * tm, wy * tm, wz * tm};
+    // segmented sums over the lanes of one ray (consecutive samples of a ray sit in consecutive lanes of a half-wave); the last lane of a
+    // segment adds the segment's sums
+    const int r32 = (int)ray;
+    const int prev = __shfl_up(r32, 1, 64);
+    const bool head = (j == 0) || (prev != r32);
+    const unsigned long long H = __ballot(head);
+    const int start = 63 - __clzll(H & (~0ull >> (63 - lane)));  // first lane of this lane's segment
+    const bool tail = (j == 31) || ((H >> (lane + 1)) & 1ull);
+#pragma unroll
+    for (int o2 = 1; o2 < 32; o2 <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float t = __shfl_up(v[k], o2, 64);
+        if (lane - o2 >= start) v[k] += t;
+      }
+    }
+    if (live && h == 0 && tail) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (v[k] != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), v[k]);
     }
   }
 }
@@ -490,6 +568,397 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restric
 #undef AB
 }
 
+// ---- backward MLP chain WITH the weight gradients (the default) ------------------------------------------------------------------
+// k_field_bwd_fused = k_field_mlp_bwd + k_wgrad_batch in one launch: the pre-activation gradients never leave the chip.
+//   Before: k_field_mlp_bwd wrote 242 MB of pre-activation gradients, k_wgrad_batch (companion stream) read them back with the saved
+//   activations (~450 MB) while k_grid_bin / k_grid_fold ran beside it -- 460 us in-step for the weight gradients and the table scatter
+//   stretched from 330 to 529 us (LDS pipe + HBM shared).
+//   Now: one wave = one 32-sample tile at a time, ONE wave per SIMD (__launch_bounds__(256, 1): the weight-gradient accumulators of all five
+//   layers live in registers for the whole kernel -- 64 + 64 + 32 + 16 + 16 = 192 of the 512).  Per layer the wave
+//     1. runs the chain step dIN^T = W^T . dOUT^T (accumulator tile = next B operand, as before),
+//     2. writes dY (just computed) and X (the saved activation, loaded for the ReLU mask anyway) of the tile to its private LDS buffers,
+//        sample-major with a 68-float row stride (conflict-free ds_write_b128 AND ds_read_b32),
+//     3. reads them back TRANSPOSED (lane = feature, k = sample) as the A / B operands of dW += dY^T X:
+//        v_mfma_f32_32x32x2_f32 for the 64-wide layers, v_mfma_f32_16x16x4_f32 for the two layers with <= 16 outputs (Linear(64,16), Linear(64,C)).
+//   Bias gradients are the lane sums of the A operands; the appearance-embedding rows are column sums of the tile's d(head input) with a
+//   running (camera, sum) pair per lane (any number of cameras; one 128-B atomic segment per camera change).
+//   Epilogue: the block's four waves add their accumulators in LDS (plain read-modify-write, one wave per turn) and ONE burst of float
+//   atomics per block goes to the gradient arena (256 blocks x 12.5 k floats).
+//   MFMA work per tile: chain 184 + weight gradients 160 (32x32x2) + 64 (16x16x4, half the cycles) -> 24 k cycles; 6 tiles per wave at 4096 rays.
+#define TSTR 68                       // LDS row stride (floats) of a [32 samples][<= 64 features] transposition tile
+#define FB_TILE_FLOATS (32 * TSTR)    // one tile buffer
+#define FB_WAVE_FLOATS (2 * FB_TILE_FLOATS + 128 + 32)  // dY tile, X tile, g3 [32][4], camera of each sample [32]
+#define FB_LDS_FLOATS (PACK_BWD_FLOATS + 4 * FB_WAVE_FLOATS)
+// block-sum layout (floats, inside the per-wave region): W3 [64][64] | W2 [64 out][64 slots] | W0 [64][32] | W4 [16][64] | W1 [16][64] | b3 b2 b0 (64 each) | b4 b1 (16 each)
+#define FB_RED_W3 0
+#define FB_RED_W2 4096
+#define FB_RED_W0 8192
+#define FB_RED_W4 10240
+#define FB_RED_W1 11264
+#define FB_RED_B3 12288
+#define FB_RED_B2 12352
+#define FB_RED_B0 12416
+#define FB_RED_B4 12480
+#define FB_RED_B1 12496
+#define FB_RED_TOTAL 12512
+static_assert(FB_RED_TOTAL + 8 * 32 + 8 <= 4 * FB_WAVE_FLOATS, "block-sum area (+ the embedding merge) must fit in the per-wave buffers");
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define WAVE_LDS_SYNC()                                   \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// D-layout tile m -> LDS tile (sample-major): registers 4g..4g+3 <-> features 32m + 8g + 4h + {0..3} of sample j
+__device__ __forceinline__ void lds_put_tile(float* __restrict__ buf, int j, int h, int m, const f32x16& v) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(buf + j * TSTR + 32 * m + 8 * g + 4 * h) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+// dW[MO x 32][MI x 32] += dY^T X over the tile's 32 samples; bsum[a] += this lane's share of sum_p dY[p][32a + j]
+template <int MO, int MI>
+__device__ __forceinline__ void wgrad_tile32(const float* __restrict__ bufY, const float* __restrict__ bufX, int j, int h, f32x16 (&acc)[MO][MI],
+                                             float (&bsum)[MO]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    float av[MO], bv[MI];
+#pragma unroll
+    for (int a = 0; a < MO; ++a) av[a] = bufY[(2 * t + h) * TSTR + 32 * a + j];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) bv[b] = bufX[(2 * t + h) * TSTR + 32 * b + j];
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+      bsum[a] += av[a];
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = MFMA(av[a], bv[b], acc[a][b]);
+    }
+  }
+}
+// dW[16][64] += dY^T X with dY [32 samples][ldy >= 16 valid columns, zero beyond ncols] ; lane l: row/col l % 16, k-slice l / 16
+__device__ __forceinline__ void wgrad_tile16(const float* __restrict__ bufY, int ldy, int ncols, const float* __restrict__ bufX, int lane,
+                                             f32x4v (&acc)[4], float& bsum) {
+  const int c = lane & 15, ks = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float av = c < ncols ? bufY[(4 * t + ks) * ldy + c] : 0.0f;
+    bsum += av;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = MFMA16(av, bufX[(4 * t + ks) * TSTR + 16 * b + c], acc[b]);
+  }
+}
+
+struct FusedGrads {
+  float *gw0, *gb0, *gw1, *gb1, *ghw0, *ghb0, *ghw1, *ghb1, *ghw2, *ghb2, *gemb;
+};
+
+// FB_ABLATE (compile-time, timing diagnostics only -- results are wrong with any bit set): 1 embedding rows, 2 32x32 weight gradients,
+// 4 16x16 weight gradients, 8 block sum + atomics
+#ifndef FB_ABLATE
+#define FB_ABLATE 0
+#endif
+// what a tile needs besides the big activation tiles (loaded one tile ahead)
+struct FbSmall {
+  float pre_logit, g_dens, sel_p;  // density logit (head-input slot 16), d density, selector
+  float g3[4];                     // sigmoid backward (half 0 only)
+  int cam;                         // camera of this lane's sample, -1 beyond the last sample
+};
+template <bool DENS_ONLY>
+__device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int64_t P, int S, int C, int num_images, const float* __restrict__ hins,
+                                                 const float* __restrict__ d_density, const float* __restrict__ sel, const float* __restrict__ ys,
+                                                 const float* __restrict__ d_rgb, const int64_t* __restrict__ cam_idx) {
+  FbSmall q;
+  const int64_t p = tile * TILE + j;
+  const bool valid = p < P;
+  const int64_t pc = valid ? p : P - 1;
+  q.pre_logit = hins[pc * 64 + 16];
+  q.g_dens = valid ? d_density[pc] : 0.0f;
+  q.sel_p = sel[pc];
+  q.g3[0] = q.g3[1] = q.g3[2] = q.g3[3] = 0.0f;
+  q.cam = -1;
+  if (!DENS_ONLY && h == 0) {
+    const int64_t cam = cam_idx[pc / S];
+    q.cam = valid ? ((cam < 0 || cam >= num_images) ? 0 : (int)cam) : -1;
+    if (valid) {
+      const float4 y4 = *reinterpret_cast<const float4*>(ys + p * 4);
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < C) q.g3[c] = d_rgb[p * C + c] * yv[c] * (1.0f - yv[c]);
+    }
+  }
+  return q;
+}
+
+template <bool DENS_ONLY>
+__global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ d_density,
+                                                            const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
+                                                            const float* __restrict__ encs, const float* __restrict__ h1s,
+                                                            const float* __restrict__ hins, const float* __restrict__ hh1s,
+                                                            const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // FB_LDS_FLOATS
+  const float* src = pack + PACK_BWD_OFF;
+  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  float* bufY = lds + PACK_BWD_FLOATS + wv * FB_WAVE_FLOATS;
+  float* bufX = bufY + FB_TILE_FLOATS;
+  float* bufG = bufX + FB_TILE_FLOATS;             // g3 [32][4]
+  int* bufC = reinterpret_cast<int*>(bufG + 128);  // camera of each sample of the tile
+  const int64_t ntiles = tn_cdiv(P, TILE);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+#define AB(layer, t, m, r) lds[fwd_off(layer) + ((((t) * layer_mo(layer) + (m)) * 16 + (r)) << 6) + lane]
+  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const f32x4v zero4 = {0, 0, 0, 0};
+  // weight-gradient accumulators (whole kernel)
+  f32x16 acc3[2][2], acc2[2][2], acc0[2][1];
+  f32x4v acc4[4], acc1[4];
+  float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs0[2] = {0.f, 0.f}, bs4 = 0.f, bs1 = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    acc0[a][0] = zero16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { acc3[a][b] = zero16; acc2[a][b] = zero16; }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { acc4[b] = zero4; acc1[b] = zero4; }
+  // appearance-embedding rows: lane = (feature e = lane & 31, half = samples 16 half .. 16 half + 15 of the tile); running sum for one camera
+  int emb_cam = -1;
+  float emb_sum = 0.0f;
+  // A wave walks a CONTIGUOUS slab of tiles: consecutive tiles share rays and cameras, so the running embedding sum is flushed (float atomics
+  // into the 128-B row of a camera) about once per camera change.  With tiles dealt round-robin every tile started a new camera and all
+  // waves of the chip were adding into the rows of the same two cameras at any time: same-line atomics execute one after the other (~25 ns
+  // each) -- 170 us of a 320 us kernel.
+  const int64_t tpw = tn_cdiv(ntiles, nwaves);
+  const int64_t tile_begin = wave * tpw;
+  const int64_t tile_end = (wave + 1) * tpw < ntiles ? (wave + 1) * tpw : ntiles;
+  // One wave per SIMD: nothing hides a load but the wave's own MFMA work, so every activation tile is requested one phase (>= 32 MFMAs)
+  // before its first use, and the first tile of the next iteration during the last phase of this one.
+  f32x16 nx0 = zero16, nx1 = zero16;  // next tile's first activation tile (hh2, or h1 for the density-only backward)
+  FbSmall nsm;
+  if (tile_begin < tile_end) {
+    const int64_t p0 = tile_begin * TILE + j, pc0 = p0 < P ? p0 : P - 1;
+    nsm = fb_load_small<DENS_ONLY>(tile_begin, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
+    nx0 = load_tile(DENS_ONLY ? h1s : hh2s, pc0, 64, 0, h);
+    nx1 = load_tile(DENS_ONLY ? h1s : hh2s, pc0, 64, 1, h);
+  }
+  for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
+    const int64_t p = tile * TILE + j;
+    const bool valid = p < P;
+    const int64_t pc = valid ? p : P - 1;
+    const FbSmall sm = nsm;
+    f32x16 di0 = zero16;
+    f32x16 s0, s1;  // h1 tile (ReLU mask of the base MLP)
+    if (!DENS_ONLY) {
+      if (h == 0) {
+        *reinterpret_cast<float4*>(bufG + j * 4) = make_float4(sm.g3[0], sm.g3[1], sm.g3[2], sm.g3[3]);
+        bufC[j] = sm.cam;
+      }
+      // ---- d hh2 = hw2^T . g3   (k-steps r=0..3 carry rows R(r,h): 0..3 for h=0, 4..7 (zero padding) for h=1)
+      f32x16 dd0 = zero16, dd1 = zero16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dd0 = MFMA(AB(4, 0, 0, r), sm.g3[r], dd0); dd1 = MFMA(AB(4, 1, 0, r), sm.g3[r], dd1); }
+      f32x16 t0 = load_tile(hh1s, pc, 64, 0, h), t1 = load_tile(hh1s, pc, 64, 1, h);  // used after the next chain step
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dd0[r] = nx0[r] > 0.0f ? dd0[r] : 0.0f; dd1[r] = nx1[r] > 0.0f ? dd1[r] : 0.0f; }
+      lds_put_tile(bufX, j, h, 0, nx0); lds_put_tile(bufX, j, h, 1, nx1);  // X of head layer 2: hh2
+      lds_put_tile(bufY, j, h, 0, dd0); lds_put_tile(bufY, j, h, 1, dd1);  // dY of head layer 1: gy_hh2
+      WAVE_LDS_SYNC();
+      if (!(FB_ABLATE & 4)) wgrad_tile16(bufG, 4, C, bufX, lane, acc4, bs4);  // d hw2 += g3^T hh2
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- d hh1 = hw1^T . d hh2
+      f32x16 dc0 = zero16, dc1 = zero16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
+      __builtin_amdgcn_sched_barrier(0);
+      WAVE_LDS_SYNC();  // the reads of bufX (hh2) are done
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dc0[r] = t0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = t1[r] > 0.0f ? dc1[r] : 0.0f; }
+      lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 1: hh1
+      t0 = load_tile(hins, pc, 64, 0, h); t1 = load_tile(hins, pc, 64, 1, h);  // head-input slots: used after the next weight-gradient block
+      WAVE_LDS_SYNC();
+      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);  // d hw1 += gy_hh2^T hh1
+      __builtin_amdgcn_sched_barrier(0);
+      WAVE_LDS_SYNC();
+      lds_put_tile(bufY, j, h, 0, dc0); lds_put_tile(bufY, j, h, 1, dc1);  // dY of head layer 0: gy_hh1
+      lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 0: head input slots
+      s0 = load_tile(h1s, pc, 64, 0, h); s1 = load_tile(h1s, pc, 64, 1, h);   // used two blocks further down
+      WAVE_LDS_SYNC();
+      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, bs2);  // d hw0 (slot space) += gy_hh1^T hin
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- d head-input slots = Wslot^T . d hh1
+      f32x16 di1 = zero16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(slot 32 + e)
+      if (!(FB_ABLATE & 1)) {
+        WAVE_LDS_SYNC();
+        lds_put_tile(bufX, j, h, 0, di1);  // [32 samples][32 features]
+        WAVE_LDS_SYNC();
+        float ev[16];
+        int ec[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { ev[q] = bufX[(16 * h + q) * TSTR + j]; ec[q] = bufC[16 * h + q]; }  // every read in flight at once
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if (ec[q] >= 0) {  // uniform over the half-wave; -1 beyond the last sample
+            if (ec[q] != emb_cam) {
+              if (emb_cam >= 0 && emb_sum != 0.0f) atomicAdd(G.gemb + (int64_t)emb_cam * 32 + j, emb_sum);
+              emb_cam = ec[q];
+              emb_sum = 0.0f;
+            }
+            emb_sum += ev[q];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      s0 = nx0; s1 = nx1;
+    }
+    // ---- d base_out rows: slots 16..31 = registers 8..15 of tile 0; row 0 (half 0, reg 0) takes the trunc_exp gradient instead
+    float dbo[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dbo[r] = di0[8 + r];
+    {
+      float g = sm.g_dens * expf(fminf(fmaxf(sm.pre_logit, -15.0f), 15.0f)) * sm.sel_p;
+      if (h == 0) dbo[0] = valid ? g : 0.0f;
+    }
+    WAVE_LDS_SYNC();
+    // dY of base layer 1: gy_bo [32][16] in the first 16 columns of bufY
+    *reinterpret_cast<float4*>(bufY + j * TSTR + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
+    *reinterpret_cast<float4*>(bufY + j * TSTR + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
+    lds_put_tile(bufX, j, h, 0, s0); lds_put_tile(bufX, j, h, 1, s1);      // X of base layer 1: h1
+    f32x16 e0 = load_tile(encs, pc, 32, 0, h);                              // used after the next weight-gradient block + chain step
+    WAVE_LDS_SYNC();
+    if (!(FB_ABLATE & 4)) wgrad_tile16(bufY, TSTR, 16, bufX, lane, acc1, bs1);  // d w1 += gy_bo^T h1
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
+    f32x16 dh0 = zero16, dh1 = zero16;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dh0[r] = s0[r] > 0.0f ? dh0[r] : 0.0f; dh1[r] = s1[r] > 0.0f ? dh1[r] : 0.0f; }
+    __builtin_amdgcn_sched_barrier(0);
+    WAVE_LDS_SYNC();
+    lds_put_tile(bufY, j, h, 0, dh0); lds_put_tile(bufY, j, h, 1, dh1);    // dY of base layer 0: gy_h1
+    lds_put_tile(bufX, j, h, 0, e0);                                       // X of base layer 0: enc
+    {
+      // the next tile's first loads ride behind the last 64 MFMAs of this one (clamped: the last iteration re-reads its own tile)
+      const int64_t tn = tile + 1 < tile_end ? tile + 1 : tile;
+      const int64_t pn = tn * TILE + j, pcn = pn < P ? pn : P - 1;
+      nsm = fb_load_small<DENS_ONLY>(tn, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
+      nx0 = load_tile(DENS_ONLY ? h1s : hh2s, pcn, 64, 0, h);
+      nx1 = load_tile(DENS_ONLY ? h1s : hh2s, pcn, 64, 1, h);
+    }
+    WAVE_LDS_SYNC();
+    if (!(FB_ABLATE & 2)) wgrad_tile32<2, 1>(bufY, bufX, j, h, acc0, bs0);  // d w0 += gy_h1^T enc
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- d enc = w0^T . d h1
+    f32x16 de = zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 0, r), dh0[r], de);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 1, r), dh1[r], de);
+    if (valid) store_tile(g_enc, p, 32, 0, h, de);
+    WAVE_LDS_SYNC();
+  }
+#undef AB
+  if (FB_ABLATE & 8) return;
+  // ---- block sum of the accumulators (plain LDS read-modify-write, one wave per turn: ds_add_f32 is lane-serialised on gfx950), then one
+  // burst of global float atomics per block; exact zeros stay exact zeros (v != 0 guard)
+  __syncthreads();  // every wave is done with its tile buffers: the sums go there
+  float* red = lds + PACK_BWD_FLOATS;
+  if (!DENS_ONLY) {
+    // the eight half-waves' running embedding sums: merged per camera inside the block first (a block's slab of rays usually holds one or two
+    // cameras), so that the end of the kernel is not 2048 half-waves adding into the same few 128-B rows at once
+    float* esum = red + FB_RED_TOTAL;                          // [8][32]
+    int* ecam = reinterpret_cast<int*>(esum + 8 * 32);          // [8]
+    esum[(2 * wv + h) * 32 + j] = emb_sum;
+    if (j == 0) ecam[2 * wv + h] = (emb_cam >= 0) ? emb_cam : -1;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      for (int e = 0; e < 8; ++e) {
+        const int cam = ecam[e];
+        if (cam < 0) continue;
+        bool first = true;
+        for (int f = 0; f < e; ++f) first = first && (ecam[f] != cam);
+        if (!first) continue;
+        float tot = 0.0f;
+        for (int f = e; f < 8; ++f)
+          if (ecam[f] == cam) tot += esum[f * 32 + threadIdx.x];
+        if (tot != 0.0f) atomicAdd(G.gemb + (int64_t)cam * 32 + threadIdx.x, tot);
+      }
+    }
+  }
+  const int c16 = lane & 15, k16 = lane >> 4;
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#define RED_PUT(idx, v) { float* d_ = &red[idx]; *d_ = (w == 0) ? (v) : *d_ + (v); }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = 32 * a + RROW(r, h);
+          if (!DENS_ONLY) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              RED_PUT(FB_RED_W3 + o * 64 + 32 * b + j, acc3[a][b][r]);
+              RED_PUT(FB_RED_W2 + o * 64 + 32 * b + j, acc2[a][b][r]);
+            }
+          }
+          RED_PUT(FB_RED_W0 + o * 32 + j, acc0[a][0][r]);
+        }
+        // bias sums: lane (j, h) holds its k-parity share of output 32a + j
+        const float s3 = bs3[a] + __shfl_xor(bs3[a], 32, 64), s2 = bs2[a] + __shfl_xor(bs2[a], 32, 64), s0_ = bs0[a] + __shfl_xor(bs0[a], 32, 64);
+        if (h == 0) {
+          if (!DENS_ONLY) { RED_PUT(FB_RED_B3 + 32 * a + j, s3); RED_PUT(FB_RED_B2 + 32 * a + j, s2); }
+          RED_PUT(FB_RED_B0 + 32 * a + j, s0_);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (!DENS_ONLY) RED_PUT(FB_RED_W4 + (4 * k16 + r) * 64 + 16 * b + c16, acc4[b][r]);
+          RED_PUT(FB_RED_W1 + (4 * k16 + r) * 64 + 16 * b + c16, acc1[b][r]);
+        }
+      float s4 = bs4 + __shfl_xor(bs4, 16, 64); s4 += __shfl_xor(s4, 32, 64);
+      float s1_ = bs1 + __shfl_xor(bs1, 16, 64); s1_ += __shfl_xor(s1_, 32, 64);
+      if (lane < 16) {
+        if (!DENS_ONLY) RED_PUT(FB_RED_B4 + lane, s4);
+        RED_PUT(FB_RED_B1 + lane, s1_);
+      }
+#undef RED_PUT
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < FB_RED_TOTAL; t += blockDim.x) {
+    const float v = red[t];
+    if (v == 0.0f) continue;
+    float* dst = nullptr;
+    if (t < FB_RED_W2) { if (!DENS_ONLY) dst = G.ghw1 + t; }
+    else if (t < FB_RED_W0) { const int q = t - FB_RED_W2, col = slot_to_col(q & 63); if (!DENS_ONLY && col >= 0) dst = G.ghw0 + (q >> 6) * 63 + col; }
+    else if (t < FB_RED_W4) dst = G.gw0 + (t - FB_RED_W0);
+    else if (t < FB_RED_W1) { const int q = t - FB_RED_W4; if (!DENS_ONLY && (q >> 6) < C) dst = G.ghw2 + q; }
+    else if (t < FB_RED_B3) dst = G.gw1 + (t - FB_RED_W1);
+    else if (t < FB_RED_B2) { if (!DENS_ONLY) dst = G.ghb1 + (t - FB_RED_B3); }
+    else if (t < FB_RED_B0) { if (!DENS_ONLY) dst = G.ghb0 + (t - FB_RED_B2); }
+    else if (t < FB_RED_B4) dst = G.gb0 + (t - FB_RED_B0);
+    else if (t < FB_RED_B1) { if (!DENS_ONLY && (t - FB_RED_B4) < C) dst = G.ghb2 + (t - FB_RED_B4); }
+    else dst = G.gb1 + (t - FB_RED_B1);
+    if (dst) atomicAdd(dst, v);
+  }
+}
+
 // ---- weight gradients: dW[o][i] += sum_p dY[p][o] X[p][i],  db[o] += sum_p dY[p][o] -----------------------------------------
 // One wave owns a contiguous range of samples; k-step = 2 samples: A lane = dY[p0 + (lane>>5)][32mo + (lane&31)],
 // B lane = X[p0 + (lane>>5)][32mi + (lane&31)].  Epilogue: register r of tile (mo,mi) is dW[32mo + R(r,h)][32mi + (lane&31)]
@@ -690,7 +1159,10 @@ static int launch_encode(const TnField* field, const float* origins, const float
                          const FieldWs& ws, tn_stream_t stream) {
   int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
   int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 256 * 32);
-  hipLaunchKernelGGL(k_field_encode, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel);
+  if (ws.jac != nullptr)  // training workspace: keep d enc / d offset for the backward
+    hipLaunchKernelGGL(k_field_encode<true>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel, ws.jac);
+  else
+    hipLaunchKernelGGL(k_field_encode<false>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel, nullptr);
   TN_CHECK_LAUNCH("tn_field_fwd(encode)");
   return TN_OK;
 }
@@ -746,6 +1218,18 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   return TN_OK;
 }
 
+// TN_FIELD_BWD_FUSED=0: the round-2 pair k_field_mlp_bwd + k_wgrad_batch (companion stream), kept for A/B timing
+static int field_bwd_fused() {
+  static int v = [] { const char* e = getenv("TN_FIELD_BWD_FUSED"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+// TN_FIELD_DPOS_JAC=0: d position inside the scatter's bin pass (round 2), for A/B timing
+static int field_dpos_jac() {
+  static int v = [] { const char* e = getenv("TN_FIELD_DPOS_JAC"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 // a level range is a grid of its own: table / gradient / resolutions shifted (g_enc columns shift by 2 per level at the call site)
 static TnGrid level_range_grid(const TnGrid& g, int level_begin, int level_end) {
   TnGrid sub = g;
@@ -778,7 +1262,31 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   hipStream_t st = tn_s(stream);
   const int C = field->num_channels;
   int rcw = TN_OK;
-  if (phases & TN_BWD_MLP) {
+  if ((phases & TN_BWD_MLP) && field_bwd_fused()) {
+    // chain + every weight gradient in one launch (k_field_bwd_fused): nothing is forked to the companion stream
+    const size_t shmem = FB_LDS_FLOATS * sizeof(float);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), 4), 256));  // one block per CU (one wave per SIMD)
+    FusedGrads G{field->gw0, field->gb0, field->gw1, field->gb1, field->ghw0, field->ghb0, field->ghw1, field->ghb1, field->ghw2, field->ghb2, field->gemb};
+    if (dens_only) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL(k_field_bwd_fused<true>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
+                         C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
+                         S, C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G);
+    }
+    TN_CHECK_LAUNCH("tn_field_bwd(fused mlp + weight gradients)");
+    if (d_origins != nullptr && field_dpos_jac()) {
+      // d position from the saved d enc / d offset (75 MB read) on the companion stream, beside the table scatter: the bin pass then
+      // runs without its own d-position path (which gathered the 8 x 16 corners of every sample again: 414 MB of the entry point's traffic)
+      hipStream_t side = tn_fork(st);
+      const int64_t tiles = tn_cdiv(P, 32);
+      hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
+                         ws.g_enc, ws.jac, N, S, d_origins, d_directions);
+      TN_CHECK_LAUNCH("tn_field_bwd(d position)");
+    }
+  } else if (phases & TN_BWD_MLP) {
     size_t shmem = PACK_BWD_FLOATS * sizeof(float);
     if (dens_only) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -814,14 +1322,18 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       rcw = launch_wgrad_batch(&e, 1, P, wst);
     }
   }
+  // with the fused backward + k_field_dpos the scatter never computes d position
+  const bool dpos_done = field_bwd_fused() && field_dpos_jac();
+  float* sc_do = dpos_done ? nullptr : d_origins;
+  float* sc_dd = dpos_done ? nullptr : d_directions;
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
-    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, d_origins, d_directions, ws.scatter, st);
+    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, sc_do, sc_dd, ws.scatter, st);
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");
     if (phases & TN_BWD_SCATTER_BIN)
-      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, d_origins, d_directions, ws.scatter, st);
+      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, sc_do, sc_dd, ws.scatter, st);
     if (rc == TN_OK && (phases & TN_BWD_SCATTER_FOLD)) rc = tn_grid_scatter_fold(field->grid, P, ws.scatter, level_begin, level_end, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);
@@ -854,8 +1366,9 @@ extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* ori
   TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd_scatter_dense: bad level range [%d, %d)",
              level_begin, level_end);
   FieldWs ws = ws_layout(workspace, N * (int64_t)S, 1);
+  const bool dpos_done = field_bwd_fused() && field_dpos_jac();  // the MLP phase already produced d position (k_field_dpos)
   return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S,
-                                d_origins, d_directions, ws.scatter, tn_s(stream), dense_sum);
+                                dpos_done ? nullptr : d_origins, dpos_done ? nullptr : d_directions, ws.scatter, tn_s(stream), dense_sum);
 }
 
 extern "C" int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,

@@ -231,7 +231,8 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
 struct BinK {
   uint16_t* idx;     // [L][nslices][cap] slot inside the bucket
   float2* val;       // same shape
-  uint32_t* count;   // [L][nslices], zeroed before pass 1
+  uint32_t* count;   // [L][nslices] x cstride words, zeroed before pass 1
+  uint32_t cstride;  // words between two counters (1; one 64-B line per counter (16) was measured 15 % SLOWER on the main grid: more lines to fetch, no gain)
   uint32_t cap;      // records per bucket (multiple of 8)
   uint32_t level_stride;  // records between levels = nslices * cap
   int slice_log2;    // log2 slots per bucket
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
       }
       if (sl < ns) {
         s_loff[li * ns + sl] = run + inc - cnt;
-        s_gbase[li * ns + sl] = cnt ? atomicAdd(&bk.count[(size_t)l * ns + sl], cnt) : 0u;
+        s_gbase[li * ns + sl] = cnt ? atomicAdd(&bk.count[((size_t)l * ns + sl) * bk.cstride], cnt) : 0u;
         s_cnt[li * ns + sl] = 0;  // becomes the rank counter of phase B
       }
       run += __shfl(inc, 63, 64);
@@ -515,7 +516,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
   // (4 chunks per bucket), which then ran twice as long as the other six.
   const uint32_t ch = (blk - bk.blk0[l]) / bk.nslices, sl = (blk - bk.blk0[l]) % bk.nslices;
   (void)chunks_per_bucket;
-  const uint32_t count = min(bk.count[l * bk.nslices + sl], bk.cap);
+  const uint32_t count = min(bk.count[(size_t)(l * bk.nslices + sl) * bk.cstride], bk.cap);
   const uint32_t begin = ch * chunk;
   if (begin >= count) return;  // whole block leaves together
   if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk] = wall_clock64();
@@ -642,6 +643,7 @@ static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
 // TN_SCATTER_MODE: 1 = binned (default), 0 = atomics with dense replicas (the round-1 path; also what the dense data-parallel exchange uses)
 static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); return m; }
 static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 8192, 1024, 32768) & ~1023; return r; }
+static int bin_count_stride() { static int r = env_int("TN_BIN_COUNT_STRIDE", 1, 1, TN_BIN_COUNT_STRIDE); return r; }
 static int merge_res() { static int r = env_int("TN_SCATTER_MERGE_RES", 256, 0, 1 << 20); return r; }
 
 // Layout of the binned scatter for (grid, P, scratch): a pure function of its arguments, so the bin pass and the fold launches of a phased
@@ -659,7 +661,8 @@ static int bin_plan(const TnGrid& grid, int64_t P, void* scratch, BinK& bk, uint
   bk.level_stride = (uint32_t)(cap * bk.nslices);
   char* base = reinterpret_cast<char*>(scratch);
   bk.count = reinterpret_cast<uint32_t*>(base);
-  const int64_t cnt_bytes = 256 + (int64_t)L * TN_BIN_MAX_SLICES * 4;
+  bk.cstride = (uint32_t)bin_count_stride();
+  const int64_t cnt_bytes = 256 + (int64_t)L * TN_BIN_MAX_SLICES * 4 * TN_BIN_COUNT_STRIDE;
   bk.val = reinterpret_cast<float2*>(base + cnt_bytes);
   bk.idx = reinterpret_cast<uint16_t*>(base + cnt_bytes + (int64_t)L * tn_bin_level_records(P) * 8);
   nblk = 0;
@@ -687,7 +690,7 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
   uint32_t nblk;
   int rc = bin_plan(grid, P, scratch, bk, nblk);
   if (rc) return rc;
-  hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4, stream);
+  hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4 * bk.cstride, stream);
   TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
   GridK gk = make_gridk(grid);
   const int blocks = (int)tn_cdiv(P, BIN_THREADS);
