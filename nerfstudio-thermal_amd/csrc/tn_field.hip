@@ -2,16 +2,17 @@
 //   Field.forward = NerfactoField.get_density + get_outputs   (fields/base_field.py:114-133, fields/nerfacto_field.py:205-229,272-348,
 //                                                              fields/thermal_nerfacto_field.py:91-99)
 //
-// Kernel split (each stage tuned for what bounds it):
-//   k_field_encode     gather-bound : lane = (sample, half of the levels); contraction + selector + 8 levels x 8 corners
-//                                     -> enc[P][32], sel[P]                (many waves in flight, few registers)
-//   k_field_mlp_fwd    MFMA chain   : one wave = 32 samples; Linear(32,64) ReLU Linear(64,16) | head Linear(64 slots,64) ReLU
-//                                     Linear(64,64) ReLU Linear(64,C) sigmoid, every layer as v_mfma_f32_32x32x2_f32 on
-//                                     OUT^T = W . IN^T so that a layer's accumulator tile IS the next layer's B operand
-//                                     (no LDS round trip, no cross-lane traffic between layers).
-//   k_field_mlp_bwd    MFMA chain   : dIN^T = W^T . dOUT^T with the same trick; writes the pre-activation gradients
-//   k_wgrad            MFMA         : dW = dY^T X (K = samples), bias sums for free, contiguous 128-B atomic epilogue
-//   k_field_scatter    atomic-bound : trilinear scatter-add of d_enc into the table gradient (+ d position)
+// Kernels:
+//   k_field_fwd_fused  gather + MFMA: one wave = 32 samples.  lane = (sample, half of the levels): contraction + selector + 8 levels x 8
+//                                     corners (all 64 fetches in flight at once) land directly in the D-layout of the first layer's B operand;
+//                                     then Linear(32,64) ReLU Linear(64,16) | head Linear(64 slots,64) ReLU Linear(64,64) ReLU Linear(64,C)
+//                                     sigmoid, every layer as v_mfma_f32_32x32x2_f32 on OUT^T = W . IN^T so that a layer's accumulator tile
+//                                     IS the next layer's B operand (no LDS round trip, no cross-lane traffic between layers).
+//   k_field_bwd_fused  MFMA chain   : dIN^T = W^T . dOUT^T with the same trick AND every weight gradient dW = dY^T X (operands transposed
+//                                     through per-wave LDS tiles), bias sums, appearance-embedding rows: one launch, one wave per SIMD
+//   k_field_dpos       streaming    : d position from d enc and the forward's saved d enc / d offset, beside the table scatter
+//   k_field_encode + k_field_density_only : the density-only evaluation (config 2's cross terms)
+//   table-gradient scatter: tn_scatter.hip
 //
 // Register layout used everywhere ("D-layout" of v_mfma_f32_32x32x2_f32): lane = (j = lane&31 -> sample in the tile,
 // h = lane>>5), accumulator register r in [0,16) holds feature row  R(r,h) = (r&3) + 8*(r>>2) + 4*h  of a 32-row tile.
@@ -106,25 +107,23 @@ __global__ void k_field_pack(FieldK f, float* __restrict__ pack) {
 }
 
 // ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
+// Saved activations are kept in FRAGMENT ORDER: [tile of 32 samples][m (32-feature tile)][g][lane] float4, where lane (j = sample, h) of
+// register group g holds features 32 m + 8 g + 4 h + {0..3} -- exactly what a wave holds in the D-layout, so every store / load instruction
+// of a wave moves one contiguous KiB (sample-major rows cost four 32-byte pieces per 128-byte line: 4x the L2 transactions; the training
+// forward writes 300 MB).  Nothing outside this file reads them.
 struct FieldWs {
   float* pack;     // PACK_TOTAL_FLOATS
-  float* enc;      // [P][32]
+  float* enc;      // [tiles][1][4][64] float4   hash encoding (32 features)
   float* sel;      // [P]
   // training only
-  float* h1;       // [P][64]  relu(base layer 0)
-  float* hin;      // [P][64]  head input in slot space: sh16 | base_out16 | emb32
-  float* hh1;      // [P][64]
-  float* hh2;      // [P][64]
+  float* h1;       // [tiles][2][4][64] float4   relu(base layer 0)
+  float* hin;      // head input in slot space: sh16 | base_out16 | emb32
+  float* hh1;      // relu(head layer 0)
+  float* hh2;      // relu(head layer 1)
   float* y;        // [P][4]   sigmoid outputs (for the sigmoid derivative)
-  float* g3;       // [P][4]   d(head pre-sigmoid)
-  float* gy_hh2;   // [P][64]  pre-activation gradients
-  float* gy_hh1;   // [P][64]
-  float* g_hin;    // [P][64]  gradient wrt head input slots (emb part feeds the embedding gradient)
-  float* gy_bo;    // [P][16]
-  float* gy_h1;    // [P][64]
-  float* g_enc;    // [P][32]
-  float* jac;      // res * d enc / d offset: 16 levels x 2 features x 3 axes per sample, in fragment order [tile of 32][q][k][lane] float4
-                   // (written by the training encode, read by k_field_dpos with the same lane mapping)
+  float* g_enc;    // [P][32]  d enc, sample-major (read by the table scatter and k_field_dpos)
+  float* jac;      // res * d enc / d offset: 16 levels x 2 features x 3 axes per sample, [tile][q][k][lane] float4
+                   // (written by the training forward, read by k_field_dpos with the same lane mapping)
   void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
   int64_t bytes;
 };
@@ -137,17 +136,17 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     off += ((floats * 4 + 255) / 256) * 256;
     return r;
   };
+  const int64_t PT = tn_cdiv(P, 32) * 32;  // whole tiles
   w.pack = take(PACK_TOTAL_FLOATS);
-  w.enc = take(P * 32);
+  w.enc = take(PT * 32);
   w.sel = take(P);
   if (training) {
-    w.h1 = take(P * 64); w.hin = take(P * 64); w.hh1 = take(P * 64); w.hh2 = take(P * 64); w.y = take(P * 4);
-    w.g3 = take(P * 4); w.gy_hh2 = take(P * 64); w.gy_hh1 = take(P * 64); w.g_hin = take(P * 64);
-    w.gy_bo = take(P * 16); w.gy_h1 = take(P * 64); w.g_enc = take(P * 32);
-    w.jac = take(tn_cdiv(P, 32) * 32 * 96);  // whole tiles (fragment order)
+    w.h1 = take(PT * 64); w.hin = take(PT * 64); w.hh1 = take(PT * 64); w.hh2 = take(PT * 64); w.y = take(P * 4);
+    w.g_enc = take(P * 32);
+    w.jac = take(PT * 96);
     w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
   } else {
-    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g3 = w.gy_hh2 = w.gy_hh1 = w.g_hin = w.gy_bo = w.gy_h1 = w.g_enc = w.jac = nullptr;
+    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g_enc = w.jac = nullptr;
     w.scatter = nullptr;
   }
   w.bytes = off;
@@ -173,14 +172,15 @@ __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __re
     int lane = (int)(idx & 63);
     int h = lane >> 5;
     int64_t p = tile * 32 + (lane & 31);
-    if (p >= N * (int64_t)S) continue;
+    const bool live = p < N * (int64_t)S;
+    if (!live) p = N * (int64_t)S - 1;  // whole tiles are written (fragment order): the lanes past the end repeat the last sample
     int64_t ray = p / S;
     int s = (int)(p - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
     Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
-    if (h == 0) sel[p] = c.sel ? 1.0f : 0.0f;
+    if (h == 0 && live) sel[p] = c.sel ? 1.0f : 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int l0 = 4 * q + 2 * h;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __re
         if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
         if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
       }
-      *reinterpret_cast<float4*>(enc + p * 32 + 8 * q + 4 * h) = make_float4(a.x, a.y, b.x, b.y);
+      reinterpret_cast<float4*>(enc)[(tile * 4 + q) * 64 + lane] = make_float4(a.x, a.y, b.x, b.y);  // fragment order
     }
   }
 }
@@ -316,31 +316,110 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int6
   return v;
 }
 
-// ---- forward MLP chain ----------------------------------------------------------------------------------------------------
+// fragment order (see FieldWs): tile m of an activation with M 32-feature tiles per sample
+__device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t tile, int M, int m, int lane, const f32x16& v) {
+  float4* b = reinterpret_cast<float4*>(base) + ((tile * M + m) * 4) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b[g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+}
+__device__ __forceinline__ f32x16 load_frag(const float* __restrict__ base, int64_t tile, int M, int m, int lane) {
+  const float4* b = reinterpret_cast<const float4*>(base) + ((tile * M + m) * 4) * 64 + lane;
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 t = b[g * 64];
+    v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+  }
+  return v;
+}
+// the density logit = head-input slot 16 = tile 0, register group 2, half 0, component 0 of sample j
+__device__ __forceinline__ int64_t hin_logit_index(int64_t tile, int j) { return (((tile * 2 + 0) * 4 + 2) * 64 + j) * 4; }
+
+// ---- forward, one launch: 16-level gather + MLP chain (the fused gather + MLP) ---------------------------------------
+// k_field_fwd_fused = k_field_encode + k_field_mlp_fwd.  The lane mapping of the encode (lane = (sample j, half h): levels 4q + 2h, 4q + 2h + 1)
+// IS the D-layout of the first layer's B operand (registers 4q .. 4q+3 = features 8q + 4h + {0..3}), so the encoding goes from the gather
+// straight into the MFMA chain: no enc[P][32] round trip (25 MB written + read), one launch and one dependent boundary less.  Two blocks per
+// CU (two waves per SIMD): one wave's gather latency is covered by the other wave's 180 MFMAs.  TRAIN keeps what the backward needs
+// (enc for the first layer's weight gradient, d enc / d offset for d position, the activations).
+#ifndef FWD_THREADS
+#define FWD_THREADS 256
+#endif
 template <bool TRAIN>
-__global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ enc, const float* __restrict__ sel,
-                                                          const float* __restrict__ directions, const int64_t* __restrict__ cam_idx,
-                                                          const float* __restrict__ emb, int num_images, int use_cam_emb, int64_t P, int S, int C,
-                                                          float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ density_pre,
-                                                          float* __restrict__ h1s, float* __restrict__ hins, float* __restrict__ hh1s,
-                                                          float* __restrict__ hh2s, float* __restrict__ ys) {
+__global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fused(GridK g, const float* __restrict__ pack, const float* __restrict__ origins,
+                                                            const float* __restrict__ directions, const float* __restrict__ e_bins,
+                                                            const int64_t* __restrict__ cam_idx, const float* __restrict__ emb, int num_images,
+                                                            int use_cam_emb, int64_t N, int S, int C, float* __restrict__ density,
+                                                            float* __restrict__ rgb, float* __restrict__ density_pre, float* __restrict__ encs,
+                                                            float* __restrict__ sels, float* __restrict__ jac, float* __restrict__ h1s,
+                                                            float* __restrict__ hins, float* __restrict__ hh1s, float* __restrict__ hh2s,
+                                                            float* __restrict__ ys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_FWD_TOTAL floats
   for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
     *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
   __syncthreads();
   const float* lbias = lds + PACK_BIAS_OFF;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const int64_t P = N * (int64_t)S;
   const int64_t ntiles = tn_cdiv(P, TILE);
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 #define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    int64_t p = tile * TILE + j;
-    bool valid = p < P;
-    int64_t pc = valid ? p : P - 1;
-    int64_t ray = pc / S;
+    const int64_t p = tile * TILE + j;
+    const bool valid = p < P;
+    const int64_t pc = valid ? p : P - 1;
+    const int64_t ray = pc / S;
+    const int s = (int)(pc - ray * S);
+    // ---------------- contraction + 8 levels x 8 corners for this lane's half of the levels
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+    const float sl = c.sel ? 1.0f : 0.0f;
+    // all 64 corner fetches of the lane are issued before the first one is used: the wave pays the table's latency (L2 miss -> Infinity
+    // Cache for most of the 64 MB) once per tile, not once per level (hipcc otherwise waits level by level: 8 loads in flight per wave)
+    f32x16 in0;
+    LevelCorners lc[8];
+    float2 fv[8][8];
+#pragma unroll
+    for (int qi = 0; qi < 8; ++qi) {
+      const int l = 4 * (qi >> 1) + 2 * h + (qi & 1);
+      const int lcl = l < g.L ? l : g.L - 1;  // (levels beyond L read level L-1 and are zeroed below)
+      tn_level_corners(c.px, c.py, c.pz, g.res[lcl], g.mask, (uint32_t)lcl * g.tsize, lc[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < 8; ++qi)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fv[qi][k] = g.table[lc[qi].idx[k]];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l0 = 4 * q + 2 * h;
+      float2 a, b;
+      if (TRAIN) {
+        float ja[6], jb[6];
+        a = tn_level_interp_jac(fv[2 * q], lc[2 * q].ox, lc[2 * q].oy, lc[2 * q].oz, g.res[l0 < g.L ? l0 : g.L - 1], ja);
+        b = tn_level_interp_jac(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz, g.res[l0 + 1 < g.L ? l0 + 1 : g.L - 1], jb);
+        if (l0 >= g.L) { a = make_float2(0.f, 0.f); ja[0] = ja[1] = ja[2] = ja[3] = ja[4] = ja[5] = 0.0f; }
+        if (l0 + 1 >= g.L) { b = make_float2(0.f, 0.f); jb[0] = jb[1] = jb[2] = jb[3] = jb[4] = jb[5] = 0.0f; }
+        float4* jp = reinterpret_cast<float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order (see k_field_encode)
+        jp[0] = make_float4(ja[0], ja[1], ja[2], ja[3]);
+        jp[64] = make_float4(ja[4], ja[5], jb[0], jb[1]);
+        jp[128] = make_float4(jb[2], jb[3], jb[4], jb[5]);
+      } else {
+        a = tn_level_interp(fv[2 * q], lc[2 * q].ox, lc[2 * q].oy, lc[2 * q].oz);
+        b = tn_level_interp(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz);
+        if (l0 >= g.L) a = make_float2(0.f, 0.f);
+        if (l0 + 1 >= g.L) b = make_float2(0.f, 0.f);
+      }
+      in0[4 * q] = a.x; in0[4 * q + 1] = a.y; in0[4 * q + 2] = b.x; in0[4 * q + 3] = b.y;
+    }
+    if (TRAIN) {  // whole tiles: lanes past the end hold the (finite) values of the last sample, their gradients are zero
+      store_frag(encs, tile, 1, 0, lane, in0);
+      if (h == 0 && valid) sels[p] = sl;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // ---------------- base MLP: Linear(32,64) ReLU Linear(64,16)
-    f32x16 in0 = load_tile(enc, pc, 32, 0, h);
     f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -349,23 +428,21 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
     }
     __builtin_amdgcn_sched_barrier(0);
     a0 = relu16(a0); a1 = relu16(a1);
-    if (TRAIN && valid) { store_tile(h1s, p, 64, 0, h, a0); store_tile(h1s, p, 64, 1, h, a1); }
+    if (TRAIN) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
     f32x16 bo = bias_tile(lbias, 1, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
     __builtin_amdgcn_sched_barrier(0);
-    // rows 0..15 live in registers 0..7; row 0 (density logit) = lane half 0, register 0
     if (valid && h == 0) {
       float pre = bo[0];
-      float sl = sel[p];
       density[p] = expf(pre) * sl;  // average_init_density (=1.0) * trunc_exp(pre) * selector
       if (density_pre) density_pre[p] = pre;
     }
     // ---------------- head input in slot space: tile 0 = sh[R(r,h)] (r<8) | base_out rows (r>=8), tile 1 = embedding
     float sh[16];
-    sh16(directions[ray * 3], directions[ray * 3 + 1], directions[ray * 3 + 2], sh);
+    sh16(d[0], d[1], d[2], sh);
     f32x16 hi0, hi1;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -373,20 +450,20 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
       hi0[8 + r] = bo[r];
     }
     {
-      const float* eb;
+      const float* ebp;
       if (use_cam_emb) {
         int64_t cam = cam_idx[ray];
         if (cam < 0 || cam >= num_images) cam = 0;
-        eb = emb + cam * 32;
+        ebp = emb + cam * 32;
       } else {
-        eb = lds + PACK_MEANEMB_OFF;  // ones * embedding.mean(0)  (fields/nerfacto_field.py:292-295)
+        ebp = lds + PACK_MEANEMB_OFF;  // ones * embedding.mean(0)  (fields/nerfacto_field.py:292-295)
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hi1[4 * g + q] = eb[8 * g + 4 * h + q];
+        for (int q = 0; q < 4; ++q) hi1[4 * gq + q] = ebp[8 * gq + 4 * h + q];
     }
-    if (TRAIN && valid) { store_tile(hins, p, 64, 0, h, hi0); store_tile(hins, p, 64, 1, h, hi1); }
+    if (TRAIN) { store_frag(hins, tile, 2, 0, lane, hi0); store_frag(hins, tile, 2, 1, lane, hi1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 0
     f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
@@ -396,7 +473,7 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
     for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
-    if (TRAIN && valid) { store_tile(hh1s, p, 64, 0, h, c0); store_tile(hh1s, p, 64, 1, h, c1); }
+    if (TRAIN) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
     // ---------------- head layer 1
     f32x16 d0 = bias_tile(lbias, 3, 0, h), d1 = bias_tile(lbias, 3, 1, h);
 #pragma unroll
@@ -405,7 +482,7 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
     for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
-    if (TRAIN && valid) { store_tile(hh2s, p, 64, 0, h, d0); store_tile(hh2s, p, 64, 1, h, d1); }
+    if (TRAIN) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 2 + sigmoid
     f32x16 e = bias_tile(lbias, 4, 0, h);
@@ -416,8 +493,8 @@ __global__ void __launch_bounds__(256, 2) k_field_mlp_fwd(const float* __restric
     if (valid && h == 0) {
       float y[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < C) { y[c] = 1.0f / (1.0f + expf(-e[c])); rgb[p * C + c] = y[c]; }
+      for (int cc = 0; cc < 4; ++cc)
+        if (cc < C) { y[cc] = 1.0f / (1.0f + expf(-e[cc])); rgb[p * C + cc] = y[cc]; }
       if (TRAIN) *reinterpret_cast<float4*>(ys + p * 4) = make_float4(y[0], y[1], y[2], y[3]);
     }
   }
@@ -444,12 +521,12 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
     int64_t p = tile * TILE + j;
     bool valid = p < P;
     int64_t pc = valid ? p : P - 1;
-    f32x16 in0 = load_tile(enc, pc, 32, 0, h);
+    f32x16 in0 = load_frag(enc, tile, 1, 0, lane);
     f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0 = MFMA(AF(0, 0, 0, r), in0[r], a0); a1 = MFMA(AF(0, 1, 0, r), in0[r], a1); }
     a0 = relu16(a0); a1 = relu16(a1);
-    if (TRAIN && valid) { store_tile(h1s, p, 64, 0, h, a0); store_tile(h1s, p, 64, 1, h, a1); }
+    if (TRAIN) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
     f32x16 bo = bias_tile(lbias, 1, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
@@ -457,115 +534,10 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
     if (valid && h == 0) {
       density[p] = expf(bo[0]) * sel[p];
-      if (TRAIN) hins[p * 64 + 16] = bo[0];
+      if (TRAIN) hins[hin_logit_index(tile, j)] = bo[0];
     }
   }
 #undef AF
-}
-
-// ---- backward MLP chain ---------------------------------------------------------------------------------------------------
-// DENS_ONLY: backward of k_field_density_only<true> -- no colour gradient, so the head layers, their saved activations and d_rgb are never
-// touched; only the density logit's row of the base output carries a gradient.
-template <bool DENS_ONLY>
-__global__ void __launch_bounds__(256, 2) k_field_mlp_bwd(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
-                                                          const float* __restrict__ d_rgb, const float* __restrict__ d_density, int64_t P, int C,
-                                                          const float* __restrict__ h1s, const float* __restrict__ hins,
-                                                          const float* __restrict__ hh1s, const float* __restrict__ hh2s, float* __restrict__ g3s,
-                                                          float* __restrict__ gy_hh2, float* __restrict__ gy_hh1, float* __restrict__ g_hin,
-                                                          float* __restrict__ gy_bo, float* __restrict__ gy_h1, float* __restrict__ g_enc) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_BWD_FLOATS
-  const float* src = pack + PACK_BWD_OFF;
-  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int64_t ntiles = tn_cdiv(P, TILE);
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  // Ab[layer][t][m][r][lane]: output tile t (input features), k from output-feature tile m
-#define AB(layer, t, m, r) lds[fwd_off(layer) + ((((t) * layer_mo(layer) + (m)) * 16 + (r)) << 6) + lane]
-  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-    int64_t p = tile * TILE + j;
-    bool valid = p < P;
-    int64_t pc = valid ? p : P - 1;
-    f32x16 di0 = zero16;
-    if (!DENS_ONLY) {
-    // ---- sigmoid backward: g3_c = d_rgb_c * y (1-y) ; rows 0..3 live in half 0, registers 0..3
-    float g3[4] = {0.f, 0.f, 0.f, 0.f};
-    if (valid && h == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (c < C) { float y = ys[p * 4 + c]; g3[c] = d_rgb[p * C + c] * y * (1.0f - y); }
-      *reinterpret_cast<float4*>(g3s + p * 4) = make_float4(g3[0], g3[1], g3[2], g3[3]);
-    }
-    // ---- d hh2 = hw2^T . g3   (k-steps r=0..3 carry rows R(r,h): 0..3 for h=0, 4..7 (zero padding) for h=1)
-    f32x16 dd0 = zero16, dd1 = zero16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { dd0 = MFMA(AB(4, 0, 0, r), g3[r], dd0); dd1 = MFMA(AB(4, 1, 0, r), g3[r], dd1); }
-    {
-      f32x16 s0 = load_tile(hh2s, pc, 64, 0, h), s1 = load_tile(hh2s, pc, 64, 1, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dd0[r] = s0[r] > 0.0f ? dd0[r] : 0.0f; dd1[r] = s1[r] > 0.0f ? dd1[r] : 0.0f; }
-    }
-    if (valid) { store_tile(gy_hh2, p, 64, 0, h, dd0); store_tile(gy_hh2, p, 64, 1, h, dd1); }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- d hh1 = hw1^T . d hh2
-    f32x16 dc0 = zero16, dc1 = zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
-    {
-      f32x16 s0 = load_tile(hh1s, pc, 64, 0, h), s1 = load_tile(hh1s, pc, 64, 1, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dc0[r] = s0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = s1[r] > 0.0f ? dc1[r] : 0.0f; }
-    }
-    if (valid) { store_tile(gy_hh1, p, 64, 0, h, dc0); store_tile(gy_hh1, p, 64, 1, h, dc1); }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- d head-input slots = Wslot^T . d hh1
-    f32x16 di1 = zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
-    if (valid) { store_tile(g_hin, p, 64, 0, h, di0); store_tile(g_hin, p, 64, 1, h, di1); }
-    __builtin_amdgcn_sched_barrier(0);
-    }  // !DENS_ONLY
-    // ---- d base_out rows: slots 16..31 = registers 8..15 of tile 0; row 0 (half 0, reg 0) takes the trunc_exp gradient instead
-    float dbo[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) dbo[r] = di0[8 + r];
-    {
-      float pre = hins[pc * 64 + 16];  // slot 16 = density logit
-      float g = d_density[pc] * expf(fminf(fmaxf(pre, -15.0f), 15.0f)) * sel[pc];
-      if (h == 0) dbo[0] = valid ? g : 0.0f;
-    }
-    if (valid) {
-      *reinterpret_cast<float4*>(gy_bo + p * 16 + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
-      *reinterpret_cast<float4*>(gy_bo + p * 16 + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
-    f32x16 dh0 = zero16, dh1 = zero16;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
-    {
-      f32x16 s0 = load_tile(h1s, pc, 64, 0, h), s1 = load_tile(h1s, pc, 64, 1, h);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dh0[r] = s0[r] > 0.0f ? dh0[r] : 0.0f; dh1[r] = s1[r] > 0.0f ? dh1[r] : 0.0f; }
-    }
-    if (valid) { store_tile(gy_h1, p, 64, 0, h, dh0); store_tile(gy_h1, p, 64, 1, h, dh1); }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- d enc = w0^T . d h1
-    f32x16 de = zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 0, r), dh0[r], de);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 1, r), dh1[r], de);
-    if (valid) store_tile(g_enc, p, 32, 0, h, de);
-  }
-#undef AB
 }
 
 // ---- backward MLP chain WITH the weight gradients (the default) ------------------------------------------------------------------
@@ -672,7 +644,7 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int
   const int64_t p = tile * TILE + j;
   const bool valid = p < P;
   const int64_t pc = valid ? p : P - 1;
-  q.pre_logit = hins[pc * 64 + 16];
+  q.pre_logit = hins[hin_logit_index(tile, j)];
   q.g_dens = valid ? d_density[pc] : 0.0f;
   q.sel_p = sel[pc];
   q.g3[0] = q.g3[1] = q.g3[2] = q.g3[3] = 0.0f;
@@ -741,10 +713,9 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   f32x16 nx0 = zero16, nx1 = zero16;  // next tile's first activation tile (hh2, or h1 for the density-only backward)
   FbSmall nsm;
   if (tile_begin < tile_end) {
-    const int64_t p0 = tile_begin * TILE + j, pc0 = p0 < P ? p0 : P - 1;
     nsm = fb_load_small<DENS_ONLY>(tile_begin, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
-    nx0 = load_tile(DENS_ONLY ? h1s : hh2s, pc0, 64, 0, h);
-    nx1 = load_tile(DENS_ONLY ? h1s : hh2s, pc0, 64, 1, h);
+    nx0 = load_frag(DENS_ONLY ? h1s : hh2s, tile_begin, 2, 0, lane);
+    nx1 = load_frag(DENS_ONLY ? h1s : hh2s, tile_begin, 2, 1, lane);
   }
   for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
     const int64_t p = tile * TILE + j;
@@ -762,7 +733,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       f32x16 dd0 = zero16, dd1 = zero16;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { dd0 = MFMA(AB(4, 0, 0, r), sm.g3[r], dd0); dd1 = MFMA(AB(4, 1, 0, r), sm.g3[r], dd1); }
-      f32x16 t0 = load_tile(hh1s, pc, 64, 0, h), t1 = load_tile(hh1s, pc, 64, 1, h);  // used after the next chain step
+      f32x16 t0 = load_frag(hh1s, tile, 2, 0, lane), t1 = load_frag(hh1s, tile, 2, 1, lane);  // used after the next chain step
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dd0[r] = nx0[r] > 0.0f ? dd0[r] : 0.0f; dd1[r] = nx1[r] > 0.0f ? dd1[r] : 0.0f; }
       lds_put_tile(bufX, j, h, 0, nx0); lds_put_tile(bufX, j, h, 1, nx1);  // X of head layer 2: hh2
@@ -781,14 +752,14 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0[r] = t0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = t1[r] > 0.0f ? dc1[r] : 0.0f; }
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 1: hh1
-      t0 = load_tile(hins, pc, 64, 0, h); t1 = load_tile(hins, pc, 64, 1, h);  // head-input slots: used after the next weight-gradient block
+      t0 = load_frag(hins, tile, 2, 0, lane); t1 = load_frag(hins, tile, 2, 1, lane);  // head-input slots: used after the next weight-gradient block
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);  // d hw1 += gy_hh2^T hh1
       __builtin_amdgcn_sched_barrier(0);
       WAVE_LDS_SYNC();
       lds_put_tile(bufY, j, h, 0, dc0); lds_put_tile(bufY, j, h, 1, dc1);  // dY of head layer 0: gy_hh1
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 0: head input slots
-      s0 = load_tile(h1s, pc, 64, 0, h); s1 = load_tile(h1s, pc, 64, 1, h);   // used two blocks further down
+      s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, bs2);  // d hw0 (slot space) += gy_hh1^T hin
       __builtin_amdgcn_sched_barrier(0);
@@ -837,7 +808,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     *reinterpret_cast<float4*>(bufY + j * TSTR + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
     *reinterpret_cast<float4*>(bufY + j * TSTR + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
     lds_put_tile(bufX, j, h, 0, s0); lds_put_tile(bufX, j, h, 1, s1);      // X of base layer 1: h1
-    f32x16 e0 = load_tile(encs, pc, 32, 0, h);                              // used after the next weight-gradient block + chain step
+    f32x16 e0 = load_frag(encs, tile, 1, 0, lane);                              // used after the next weight-gradient block + chain step
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 4)) wgrad_tile16(bufY, TSTR, 16, bufX, lane, acc1, bs1);  // d w1 += gy_bo^T h1
     __builtin_amdgcn_sched_barrier(0);
@@ -854,10 +825,9 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     {
       // the next tile's first loads ride behind the last 64 MFMAs of this one (clamped: the last iteration re-reads its own tile)
       const int64_t tn = tile + 1 < tile_end ? tile + 1 : tile;
-      const int64_t pn = tn * TILE + j, pcn = pn < P ? pn : P - 1;
       nsm = fb_load_small<DENS_ONLY>(tn, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
-      nx0 = load_tile(DENS_ONLY ? h1s : hh2s, pcn, 64, 0, h);
-      nx1 = load_tile(DENS_ONLY ? h1s : hh2s, pcn, 64, 1, h);
+      nx0 = load_frag(DENS_ONLY ? h1s : hh2s, tn, 2, 0, lane);
+      nx1 = load_frag(DENS_ONLY ? h1s : hh2s, tn, 2, 1, lane);
     }
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 2)) wgrad_tile32<2, 1>(bufY, bufX, j, h, acc0, bs0);  // d w0 += gy_h1^T enc
@@ -959,169 +929,6 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   }
 }
 
-// ---- weight gradients: dW[o][i] += sum_p dY[p][o] X[p][i],  db[o] += sum_p dY[p][o] -----------------------------------------
-// One wave owns a contiguous range of samples; k-step = 2 samples: A lane = dY[p0 + (lane>>5)][32mo + (lane&31)],
-// B lane = X[p0 + (lane>>5)][32mi + (lane&31)].  Epilogue: register r of tile (mo,mi) is dW[32mo + R(r,h)][32mi + (lane&31)]
-// -> each atomic wave-instruction is two contiguous 128-B segments (the shape global float atomics run at full rate).
-// MODE 0: plain.  MODE 1: X columns are head slots (slot_to_col).  MODE 2: dY is the one-hot of the sample's camera (embedding rows).
-template <int MO, int MI, int MODE>
-__device__ __forceinline__ void wgrad_body(const float* __restrict__ dY, int ldy, int out_dim, const float* __restrict__ X, int ldx, int in_dim,
-                                           int x_col0, const int64_t* __restrict__ cam_idx, int out_base, int S, int64_t P,
-                                           float* __restrict__ dW, int ldw, float* __restrict__ db, int nblocks, float* __restrict__ red) {
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)nblocks * (blockDim.x >> 6);
-  int64_t per = tn_cdiv(tn_cdiv(P, 2), nwaves) * 2;  // samples per wave (even)
-  int64_t p_begin = wave * per, p_end = p_begin + per;
-  if (p_end > P) p_end = P;
-  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  f32x16 acc[MO][MI];
-  float bsum[MO];
-#pragma unroll
-  for (int a = 0; a < MO; ++a) {
-    bsum[a] = 0.0f;
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = zero16;
-  }
-  // U k-steps per iteration: all loads of the iteration are issued before the first MFMA consumes one (the loop was latency-bound with
-  // one dependent load pair per k-step)
-  constexpr int U = 8;
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += 2 * U) {
-    float av[U][MO], bv[U][MI];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int64_t p = p0 + 2 * u + h;
-      bool ok = p < p_end;
-      // loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a "load or 0" select makes hipcc branch around
-      // every load and wait for each one separately (the loop ran at 1/6 of its speed that way)
-      int64_t pc = ok ? p : p_begin;
-#pragma unroll
-      for (int a = 0; a < MO; ++a) {
-        int o = 32 * a + j;
-        int oc = o < out_dim ? o : out_dim - 1;
-        if (MODE == 2) {
-          int64_t cam = cam_idx[pc / S];
-          av[u][a] = (ok && o < out_dim && cam == (int64_t)(out_base + o)) ? 1.0f : 0.0f;
-        } else {
-          // multiply by a 0/1 mask instead of selecting: a select lets hipcc sink the load back under a branch
-          av[u][a] = __builtin_nontemporal_load(dY + pc * ldy + oc) * ((ok && o < out_dim) ? 1.0f : 0.0f);  // streamed once: keep the tables cached
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < MI; ++b) {
-        int i = 32 * b + j;
-        int ic = i < in_dim ? i : in_dim - 1;
-        bv[u][b] = __builtin_nontemporal_load(X + pc * ldx + x_col0 + ic) * ((ok && i < in_dim) ? 1.0f : 0.0f);
-      }
-    }
-    // keep the whole batch of loads in flight: without the fence hipcc sinks each load next to the MFMA that consumes it (vmcnt(0..3)),
-    // which leaves ~2 loads outstanding per wave and makes the loop latency-bound
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int a = 0; a < MO; ++a) {
-        bsum[a] += av[u][a];
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = MFMA(av[u][a], bv[u][b], acc[a][b]);
-      }
-    }
-  }
-  // Epilogue.  Same-line global atomics serialise at ~25 ns each (measured: 4096 waves adding into one 64-B line = 100 us), so the block's
-  // waves are first summed in LDS and then ONE coalesced burst per block goes out (16 consecutive floats per 64-B request).
-  // The LDS sum takes turns, one wave per barrier interval, with plain read-add-write: ds_add_f32 is executed lane by lane on gfx950
-  // (~195 cycles per wave instruction, scripts/microbench/lds_atomic_rate.hip) -- the 16 x tiles float atomics per wave used to cost
-  // as much as the K loop and kept the LDS pipe busy that the concurrent table scatter (k_grid_bin / k_grid_fold) is bound by.
-  const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  for (int w = 0; w < nwv; ++w) {
-    if (wv == w) {
-#pragma unroll
-      for (int a = 0; a < MO; ++a) {
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float* dst = &red[((a * 32 + RROW(r, h)) * MI + b) * 32 + j];
-            float v = acc[a][b][r];
-            *dst = (w == 0) ? v : *dst + v;
-          }
-        float sb = bsum[a] + __shfl_xor(bsum[a], 32, 64);
-        if (h == 0) {
-          float* dst = &red[MO * MI * 1024 + 32 * a + j];
-          *dst = (w == 0) ? sb : *dst + sb;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  for (int t = threadIdx.x; t < MO * MI * 1024; t += blockDim.x) {
-    int i = t % (32 * MI), o = t / (32 * MI);  // row-major over the padded [32*MO][32*MI] tile: consecutive threads = consecutive columns
-    float v = red[t];
-    int col = (MODE == 1) ? slot_to_col(i) : i;
-    if (o < out_dim && i < in_dim && col >= 0 && v != 0.0f) atomicAdd(dW + (int64_t)o * ldw + col, v);
-  }
-  if (db != nullptr) {
-    for (int t = threadIdx.x; t < MO * 32; t += blockDim.x) {
-      float v = red[MO * MI * 1024 + t];
-      if (t < out_dim && v != 0.0f) atomicAdd(db + t, v);
-    }
-  }
-}
-
-// Several weight-gradient problems in ONE launch (blockIdx.y = problem): each problem alone is latency-bound at ~1 wave per SIMD, so the
-// five layers of the field (+ the embedding rows), or the two layers of a proposal net, overlap instead of queueing behind each other.
-struct WgradProb {
-  const float* dY; const float* X; float* dW; float* db; const int64_t* cam_idx;
-  int ldy, out_dim, ldx, in_dim, x_col0, out_base, ldw, mode, nblocks, S;
-};
-#define WGRAD_MAX_PROBS 8
-struct WgradBatch { WgradProb p[WGRAD_MAX_PROBS]; int64_t P; };
-
-__global__ void __launch_bounds__(256) k_wgrad_batch(WgradBatch bt) {
-  __shared__ float red[2 * 2 * 1024 + 64];
-  const WgradProb& q = bt.p[blockIdx.y];
-  if ((int)blockIdx.x >= q.nblocks) return;  // whole block leaves together
-  const int mo = q.out_dim > 32 ? 2 : 1, mi = q.in_dim > 32 ? 2 : 1;
-#define WG_CALL(MO_, MI_, MODE_) wgrad_body<MO_, MI_, MODE_>(q.dY, q.ldy, q.out_dim, q.X, q.ldx, q.in_dim, q.x_col0, q.cam_idx, q.out_base, q.S, bt.P, q.dW, q.ldw, q.db, q.nblocks, red)
-  if (q.mode == 2) WG_CALL(1, 1, 2);
-  else if (q.mode == 1) WG_CALL(2, 2, 1);
-  else if (mo == 1 && mi == 1) WG_CALL(1, 1, 0);
-  else if (mo == 1 && mi == 2) WG_CALL(1, 2, 0);
-  else if (mo == 2 && mi == 1) WG_CALL(2, 1, 0);
-  else WG_CALL(2, 2, 0);
-#undef WG_CALL
-}
-
-static WgradProb make_prob(const float* dY, int ldy, int out_dim, const float* X, int ldx, int in_dim, int x_col0, float* dW, int ldw, float* db,
-                           int mode = 0, const int64_t* cam = nullptr, int out_base = 0, int S = 1) {
-  WgradProb q;
-  q.dY = dY; q.X = X; q.dW = dW; q.db = db; q.cam_idx = cam;
-  q.ldy = ldy; q.out_dim = out_dim; q.ldx = ldx; q.in_dim = in_dim; q.x_col0 = x_col0; q.out_base = out_base; q.ldw = ldw; q.mode = mode; q.S = S;
-  int tiles = (out_dim > 32 ? 2 : 1) * (in_dim > 32 ? 2 : 1);
-  q.nblocks = tiles >= 4 ? 256 : (tiles == 2 ? 512 : 1024);  // small tiles: cheap epilogue, spread over more waves
-  return q;
-}
-static int launch_wgrad_batch(const WgradProb* probs, int n, int64_t P, hipStream_t stream) {
-  TN_REQUIRE(n >= 1 && n <= WGRAD_MAX_PROBS, "wgrad batch: bad problem count");
-  if (P == 0) return TN_OK;
-  WgradBatch bt;
-  bt.P = P;
-  int maxb = 0;
-  for (int i = 0; i < n; ++i) { bt.p[i] = probs[i]; maxb = std::max(maxb, probs[i].nblocks); }
-  for (int i = n; i < WGRAD_MAX_PROBS; ++i) { bt.p[i] = probs[0]; bt.p[i].nblocks = 0; }
-  hipLaunchKernelGGL(k_wgrad_batch, dim3(maxb, n), dim3(256), 0, stream, bt);
-  TN_CHECK_LAUNCH("k_wgrad_batch");
-  return TN_OK;
-}
-
-// the two weight-gradient GEMMs of a proposal network (tn_prop.hip)
-int tn_wgrad_launch2(const float* dY0, int ldy0, int out0, const float* X0, int ldx0, int in0, float* dW0, int ldw0, float* db0, const float* dY1,
-                     int ldy1, int out1, const float* X1, int ldx1, int in1, float* dW1, int ldw1, float* db1, int64_t P, hipStream_t stream) {
-  TN_REQUIRE(dY0 && X0 && dW0 && dY1 && X1 && dW1 && out0 <= 64 && in0 <= 64 && out1 <= 64 && in1 <= 64 && P >= 0, "tn_wgrad_launch2: bad argument");
-  WgradProb pr[2] = {make_prob(dY0, ldy0, out0, X0, ldx0, in0, 0, dW0, ldw0, db0), make_prob(dY1, ldy1, out1, X1, ldx1, in1, 0, dW1, ldw1, db1)};
-  return launch_wgrad_batch(pr, 2, P, stream);
-}
-
 // ---- host entry points -----------------------------------------------------------------------------------------------------
 static int check_field(const TnField* f, const char* who, bool need_grad) {
   TN_REQUIRE(f != nullptr, "%s: null field", who);
@@ -1178,20 +985,22 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
   if (N == 0) return TN_OK;
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, training);
-  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
-  if (rc) return rc;
-  size_t shmem = PACK_FWD_TOTAL * sizeof(float);
-  int grid = mlp_grid(P);
+  // gather + MLP chain in one launch; 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
+  const size_t shmem = PACK_FWD_TOTAL * sizeof(float);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), FWD_THREADS / 64), 512));
+  GridK gk = make_gridk(field->grid);
   if (training) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_mlp_fwd<true>, dim3(grid), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, directions, camera_indices, field->emb,
-                       field->num_images, 1, P, S, field->num_channels, density, rgb, density_pre, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_fwd_fused<true>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), gk, ws.pack, origins, directions, e_bins, camera_indices,
+                       field->emb, field->num_images, 1, N, S, field->num_channels, density, rgb, density_pre, ws.enc, ws.sel, ws.jac, ws.h1, ws.hin,
+                       ws.hh1, ws.hh2, ws.y);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_mlp_fwd<false>, dim3(grid), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, directions, camera_indices,
-                       field->emb, field->num_images, 0, P, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr, nullptr);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_fwd_fused<false>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), gk, ws.pack, origins, directions, e_bins, camera_indices,
+                       field->emb, field->num_images, 0, N, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr);
   }
-  TN_CHECK_LAUNCH("tn_field_fwd(mlp)");
+  TN_CHECK_LAUNCH("tn_field_fwd");
   return TN_OK;
 }
 
@@ -1216,18 +1025,6 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   }
   TN_CHECK_LAUNCH("tn_field_density_fwd");
   return TN_OK;
-}
-
-// TN_FIELD_BWD_FUSED=0: the round-2 pair k_field_mlp_bwd + k_wgrad_batch (companion stream), kept for A/B timing
-static int field_bwd_fused() {
-  static int v = [] { const char* e = getenv("TN_FIELD_BWD_FUSED"); return e ? atoi(e) : 1; }();
-  return v;
-}
-
-// TN_FIELD_DPOS_JAC=0: d position inside the scatter's bin pass (round 2), for A/B timing
-static int field_dpos_jac() {
-  static int v = [] { const char* e = getenv("TN_FIELD_DPOS_JAC"); return e ? atoi(e) : 1; }();
-  return v;
 }
 
 // a level range is a grid of its own: table / gradient / resolutions shifted (g_enc columns shift by 2 per level at the call site)
@@ -1261,9 +1058,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   FieldWs ws = ws_layout(workspace, P, 1);
   hipStream_t st = tn_s(stream);
   const int C = field->num_channels;
-  int rcw = TN_OK;
-  if ((phases & TN_BWD_MLP) && field_bwd_fused()) {
-    // chain + every weight gradient in one launch (k_field_bwd_fused): nothing is forked to the companion stream
+  if (phases & TN_BWD_MLP) {
+    // chain + every weight gradient in one launch (k_field_bwd_fused)
     const size_t shmem = FB_LDS_FLOATS * sizeof(float);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), 4), 256));  // one block per CU (one wave per SIMD)
     FusedGrads G{field->gw0, field->gb0, field->gw1, field->gb1, field->ghw0, field->ghb0, field->ghw1, field->ghb1, field->ghw2, field->ghb2, field->gemb};
@@ -1276,56 +1072,20 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
                          S, C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G);
     }
-    TN_CHECK_LAUNCH("tn_field_bwd(fused mlp + weight gradients)");
-    if (d_origins != nullptr && field_dpos_jac()) {
-      // d position from the saved d enc / d offset (75 MB read) on the companion stream, beside the table scatter: the bin pass then
-      // runs without its own d-position path (which gathered the 8 x 16 corners of every sample again: 414 MB of the entry point's traffic)
+    TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
+    if (d_origins != nullptr) {
+      // d position from the saved d enc / d offset (75 MB read) on the companion stream, beside the table scatter: the bin pass
+      // runs without a d-position path of its own (which gathered the 8 x 16 corners of every sample again: 414 MB of the entry point's traffic)
       hipStream_t side = tn_fork(st);
       const int64_t tiles = tn_cdiv(P, 32);
       hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
                          ws.g_enc, ws.jac, N, S, d_origins, d_directions);
       TN_CHECK_LAUNCH("tn_field_bwd(d position)");
     }
-  } else if (phases & TN_BWD_MLP) {
-    size_t shmem = PACK_BWD_FLOATS * sizeof(float);
-    if (dens_only) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL(k_field_mlp_bwd<true>, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin,
-                         ws.hh1, ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL(k_field_mlp_bwd<false>, dim3(mlp_grid(P)), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, P, C, ws.h1, ws.hin,
-                         ws.hh1, ws.hh2, ws.g3, ws.gy_hh2, ws.gy_hh1, ws.g_hin, ws.gy_bo, ws.gy_h1, ws.g_enc);
-    }
-    TN_CHECK_LAUNCH("tn_field_bwd(mlp)");
-    // weight gradients: all layers (+ the appearance-embedding rows) in one batched launch, on the companion stream beside the table scatter
-    // (the GEMMs stream the saved activations from HBM, the scatter is bound by atomic requests: they overlap almost perfectly)
-    hipStream_t side = tn_fork(st);
-    hipStream_t wst = side ? side : st;
-    const int64_t* ci = camera_indices;
-    WgradProb pr[WGRAD_MAX_PROBS];
-    int n = 0;
-    if (!dens_only) {
-      pr[n++] = make_prob(ws.gy_hh2, 64, 64, ws.hh1, 64, 64, 0, field->ghw1, 64, field->ghb1);
-      pr[n++] = make_prob(ws.gy_hh1, 64, 64, ws.hin, 64, 64, 0, field->ghw0, 63, field->ghb0, 1);
-      pr[n++] = make_prob(ws.g3, 4, C, ws.hh2, 64, 64, 0, field->ghw2, 64, field->ghb2);
-    }
-    pr[n++] = make_prob(ws.gy_bo, 16, 16, ws.h1, 64, 64, 0, field->gw1, 64, field->gb1);
-    pr[n++] = make_prob(ws.gy_h1, 64, 64, ws.enc, 32, 32, 0, field->gw0, 32, field->gb0);
-    // appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(head input slot 32+e); 32 cameras per problem
-    int base = dens_only ? field->num_images : 0;  // the embedding only feeds the colour head
-    for (; base < field->num_images && n < WGRAD_MAX_PROBS; base += 32)
-      pr[n++] = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
-    rcw = launch_wgrad_batch(pr, n, P, wst);
-    for (; rcw == TN_OK && base < field->num_images; base += 32) {  // > 96 cameras: the remaining embedding rows
-      WgradProb e = make_prob(nullptr, 0, std::min(32, field->num_images - base), ws.g_hin, 64, 32, 32, field->gemb + (int64_t)base * 32, 32, nullptr, 2, ci, base, S);
-      rcw = launch_wgrad_batch(&e, 1, P, wst);
-    }
   }
-  // with the fused backward + k_field_dpos the scatter never computes d position
-  const bool dpos_done = field_bwd_fused() && field_dpos_jac();
-  float* sc_do = dpos_done ? nullptr : d_origins;
-  float* sc_dd = dpos_done ? nullptr : d_directions;
+  // d position comes from k_field_dpos (MLP phase): the scatter never computes it
+  float* sc_do = nullptr;
+  float* sc_dd = nullptr;
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, sc_do, sc_dd, ws.scatter, st);
@@ -1337,7 +1097,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     if (rc == TN_OK && (phases & TN_BWD_SCATTER_FOLD)) rc = tn_grid_scatter_fold(field->grid, P, ws.scatter, level_begin, level_end, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);
-  return rcw ? rcw : rc;
+  return rc;
 }
 
 extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
@@ -1366,9 +1126,9 @@ extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* ori
   TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd_scatter_dense: bad level range [%d, %d)",
              level_begin, level_end);
   FieldWs ws = ws_layout(workspace, N * (int64_t)S, 1);
-  const bool dpos_done = field_bwd_fused() && field_dpos_jac();  // the MLP phase already produced d position (k_field_dpos)
+  // (d position was produced by the MLP phase: k_field_dpos)
   return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S,
-                                dpos_done ? nullptr : d_origins, dpos_done ? nullptr : d_directions, ws.scatter, tn_s(stream), dense_sum);
+                                nullptr, nullptr, ws.scatter, tn_s(stream), dense_sum);
 }
 
 extern "C" int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,

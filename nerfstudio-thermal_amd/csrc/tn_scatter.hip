@@ -456,7 +456,9 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
   }
 }
 
+#ifndef FOLD_THREADS
 #define FOLD_THREADS 512
+#endif
 // How the fold sums a bucket's records in LDS.  LDS float atomics are no way to do it: ds_add_f32 is serialised lane by lane on gfx950
 // (~3 cycles per ACTIVE lane + ~20 per instruction, conflicts or not: scripts/microbench/lds_atomic_rate.hip; integer LDS atomics take 5-11
 // cycles per wave-instruction).  Block-wide passes separated by barriers are no way either: a barrier interval costs ~1 us with 32 waves on

@@ -3,6 +3,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from nerfstudio_thermal_amd import _lib
+if os.environ.get("TN_LIB"):  # A/B timing against another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["TN_LIB"])
 import bench
 from nerfstudio_thermal_amd import ops
 dev = torch.device("cuda", 0)
