@@ -104,16 +104,18 @@ def _datamanager(owner, cam_t, cache, num_rays):
     return dm
 
 
-def one_step(eng, cam_t, cache, num_rays, step, hook):
+def one_step(eng, cam_t, cache, num_rays, step, hook, scaler=None):
     """Fused step.  datamanager.next_train (data/datamanagers/base_datamanager.py:538-547): this step's 2x2 pixel patches over the jagged image
     list, their ground truth and the rays, all on the device (nerfstudio_thermal_amd/data.py); then RenderEngine.train_step."""
     o, d, cam, img, is_th = _datamanager(eng, cam_t, cache, num_rays).next_train(step)
-    return eng.train_step(o, d, cam, img, is_th, step, grad_hook=hook)
+    return eng.train_step(o, d, cam, img, is_th, step, grad_hook=hook, grad_scaler=scaler)
 
 
-def one_step_api(model, optimizers, cam_t, cache, num_rays, step):
-    """The reference Trainer's own sequence (engine/trainer.py:455-499) on the drop-in objects: callbacks, zero_grad, model(ray_bundle),
-    get_metrics_dict, get_loss_dict, reduce(add).backward(), optimiser + scheduler steps."""
+def one_step_api(model, optimizers, cam_t, cache, num_rays, step, grad_scaler=None, call=None):
+    """The reference Trainer's own sequence (engine/trainer.py:455-499) on the drop-in objects, statement for statement: callbacks,
+    zero_grad_some, torch.autocast around model(ray_bundle) / get_metrics_dict / get_loss_dict (mixed_precision=True in thermal-nerfacto's method
+    config), grad_scaler.scale(loss).backward(), optimizer_scaler_step_some, grad_scaler.update(), scheduler steps only when the scale did not
+    drop.  `call`: the module to call for the forward (the DistributedDataParallel wrapper in multi-GPU runs)."""
     import functools
 
     from nerfstudio_thermal_amd.model import TrainingCallbackLocation as Loc
@@ -123,15 +125,26 @@ def one_step_api(model, optimizers, cam_t, cache, num_rays, step):
     cbs = model.__dict__.setdefault("_bench_cbs", model.get_training_callbacks())
     for cb in cbs:
         cb.run_callback_at_location(step, Loc.BEFORE_TRAIN_ITERATION)
-    optimizers.zero_grad_all()
+    groups = model.__dict__.setdefault("_bench_groups", list(optimizers.optimizers.keys()))
+    optimizers.zero_grad_some(groups)
     rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
     batch = {"image": img, "is_thermal": is_th}
-    out = model(rb)
-    metrics = model.get_metrics_dict(out, batch)
-    losses = model.get_loss_dict(out, batch, metrics)
-    functools.reduce(torch.add, losses.values()).backward()
-    optimizers.optimizer_step_all(step)
-    optimizers.scheduler_step_all(step)
+    with torch.autocast(device_type="cuda", enabled=grad_scaler is not None and grad_scaler.is_enabled()):
+        out = (call or model)(rb)
+        metrics = model.get_metrics_dict(out, batch)
+        losses = model.get_loss_dict(out, batch, metrics)
+        loss = functools.reduce(torch.add, losses.values())
+    if grad_scaler is None:
+        loss.backward()
+        optimizers.optimizer_step_all(step)
+        optimizers.scheduler_step_all(step)
+    else:
+        grad_scaler.scale(loss).backward()
+        optimizers.optimizer_scaler_step_some(grad_scaler, groups)
+        scale = grad_scaler.get_scale()
+        grad_scaler.update()
+        if scale <= grad_scaler.get_scale():
+            optimizers.scheduler_step_all(step)
     for cb in cbs:
         cb.run_callback_at_location(step, Loc.AFTER_TRAIN_ITERATION)
     return losses
@@ -395,6 +408,8 @@ def main():
                     "reference Trainer's sequence forward -> get_metrics_dict -> get_loss_dict -> backward -> optimisers on ThermalNerfactoModel")
     ap.add_argument("--api-optimizer", default="hip", choices=["hip", "torch"], help="--path model-api: HipFusedAdam (one launch per group over the arena) or "
                     "torch.optim.Adam on the same parameters")
+    ap.add_argument("--no-grad-scaler", action="store_true", help="drop the GradScaler semantics of the reference Trainer (mixed_precision=True in thermal-nerfacto's "
+                    "method config): fused path = no non-finite check / device-side skip (optim.DeviceGradScaler), model-api path = plain backward + step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(host cores, 16): more threads make the"
@@ -467,10 +482,21 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # GradScaler semantics of the reference's train_iteration (engine/trainer.py:470-495): the drop-in path runs torch.amp.GradScaler itself,
+    # the fused step its device-side equivalent (non-finite check of every group's gradients, skip / backoff / schedule lag on the device)
+    scaler = None
+    if not args.no_grad_scaler:
+        if api:
+            scaler = torch.amp.GradScaler("cuda")
+        elif hook is None or not getattr(hook, "adam_per_range", False):
+            from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+            scaler = DeviceGradScaler(device, num_groups=len(arena.optimised_groups))
+
     def run(step):
         if api:
-            return one_step_api(model, optimizers, cam_t, cache, rays, step)
-        return one_step(eng, cam_t, cache, rays, step, hook)
+            return one_step_api(model, optimizers, cam_t, cache, rays, step, scaler)
+        return one_step(eng, cam_t, cache, rays, step, hook, scaler)
 
     step = 0
     for _ in range(args.warmup):
@@ -584,6 +610,7 @@ def main():
             "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (pixel sampling+raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
                                    f"256/96 proposal + {args.nerf_samples} field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
                        "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam)" if api else ""),
+                       "grad_scaler": (None if scaler is None else ("torch.amp.GradScaler + autocast" if api else "device-side (optim.DeviceGradScaler)")),
                        "final_loss": final_loss},
             "rccl_ranks": rccl_ranks,
             "per_rank_ms_per_step": per_rank_ms,

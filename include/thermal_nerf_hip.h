@@ -343,6 +343,26 @@ int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                         const int64_t* counts, const int32_t* steps, const double* lrs, double beta1, double beta2, double eps,
                         tn_stream_t stream);
+/* GradScaler semantics without a host round trip (engine/trainer.py:470-495 -> torch/amp/grad_scaler.py; engine/optimizers.py:144-183).
+ * GradScaler decides per optimiser, i.e. per parameter group: found_inf is a device array of num_flags floats, one per group.
+ *  - tn_grad_nonfinite sets *found_inf = 1 when any of `count` gradients is inf or NaN (it never clears it: zero-fill once per step).
+ *  - tn_adam_step_ranges_amp is tn_adam_step_ranges with the decision on the device.  Range k belongs to group flag_index[k] (HOST array, NULL =
+ *    all 0):  found_inf[flag] != 0 -> range k is not touched (parameters and both moments bit-identical) and, when count_skip != 0,
+ *    skipped[flag] += 1;  inv_scale (device float or NULL): gradients are multiplied by *inv_scale as they are read;  skipped (device int32
+ *    array or NULL): the bias corrections use steps[k] - skipped[flag], as torch's fused Adam keeps its step tensors (torch/optim/adam.py:
+ *    step -= found_inf);  lr_finals / sched_max_steps (HOST arrays or NULL) + sched_step: when given, lrs[k] is lr_init and the kernel
+ *    evaluates the reference's ExponentialDecayScheduler (engine/schedulers.py:109-141) at sched_step - skipped[lag_index] (lag_index = -1:
+ *    no lag): the trainer does not step the schedulers in an iteration whose scale dropped (engine/trainer.py:491-495).
+ *  - tn_grad_scaler_update is GradScaler.update() on the device (backoff / growth of *scale, growth tracker) and adds 1 to *lag (may be NULL)
+ *    when any of the num_flags entries of found_inf is set. */
+int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream);
+int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                            const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                            const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                            const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                            int32_t lag_index, int32_t count_skip, tn_stream_t stream);
+int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int32_t num_flags, int32_t* lag,
+                          double growth_factor, double backoff_factor, int32_t growth_interval, tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------

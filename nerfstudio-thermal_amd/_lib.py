@@ -11,6 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
+ABI_VERSION = 300  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
@@ -105,6 +106,9 @@ SIGNATURES = {
     "tn_train_metrics": (C.c_int, [_p, _i64, _f, _p, _i32, _p, _i32, _p, _p]),
     "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
     "tn_adam_step_ranges": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _d, _d, _d, _p]),
+    "tn_grad_nonfinite": (C.c_int, [_p, _i64, _p, _p]),
+    "tn_adam_step_ranges_amp": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _p]),
+    "tn_grad_scaler_update": (C.c_int, [_p, _p, _p, _i32, _p, _d, _d, _i32, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
@@ -134,6 +138,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.tn_version() != ABI_VERSION:  # signatures are positional: a stale build would take a workspace pointer for a flag
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {lib.tn_version()}, this binding needs {ABI_VERSION}: rebuild it (__graft_entry__.build())")
         _lib = lib
     return _lib
 

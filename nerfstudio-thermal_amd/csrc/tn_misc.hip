@@ -72,7 +72,7 @@ void tn_join(hipStream_t user, hipStream_t companion) {
   (void)hipStreamWaitEvent(user, c->join_ev, 0);
 }
 
-extern "C" int tn_version(void) { return 100; }
+extern "C" int tn_version(void) { return 300; }  // round 3: signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
   TN_REQUIRE(ptr != nullptr && bytes >= 0, "tn_fill_zero: bad argument");
@@ -758,5 +758,184 @@ extern "C" int tn_adam_step_ranges(float* params, const float* grads, float* exp
   hipLaunchKernelGGL(k_adam_ranges, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, (float)beta1, (float)beta2,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
   TN_CHECK_LAUNCH("tn_adam_step_ranges");
+  return TN_OK;
+}
+
+// ---- GradScaler semantics on the device (torch/amp/grad_scaler.py as engine/trainer.py:470-495 drives it) ------------------------------
+// found_inf: set to 1 if any gradient is non-finite (never cleared here: the caller zero-fills it once per step and may check several slices)
+__global__ void __launch_bounds__(256) k_grad_nonfinite(const float4* __restrict__ g, int64_t n4, const float* __restrict__ gt, int tail,
+                                                         float* __restrict__ found_inf) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const v4f v = reinterpret_cast<const v4f*>(g)[i];
+    // x - x is 0 for finite x, NaN for inf / NaN
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad = bad || (t != 0.0f);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) { const float x = gt[threadIdx.x]; bad = bad || ((x - x) != 0.0f); }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;  // plain store of the same value from any number of waves
+}
+extern "C" int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream) {
+  if (count == 0) return TN_OK;
+  TN_REQUIRE(grads && found_inf && count > 0, "tn_grad_nonfinite: bad argument");
+  TN_REQUIRE(((uintptr_t)grads % 16) == 0, "tn_grad_nonfinite: grads must be 16-byte aligned");
+  const int64_t n4 = count / 4;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(n4, 256 * 4), 256 * 8));
+  hipLaunchKernelGGL(k_grad_nonfinite, dim3(grid), dim3(256), 0, tn_s(stream), reinterpret_cast<const float4*>(grads), n4, grads + n4 * 4, (int)(count - n4 * 4),
+                     found_inf);
+  TN_CHECK_LAUNCH("tn_grad_nonfinite");
+  return TN_OK;
+}
+
+// Adam with the skip / unscale decision ON THE DEVICE: no host synchronisation between backward and optimiser step.  GradScaler decides per
+// OPTIMISER (torch/amp/grad_scaler.py: found_inf_per_device of that optimiser's gradients), i.e. per parameter group here:
+//   found_inf[flag[k]] != 0 -> range k is not touched (parameters and both moments stay bit-identical); if `count_skip`, skipped[flag[k]] += 1
+//   inv_scale               -> gradients are multiplied by *inv_scale as they are read (GradScaler.step on not-yet-unscaled gradients)
+//   skipped[flag[k]]        -> steps of that group skipped so far: the bias corrections use (host step count - skipped), as torch's fused Adam
+//                              keeps its step tensors (torch/optim/adam.py _fused_adam: step -= found_inf)
+//   skipped[lag_index]      -> iterations in which ANY group found an inf (the scale dropped, the trainer did not step the schedulers): the LR
+//                              schedule is evaluated at sched_step - that; tn_grad_scaler_update maintains it
+struct AdamRangesAmp {
+  int64_t off[TN_ADAM_MAX_RANGES], cnt[TN_ADAM_MAX_RANGES];
+  int32_t step[TN_ADAM_MAX_RANGES], flag[TN_ADAM_MAX_RANGES];
+  double lr[TN_ADAM_MAX_RANGES];        // the learning rate, or lr_init of the schedule below
+  double lr_final[TN_ADAM_MAX_RANGES];  // ExponentialDecayScheduler (engine/schedulers.py:109-141) evaluated on the device when max_steps > 0:
+  int32_t max_steps[TN_ADAM_MAX_RANGES];  //   lr = exp(lerp(log lr_init, log lr_final, clip((sched_step - lag) / max_steps, 0, 1)))
+  int32_t sched_step;                     // scheduler steps on the host's count
+  int32_t num_flags, lag_index;           // entries of found_inf; index of the schedule lag in skipped (-1: none)
+};
+__global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
+                                  double beta1, double beta2, float eps, const float* __restrict__ inv_scale, const float* __restrict__ found_inf,
+                                  int32_t* __restrict__ skipped, int count_skip) {
+  const int k = blockIdx.y;
+  const int fl = r.flag[k];
+  // schedule lag = iterations so far in which the scale dropped; maintained by tn_grad_scaler_update AFTER this launch (stream order)
+  const int lag = (skipped != nullptr && r.lag_index >= 0) ? skipped[r.lag_index] : 0;
+  if (found_inf != nullptr && found_inf[fl] != 0.0f) {  // uniform over the range's blocks
+    if (count_skip && skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&skipped[fl], 1);
+    return;
+  }
+  const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
+  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) return;
+  __shared__ float s_ns, s_bc;
+  if (threadIdx.x == 0) {
+    const int sk = skipped ? skipped[fl] : 0;
+    const int eff = r.step[k] - sk;
+    const double bc1 = 1.0 - pow(beta1, (double)(eff < 1 ? 1 : eff)), bc2 = 1.0 - pow(beta2, (double)(eff < 1 ? 1 : eff));
+    double lr = r.lr[k];
+    if (r.max_steps[k] > 0) {
+      double t = (double)(r.sched_step - lag) / (double)r.max_steps[k];
+      t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+      lr = exp(log(r.lr[k]) * (1.0 - t) + log(r.lr_final[k]) * t);
+    }
+    s_ns = (float)(-(lr / bc1));
+    s_bc = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float neg_step = s_ns, bc2_sqrt = s_bc, b1 = (float)beta1, b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const float is = inv_scale ? *inv_scale : 1.0f;
+  float4* p4 = reinterpret_cast<float4*>(p + off);
+  const float4* g4 = reinterpret_cast<const float4*>(g + off);
+  float4* m4 = reinterpret_cast<float4*>(m + off);
+  float4* v4 = reinterpret_cast<float4*>(v + off);
+#define ADAM1(P, G, M, V)                         \
+  {                                               \
+    float g_ = inv_scale ? (G) * is : (G);        \
+    float m_new_ = M * b1 + g_ * omb1;            \
+    float v_new_ = V * b2 + (omb2 * g_) * g_;     \
+    float den_ = sqrtf(v_new_) / bc2_sqrt + eps;  \
+    P = P + neg_step * (m_new_ / den_);           \
+    M = m_new_;                                   \
+    V = v_new_;                                   \
+  }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    float4 pp = p4[i];
+    v4f gg = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g4) + i);
+    v4f mm4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m4) + i);
+    v4f vv4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v4) + i);
+    ADAM1(pp.x, gg.x, mm4.x, vv4.x)
+    ADAM1(pp.y, gg.y, mm4.y, vv4.y)
+    ADAM1(pp.z, gg.z, mm4.z, vv4.z)
+    ADAM1(pp.w, gg.w, mm4.w, vv4.w)
+    p4[i] = pp;
+    __builtin_nontemporal_store(mm4, reinterpret_cast<v4f*>(m4) + i);
+    __builtin_nontemporal_store(vv4, reinterpret_cast<v4f*>(v4) + i);
+  }
+  const int tail = (int)(n - n4 * 4);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
+    const int64_t i = off + n4 * 4 + threadIdx.x;
+    float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    ADAM1(pp, gg, mm, vv)
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+#undef ADAM1
+}
+extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                       const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                       const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                                       const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                                       int32_t lag_index, int32_t count_skip, tn_stream_t stream) {
+  if (num_ranges == 0) return TN_OK;
+  TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges_amp: null pointer");
+  TN_REQUIRE(num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES, "tn_adam_step_ranges_amp: %d ranges (at most %d)", num_ranges, TN_ADAM_MAX_RANGES);
+  TN_REQUIRE(((uintptr_t)params % 16 == 0) && ((uintptr_t)grads % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
+             "tn_adam_step_ranges_amp: arena pointers must be 16-byte aligned");
+  TN_REQUIRE(num_flags >= 1 && num_flags <= 64 && lag_index >= -1 && lag_index <= 64, "tn_adam_step_ranges_amp: bad num_flags / lag_index");
+  AdamRangesAmp r{};
+  int64_t max_n4 = 0;
+  int n = 0;
+  for (int k = 0; k < num_ranges; ++k) {
+    TN_REQUIRE(offsets[k] >= 0 && offsets[k] % 4 == 0 && counts[k] >= 0 && steps[k] >= 1, "tn_adam_step_ranges_amp: bad range %d (offset %lld count %lld step %d)",
+               k, (long long)offsets[k], (long long)counts[k], steps[k]);
+    const int fl = flag_index ? flag_index[k] : 0;
+    TN_REQUIRE(fl >= 0 && fl < num_flags, "tn_adam_step_ranges_amp: flag index %d of range %d outside [0, %d)", fl, k, num_flags);
+    if (counts[k] == 0) continue;
+    r.off[n] = offsets[k]; r.cnt[n] = counts[k]; r.step[n] = steps[k]; r.lr[n] = lrs[k]; r.flag[n] = fl;
+    r.lr_final[n] = lr_finals ? lr_finals[k] : lrs[k];
+    r.max_steps[n] = (lr_finals && sched_max_steps) ? sched_max_steps[k] : 0;
+    max_n4 = std::max<int64_t>(max_n4, counts[k] / 4);
+    ++n;
+  }
+  if (n == 0) return TN_OK;
+  r.sched_step = sched_step;
+  r.num_flags = num_flags;
+  r.lag_index = lag_index;
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256), 256 * 16));
+  hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
+                     found_inf, skipped, (int)count_skip);
+  TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
+  return TN_OK;
+}
+
+// GradScaler.update() (torch/amp/grad_scaler.py -> amp_update_scale_cuda_kernel) for the fused step, one thread: backoff when any of the
+// num_flags found_inf entries is set (and the schedule lag grows by one: the trainer does not step the LR schedulers then,
+// engine/trainer.py:491-495), growth after `growth_interval` clean iterations in a row.
+__global__ void k_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int num_flags, int32_t* lag, float growth_factor,
+                                     float backoff_factor, int growth_interval) {
+  bool any = false;
+  for (int i = 0; i < num_flags; ++i) any = any || (found_inf[i] != 0.0f);
+  if (any) {
+    *scale = *scale * backoff_factor;
+    *growth_tracker = 0;
+    if (lag != nullptr) *lag += 1;
+  } else {
+    const int successful = *growth_tracker + 1;
+    if (successful == growth_interval) {
+      const float ns = *scale * growth_factor;
+      if ((ns - ns) == 0.0f) *scale = ns;  // finite
+      *growth_tracker = 0;
+    } else {
+      *growth_tracker = successful;
+    }
+  }
+}
+extern "C" int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int32_t num_flags, int32_t* lag,
+                                     double growth_factor, double backoff_factor, int32_t growth_interval, tn_stream_t stream) {
+  TN_REQUIRE(scale && growth_tracker && found_inf && num_flags >= 1 && growth_interval >= 1, "tn_grad_scaler_update: bad argument");
+  hipLaunchKernelGGL(k_grad_scaler_update, dim3(1), dim3(1), 0, tn_s(stream), scale, growth_tracker, found_inf, (int)num_flags, lag, (float)growth_factor,
+                     (float)backoff_factor, (int)growth_interval);
+  TN_CHECK_LAUNCH("tn_grad_scaler_update");
   return TN_OK;
 }

@@ -471,13 +471,17 @@ class RenderEngine:
         return losses
 
     # ---------------------------------------------------------------- optimiser
-    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None) -> None:
+    def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,
+                       grad_scaler=None) -> None:
         """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307).
 
         torch.optim.Adam skips parameters whose .grad is None and advances its per-parameter step count (bias correction) only when it
         updates them.  The only parameters that have no gradient in some iterations are the proposal networks on steps where the sampler
         ran them under no_grad (ray_samplers.py:605-610): `skip_groups` names them, and each group keeps its own Adam step count.  The LR
-        schedule (LambdaLR) advances every iteration for every group."""
+        schedule (LambdaLR) advances every iteration for every group.
+
+        grad_scaler (optim.DeviceGradScaler): GradScaler semantics on the device -- the step is a no-op when the gradients hold an inf / NaN,
+        bias corrections and LR schedule are evaluated at (count - skipped steps), the scale is updated (engine/trainer.py:470-495)."""
         self.adam_step_count += 1
         if not hasattr(self, "group_steps"):
             self.group_steps = {}
@@ -493,6 +497,23 @@ class RenderEngine:
             if lr_overrides and gname in lr_overrides:
                 lr = lr_overrides[gname]
             hyper[gname] = (self.group_steps[gname], lr)
+        if grad_scaler is not None and grad_scaler.enabled:
+            assert ranges is None, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
+            names = list(hyper)
+            gidx = {g: i for i, g in enumerate(a.optimised_groups)}
+            for g in names:  # GradScaler decides per optimiser = per parameter group
+                lo, hi = a.group_range[g]
+                grad_scaler.check(gidx[g], a.grads[lo:hi])
+            sched = None
+            rng = [a.group_range[g] + hyper[g] for g in names]
+            if scheduled and not lr_overrides:  # schedule on the device: lr_init + (lr_final, max_steps), evaluated at count - lag
+                rng = [a.group_range[g] + (hyper[g][0], OPTIMIZERS[g][0]) for g in names]
+                sched = [(OPTIMIZERS[g][1], OPTIMIZERS[g][2]) for g in names]
+            ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, eps=1e-15, found_inf=grad_scaler.found_inf,
+                                     flags=[gidx[g] for g in names], skipped=grad_scaler.skipped, lag_index=grad_scaler.lag_index, count_skip=True,
+                                     schedule=sched, sched_step=self.adam_step_count - 1)
+            grad_scaler.update()
+            return
         if ranges is None:  # every group at once: one launch
             ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [a.group_range[g] + hyper[g] for g in hyper], eps=1e-15)
             return
@@ -548,9 +569,12 @@ class RenderEngine:
             self.steps_since_update, self.sampler_step, self.anneal = int(smp["steps_since_update"]), int(smp["step"]), float(smp["anneal"])
 
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
-                   jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True) -> Dict[str, Tensor]:
-        """Trainer.train_iteration (engine/trainer.py:455-499) for this model: callbacks, forward, losses, backward, (all-reduce), Adam."""
+                   jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True, grad_scaler=None) -> Dict[str, Tensor]:
+        """Trainer.train_iteration (engine/trainer.py:455-499) for this model: callbacks, forward, losses, backward, (all-reduce), Adam.
+        grad_scaler: optim.DeviceGradScaler or None (see optimizer_step)."""
         self.set_anneal_for_step(step)
+        if grad_scaler is not None:
+            grad_scaler.begin_step()
         self.arena.zero_grad()
         out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
@@ -566,12 +590,12 @@ class RenderEngine:
                 self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
             else:
                 grad_hook.finish(skip=idle)
-                self.optimizer_step(scheduled=scheduled, skip_groups=skip)
+                self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler)
         else:
             losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
             if grad_hook is not None:
                 grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
             skip = () if branches[""].prop_grad else ("proposal_networks",)
-            self.optimizer_step(scheduled=scheduled, skip_groups=skip)
+            self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler)
         self.step_cb(step)
         return losses

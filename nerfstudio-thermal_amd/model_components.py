@@ -46,10 +46,11 @@ class HashMLPDensityField(nn.Module):
 
     def __init__(self, aabb: Tensor, net: PropNetParams, max_res: int, params: Dict[str, nn.Parameter]):
         super().__init__()
-        self.register_buffer("aabb", aabb)
-        self.register_buffer("max_res", torch.tensor(max_res))
-        self.register_buffer("num_levels", torch.tensor(net.num_levels))
-        self.register_buffer("log2_hashmap_size", torch.tensor(net.log2_hashmap_size))
+        dev = params["table"].device  # buffers live with the parameters (the reference moves the whole module: DDP broadcasts module states)
+        self.register_buffer("aabb", aabb.to(dev))
+        self.register_buffer("max_res", torch.tensor(max_res, device=dev))
+        self.register_buffer("num_levels", torch.tensor(net.num_levels, device=dev))
+        self.register_buffer("log2_hashmap_size", torch.tensor(net.log2_hashmap_size, device=dev))
         self.net = net
         register_dotted(self, "encoding.hash_table", params["table"])
         register_dotted(self, "mlp_base.0.hash_table", params["table"])
@@ -88,10 +89,11 @@ class ThermalNerfactoField(nn.Module):
     def __init__(self, aabb: Tensor, fld: FieldParams, max_res: int, params: Dict[str, nn.Parameter], prefix_names: Dict[str, str],
                  use_average_appearance_embedding: bool = True):
         super().__init__()
-        self.register_buffer("aabb", aabb)
-        self.register_buffer("max_res", torch.tensor(max_res))
-        self.register_buffer("num_levels", torch.tensor(fld.num_levels))
-        self.register_buffer("log2_hashmap_size", torch.tensor(fld.log2_hashmap_size))
+        dev = params["table"].device
+        self.register_buffer("aabb", aabb.to(dev))
+        self.register_buffer("max_res", torch.tensor(max_res, device=dev))
+        self.register_buffer("num_levels", torch.tensor(fld.num_levels, device=dev))
+        self.register_buffer("log2_hashmap_size", torch.tensor(fld.log2_hashmap_size, device=dev))
         self.fld = fld
         self.use_average_appearance_embedding = use_average_appearance_embedding
         for short, dotted in prefix_names.items():

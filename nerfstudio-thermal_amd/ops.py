@@ -877,3 +877,50 @@ def adam_step_ranges(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq:
     lrs = (C.c_double * n)(*[float(r[3]) for r in ranges])
     check(_lib.load().tn_adam_step_ranges(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n,
                                           offs, cnts, steps, lrs, float(beta1), float(beta2), float(eps), _stream()), "tn_adam_step_ranges")
+
+
+def grad_nonfinite(grads: Tensor, found_inf: Tensor) -> None:
+    """found_inf[0] = 1 if any element of the (contiguous fp32) gradient slice is inf / NaN; never cleared here."""
+    if grads.numel() == 0:
+        return
+    check(_lib.load().tn_grad_nonfinite(_f32(grads, "grads"), grads.numel(), _f32(found_inf, "found_inf", (1,)), _stream()), "tn_grad_nonfinite")
+
+
+def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, ranges, beta1: float = 0.9, beta2: float = 0.999,
+                         eps: float = 1e-15, inv_scale: Optional[Tensor] = None, found_inf: Optional[Tensor] = None, flags=None,
+                         skipped: Optional[Tensor] = None, lag_index: int = -1, count_skip: bool = False, schedule=None, sched_step: int = 0) -> None:
+    """adam_step_ranges with GradScaler's skip / unscale decision on the device (no host sync): see tn_adam_step_ranges_amp.
+    found_inf: float device tensor with one entry per parameter group; flags: the entry of each range (default 0); skipped: int32 device
+    tensor (per-group skip counts, and the schedule lag at lag_index).
+    schedule: None, or one (lr_final, max_steps) per range: the range's lr is then lr_init and the exponential-decay schedule is evaluated on the
+    device at sched_step - skipped[lag_index]."""
+    n = len(ranges)
+    if n == 0:
+        return
+    for lo, hi, _, _ in ranges:
+        if not (0 <= lo <= hi <= params.numel()):
+            raise ValueError(f"Adam range [{lo}, {hi}) outside the arena")
+    nflags = int(found_inf.numel()) if found_inf is not None else 1
+    if skipped is not None and (skipped.dtype != torch.int32 or not skipped.is_cuda or skipped.numel() < max(nflags, lag_index + 1)):
+        raise ValueError("skipped must be an int32 device tensor with an entry per flag (and the lag entry)")
+    offs = (C.c_int64 * n)(*[r[0] for r in ranges])
+    cnts = (C.c_int64 * n)(*[r[1] - r[0] for r in ranges])
+    steps = (C.c_int32 * n)(*[int(r[2]) for r in ranges])
+    lrs = (C.c_double * n)(*[float(r[3]) for r in ranges])
+    lrf = (C.c_double * n)(*[float(x[0]) for x in schedule]) if schedule is not None else None
+    smax = (C.c_int32 * n)(*[int(x[1]) for x in schedule]) if schedule is not None else None
+    fl = (C.c_int32 * n)(*[int(x) for x in flags]) if flags is not None else None
+    check(_lib.load().tn_adam_step_ranges_amp(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n,
+                                              offs, cnts, steps, lrs, lrf, smax, int(sched_step), float(beta1), float(beta2), float(eps),
+                                              _f32(inv_scale, "inv_scale", (1,), True) if inv_scale is not None else None,
+                                              _f32(found_inf, "found_inf", None, True) if found_inf is not None else None, fl, nflags,
+                                              C.c_void_p(skipped.data_ptr()) if skipped is not None else None, int(lag_index), 1 if count_skip else 0,
+                                              _stream()), "tn_adam_step_ranges_amp")
+
+
+def grad_scaler_update(scale: Tensor, growth_tracker: Tensor, found_inf: Tensor, lag: Optional[Tensor], growth_factor: float, backoff_factor: float,
+                       growth_interval: int) -> None:
+    """GradScaler.update() on the device; lag (1-element int32 view or None) += 1 when any found_inf entry is set."""
+    check(_lib.load().tn_grad_scaler_update(_f32(scale, "scale", (1,)), C.c_void_p(growth_tracker.data_ptr()), _f32(found_inf, "found_inf"),
+                                            int(found_inf.numel()), C.c_void_p(lag.data_ptr()) if lag is not None else None, float(growth_factor),
+                                            float(backoff_factor), int(growth_interval), _stream()), "tn_grad_scaler_update")

@@ -22,6 +22,10 @@ from .arena import ParamArena
 
 
 class HipFusedAdam(torch.optim.Optimizer):
+    # torch.amp.GradScaler.step() hands `grad_scale` / `found_inf` (device tensors) to optimisers that declare this and lets THEM skip the step
+    # on the device (torch/amp/grad_scaler.py: the branch torch's fused Adam takes) instead of synchronising the host on found_inf.item()
+    _step_supports_amp_scaling = True
+
     def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, **kwargs):
         if weight_decay != 0.0 or kwargs.get("amsgrad", False) or kwargs.get("maximize", False):
             raise NotImplementedError("HipFusedAdam implements plain Adam (weight_decay = 0, no amsgrad): what the thermal-nerfacto optimisers use")
@@ -29,6 +33,7 @@ class HipFusedAdam(torch.optim.Optimizer):
         self._where: Dict[int, tuple] = {}  # id(p) -> (arena, offset, numel)
         self._steps: Dict[int, int] = {}    # id(p) -> Adam step count (torch keeps a tensor per parameter; a Python int costs nothing per step)
         self._plans: Dict[int, tuple] = {}
+        self._skipped: Optional[torch.Tensor] = None  # device int32: steps skipped on found_inf (created with the first AMP step)
         for group in self.param_groups:
             for p in group["params"]:
                 arena = ParamArena.owner_of(p)
@@ -62,6 +67,9 @@ class HipFusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         steps = self._steps
+        # set by torch.amp.GradScaler.step() for this call only (and deleted by it afterwards)
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        launches = []
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             rows, full_runs = self._group_plan(gi)
@@ -92,15 +100,37 @@ class HipFusedAdam(torch.optim.Optimizer):
                         runs[-1][2] = off + n
                     else:
                         runs.append([arena, off, off + n, k])
+            amp = found_inf is not None or grad_scale is not None
             for i in range(0, len(runs), 8):
                 chunk = runs[i:i + 8]
                 a = chunk[0][0]
                 assert all(r[0] is a for r in chunk)
-                ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq,
-                                     [(r[1], (r[2] + 3) // 4 * 4, r[3], group["lr"]) for r in chunk], beta1=b1, beta2=b2, eps=group["eps"])
+                rng = [(r[1], (r[2] + 3) // 4 * 4, r[3], group["lr"]) for r in chunk]
+                if amp:
+                    launches.append((a, rng, b1, b2, group["eps"]))
+                else:
+                    ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, beta1=b1, beta2=b2, eps=group["eps"])
+        if launches:
+            # GradScaler path: the skip / unscale decision stays on the device; only the LAST launch of this step() counts a skipped step
+            if self._skipped is None:
+                self._skipped = torch.zeros(1, dtype=torch.int32, device=launches[0][0].params.device)
+            inv = None if grad_scale is None else grad_scale.to(torch.float32).reciprocal().reshape(1)
+            fi = None if found_inf is None else found_inf.to(torch.float32).reshape(1)
+            for k, (a, rng, b1, b2, eps) in enumerate(launches):
+                ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, beta1=b1, beta2=b2, eps=eps, inv_scale=inv, found_inf=fi,
+                                         skipped=self._skipped, count_skip=(k == len(launches) - 1))  # one optimiser = one flag, one counter
         return loss
 
+    def num_skipped(self) -> int:
+        """Steps that GradScaler's found_inf turned into no-ops on the device (synchronises: checkpoints and tests only)."""
+        return int(self._skipped.item()) if self._skipped is not None else 0
+
     def _sync_step_tensors(self) -> None:
+        sk = self.num_skipped()  # the host-side counts include the skipped steps; torch's step tensors do not
+        if sk:
+            for k in list(self._steps):
+                self._steps[k] = max(0, self._steps[k] - sk)
+            self._skipped.zero_()
         for group in self.param_groups:
             for p in group["params"]:
                 self.state[p]["step"] = torch.tensor(float(self._steps.get(id(p), 0)))
@@ -113,21 +143,77 @@ class HipFusedAdam(torch.optim.Optimizer):
         super().zero_grad(set_to_none=set_to_none)
 
     def load_state_dict(self, state_dict):
-        """torch's loader replaces the state tensors; copy them back into the arena so that the moments stay views of it."""
+        """torch's loader replaces the state tensors; copy them back into the arena so that the moments stay views of it.  A checkpoint
+        written by torch.optim.Adam (or by the reference Trainer) has NO entry for parameters that never received a gradient -- Adam creates
+        its state lazily -- e.g. the thermal twins in shared mode: those get zero moments and step 0 here, and a full entry again."""
         super().load_state_dict(state_dict)
+        if self._skipped is not None:
+            self._skipped.zero_()  # the loaded step counts are final
         for group in self.param_groups:
             for p in group["params"]:
                 arena, off, n = self._where[id(p)]
                 st = self.state.get(p)
-                if not st:
+                views = {"exp_avg": arena.exp_avg[off:off + n].view(p.shape), "exp_avg_sq": arena.exp_avg_sq[off:off + n].view(p.shape)}
+                if not st or "exp_avg" not in st:
+                    for v in views.values():
+                        v.zero_()
+                    self._steps[id(p)] = 0
+                    self.state[p] = {"step": torch.tensor(0.0), **views}
                     continue
-                for key, buf in (("exp_avg", arena.exp_avg), ("exp_avg_sq", arena.exp_avg_sq)):
-                    view = buf[off:off + n].view(p.shape)
+                for key, view in views.items():
                     if st[key].data_ptr() != view.data_ptr():
                         view.copy_(st[key].to(view.device, view.dtype))
                         st[key] = view
                 self._steps[id(p)] = int(float(st["step"]))
                 st["step"] = torch.tensor(float(self._steps[id(p)]))
+
+class DeviceGradScaler:
+    """torch.amp.GradScaler's state machine (torch/amp/grad_scaler.py) for the FUSED step (RenderEngine.train_step), kept on the device: the
+    reference Trainer runs every iteration through `grad_scaler.scale(loss).backward()`, `optimizer_scaler_step_some`, `grad_scaler.update()` and
+    steps the LR schedulers only when the scale did not drop (engine/trainer.py:470-495; `mixed_precision=True` in thermal-nerfacto's method
+    config, configs/method_configs.py:260).
+
+    What carries over to the fused step, which computes in fp32 end to end (autocast has nothing to cast in it):
+      * the multiplication of the loss by the scale and the division of the gradients by it cancel exactly in fp32 (powers of two), so they are
+        not performed; the scale itself evolves exactly as GradScaler's (torch._amp_update_scale_ on the device: growth after `growth_interval`
+        clean steps, backoff on a non-finite gradient) and can be read back with get_scale();
+      * a step whose gradients contain an inf / NaN changes NOTHING: tn_grad_nonfinite raises `found_inf` over the live gradient range and
+        tn_adam_step_ranges_amp returns without touching parameters or moments, counts the skipped step on the device, and evaluates the
+        bias corrections and the LR schedule at (count - skipped) -- the trainer's "do not step the scheduler" -- without any host sync.
+    (The overflow threshold differs: GradScaler sees the gradients times the scale, this sees them unscaled.)"""
+
+    def __init__(self, device, num_groups: int = 6, init_scale: float = 2.0**16, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.num_groups = num_groups
+        self.scale = torch.full((1,), float(init_scale), device=device)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.found_inf = torch.zeros(num_groups, device=device)                         # one flag per optimiser group (GradScaler decides per optimiser)
+        self.skipped = torch.zeros(num_groups + 1, dtype=torch.int32, device=device)   # per-group skipped steps, then the LR-schedule lag
+
+    @property
+    def lag_index(self) -> int:
+        return self.num_groups
+
+    def begin_step(self) -> None:
+        self.found_inf.zero_()
+
+    def check(self, group: int, grads: torch.Tensor) -> None:
+        ops.grad_nonfinite(grads, self.found_inf[group:group + 1])
+
+    def update(self) -> None:
+        ops.grad_scaler_update(self.scale, self.growth_tracker, self.found_inf, self.skipped[self.num_groups:], self.growth_factor, self.backoff_factor,
+                               self.growth_interval)
+
+    def get_scale(self) -> float:
+        return float(self.scale.item())
+
+    def num_skipped(self, group: int = 0) -> int:
+        return int(self.skipped[group].item())
+
+    def schedule_lag(self) -> int:
+        return int(self.skipped[self.num_groups].item())
 
 
 class ExponentialDecayLR:
@@ -163,11 +249,15 @@ class ExponentialDecayLR:
 class Optimizers:
     """engine/optimizers.py:73-210 for this model: one optimiser (+ scheduler) per parameter group, stepped together."""
 
-    def __init__(self, param_groups: Dict[str, List[torch.nn.Parameter]], table: Optional[Dict[str, tuple]] = None, optimizer_cls=HipFusedAdam):
+    def __init__(self, param_groups: Dict[str, List[torch.nn.Parameter]], table: Optional[Dict[str, tuple]] = None, optimizer_cls=HipFusedAdam,
+                 max_norm: Optional[Dict[str, float]] = None):
+        """max_norm: per-group gradient-norm clip (OptimizerConfig.max_norm, engine/optimizers.py:47; None everywhere in thermal-nerfacto's
+        method config, configs/method_configs.py:274-307)."""
         from .engine import OPTIMIZERS
 
         table = table or OPTIMIZERS
         self.optimizers, self.schedulers, self.parameters = {}, {}, {}
+        self.max_norm: Dict[str, float] = dict(max_norm or {})
         for name, params in param_groups.items():
             lr, lr_final, max_steps = table[name]
             self.optimizers[name] = optimizer_cls(params, lr=lr, eps=1e-15)
@@ -178,8 +268,33 @@ class Optimizers:
         for o in self.optimizers.values():
             o.zero_grad()
 
+    def zero_grad_some(self, param_groups: List[str]) -> None:
+        """engine/optimizers.py:139-143"""
+        for name in param_groups:
+            self.optimizers[name].zero_grad()
+
+    def optimizer_scaler_step_some(self, grad_scaler, param_groups: List[str]) -> None:
+        """engine/optimizers.py:160-173: unscale + clip when the group has a max_norm, then GradScaler.step -- which skips the optimiser when an
+        inf / NaN was found (on the device for HipFusedAdam, through found_inf.item() for torch.optim.Adam) -- for groups with any gradient."""
+        for name in param_groups:
+            optimizer = self.optimizers[name]
+            max_norm = self.max_norm.get(name)
+            if max_norm is not None:
+                grad_scaler.unscale_(optimizer)
+                torch.nn.utils.clip_grad_norm_(self.parameters[name], max_norm)
+            if any(any(p.grad is not None for p in g["params"]) for g in optimizer.param_groups):
+                grad_scaler.step(optimizer)
+
+    def optimizer_scaler_step_all(self, grad_scaler) -> None:
+        """engine/optimizers.py:145-158"""
+        self.optimizer_scaler_step_some(grad_scaler, list(self.optimizers.keys()))
+
     def optimizer_step_all(self, step: int = 0) -> None:
-        for o in self.optimizers.values():
+        """engine/optimizers.py:175-183"""
+        for name, o in self.optimizers.items():
+            max_norm = self.max_norm.get(name)
+            if max_norm is not None:
+                torch.nn.utils.clip_grad_norm_(self.parameters[name], max_norm)
             o.step()
 
     def scheduler_step_all(self, step: int = 0) -> None:
