@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 RAYS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def source_hash() -> str:
@@ -163,9 +163,10 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# bench row -> kernels of profiles/r02_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
+# bench row -> kernels of profiles/r03_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
+DOMINANT = "scatter(main grid)"  # the launch pair with the largest share of the step (every step; the proposal grids' only on update steps)
 PMC_KEYS = {
-    "scatter(main grid)": ["k_grid_bin<true> 196608x2", "k_grid_fold 196608x2"],
+    "scatter(main grid)": ["k_grid_bin<false> 196608x2", "k_grid_fold 196608x2"],
     "scatter(prop0 grid)": ["k_grid_bin<true> 1048576x1", "k_grid_fold 1048576x1"],
     "scatter(prop1 grid)": ["k_grid_bin<true> 393216x1", "k_grid_fold 393216x1"],
     "k_prop_fwd(level0)": ["k_prop_fwd 1048576x1"],
@@ -176,11 +177,11 @@ PMC_KEYS = {
 def load_pmc():
     """PMC figures measured by scripts/pmc_passes.sh, or (None, why) when they were taken on other kernel sources than the ones running."""
     if not os.path.exists(PMC_JSON):
-        return None, "no profiles/r02_pmc.json"
+        return None, "no profiles/r03_pmc.json"
     with open(PMC_JSON) as f:
         j = json.load(f)
     if j.get("source_hash") != source_hash():
-        return None, f"profiles/r02_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
+        return None, f"profiles/r03_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
     return j["kernels"], None
 
 
@@ -206,8 +207,12 @@ def kernel_roofline(eng, cam_t, idx):
     for name, net, L in grids:
         ld = 16 if net.num_levels == 5 else 32
         g_enc = torch.randn((N * L.S, ld), device=o.device) * 1e-3
+        if net.num_levels != 5:  # the main field's backward hands its d enc over level-major
+            g_enc = g_enc.reshape(N * L.S, net.num_levels, 2).permute(1, 0, 2).contiguous()
+        # as the step calls it: the proposal grids' scatter also yields d position; the main field's does not (k_field_dpos does, beside it)
+        dpos = (d_o, d_d) if net.num_levels == 5 else (None, None)
         ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
-                                              L.e_bins, g_enc, d_o, d_d))
+                                              L.e_bins, g_enc, *dpos))
         rows.append((f"scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
     eng.arena.zero_grad()
     return rows
@@ -273,18 +278,19 @@ def bench_splat(args):
     Replicas only across GPUs (every rank renders its own frames: a frame does not shard in the reference either)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerfstudio_thermal_amd  # noqa: F401
-    import splat_oracle as so  # synthetic scene generator + the CPU baseline (checker only)
+    import splat_oracle as so  # the CPU baseline leg only (checker, never the thing measured)
+    from nerfstudio_thermal_amd import synth
     from nerfstudio_thermal_amd.parallel import init_distributed
     from nerfstudio_thermal_amd.splat import PinholeCamera, ThermalSplatfactoModel, ThermalSplatfactoModelConfig
 
     rank, local, world = init_distributed()
     torch.cuda.set_device(local)
     N, W, H = args.gaussians, 1920, 1080
-    p = so.synth_gaussians(N, seed=11 + rank, extent=1.5, scale_range=(-5.5, -3.5))
+    p = synth.synth_gaussians(N, seed=11 + rank, extent=1.5, scale_range=(-5.5, -3.5))
     m = ThermalSplatfactoModel(ThermalSplatfactoModelConfig(), num_points=4, device=f"cuda:{local}")
     m.load_gaussians(p)
     m.step = 10**6  # all SH degrees active
-    cam = PinholeCamera(so.look_at_camera((3.2, 0.5, 0.8)), 1400.0, 1400.0, 960.0, 540.0, W, H)
+    cam = PinholeCamera(synth.look_at_camera((3.2, 0.5, 0.8)), 1400.0, 1400.0, 960.0, 540.0, W, H)
     for _ in range(args.warmup):
         m.get_outputs(cam)
     gc.collect()
@@ -338,7 +344,7 @@ def bench_splat(args):
         ps = {k: v[:n_s] for k, v in p.items()}
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         t0 = time.perf_counter()
-        so.render(ps, so.look_at_camera((3.2, 0.5, 0.8)), 1400.0 / 8, 1400.0 / 8, 960.0 / 8, 540.0 / 8, Ws, Hs)
+        so.render(ps, synth.look_at_camera((3.2, 0.5, 0.8)), 1400.0 / 8, 1400.0 / 8, 960.0 / 8, 540.0 / 8, Ws, Hs)
         tc = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": 1.0 / (tc * 64.0), "unit": "frames/s (extrapolated x64 from the sample)", "cores": torch.get_num_threads(), "kind": "port",
                                 "sample": f"{Ws}x{Hs} pixels, {n_s} Gaussians by oracle/splat_oracle.py in {tc:.1f} s"}
@@ -572,7 +578,7 @@ def main():
         if args.ops:
             for name, ms, nbytes in rows:
                 print(f"{name:60s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s algorithmic", file=sys.stderr)
-        name, ms, nbytes = max(rows, key=lambda r: r[1])
+        name, ms, nbytes = next(r for r in rows if r[0] == DOMINANT)
         achieved = nbytes / (ms * 1e-3) / 1e9
         pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
         traffic = None
@@ -581,9 +587,27 @@ def main():
         upd = updates / max(args.steps, 1)
         step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
         step_gbs = step_bytes / (dt / args.steps) / 1e9
+        # the same launch pair INSIDE the step (HIP events on the launch stream around the scatter phase, 20 extra steps): what runs beside it
+        # (k_field_dpos; on update steps the proposal networks' backward on the side streams) shares the chip with it
+        in_step = None
+        if not api and world == 1 and hook is None:
+            eng.scatter_events = []
+            for _ in range(20):
+                run(step)
+                step += 1
+            torch.cuda.synchronize()
+            tms = [(e0.elapsed_time(e1), u) for e0, e1, u in eng.scatter_events]
+            eng.scatter_events = None
+            if tms:
+                in_step = {"mean_ms": float(np.mean([t for t, _ in tms])),
+                           "mean_ms_update_steps": float(np.mean([t for t, u in tms if u])) if any(u for _, u in tms) else None,
+                           "mean_ms_other_steps": float(np.mean([t for t, u in tms if not u])) if any(not u for _, u in tms) else None}
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
-                    "note": "the scatter entry point = k_grid_bin + k_grid_fold; both run on the LDS unit, not on HBM (profiles/r02_scatter_alternatives.md)",
+                    "avg_launch_ms_in_step": None if in_step is None else in_step["mean_ms"], "in_step": in_step,
+                    "frac_in_step": None if in_step is None else nbytes / (in_step["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "the main grid's scatter entry point = k_grid_bin + k_grid_fold as the field backward calls it (d position comes from "
+                            "k_field_dpos); both passes run on the LDS unit, not on HBM (profiles/r02_scatter_alternatives.md)",
                     "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows},
                     # SURVEY 8d's whole-step figure: (N x bytes_ray + bytes_step) / t_step against the HBM peak
                     "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "proposal_update_fraction": upd}}
@@ -592,8 +616,8 @@ def main():
         else:
             roofline["traffic_all_kernels"] = {n: sum(pmc[k]["traffic_bytes"] for k in ks) for n, ks in PMC_KEYS.items() if all(k in pmc for k in ks)}
             roofline["mfma_busy_frac"] = {k.split(" ")[0]: v["mfma_busy_frac"] for k, v in pmc.items()
-                                          if k.split(" ")[0] in ("k_field_mlp_fwd<true>", "k_field_mlp_bwd<false>", "k_wgrad_batch") and "mfma_busy_frac" in v}
-            roofline["pmc_source"] = "profiles/r02_pmc.json"
+                                          if k.split(" ")[0] in ("k_field_fwd_fused<true>", "k_field_bwd_fused<false>") and "mfma_busy_frac" in v}
+            roofline["pmc_source"] = "profiles/r03_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
         result = {
             "metric": "train rays/sec (4096-ray batch, 96 samples/ray)",
             "value": world * rays * args.steps / dt,
@@ -621,7 +645,9 @@ def main():
             torch.cuda.synchronize()
             cores = args.cpu_threads or min(os.cpu_count() or 1, 16)
             v, t = cpu_baseline(rays, args.cpu_steps if args.mode == "shared" else max(2, args.cpu_steps // 2), cores, args.mode)
-            result["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": cores, "kind": "port",
+            result["cpu_baseline"] = {"value": v, "unit": "rays/s", "cores": cores, "kind": "port", "host_cores": os.cpu_count(),
+                                      "threads_note": "min(host cores, 16) torch threads: more threads make this op mix SLOWER on the GPU box's 256-thread host "
+                                                      "(measured at 1024 rays: 8 -> 2427, 16 -> 2286, 32 -> 1906, 64 -> 1025, 256 -> 24 rays/s); --cpu-threads overrides",
                                       "sample": f"{args.cpu_steps if args.mode == 'shared' else max(2, args.cpu_steps // 2)} steps (after 1 warm-up) of the same "
                                                 f"{rays}-ray {args.mode}-density train step (fwd+losses+bwd+Adam) by the oracle, median {t:.2f} s/step"}
             if args.mode == "shared":  # comparability with the figures of SURVEY 6 / BASELINE.md: 8 threads, and 1 thread on a quarter batch

@@ -131,6 +131,7 @@ int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float*
 
 /* ---- a9 (backward)  autograd of HashEncoding.pytorch_fwd (field_components/encodings.py:420-461) with respect to the table (and the sample
  *          position): trilinear scatter-add of g_enc [N*S, ld] (feature 2*level + f) into grid->table_grad; d_origins/d_directions optional.
+ *          ld == -1: g_enc is LEVEL-major, [num_levels][N*S][2] (what the main field's backward produces: coalesced reads per level).
  *          Used by tn_prop_density_bwd and tn_field_bwd; exposed because it is the dominant kernel of the training step.
  *          workspace: tn_hash_scatter_workspace_bytes(N*S, num_levels) of 256-byte-aligned device scratch (contents irrelevant), or NULL.
  *          With it the scatter is atomic-free: every contribution is written once as a (slot, value) record into the bucket of its
@@ -354,15 +355,18 @@ int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float
  *    evaluates the reference's ExponentialDecayScheduler (engine/schedulers.py:109-141) at sched_step - skipped[lag_index] (lag_index = -1:
  *    no lag): the trainer does not step the schedulers in an iteration whose scale dropped (engine/trainer.py:491-495).
  *  - tn_grad_scaler_update is GradScaler.update() on the device (backoff / growth of *scale, growth tracker) and adds 1 to *lag (may be NULL)
- *    when any of the num_flags entries of found_inf is set. */
+ *    when any of the num_flags entries of found_inf is set; clear_found_inf != 0 zero-fills found_inf afterwards (ready for the next step). */
 int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream);
+/* the same for up to 8 ranges of one gradient arena in ONE launch: range k raises found_inf[flag_index[k]] (offsets, counts, flag_index: HOST arrays) */
+int tn_grad_nonfinite_ranges(const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
+                             int32_t num_flags, float* found_inf, tn_stream_t stream);
 int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                             const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                             const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                             const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
                             int32_t lag_index, int32_t count_skip, tn_stream_t stream);
-int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int32_t num_flags, int32_t* lag,
-                          double growth_factor, double backoff_factor, int32_t growth_interval, tn_stream_t stream);
+int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
+                          double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------

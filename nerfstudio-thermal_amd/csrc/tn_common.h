@@ -339,7 +339,9 @@ struct ReplicaK {
   uint32_t first[TN_MAX_LEVELS];   // prefix sum of n over the replicated levels (reduce-thread index of the level's entry 0)
   uint8_t R[TN_MAX_LEVELS];        // replicas of level l
 };
-// g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order.
+// g_enc: [P, ld] gradient of the encoding (feature 2*level + f), rows in ray-major sample order; or, with ld == TN_LD_LEVEL_MAJOR,
+// [levels][P] float2 (level-major: what the main field's backward writes for the bin pass and k_field_dpos).
+#define TN_LD_LEVEL_MAJOR (-1)
 // scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.

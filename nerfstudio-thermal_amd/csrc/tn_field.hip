@@ -121,7 +121,7 @@ struct FieldWs {
   float* hh1;      // relu(head layer 0)
   float* hh2;      // relu(head layer 1)
   float* y;        // [P][4]   sigmoid outputs (for the sigmoid derivative)
-  float* g_enc;    // [P][32]  d enc, sample-major (read by the table scatter and k_field_dpos)
+  float* g_enc;    // [16][P] float2  d enc, LEVEL-major (read by the table scatter's bin pass and k_field_dpos)
   float* jac;      // res * d enc / d offset: 16 levels x 2 features x 3 axes per sample, [tile][q][k][lane] float4
                    // (written by the training forward, read by k_field_dpos with the same lane mapping)
   void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
@@ -220,7 +220,9 @@ __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ or
     float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 gv = *reinterpret_cast<const float4*>(g_enc + pc * 32 + 8 * q + 4 * h);
+      const float2 ga = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h) * 2 * P + 2 * pc);      // level-major [16][P] float2
+      const float2 gb = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h + 1) * 2 * P + 2 * pc);
+      const float4 gv = make_float4(ga.x, ga.y, gb.x, gb.y);
       const float4* jp = reinterpret_cast<const float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order, as k_field_encode wrote it
       const float4 j0 = jp[0], j1 = jp[64], j2 = jp[128];
       dx += gv.x * j0.x + gv.y * j0.w + gv.z * j1.z + gv.w * j2.y;
@@ -838,7 +840,13 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 0, r), dh0[r], de);
 #pragma unroll
     for (int r = 0; r < 16; ++r) de = MFMA(AB(0, 0, 1, r), dh1[r], de);
-    if (valid) store_tile(g_enc, p, 32, 0, h, de);
+    if (valid) {  // d enc, level-major [16][P] float2: registers 4g..4g+3 = levels 4g + 2h (f0, f1), 4g + 2h + 1 (f0, f1)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float2*>(g_enc + (int64_t)(4 * g + 2 * h) * 2 * P + 2 * p) = make_float2(de[4 * g], de[4 * g + 1]);
+        *reinterpret_cast<float2*>(g_enc + (int64_t)(4 * g + 2 * h + 1) * 2 * P + 2 * p) = make_float2(de[4 * g + 2], de[4 * g + 3]);
+      }
+    }
     WAVE_LDS_SYNC();
   }
 #undef AB
@@ -1088,12 +1096,12 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   float* sc_dd = nullptr;
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
-    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S, sc_do, sc_dd, ws.scatter, st);
+    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st);
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");
     if (phases & TN_BWD_SCATTER_BIN)
-      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, 32, N, S, sc_do, sc_dd, ws.scatter, st);
+      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st);
     if (rc == TN_OK && (phases & TN_BWD_SCATTER_FOLD)) rc = tn_grid_scatter_fold(field->grid, P, ws.scatter, level_begin, level_end, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);
@@ -1127,8 +1135,8 @@ extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* ori
              level_begin, level_end);
   FieldWs ws = ws_layout(workspace, N * (int64_t)S, 1);
   // (d position was produced by the MLP phase: k_field_dpos)
-  return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins, ws.g_enc + 2 * level_begin, 32, N, S,
-                                nullptr, nullptr, ws.scatter, tn_s(stream), dense_sum);
+  return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins,
+                                ws.g_enc + (int64_t)level_begin * 2 * N * S, TN_LD_LEVEL_MAJOR, N, S, nullptr, nullptr, ws.scatter, tn_s(stream), dense_sum);
 }
 
 extern "C" int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,

@@ -787,6 +787,46 @@ extern "C" int tn_grad_nonfinite(const float* grads, int64_t count, float* found
   TN_CHECK_LAUNCH("tn_grad_nonfinite");
   return TN_OK;
 }
+// several ranges of one gradient arena in ONE launch (blockIdx.y = range): range k raises found_inf[flag_index[k]]
+struct NonfiniteRanges { int64_t off[TN_ADAM_MAX_RANGES], cnt[TN_ADAM_MAX_RANGES]; int32_t flag[TN_ADAM_MAX_RANGES]; };
+__global__ void __launch_bounds__(256) k_grad_nonfinite_ranges(const float* __restrict__ g, NonfiniteRanges r, float* __restrict__ found_inf) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int k = blockIdx.y;
+  const int64_t n = r.cnt[k], n4 = n / 4;
+  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) return;
+  const float* base = g + r.off[k];
+  bool bad = false;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const v4f v = reinterpret_cast<const v4f*>(base)[i];
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad = bad || (t != 0.0f);
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - n4 * 4) { const float x = base[n4 * 4 + threadIdx.x]; bad = bad || ((x - x) != 0.0f); }
+  if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[r.flag[k]] = 1.0f;
+}
+extern "C" int tn_grad_nonfinite_ranges(const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
+                                        int32_t num_flags, float* found_inf, tn_stream_t stream) {
+  if (num_ranges == 0) return TN_OK;
+  TN_REQUIRE(grads && offsets && counts && found_inf && num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES && num_flags >= 1,
+             "tn_grad_nonfinite_ranges: bad argument");
+  TN_REQUIRE(((uintptr_t)grads % 16) == 0, "tn_grad_nonfinite_ranges: grads must be 16-byte aligned");
+  NonfiniteRanges r{};
+  int64_t max_n4 = 0;
+  int n = 0;
+  for (int k = 0; k < num_ranges; ++k) {
+    const int fl = flag_index ? flag_index[k] : 0;
+    TN_REQUIRE(offsets[k] >= 0 && offsets[k] % 4 == 0 && counts[k] >= 0 && fl >= 0 && fl < num_flags, "tn_grad_nonfinite_ranges: bad range %d", k);
+    if (counts[k] == 0) continue;
+    r.off[n] = offsets[k]; r.cnt[n] = counts[k]; r.flag[n] = fl;
+    max_n4 = std::max<int64_t>(max_n4, counts[k] / 4);
+    ++n;
+  }
+  if (n == 0) return TN_OK;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256 * 4), 256 * 8));
+  hipLaunchKernelGGL(k_grad_nonfinite_ranges, dim3(grid, n), dim3(256), 0, tn_s(stream), grads, r, found_inf);
+  TN_CHECK_LAUNCH("tn_grad_nonfinite_ranges");
+  return TN_OK;
+}
 
 // Adam with the skip / unscale decision ON THE DEVICE: no host synchronisation between backward and optimiser step.  GradScaler decides per
 // OPTIMISER (torch/amp/grad_scaler.py: found_inf_per_device of that optimiser's gradients), i.e. per parameter group here:
@@ -912,10 +952,13 @@ extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float*
 // GradScaler.update() (torch/amp/grad_scaler.py -> amp_update_scale_cuda_kernel) for the fused step, one thread: backoff when any of the
 // num_flags found_inf entries is set (and the schedule lag grows by one: the trainer does not step the LR schedulers then,
 // engine/trainer.py:491-495), growth after `growth_interval` clean iterations in a row.
-__global__ void k_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int num_flags, int32_t* lag, float growth_factor,
-                                     float backoff_factor, int growth_interval) {
+__global__ void k_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int num_flags, int32_t* lag, float growth_factor,
+                                     float backoff_factor, int growth_interval, int clear) {
   bool any = false;
-  for (int i = 0; i < num_flags; ++i) any = any || (found_inf[i] != 0.0f);
+  for (int i = 0; i < num_flags; ++i) {
+    any = any || (found_inf[i] != 0.0f);
+    if (clear) found_inf[i] = 0.0f;  // ready for the next iteration: no separate zero-fill launch
+  }
   if (any) {
     *scale = *scale * backoff_factor;
     *growth_tracker = 0;
@@ -931,11 +974,11 @@ __global__ void k_grad_scaler_update(float* scale, int32_t* growth_tracker, cons
     }
   }
 }
-extern "C" int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, const float* found_inf, int32_t num_flags, int32_t* lag,
-                                     double growth_factor, double backoff_factor, int32_t growth_interval, tn_stream_t stream) {
+extern "C" int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
+                                     double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream) {
   TN_REQUIRE(scale && growth_tracker && found_inf && num_flags >= 1 && growth_interval >= 1, "tn_grad_scaler_update: bad argument");
   hipLaunchKernelGGL(k_grad_scaler_update, dim3(1), dim3(1), 0, tn_s(stream), scale, growth_tracker, found_inf, (int)num_flags, lag, (float)growth_factor,
-                     (float)backoff_factor, (int)growth_interval);
+                     (float)backoff_factor, (int)growth_interval, (int)clear_found_inf);
   TN_CHECK_LAUNCH("tn_grad_scaler_update");
   return TN_OK;
 }

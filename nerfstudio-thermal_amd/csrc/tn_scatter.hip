@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
 #pragma unroll
     for (int li = 0; li < TN_MAX_LEVELS; ++li) {
       int l = blockIdx.y + li * level_groups;
-      gvs[li] = (live && l < g.L) ? g_enc[p * ld + 2 * l + ft] : 0.0f;
+      gvs[li] = (live && l < g.L) ? g_enc[ld > 0 ? p * ld + 2 * l + ft : (int64_t)l * 2 * P + 2 * p + ft] : 0.0f;
     }
     if (want_dpos) {
 #pragma unroll 1
@@ -361,7 +361,9 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
     const bool merge = (bk.merge_mask >> l) & 1u;
     BinLevel b;
     bin_level(c, res, g.mask, merge, live, lane, b);
-    const float2 gv = live ? *reinterpret_cast<const float2*>(g_enc + p * ld + 2 * l) : make_float2(0.f, 0.f);
+    // row-major [P][ld], or level-major [L][P] float2 (TN_LD_LEVEL_MAJOR: the 64 lanes of a wave then read four runs of 16 consecutive float2
+    // instead of 64 pieces of 8 bytes 128 B apart -- 114 MB fetched for the main grid's 25 MB of d enc)
+    const float2 gv = live ? *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p) : make_float2(0.f, 0.f);
     if (WANT_DPOS) {
       // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
       const float2* tb = g.table + (size_t)l * g.tsize;
@@ -778,7 +780,8 @@ static int grid_scatter_binned(const TnGrid& grid, const float* origins, const f
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
-  TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && ld >= 2 * grid.num_levels, "tn_grid_scatter: bad level count / row stride");
+  TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && (ld >= 2 * grid.num_levels || ld == TN_LD_LEVEL_MAJOR),
+             "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
   if (dense_sum == nullptr && tn_grid_scatter_is_binned(grid, P, scratch))

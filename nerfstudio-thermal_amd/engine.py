@@ -430,7 +430,20 @@ class RenderEngine:
                     with torch.cuda.stream(side1):
                         dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, dws[1])
                         ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="side1")
-                ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
+                ev = getattr(self, "scatter_events", None)
+                if ev is not None and not sfx:
+                    # measurement hook (bench.py: roofline.avg_launch_ms_in_step): the same three phases as one tn_field_bwd call, with a HIP
+                    # event pair around the table scatter on the launch stream -- whatever runs beside it in the step still does
+                    ph = ops._lib
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, 0, fld.num_levels)
+                    e1.record()
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
+                    ev.append((e0, e1, bool(br.prop_grad)))
+                else:
+                    ops.field_bwd(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d)
                 if side1 is not None:
                     torch.cuda.current_stream().wait_stream(side1)
             if side is not None:
@@ -501,9 +514,8 @@ class RenderEngine:
             assert ranges is None, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
             names = list(hyper)
             gidx = {g: i for i, g in enumerate(a.optimised_groups)}
-            for g in names:  # GradScaler decides per optimiser = per parameter group
-                lo, hi = a.group_range[g]
-                grad_scaler.check(gidx[g], a.grads[lo:hi])
+            # GradScaler decides per optimiser = per parameter group: one flag per group, all groups checked in one launch
+            grad_scaler.check_ranges(a.grads, [a.group_range[g] for g in names], [gidx[g] for g in names])
             sched = None
             rng = [a.group_range[g] + hyper[g] for g in names]
             if scheduled and not lr_overrides:  # schedule on the device: lr_init + (lr_final, max_steps), evaluated at count - lag

@@ -541,10 +541,13 @@ _SCATTER_WS: dict = {}
 
 def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashmap_size: int, res, origins: Tensor, directions: Tensor, e_bins: Tensor,
                  g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, use_workspace: bool = True) -> None:
-    """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] into table_grad.
-    use_workspace=False adds every level straight into the hashed gradient (no dense replicas for the coarse levels)."""
+    """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] -- or, level-major, [num_levels, N*S, 2]
+    -- into table_grad.  use_workspace=False adds every level straight into the hashed gradient (no dense replicas for the coarse levels)."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
-    ld = g_enc.shape[1]
+    level_major = g_enc.dim() == 3
+    if level_major and tuple(g_enc.shape) != (num_levels, N * S, 2):
+        raise ValueError(f"level-major g_enc must be [{num_levels}, {N * S}, 2], got {tuple(g_enc.shape)}")
+    ld = -1 if level_major else g_enc.shape[1]
     ws = None
     if use_workspace:
         need = int(_lib.load().tn_hash_scatter_workspace_bytes(N * S, num_levels))
@@ -554,7 +557,7 @@ def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashma
             _SCATTER_WS[str(origins.device)] = ws
     g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
     check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),
-                                      _f32(g_enc, "g_enc", (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
+                                      _f32(g_enc, "g_enc", None if level_major else (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
                                       _f32(d_directions, "d_directions", (N, 3), True), C.c_void_p(ws.data_ptr()) if ws is not None else None,
                                       _stream()), "tn_hash_scatter")
 
@@ -886,6 +889,18 @@ def grad_nonfinite(grads: Tensor, found_inf: Tensor) -> None:
     check(_lib.load().tn_grad_nonfinite(_f32(grads, "grads"), grads.numel(), _f32(found_inf, "found_inf", (1,)), _stream()), "tn_grad_nonfinite")
 
 
+def grad_nonfinite_ranges(grads: Tensor, ranges, flags, found_inf: Tensor) -> None:
+    """One launch: found_inf[flags[k]] = 1 if grads[lo_k:hi_k] holds an inf / NaN (ranges: (lo, hi) element offsets, multiples of 4)."""
+    n = len(ranges)
+    if n == 0:
+        return
+    offs = (C.c_int64 * n)(*[int(r[0]) for r in ranges])
+    cnts = (C.c_int64 * n)(*[int(r[1] - r[0]) for r in ranges])
+    fl = (C.c_int32 * n)(*[int(x) for x in flags])
+    check(_lib.load().tn_grad_nonfinite_ranges(_f32(grads, "grads"), n, offs, cnts, fl, int(found_inf.numel()), _f32(found_inf, "found_inf"), _stream()),
+          "tn_grad_nonfinite_ranges")
+
+
 def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, ranges, beta1: float = 0.9, beta2: float = 0.999,
                          eps: float = 1e-15, inv_scale: Optional[Tensor] = None, found_inf: Optional[Tensor] = None, flags=None,
                          skipped: Optional[Tensor] = None, lag_index: int = -1, count_skip: bool = False, schedule=None, sched_step: int = 0) -> None:
@@ -919,8 +934,8 @@ def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg
 
 
 def grad_scaler_update(scale: Tensor, growth_tracker: Tensor, found_inf: Tensor, lag: Optional[Tensor], growth_factor: float, backoff_factor: float,
-                       growth_interval: int) -> None:
-    """GradScaler.update() on the device; lag (1-element int32 view or None) += 1 when any found_inf entry is set."""
+                       growth_interval: int, clear: bool = True) -> None:
+    """GradScaler.update() on the device; lag (1-element int32 view or None) += 1 when any found_inf entry is set; clear: zero found_inf after."""
     check(_lib.load().tn_grad_scaler_update(_f32(scale, "scale", (1,)), C.c_void_p(growth_tracker.data_ptr()), _f32(found_inf, "found_inf"),
                                             int(found_inf.numel()), C.c_void_p(lag.data_ptr()) if lag is not None else None, float(growth_factor),
-                                            float(backoff_factor), int(growth_interval), _stream()), "tn_grad_scaler_update")
+                                            float(backoff_factor), int(growth_interval), 1 if clear else 0, _stream()), "tn_grad_scaler_update")

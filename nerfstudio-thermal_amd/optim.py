@@ -197,10 +197,14 @@ class DeviceGradScaler:
         return self.num_groups
 
     def begin_step(self) -> None:
-        self.found_inf.zero_()
+        """found_inf is zero here: created so, and update() clears it again in the launch that consumed it."""
 
     def check(self, group: int, grads: torch.Tensor) -> None:
         ops.grad_nonfinite(grads, self.found_inf[group:group + 1])
+
+    def check_ranges(self, arena_grads: torch.Tensor, ranges, groups) -> None:
+        """every group's gradient range in one launch"""
+        ops.grad_nonfinite_ranges(arena_grads, ranges, groups, self.found_inf)
 
     def update(self) -> None:
         ops.grad_scaler_update(self.scale, self.growth_tracker, self.found_inf, self.skipped[self.num_groups:], self.growth_factor, self.backoff_factor,

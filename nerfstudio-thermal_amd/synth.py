@@ -15,6 +15,7 @@ import zlib
 from typing import Dict, Tuple
 
 import numpy as np
+import torch
 
 _MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -204,3 +205,26 @@ def cube_scene_images(origins: np.ndarray, directions: np.ndarray, is_thermal: b
         return np.repeat(val[:, None], 3, axis=1).astype(np.float32)
     bg = 0.5 + 0.35 * d
     return np.where(hit[:, None], face_rgb[face] * tex[:, None], bg).astype(np.float32)
+
+
+# ---- thermal-splatfacto (N4): synthetic Gaussians and a look-at camera (inputs of bench.py --workload splat and of the splat tests)
+def synth_gaussians(num: int, seed: int = 0, extent: float = 1.0, scale_range=(-4.5, -2.5)) -> "Dict[str, torch.Tensor]":
+    """Deterministic synthetic scene: Gaussians in a cube of half-size `extent`, log-scales uniform in scale_range, random rotations,
+    mixed opacities, random SH coefficients (degree-3 RGB + thermal)."""
+    g = np.random.default_rng(seed)
+    f = lambda *s: torch.from_numpy(g.standard_normal(s).astype(np.float32))  # noqa: E731
+    u = lambda lo, hi, *s: torch.from_numpy(g.uniform(lo, hi, s).astype(np.float32))  # noqa: E731
+    return {"means": u(-extent, extent, num, 3), "scales": u(scale_range[0], scale_range[1], num, 3), "quats": f(num, 4), "opacities": u(-2.0, 4.0, num, 1),
+            "features_dc": f(num, 3) * 0.8, "features_rest": f(num, 15, 3) * 0.15, "features_dc_thermal": f(num, 1) * 0.8,
+            "features_rest_thermal": f(num, 15, 1) * 0.15}
+
+
+def look_at_camera(eye, target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)) -> "torch.Tensor":
+    """camera-to-world [3,4] in nerfstudio's convention (x right, y up, z back)."""
+    eye, target, up = (torch.tensor(v, dtype=torch.float32) for v in (eye, target, up))
+    back = eye - target
+    back = back / back.norm()
+    right = torch.linalg.cross(up, back)
+    right = right / right.norm()
+    upv = torch.linalg.cross(back, right)
+    return torch.stack([right, upv, back, eye], 1)

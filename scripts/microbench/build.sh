@@ -3,7 +3,7 @@
 #   gpurun -- 'timeout 120 scripts/microbench/atomic_shapes'
 set -e
 cd "$(dirname "$0")"
-for f in atomic_*.hip lds_*.hip; do
+for f in atomic_*.hip lds_*.hip pmc_*.hip; do
   hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-result "$f" -o "${f%.hip}"
 done
-ls -1 atomic_* lds_* | grep -v '\.hip$'
+ls -1 atomic_* lds_* pmc_* | grep -v '\.hip$'

@@ -15,4 +15,10 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT
   rm -rf $out/p$i
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/p$i -- python3 scripts/pmc_target.py > $out/p$i.log 2>&1
   echo "pass $i [$c] rc=$? $(find $out/p$i -name '*counter_collection.csv' | head -1)"
+  # calibration kernels (known byte counts per access shape) under the same traffic counters
+  if [ $i -le 3 ]; then
+    rm -rf $out/c$i
+    timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/c$i -- scripts/microbench/pmc_calib > $out/c$i.log 2>&1
+    echo "calib $i rc=$?"
+  fi
 done

@@ -25,13 +25,18 @@ torch.cuda.synchronize()
 for net, L in ((eng.props[0], lv[0]), (eng.props[1], lv[1]), (eng.field, lv[2])):
     N, S = L.e_bins.shape[0], L.e_bins.shape[1] - 1
     g_enc = torch.randn((N * S, 16 if net.num_levels == 5 else 32), device=dev) * 1e-3
+    if net.num_levels != 5:  # the main field's backward hands its d enc over level-major
+        g_enc = g_enc.reshape(N * S, net.num_levels, 2).permute(1, 0, 2).contiguous()
+    # the proposal grids' scatter computes d position itself; the main field's does not (k_field_dpos does, from the saved d enc / d offset)
+    with_dpos = net.num_levels == 5
     for _ in range(R):
-        ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions, L.e_bins, g_enc, d_o, d_d)
+        ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions, L.e_bins, g_enc,
+                         d_o if with_dpos else None, d_d if with_dpos else None)
     torch.cuda.synchronize()
 gd = torch.rand_like(lv[2].density) * 1e-2; gc = torch.rand_like(b.rgb_samples)
 ph = ops._lib
 for _ in range(R):
-    ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv[2].e_bins, gd, gc, None, None, ph.TN_BWD_MLP | ph.TN_BWD_JOIN)
+    ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv[2].e_bins, gd, gc, d_o, d_d, ph.TN_BWD_MLP | ph.TN_BWD_JOIN)  # + k_field_dpos
     torch.cuda.synchronize()
 eng.arena.zero_grad()
 a = eng.arena

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
 import nerfstudio_thermal_amd  # noqa
 from nerfstudio_thermal_amd.splat import ThermalSplatfactoModel, ThermalSplatfactoModelConfig, PinholeCamera
-import splat_oracle as so
+import splat_oracle as so  # noqa
 
 N = int(os.environ.get("SPLAT_N", 1_000_000))
 mode = os.environ.get("SPLAT_MODE", "classic")

@@ -325,6 +325,15 @@ def test_hash_scatter_matches_autograd_of_hash_encode():
         # untouched entries must stay exactly zero on both paths (Adam's eps = 1e-15 turns any residue into a full-size update)
         assert torch.equal(zero_patterns[0], zero_patterns[1])
         assert torch.equal(zero_patterns[0], table.grad == 0)
+        # the same gradient handed over level-major [L, P, 2] (ld = -1: what the main field's backward produces): identical result
+        g_lm = g_enc[:, : 2 * L].reshape(N * S, L, 2).permute(1, 0, 2).contiguous()
+        for use_ws in (True, False):
+            tg2 = torch.zeros((L * 2**log2T, 2), device=DEV)
+            d_o2, d_d2 = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
+            ops.hash_scatter(g(table.detach()), tg2, L, log2T, res.tolist(), g(r["origins"]), g(r["directions"]), g(e), g(g_lm), d_o2, d_d2, use_workspace=use_ws)
+            assert md(tg2, table.grad) <= 2e-5 * float(table.grad.abs().max()), (L, use_ws, "level-major")
+            assert md(d_o2, o.grad) <= 2e-4 * float(o.grad.abs().max()), (L, use_ws, "level-major")
+            assert torch.equal((tg2 == 0).cpu(), zero_patterns[0])
 
 
 def test_render_psnr_vs_oracle():
