@@ -21,6 +21,10 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+#ifndef FRAG_NT
+#define FRAG_NT 1  // non-temporal stores / loads of the saved activations (see store_frag)
+#endif
 
 #define TILE 32
 #define FRAG 64  // floats per A fragment (one per lane)
@@ -191,10 +195,10 @@ __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __re
         if (l0 + 1 < g.L) b = tn_encode_level_jac(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize, jb);
         // fragment order [tile][q][k][lane] float4: every store instruction of the wave writes one contiguous KiB (sample-major rows would be
         // 48-byte pieces 384 B apart: the 75 MB cost 35 us that way)
-        float4* jp = reinterpret_cast<float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;
-        jp[0] = make_float4(ja[0], ja[1], ja[2], ja[3]);
-        jp[64] = make_float4(ja[4], ja[5], jb[0], jb[1]);
-        jp[128] = make_float4(jb[2], jb[3], jb[4], jb[5]);
+        v4f_t* jp = reinterpret_cast<v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;
+        const v4f_t j0 = {ja[0], ja[1], ja[2], ja[3]}, j1 = {ja[4], ja[5], jb[0], jb[1]}, j2 = {jb[2], jb[3], jb[4], jb[5]};
+        if (FRAG_NT) { __builtin_nontemporal_store(j0, jp); __builtin_nontemporal_store(j1, jp + 64); __builtin_nontemporal_store(j2, jp + 128); }
+        else { jp[0] = j0; jp[64] = j1; jp[128] = j2; }
       } else {
         if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
         if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
@@ -223,8 +227,9 @@ __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ or
       const float2 ga = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h) * 2 * P + 2 * pc);      // level-major [16][P] float2
       const float2 gb = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h + 1) * 2 * P + 2 * pc);
       const float4 gv = make_float4(ga.x, ga.y, gb.x, gb.y);
-      const float4* jp = reinterpret_cast<const float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order, as k_field_encode wrote it
-      const float4 j0 = jp[0], j1 = jp[64], j2 = jp[128];
+      const v4f_t* jp = reinterpret_cast<const v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order, as the forward wrote it
+      const v4f_t j0 = FRAG_NT ? __builtin_nontemporal_load(jp) : jp[0], j1 = FRAG_NT ? __builtin_nontemporal_load(jp + 64) : jp[64],
+                  j2 = FRAG_NT ? __builtin_nontemporal_load(jp + 128) : jp[128];
       dx += gv.x * j0.x + gv.y * j0.w + gv.z * j1.z + gv.w * j2.y;
       dy += gv.x * j0.y + gv.y * j1.x + gv.z * j1.w + gv.w * j2.z;
       dz += gv.x * j0.z + gv.y * j1.y + gv.z * j2.x + gv.w * j2.w;
@@ -319,17 +324,22 @@ __device__ __forceinline__ f32x16 load_tile(const float* __restrict__ base, int6
 }
 
 // fragment order (see FieldWs): tile m of an activation with M 32-feature tiles per sample
+// Non-temporal on both sides: the activations are written once and read once (600 MB per step at 4096 rays), the hash tables are gathered from
+// again and again -- streaming the activations past the caches keeps the tables in the Infinity Cache (the Adam kernels do the same with moments).
 __device__ __forceinline__ void store_frag(float* __restrict__ base, int64_t tile, int M, int m, int lane, const f32x16& v) {
-  float4* b = reinterpret_cast<float4*>(base) + ((tile * M + m) * 4) * 64 + lane;
+  v4f_t* b = reinterpret_cast<v4f_t*>(base) + ((tile * M + m) * 4) * 64 + lane;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) b[g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  for (int g = 0; g < 4; ++g) {
+    const v4f_t t = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+    if (FRAG_NT) __builtin_nontemporal_store(t, b + g * 64); else b[g * 64] = t;
+  }
 }
 __device__ __forceinline__ f32x16 load_frag(const float* __restrict__ base, int64_t tile, int M, int m, int lane) {
-  const float4* b = reinterpret_cast<const float4*>(base) + ((tile * M + m) * 4) * 64 + lane;
+  const v4f_t* b = reinterpret_cast<const v4f_t*>(base) + ((tile * M + m) * 4) * 64 + lane;
   f32x16 v;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4 t = b[g * 64];
+    const v4f_t t = FRAG_NT ? __builtin_nontemporal_load(b + g * 64) : b[g * 64];
     v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
   }
   return v;
@@ -404,10 +414,10 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
         b = tn_level_interp_jac(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz, g.res[l0 + 1 < g.L ? l0 + 1 : g.L - 1], jb);
         if (l0 >= g.L) { a = make_float2(0.f, 0.f); ja[0] = ja[1] = ja[2] = ja[3] = ja[4] = ja[5] = 0.0f; }
         if (l0 + 1 >= g.L) { b = make_float2(0.f, 0.f); jb[0] = jb[1] = jb[2] = jb[3] = jb[4] = jb[5] = 0.0f; }
-        float4* jp = reinterpret_cast<float4*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order (see k_field_encode)
-        jp[0] = make_float4(ja[0], ja[1], ja[2], ja[3]);
-        jp[64] = make_float4(ja[4], ja[5], jb[0], jb[1]);
-        jp[128] = make_float4(jb[2], jb[3], jb[4], jb[5]);
+        v4f_t* jp = reinterpret_cast<v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order (see k_field_encode)
+        const v4f_t j0 = {ja[0], ja[1], ja[2], ja[3]}, j1 = {ja[4], ja[5], jb[0], jb[1]}, j2 = {jb[2], jb[3], jb[4], jb[5]};
+        if (FRAG_NT) { __builtin_nontemporal_store(j0, jp); __builtin_nontemporal_store(j1, jp + 64); __builtin_nontemporal_store(j2, jp + 128); }
+        else { jp[0] = j0; jp[64] = j1; jp[128] = j2; }
       } else {
         a = tn_level_interp(fv[2 * q], lc[2 * q].ox, lc[2 * q].oy, lc[2 * q].oz);
         b = tn_level_interp(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz);
@@ -671,8 +681,10 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
                                                             const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
                                                             const float* __restrict__ encs, const float* __restrict__ h1s,
                                                             const float* __restrict__ hins, const float* __restrict__ hh1s,
-                                                            const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G) {
+                                                            const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G,
+                                                            uint32_t* __restrict__ zero_ptr, int zero_words) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // FB_LDS_FLOATS
+  tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the table scatter that follows on this stream
   const float* src = pack + PACK_BWD_OFF;
   for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
     *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
@@ -1071,14 +1083,17 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     const size_t shmem = FB_LDS_FLOATS * sizeof(float);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), 4), 256));  // one block per CU (one wave per SIMD)
     FusedGrads G{field->gw0, field->gb0, field->gw1, field->gb1, field->ghw0, field->ghb0, field->ghw1, field->ghb1, field->ghw2, field->ghb2, field->gemb};
+    uint32_t* zp;
+    int zw;
+    tn_grid_scatter_counters(field->grid, P, ws.scatter, &zp, &zw);  // the bin pass then starts without a memset launch of its own
     if (dens_only) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<true>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
-                         C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G);
+                         C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
-                         S, C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G);
+                         S, C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
     if (d_origins != nullptr) {
@@ -1096,7 +1111,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   float* sc_dd = nullptr;
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
-    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st);
+    // (counters zeroed by the MLP phase only when this call runs both and covers the whole grid in one scatter)
+    const bool cz = (phases & TN_BWD_MLP) && level_begin == 0 && level_end == field->grid.num_levels;
+    rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
+                                nullptr, cz);
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");

@@ -76,8 +76,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
                                                       const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
-                                                      float* __restrict__ ws_denc) {
+                                                      float* __restrict__ ws_denc, uint32_t* __restrict__ zero_ptr, int zero_words) {
   __shared__ float lds[4][2][64 * 16];  // per wave: operand A, operand B (8 KB)
+  tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the scatter that follows on this stream
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* bufA = lds[wv][0];
   float* bufB = lds[wv][1];
@@ -223,8 +224,11 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   // (same-line global atomics serialise at ~25 ns each)
   int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 1024);
   hipStream_t st = tn_s(stream);
-  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc);
+  void* scratch = reinterpret_cast<char*>(workspace) + prop_scratch_offset(P);
+  uint32_t* zp;
+  int zw;
+  tn_grid_scatter_counters(net->grid, P, scratch, &zp, &zw);
+  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
-  return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions,
-                                reinterpret_cast<char*>(workspace) + prop_scratch_offset(P), st);
+  return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions, scratch, st, nullptr, zw > 0);
 }

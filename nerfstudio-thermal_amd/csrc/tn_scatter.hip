@@ -686,16 +686,29 @@ static int bin_plan(const TnGrid& grid, int64_t P, void* scratch, BinK& bk, uint
   return TN_OK;
 }
 
+void tn_grid_scatter_counters(const TnGrid& grid, int64_t P, void* scratch, uint32_t** ptr, int* words) {
+  *ptr = nullptr;
+  *words = 0;
+  if (P <= 0 || !tn_grid_scatter_is_binned(grid, P, scratch)) return;
+  BinK bk;
+  uint32_t nblk;
+  if (bin_plan(grid, P, scratch, bk, nblk) != TN_OK) return;
+  *ptr = bk.count;
+  *words = grid.num_levels * bk.nslices * (int)bk.cstride;
+}
+
 int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
-                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
+                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed) {
   const int64_t P = N * (int64_t)S;
   const int L = grid.num_levels;
   BinK bk;
   uint32_t nblk;
   int rc = bin_plan(grid, P, scratch, bk, nblk);
   if (rc) return rc;
-  hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4 * bk.cstride, stream);
-  TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
+  if (!counters_zeroed) {  // (the field / proposal backward kernels zero them on their way: tn_grid_scatter_counters)
+    hipError_t e = hipMemsetAsync(bk.count, 0, (size_t)L * bk.nslices * 4 * bk.cstride, stream);
+    TN_REQUIRE(e == hipSuccess, "tn_grid_scatter: memset failed: %s", hipGetErrorString(e));
+  }
   GridK gk = make_gridk(grid);
   const int blocks = (int)tn_cdiv(P, BIN_THREADS);
   // enough resident work for every CU: split the levels over blockIdx.y while the batch alone gives fewer than ~6 blocks per CU
@@ -771,21 +784,22 @@ bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratc
 }
 
 static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream) {
-  int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream);
+                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed) {
+  int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed);
   if (rc) return rc;
   return tn_grid_scatter_fold(grid, N * (int64_t)S, scratch, 0, grid.num_levels, stream);
 }
 
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum) {
+                           int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum,
+                           bool counters_zeroed) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && (ld >= 2 * grid.num_levels || ld == TN_LD_LEVEL_MAJOR),
              "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
   if (dense_sum == nullptr && tn_grid_scatter_is_binned(grid, P, scratch))
-    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream);
+    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed);
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
   // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups
   int level_groups = 1;

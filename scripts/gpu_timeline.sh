@@ -3,7 +3,7 @@ tag=${1:-t}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
 rm -rf gpurun_out/$tag/prof
-rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/prof -o a -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 10 --long-steps 0 > gpurun_out/$tag/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/prof -o a -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 10 --long-steps 0 $BENCH_ARGS > gpurun_out/$tag/prof.log 2>&1
 db=$(find gpurun_out/$tag/prof -name '*.db' | head -1)
 python scripts/rocpd_stats.py $db gpurun_out/$tag/kernel_stats.csv --split-grid --tail 10 > gpurun_out/$tag/kernel_stats.txt 2>&1
 python scripts/rocpd_timeline.py $db gpurun_out/$tag/timeline.md --step-from-end 4 > /dev/null 2> gpurun_out/$tag/timeline.err

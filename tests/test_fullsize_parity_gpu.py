@@ -198,3 +198,53 @@ def test_prop_bwd_production_shape(lvl, S):
         assert md(arena.grad_view(k[short]), r) <= 3e-4 * scale, (short, md(arena.grad_view(k[short]), r), scale)
     assert md(d_o, o.grad) <= 3e-4 * float(o.grad.abs().max())
     assert md(d_d, d.grad) <= 3e-4 * float(d.grad.abs().max())
+
+
+@pytest.mark.parametrize("prefix,C", [("field", 3), ("field_thermal", 1)])
+def test_separate_mode_field_bwd_with_cross_terms_8192(prefix, C):
+    """BASELINE configs[2] at ITS size: density_mode=separate, 8192 rays.  One field's whole backward as the training step runs it -- the own
+    branch (C = 3 colour head for `field`, C = 1 for `field_thermal`) AND the cross-evaluated density of the other branch's samples
+    (density2 / density2_thermal, models/thermal_nerfacto.py:447-458: get_density only, no colour path), both accumulated into the SAME table
+    and MLP gradients -- against oracle autograd on identical samples.  The detach asymmetry of the density loss (:328-344) reaches this level
+    as different upstream weights on the own density (rgb_density_loss_mult * density_loss_mult) and on the cross density (density_loss_mult)."""
+    n = 8192
+    ocfg = orc.OracleConfig(density_mode="separate")
+    shapes = {k: v for k, v in orc.param_shapes(ocfg).items() if k.startswith(prefix + ".")}
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_params(shapes, seed=SEED).items()}
+    cfg = ThermalNerfactoModelConfig(density_mode="separate")
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    S = 48
+    o0, d0, cam = patch_rays(n)
+    _, e_own = resampled_bins(n, S, prefix + "_own")
+    _, e_x = resampled_bins(n, S, prefix + "_cross")  # the OTHER branch's sampler put its samples elsewhere
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o = o0.clone().requires_grad_(True)
+    d = d0.clone().requires_grad_(True)
+    dens, geo, _, _ = orc.field_density(p, prefix, ocfg, orc.Samples(s_bins=e_own, e_bins=e_own).positions(o, d))
+    rgb = orc.field_color(p, prefix, ocfg, d.detach(), geo, cam, True)
+    assert rgb.shape[-1] == C
+    dens2, _, _, _ = orc.field_density(p, prefix, ocfg, orc.Samples(s_bins=e_x, e_bins=e_x).positions(o, d))
+    fld = field_params(arena, prefix, cfg, with_grads=True)
+    hd, hrgb, _ = ops.field_fwd(fld, g(o0), g(d0), g(cam), g(e_own), True)
+    hd2 = ops.field_density_fwd(fld, g(o0), g(d0), g(e_x), training=True, tag="cross")
+    assert md(hd, dens[..., 0]) <= 1e-4 and md(hrgb, rgb) <= 1e-4 and md(hd2, dens2[..., 0]) <= 1e-4
+    c_own, c_x = 0.01 * 5e-5, 5e-5  # rgb_density_loss_mult * density_loss_mult, density_loss_mult (per-sample |.| gradients are +-c / count)
+    gd = torch.from_numpy(synth.uniform("fs8_gd", (n, S, 1), seed=SEED)) * 1e-2 + torch.sign(torch.from_numpy(synth.uniform("fs8_s1", (n, S, 1), seed=SEED))) * c_own
+    gd2 = torch.sign(torch.from_numpy(synth.uniform("fs8_s2", (n, S, 1), seed=SEED))) * c_x
+    gc = torch.from_numpy(synth.uniform("fs8_gc", (n, S, C), seed=SEED))
+    ((dens * gd).sum() + (rgb * gc).sum() + (dens2 * gd2).sum()).backward()
+    arena.zero_grad()
+    d_o, d_d = torch.zeros((n, 3), device=DEV), torch.zeros((n, 3), device=DEV)
+    ops.field_bwd(fld, g(o0), g(d0), g(cam), g(e_own), g(gd[..., 0]), g(gc), d_o, d_d)
+    ops.field_bwd(fld, g(o0), g(d0), g(cam), g(e_x), g(gd2[..., 0]), None, d_o, d_d, tag="cross")  # density-only backward, same gradient buffers
+    k = orc.field_keys(prefix)
+    check_table_grad(arena.grad_view(k["table"]), p[k["table"]].grad, 3e-4, f"{prefix} table (own + cross)", relu_flips=1024)
+    for short in ("w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
+        ref = p[k[short]].grad
+        scale = float(ref.abs().max())
+        assert md(arena.grad_view(k[short]), ref) <= 5e-3 * scale, (short, md(arena.grad_view(k[short]), ref), scale)
+    for got, ref in ((d_o, o.grad), (d_d, d.grad)):
+        err = (got.detach().cpu() - ref).abs().amax(dim=1) / float(ref.abs().max())
+        assert int((err > 3e-4).sum()) <= 32, int((err > 3e-4).sum())
+        assert float(err.max()) <= 0.1, float(err.max())
