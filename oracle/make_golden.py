@@ -1,6 +1,7 @@
 """Generate golden vectors from the REFERENCE itself (build container only; test infrastructure).
 
     python oracle/make_golden.py            # writes tests/golden/*.npz (the "tiny" set: 2^12 / 2^10 tables, 32 rays)
+    python oracle/make_golden.py --default --rays 256   # the same at 256 rays -> model_{shared,separate}_default256.npz
     python oracle/make_golden.py --default  # writes tests/golden/model_{shared,separate}_default.npz: the reference at its DEFAULT table
                                             # sizes (16 x 2^19 main, 5 x 2^17 proposal) on 64 rays; only the rays and the outputs are stored,
                                             # the 22 M / 39 M parameters are regenerated on both sides by synth.synth_params
@@ -46,8 +47,10 @@ from nerfstudio.models.thermal_nerfacto import ThermalNerfactoModelConfig  # noq
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEFAULT = "--default" in sys.argv
 TINY = {} if DEFAULT else dict(log2_hashmap_size=12, prop_log2_hashmap_size=10)  # {} = the reference's defaults
-N_RAYS = 64 if DEFAULT else 32
-SUFFIX = "_default" if DEFAULT else ""
+# --default [--rays 256]: 64 rays by default; any other count goes to its own files (model_{mode}_default256.npz)
+_RAYS = int(sys.argv[sys.argv.index("--rays") + 1]) if "--rays" in sys.argv else 64
+N_RAYS = _RAYS if DEFAULT else 32
+SUFFIX = ("_default" if _RAYS == 64 else f"_default{_RAYS}") if DEFAULT else ""
 SEED = 0
 
 

@@ -18,7 +18,7 @@ def tiny_cfg(mode="shared", **kw):
 
 
 # golden sets produced by oracle/make_golden.py from the reference itself: name -> (table-size overrides, rays, file suffix)
-SIZES = {"tiny": (TINY, GOLDEN_RAYS, ""), "default": ({}, 64, "_default")}
+SIZES = {"tiny": (TINY, GOLDEN_RAYS, ""), "default": ({}, 64, "_default"), "default256": ({}, 256, "_default256")}
 
 
 def size_cfg(size, mode="shared", **kw):

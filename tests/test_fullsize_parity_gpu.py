@@ -67,7 +67,22 @@ def touched_slots(p_unit, res, log2T):
     return torch.from_numpy(out)
 
 
-def check_table_grad(got, ref, tol_rel, what, touched=None, relu_flips=0):
+def near_zero_relu_samples(params, prefix, ocfg, enc, geo_dirs_cam, eps):
+    """bool [P]: samples with at least one hidden ReLU unit of the field whose ORACLE pre-activation lies within eps of zero (relative to the
+    layer's largest pre-activation): base layer 0, head layers 0 and 1."""
+    k = orc.field_keys(prefix)
+    with torch.no_grad():
+        pre0 = enc @ params[k["w0"]].T + params[k["b0"]]
+        flag = (pre0.abs() <= eps * float(pre0.abs().max())).any(dim=1)
+        hin = geo_dirs_cam  # [P, 63] head input as the oracle assembles it
+        pre1 = hin @ params[k["hw0"]].T + params[k["hb0"]]
+        flag |= (pre1.abs() <= eps * float(pre1.abs().max())).any(dim=1)
+        pre2 = torch.relu(pre1) @ params[k["hw1"]].T + params[k["hb1"]]
+        flag |= (pre2.abs() <= eps * float(pre2.abs().max())).any(dim=1)
+    return flag
+
+
+def check_table_grad(got, ref, tol_rel, what, touched=None, relu_flips=0, flip_slots=None):
     """every entry within tol_rel of the largest entry (a deterministic 200k-entry sample first, then the whole table) and the zero
     pattern: a slot no sample touches must be EXACTLY zero (Adam's eps = 1e-15 turns any residue into a full-size step); where the oracle's
     zero is an exact cancellation of several contributions, a different summation order may leave a residue below the tolerance.
@@ -85,6 +100,12 @@ def check_table_grad(got, ref, tol_rel, what, touched=None, relu_flips=0):
     assert bad <= relu_flips, (what, bad, float(dif.max()), scale)
     if relu_flips:
         assert float(dif.max()) <= 5e-3 * scale, (what, float(dif.max()), scale)
+    if relu_flips and flip_slots is not None and bad:
+        # the count above is a bound; this is the claim itself: EVERY entry beyond the tolerance is a table slot touched by a sample that has a
+        # hidden unit whose oracle pre-activation is within rounding of zero (the only place where the two sides may take different branches)
+        off = (dif > tol_rel * scale).any(dim=-1) if dif.dim() == 2 else (dif > tol_rel * scale)
+        stray = int((off & ~flip_slots).sum())
+        assert stray == 0, (what, "entries beyond the tolerance that no near-zero ReLU unit explains", stray, bad)
     differ = (got == 0) != (ref == 0)
     assert int(differ.sum()) <= 4, (what, int(differ.sum()))
     if touched is not None:
@@ -149,7 +170,18 @@ def test_field_bwd_production_shape():
     d_d = torch.zeros((N_RAYS, 3), device=DEV)
     ops.field_bwd(fld, g(o0), g(d0), g(cam), g(e), g(gd[..., 0]), g(gc), d_o, d_d)
     k = orc.field_keys("field")
-    check_table_grad(arena.grad_view(k["table"]), p[k["table"]].grad, 3e-4, "field table", relu_flips=512)  # the scatter alone holds 2e-5 above
+    # which table slots can a ReLU flip reach?  the 8 x 16 corners of every sample with a hidden pre-activation within 1e-6 of zero (relative)
+    with torch.no_grad():
+        pos = smp.positions(o0, d0)
+        pu, _ = orc.unit_cube_positions(pos)
+        res = orc.level_resolutions(16, 16, 2048)
+        enc_o = orc.hash_encode(pu.view(-1, 3), params[k["table"]], res, 19)
+        dsh = orc.sh16((d0 + 1.0) / 2.0)[:, None, :].expand(N_RAYS, S, 16)  # the head input as orc.field_color assembles it
+        emb = params[k["emb"]][cam][:, None, :].expand(N_RAYS, S, 32)
+        hin_o = torch.cat([dsh.reshape(-1, 16), geo.detach().reshape(-1, 15), emb.reshape(-1, 32)], dim=-1)
+    near = near_zero_relu_samples(params, "field", ocfg, enc_o, hin_o, 1e-6)
+    flip_slots = touched_slots(pu.view(-1, 3)[near], res, 19)
+    check_table_grad(arena.grad_view(k["table"]), p[k["table"]].grad, 3e-4, "field table", relu_flips=512, flip_slots=flip_slots)  # the scatter alone holds 2e-5 above
     # MLP weights: sums over all 196 608 samples.  The few samples whose ReLU derivative flips (see check_table_grad) move a whole row of
     # d pre-activations by O(1), i.e. a weight-gradient entry by up to one sample's contribution: 5e-3 of the largest entry bounds it
     # (measured 2.6e-3 on w0; the small-batch op test holds 3e-4, where no unit sits that close to zero).

@@ -46,7 +46,7 @@ def assert_density_chain(got, ref, what):
     assert float((err > DENS_TOL).double().mean()) <= 0.03, (what, float((err > DENS_TOL).double().mean()))
 
 
-@pytest.mark.parametrize("size", ["tiny", "default"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
+@pytest.mark.parametrize("size", ["tiny", "default", "default256"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_eval_render_matches_reference_golden(golden_dir, mode, size):
     g = golden_file(golden_dir, mode, size)
@@ -71,7 +71,7 @@ def test_eval_render_matches_reference_golden(golden_dir, mode, size):
         assert outlier_fraction(out[k], g[f"eval/{k}"], 1e-5) <= 0.07, k  # <= 2 of 32 rays
 
 
-@pytest.mark.parametrize("size", ["tiny", "default"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
+@pytest.mark.parametrize("size", ["tiny", "default", "default256"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_train_step_matches_reference_golden(golden_dir, mode, size):
     g = golden_file(golden_dir, mode, size)
@@ -115,7 +115,11 @@ def test_train_step_matches_reference_golden(golden_dir, mode, size):
         e_norm = abs(float(got.double().norm()) - ref_norm) / max(ref_norm, 1e-12)
         diff = (got[ii].detach().cpu().double() - ref.double()).abs() / scale
         e_max, e_p95 = float(diff.max()), float(torch.quantile(diff, 0.95))
-        if e_norm > 5e-3 or (diff.numel() >= 1000 and e_p95 > 2e-3) or e_max > 5e-2:  # p95 is meaningless on the 48-entry pose tensors
+        # (the 48-entry pose tensors sum d position over every ray of the batch: the few samples that change cell under a 1-ulp shift move
+        # their norm by up to 1 % -- helpers.oracle_grad_sensitivity measures 3 % on the reference itself; d position is pinned strictly, per
+        # ray, on identical samples in tests/test_fullsize_parity_gpu.py)
+        norm_tol = 5e-3 if diff.numel() >= 1000 else 1e-2
+        if e_norm > norm_tol or (diff.numel() >= 1000 and e_p95 > 2e-3) or e_max > 5e-2:  # p95 is meaningless on the 48-entry pose tensors
             bad.append((name, e_norm, e_p95, e_max))
     assert not bad, bad
     eng.optimizer_step(scheduled=False)
@@ -164,7 +168,7 @@ def test_fused_launches_equal_one_launch_per_seam(golden_dir, mode, monkeypatch)
     assert torch.equal(grad_a == 0, grad_b == 0)  # the same parameters receive a gradient
 
 
-@pytest.mark.parametrize("size", ["tiny", "default"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
+@pytest.mark.parametrize("size", ["tiny", "default", "default256"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_density_on_identical_samples(golden_dir, mode, size):
     """The strict bound: on the reference's OWN sample bins (stored in the golden file) density must agree to 1e-4 and RGB(T) to 1e-3."""
@@ -370,3 +374,79 @@ def test_density_chain_strict_on_init_scale_tables(golden_dir, mode):
         assert float(ref[f"density{s}"].max()) > 1e-2  # the densities are not trivially zero
     assert md(out["rgb"], ref["rgb"]) <= RGB_TOL and md(out["rgb_thermal"], ref["rgb_thermal"]) <= RGB_TOL
     assert md(out["expected_depth"], ref["expected_depth"]) <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_density_chain_strict_default_table_size(golden_dir, mode):
+    """The unrelaxed whole-chain bound (density 1e-4 on EVERY sample, RGB / thermal 1e-3) at the DEFAULT table sizes (16 x 2^19, 5 x 2^17) with
+    parameters at the scale training starts from, 256 rays: the configuration ns-train ships."""
+    ocfg = size_cfg("default256", mode)
+    cfg = pkg_cfg(ocfg)
+    params = init_scale_params(ocfg)
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    gi, o, d, cam = dev_inputs(golden_dir, "default256")
+    with torch.no_grad():
+        ref = orc.get_outputs(params, ocfg, gi["origins"], gi["directions"], gi["camera_indices"], training=False)
+    out, _ = eng.get_outputs(o, d, cam, training=False)
+    for s in ("", "_thermal") if mode == "separate" else ("",):
+        err = (out[f"density{s}"].cpu() - ref[f"density{s}"]).abs()
+        assert float(err.max()) <= DENS_TOL, (s, float(err.max()))
+        assert float(ref[f"density{s}"].max()) > 1e-2
+    assert md(out["rgb"], ref["rgb"]) <= RGB_TOL and md(out["rgb_thermal"], ref["rgb_thermal"]) <= RGB_TOL
+    assert md(out["expected_depth"], ref["expected_depth"]) <= 1e-3
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_density_after_training(golden_dir, mode):
+    """Weights that 200 training iterations produced (tiny tables, init-scale start), read back from the arena and given to the oracle (with the
+    sampler's annealing exponent of that iteration).  (a) On IDENTICAL sample positions -- the engine's own final bins fed to the oracle's
+    field -- every sample's density holds north_star's bound unrelaxed: 1e-4 absolute below 1, 1e-4 relative above (a trained logit makes
+    exp() large: thousands in separate mode).  (b) Through the WHOLE chain RGB / thermal hold 1e-3 on every ray (measured ~1e-5); the chained
+    density is measured against what the chain itself defines: the share of samples beyond 1e-4 (relative to scale) at most 3 % or 3x the
+    share the ORACLE itself moves that far when its ray origins move by one ulp, and none further off than 10x the ORACLE's own response to a 1-ulp move of the ray origins (or 1e-3) -- trained tables are high-variance, a resampled bin that
+    moves by one ulp moves the reference's own density by up to 1e-2 there (scripts/diag_trained_chain.py)."""
+    from nerfstudio_thermal_amd import ops
+
+    ocfg = size_cfg("tiny", mode)
+    cfg = pkg_cfg(ocfg)
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(init_scale_params(ocfg))
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    gi, o, d, cam = dev_inputs(golden_dir, "tiny")
+    img, is_th = gi["image"].to(DEV), gi["is_thermal"].to(DEV)
+    first = last = None
+    for step in range(200):
+        losses = eng.train_step(o, d, cam, img, is_th, step)
+        tot = float(sum(float(v) for v in losses.values()))
+        first = tot if first is None else first
+        last = tot
+    assert np.isfinite(last) and last < first  # it trained
+    params = {k: arena.view(k).detach().cpu().clone() for k in arena.names()}
+    with torch.no_grad():
+        ref = orc.get_outputs(params, ocfg, gi["origins"], gi["directions"], gi["camera_indices"], training=False, anneal=eng.anneal)
+        # the oracle against ITSELF with the ray origins moved by one fp32 ulp: how far the chain's own arithmetic defines its densities
+        ref_ulp = orc.get_outputs(params, ocfg, torch.nextafter(gi["origins"], torch.tensor(9.0)), gi["directions"], gi["camera_indices"],
+                                  training=False, anneal=eng.anneal)
+    out, branches = eng.get_outputs(o, d, cam, training=False)
+    assert md(out["rgb"], ref["rgb"]) <= RGB_TOL and md(out["rgb_thermal"], ref["rgb_thermal"]) <= RGB_TOL
+    for s, prefix in (("", "field"), ("_thermal", "field_thermal")) if mode == "separate" else (("", "field"),):
+        br = branches[s]
+        e2 = br.levels[2].e_bins
+        # (a) identical samples: the oracle's field on the engine's bins and pose-corrected rays
+        with torch.no_grad():
+            pos = orc.Samples(s_bins=e2.cpu(), e_bins=e2.cpu()).positions(br.origins.cpu(), br.directions.cpu())
+            dref, _, _, _ = orc.field_density(params, prefix, ocfg, pos)
+        err = (br.levels[2].density.cpu() - dref[..., 0]).abs()
+        tol = DENS_TOL * torch.clamp(dref[..., 0].abs(), min=1.0)
+        assert bool((err <= tol).all()), (s, "identical samples", float((err / tol).max()))
+        assert float(dref.max()) > 0.1  # training produced real densities
+        # (b) whole chain, every sample
+        scale = torch.clamp(ref[f"density{s}"].abs(), min=1.0)
+        cerr = (out[f"density{s}"].cpu() - ref[f"density{s}"]).abs() / scale
+        serr = (ref_ulp[f"density{s}"] - ref[f"density{s}"]).abs() / scale
+        sens, sens_frac = float(serr.max()), float((serr > DENS_TOL).float().mean())
+        frac = float((cerr > DENS_TOL).float().mean())
+        assert frac <= max(0.03, 3.0 * sens_frac), (s, "chain", frac, sens_frac)
+        assert float(cerr.max()) <= max(1e-3, 10.0 * sens), (s, "chain", float(cerr.max()), sens)

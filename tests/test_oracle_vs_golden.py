@@ -88,7 +88,7 @@ EVAL_KEYS = ["rgb", "rgb_thermal", "accumulation", "depth", "expected_depth", "d
 
 
 # "default": the reference at its default table sizes (16 x 2^19 / 5 x 2^17), 64 rays -- SURVEY 8c's second golden set
-@pytest.mark.parametrize("size", ["tiny", "default"])
+@pytest.mark.parametrize("size", ["tiny", "default", "default256"])
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_model_eval(golden_dir, mode, size):
     g = golden_file(golden_dir, mode, size)
@@ -108,7 +108,7 @@ def test_model_eval(golden_dir, mode, size):
         assert maxdiff(out[k], ref) <= 2e-6, (k, maxdiff(out[k], ref))
 
 
-@pytest.mark.parametrize("size", ["tiny", "default"])
+@pytest.mark.parametrize("size", ["tiny", "default", "default256"])
 @pytest.mark.parametrize("mode", ["shared", "separate"])
 def test_model_train_losses_grads_adam(golden_dir, mode, size):
     g = golden_file(golden_dir, mode, size)
