@@ -14,6 +14,23 @@
  *  - all float tensors are fp32, contiguous, row-major; sample tensors are dense [N, S] per level
  *    (N rays, S samples; "bins" tensors are [N, S+1]).
  *  - operand-shape violations are rejected on the host (TN_EINVAL) before anything is launched.
+ *
+ * State and environment (everything the library keeps or reads besides its arguments):
+ *  - Process-wide state: ONE map of companion streams -- a second HIP stream (+ two events) per (device, caller stream), created the first time
+ *    an entry point forks work beside the caller's stream (tn_field_bwd*: k_field_dpos beside the table scatter) and kept for the life of the
+ *    process; tn_shutdown() waits for them and destroys them (they are re-created on demand).  The last error string (tn_last_error) is
+ *    per process too.  There is no other hidden state: no context object, no caches, no allocations -- workspaces are the caller's.
+ *    (SURVEY.md 8b proposed tn_create / tn_destroy around an opaque context; with the state reduced to this map a context would own nothing
+ *    else, so the teardown is the one call.)
+ *  - The data-parallel gradient exchange is NOT part of this ABI (no tn_allreduce_grads): it is torch.distributed over RCCL on slices of the
+ *    caller's gradient arena (nerfstudio_thermal_amd/parallel.py), exactly where the reference has torch DDP.
+ *  - Environment switches, read once per process, all tuning / diagnostic aids whose defaults are the product path:
+ *      TN_NO_FORK=1               no companion streams (everything on the caller's stream)
+ *      TN_SCATTER_MODE=0          the round-1 global-atomic scatter with dense replicas instead of the binned scatter (A/B timing)
+ *      TN_SCATTER_REPLICAS=n, TN_SCATTER_SPARSE_CHUNK=n, TN_SCATTER_MERGE_RES=n      tuning knobs of the two scatter paths
+ *      TN_FOLD_TRACE=1 [TN_FOLD_TRACE_FILE=path]   per-block timing of the fold pass (synchronises and prints: diagnostics only)
+ *    The Python package adds GPU_MAX_HW_QUEUES=8 (unless set) before the first HIP call and TN_FUSE_SMALL=0 (one launch per reference seam
+ *    instead of the fused small kernels: test aid).
  */
 #ifndef THERMAL_NERF_HIP_H
 #define THERMAL_NERF_HIP_H
@@ -368,6 +385,8 @@ int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, f
 int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
                           double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
+/* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */
+int tn_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * N4: forward Gaussian-splat render, RGB + thermal colour per Gaussian.  Replaces the gsplat calls of

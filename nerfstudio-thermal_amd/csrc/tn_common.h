@@ -295,7 +295,7 @@ __device__ __forceinline__ float tn_wave_incl_rscan(float v, int lane) {
 
 // Work-item -> (ray, sample) in PATCH order: groups of 4 consecutive rays (a 2x2 pixel patch from PatchPixelSampler: neighbouring pixels,
 // near-identical rays) walked sample-major, so consecutive lanes are the same depth of neighbouring rays, then the next depth.  Runs of
-// lanes in one grid cell become ~3x longer than in ray-major order (scripts/analyze_scatter.py), which is what the run-length merging of the
+// lanes in one grid cell become ~3x longer than in ray-major order (measured in round 1), which is what the run-length merging of the
 // scatter-add feeds on.  Any N is handled (the last group may hold fewer than 4 rays).
 __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int64_t& ray, int& s) {
   int64_t per = 4 * (int64_t)S;

@@ -72,6 +72,26 @@ void tn_join(hipStream_t user, hipStream_t companion) {
   (void)hipStreamWaitEvent(user, c->join_ev, 0);
 }
 
+// Teardown of the only process-wide state the library keeps: the companion streams and their events (created lazily by tn_fork, one per
+// (device, caller stream)).  Waits for the companions, destroys them, forgets them; a later call simply creates new ones.
+extern "C" int tn_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_comp_mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  int rc = TN_OK;
+  for (auto& kv : g_comp) {
+    (void)hipSetDevice(kv.first.first);
+    Companion& c = kv.second;
+    if (c.side != nullptr && hipStreamSynchronize(c.side) != hipSuccess) rc = TN_ELAUNCH;
+    if (c.fork_ev) (void)hipEventDestroy(c.fork_ev);
+    if (c.join_ev) (void)hipEventDestroy(c.join_ev);
+    if (c.side) (void)hipStreamDestroy(c.side);
+  }
+  g_comp.clear();
+  (void)hipSetDevice(cur);
+  return rc;
+}
+
 extern "C" int tn_version(void) { return 300; }  // round 3: signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {

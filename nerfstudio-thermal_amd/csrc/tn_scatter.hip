@@ -647,7 +647,6 @@ static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
 // TN_SCATTER_MODE: 1 = binned (default), 0 = atomics with dense replicas (the round-1 path; also what the dense data-parallel exchange uses)
 static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); return m; }
 static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 8192, 1024, 32768) & ~1023; return r; }
-static int bin_count_stride() { static int r = env_int("TN_BIN_COUNT_STRIDE", 1, 1, TN_BIN_COUNT_STRIDE); return r; }
 static int merge_res() { static int r = env_int("TN_SCATTER_MERGE_RES", 256, 0, 1 << 20); return r; }
 
 // Layout of the binned scatter for (grid, P, scratch): a pure function of its arguments, so the bin pass and the fold launches of a phased
@@ -665,7 +664,7 @@ static int bin_plan(const TnGrid& grid, int64_t P, void* scratch, BinK& bk, uint
   bk.level_stride = (uint32_t)(cap * bk.nslices);
   char* base = reinterpret_cast<char*>(scratch);
   bk.count = reinterpret_cast<uint32_t*>(base);
-  bk.cstride = (uint32_t)bin_count_stride();
+  bk.cstride = 1;  // one 64-B line per counter (16) was measured 15 % SLOWER on the main grid: more lines to fetch, no gain
   const int64_t cnt_bytes = 256 + (int64_t)L * TN_BIN_MAX_SLICES * 4 * TN_BIN_COUNT_STRIDE;
   bk.val = reinterpret_cast<float2*>(base + cnt_bytes);
   bk.idx = reinterpret_cast<uint16_t*>(base + cnt_bytes + (int64_t)L * tn_bin_level_records(P) * 8);
@@ -736,11 +735,9 @@ int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level
   GridK gk = make_gridk(grid);
   const uint32_t first_block = bk.blk0[level_begin], nblk = bk.blk0[level_end] - bk.blk0[level_begin];
   const size_t shmem = ((size_t)(4u << bk.slice_log2) + (((1u << bk.slice_log2) + 31) / 32) + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_fold), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((4u << TN_BIN_SLICE_LOG2) + ((1u << TN_BIN_SLICE_LOG2) / 32) + 1) * sizeof(float)));
-    attr_set = true;
-  }
+  // per launch, not once per process: the attribute is per device (a process that drives a second GPU would otherwise fail the fold there)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(((4u << TN_BIN_SLICE_LOG2) + ((1u << TN_BIN_SLICE_LOG2) / 32) + 1) * sizeof(float)));
   static int trace_on = env_int("TN_FOLD_TRACE", 0, 0, 1);
   static unsigned long long* trace_buf = nullptr;
   if (trace_on) {  // diagnostics only: synchronises and prints

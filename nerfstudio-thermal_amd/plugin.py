@@ -31,17 +31,21 @@ class MethodDescription:
 
 
 def _build():
-    try:  # inside a nerfstudio installation: a real MethodSpecification
+    """Inside a nerfstudio installation: a real MethodSpecification (plugins/types.py:23-33) whose TrainerConfig is a copy of
+    method_configs["thermal-nerfacto"] (configs/method_configs.py:255-310) with this package's model config swapped in.  Only the ABSENCE of
+    nerfstudio (ImportError) selects the stand-alone description; anything else -- a method table without "thermal-nerfacto", a config of another
+    shape -- is an error the user must see, not a silent fallback."""
+    try:
         from nerfstudio.configs.method_configs import method_configs
         from nerfstudio.plugins.types import MethodSpecification
-        import copy
-
-        base = copy.deepcopy(method_configs["thermal-nerfacto"])
-        base.method_name = "thermal-nerfacto-hip"
-        base.pipeline.model = model_config()
-        return MethodSpecification(config=base, description=MethodDescription().description)
-    except Exception:
+    except ImportError:
         return MethodDescription()
+    import copy
+
+    base = copy.deepcopy(method_configs["thermal-nerfacto"])
+    base.method_name = "thermal-nerfacto-hip"
+    base.pipeline.model = model_config()
+    return MethodSpecification(config=base, description=MethodDescription().description)
 
 
 thermal_nerfacto_hip = _build()

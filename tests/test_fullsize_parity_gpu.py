@@ -90,7 +90,7 @@ def check_table_grad(got, ref, tol_rel, what, touched=None, relu_flips=0, flip_s
     relu_flips: entries allowed beyond the tolerance when the gradient comes through the MLPs.  Of the 38 M hidden ReLU units of a
     4096 x 48 batch a handful sit within fp32 rounding of zero, and the MFMA chain and ATen's GEMM round differently: for those samples the
     ReLU derivative is 1 on one side and 0 on the other, and the 128 table entries each of them touches move by up to a percent of the
-    largest entry (scripts/debug_field_bwd.py: 121 of 16.7 M entries above 2.4e-4, mean |difference| 6e-9 of the largest entry)."""
+    largest entry (measured in round 2: 121 of 16.7 M entries above 2.4e-4, mean |difference| 6e-9 of the largest entry)."""
     got = got.detach().cpu()
     scale = float(ref.abs().max())
     assert scale > 0
