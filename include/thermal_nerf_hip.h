@@ -289,6 +289,23 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
                          const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace, float* out,
                          tn_stream_t stream);
 
+/* The TRAINING backward of one branch as ONE call, the counterpart of tn_render_rays_train: everything autograd runs behind d(composite) and
+ * d(weights) in ThermalNerfactoModel's training step (models/thermal_nerfacto.py:403-489 backwards; cameras/rays.py:128-150,
+ * model_components/renderers.py, fields/nerfacto_field.py:205-348, fields/density_fields.py:95-118 under autograd).  fwd_out is the buffer
+ * tn_render_rays_train filled (same N, S, field); origins / directions [N,3] the pose-corrected rays that forward used; d_comp [N,C]; d_weights2 [N,S2] (losses on the fine weights); d_weights0 / d_weights1
+ * [N,S0] / [N,S1] or both NULL when the proposal networks take no gradient this iteration (model_components/ray_samplers.py:591,605-610);
+ * d_density_extra [N,S2] or NULL (the density loss's gradient on this branch's density, separate mode).  The library enqueues tn_render_bwd,
+ * then -- on two companion streams of `stream` -- tn_weights_bwd + tn_prop_density_bwd per proposal level, beside tn_field_bwd on `stream`, and
+ * joins: same launches and results as those calls made one by one.  tmp: tn_render_rays_train_bwd_tmp_floats(...) floats of scratch;
+ * prop_workspace_k: tn_prop_workspace_bytes(N*S_k) (may be NULL without d_weights).  d_origins / d_directions [N,3] accumulate (or both NULL). */
+int64_t tn_render_rays_train_bwd_tmp_floats(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
+int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+                             const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
+                             const float* fwd_out, const float* d_comp, const float* d_weights0,
+                             const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
+                             void* prop_workspace0, void* prop_workspace1, float* tmp, float* d_origins, float* d_directions,
+                             tn_stream_t stream);
+
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
 int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,

@@ -112,6 +112,8 @@ SIGNATURES = {
     "tn_grad_scaler_update": (C.c_int, [_p, _p, _p, _i32, _p, _d, _d, _i32, _i32, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_shutdown": (C.c_int, []),
+    "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
+    "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 13),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
     "tn_splat_bin": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p]),

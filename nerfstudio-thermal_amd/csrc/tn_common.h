@@ -33,6 +33,9 @@ static inline hipStream_t tn_s(tn_stream_t s) { return reinterpret_cast<hipStrea
 // the companion.  Both are plain event record/wait pairs (capturable into a hipGraph).  Companion streams are created once per
 // (device, user stream) and live for the process.  Returns nullptr (caller then stays on `user`) if a stream/event cannot be created.
 hipStream_t tn_fork(hipStream_t user);
+// further companions of the same caller stream (idx 1, 2: the proposal networks' backward inside tn_render_rays_train_bwd); idx 0 == tn_fork
+hipStream_t tn_fork_n(hipStream_t user, int idx);
+void tn_join_n(hipStream_t user, int idx);
 void tn_join(hipStream_t user, hipStream_t companion);
 // join whatever companion stream `user` has (no-op if it never forked)
 void tn_join_all(hipStream_t user);

@@ -25,48 +25,56 @@ struct Companion {
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
 };
 std::mutex g_comp_mu;
-std::map<std::pair<int, hipStream_t>, Companion> g_comp;
-Companion* companion_of(hipStream_t user) {
+// key: (device, caller stream, companion index).  Index 0: the field backward's d-position kernel; 1, 2: the proposal networks' backward in
+// tn_render_rays_train_bwd.
+struct CompKey {
+  int dev; hipStream_t user; int idx;
+  bool operator<(const CompKey& o) const { return dev != o.dev ? dev < o.dev : (user != o.user ? user < o.user : idx < o.idx); }
+};
+std::map<CompKey, Companion> g_comp;
+Companion* companion_of(hipStream_t user, int idx) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(g_comp_mu);
-  auto key = std::make_pair(dev, user);
+  CompKey key{dev, user, idx};
   auto it = g_comp.find(key);
   if (it != g_comp.end()) return &it->second;
   if (getenv("TN_NO_FORK") != nullptr) return nullptr;  // debugging aid: everything on the caller's stream
   Companion c;
-  // highest priority: the companion's GEMMs are short and finish while the scatter on the caller's stream keeps the atomic units busy;
+  // highest priority: the companion's kernels are short and finish while the scatter on the caller's stream keeps the LDS units busy;
   // at equal priority the scatter's thousands of resident blocks starve them and the join waits for a tail
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+  if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, idx == 0 ? hi : 0) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c.join_ev, hipEventDisableTiming) != hipSuccess)
     return nullptr;
   return &(g_comp[key] = c);
 }
 }  // namespace
-hipStream_t tn_fork(hipStream_t user) {
-  Companion* c = companion_of(user);
+hipStream_t tn_fork_n(hipStream_t user, int idx) {
+  Companion* c = companion_of(user, idx);
   if (c == nullptr) return nullptr;
   if (hipEventRecord(c->fork_ev, user) != hipSuccess || hipStreamWaitEvent(c->side, c->fork_ev, 0) != hipSuccess) return nullptr;
   return c->side;
 }
-void tn_join_all(hipStream_t user) {
+hipStream_t tn_fork(hipStream_t user) { return tn_fork_n(user, 0); }
+void tn_join_n(hipStream_t user, int idx) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return;
   Companion c;
   {
     std::lock_guard<std::mutex> lk(g_comp_mu);
-    auto it = g_comp.find(std::make_pair(dev, user));
+    auto it = g_comp.find(CompKey{dev, user, idx});
     if (it == g_comp.end()) return;
     c = it->second;
   }
   (void)hipEventRecord(c.join_ev, c.side);
   (void)hipStreamWaitEvent(user, c.join_ev, 0);
 }
+void tn_join_all(hipStream_t user) { tn_join_n(user, 0); }
 void tn_join(hipStream_t user, hipStream_t companion) {
-  Companion* c = companion_of(user);
+  Companion* c = companion_of(user, 0);
   if (c == nullptr || companion != c->side) return;
   (void)hipEventRecord(c->join_ev, c->side);
   (void)hipStreamWaitEvent(user, c->join_ev, 0);
@@ -80,7 +88,7 @@ extern "C" int tn_shutdown(void) {
   (void)hipGetDevice(&cur);
   int rc = TN_OK;
   for (auto& kv : g_comp) {
-    (void)hipSetDevice(kv.first.first);
+    (void)hipSetDevice(kv.first.dev);
     Companion& c = kv.second;
     if (c.side != nullptr && hipStreamSynchronize(c.side) != hipSuccess) rc = TN_ELAUNCH;
     if (c.fork_ev) (void)hipEventDestroy(c.fork_ev);

@@ -141,3 +141,65 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
   return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
                        at(TRO_SCRATCH), stream);
 }
+
+// ---- the TRAINING backward of one branch as one call: everything behind d(composite) / d(weights) of the losses -- tn_render_bwd (get_weights +
+// renderers), the field's backward (MLP chain + weight gradients, d position, table scatter) and, when the proposal networks take a gradient
+// this iteration, tn_weights_bwd + tn_prop_density_bwd of both levels on two companion streams of `stream` (forked after the renderer backward,
+// joined before returning) -- enqueued by the library: the same launches, in the same order per stream, as the caller would make one by one
+// (nerfstudio_thermal_amd/engine.py: loss_and_backward), without ~15 host round trips through the binding.
+__global__ void k_add_inplace(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
+}
+extern "C" int64_t tn_render_rays_train_bwd_tmp_floats(int64_t N, int32_t S0, int32_t S1, int32_t S2, int32_t C) {
+  if (N < 0 || S0 < 1 || S1 < 1 || S2 < 1 || C < 1 || C > 4) return TN_EINVAL;
+  auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
+  return up(N * (int64_t)S2 * C) + up(N * (int64_t)S2) + up(N * (int64_t)S0) + up(N * (int64_t)S1);
+}
+extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+                                        const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
+                                        const float* fwd_out, const float* d_comp, const float* d_weights0,
+                                        const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
+                                        void* prop_workspace0, void* prop_workspace1, float* tmp, float* d_origins, float* d_directions,
+                                        tn_stream_t stream) {
+  if (N == 0) return TN_OK;
+  TN_REQUIRE(field && origins && directions && camera_indices && fwd_out && d_comp && d_weights2 && field_workspace && tmp,
+             "tn_render_rays_train_bwd: null pointer");
+  TN_REQUIRE((d_weights0 == nullptr) == (d_weights1 == nullptr), "tn_render_rays_train_bwd: d_weights0 and d_weights1 come together (or not at all)");
+  const bool prop_grad = d_weights0 != nullptr;
+  if (prop_grad) TN_REQUIRE(prop0 && prop1 && prop_workspace0 && prop_workspace1, "tn_render_rays_train_bwd: proposal networks / workspaces missing");
+  TN_REQUIRE(N > 0 && S0 >= 1 && S1 >= 1 && S2 >= 1 && S0 <= TN_MAX_SAMPLES && S1 <= TN_MAX_SAMPLES && S2 <= TN_MAX_SAMPLES,
+             "tn_render_rays_train_bwd: bad N=%lld S=(%d, %d, %d)", (long long)N, S0, S1, S2);
+  TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_render_rays_train_bwd: d_origins and d_directions must both be given or both NULL");
+  const int C = field->num_channels;
+  int64_t off[TRO_COUNT];
+  train_layout(N, S0, S1, S2, C, off);
+  auto at = [&](int slot) { return fwd_out + off[slot]; };
+  auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
+  float* d_rgb = tmp;
+  float* d_dens = d_rgb + up(N * (int64_t)S2 * C);
+  float* dd0 = d_dens + up(N * (int64_t)S2);
+  float* dd1 = dd0 + up(N * (int64_t)S0);
+  const float* o = origins;  // the pose-corrected rays the forward used (its TRO_ORIGINS / TRO_DIRECTIONS slots, or its inputs without a pose)
+  const float* d = directions;
+  hipStream_t st = tn_s(stream);
+  int rc;
+  if ((rc = tn_render_bwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), at(TRO_W2), d_comp, d_weights2, N, S2, C, d_rgb, d_dens, stream))) return rc;
+  if (d_density_extra != nullptr) {  // the density loss's gradient on this branch's own density (separate mode)
+    const int64_t n = N * (int64_t)S2;
+    hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)std::min<int64_t>(tn_cdiv(n, 256), 4096)), dim3(256), 0, st, d_dens, d_density_extra, n);
+    TN_CHECK_LAUNCH("tn_render_rays_train_bwd(add)");
+  }
+  int rc0 = TN_OK, rc1 = TN_OK;
+  if (prop_grad) {
+    // the proposal networks' backward (own tables, MLPs, scatter; d origins / d directions accumulated atomically) is independent of the field's
+    hipStream_t s0 = tn_fork_n(st, 1), s1 = tn_fork_n(st, 2);
+    tn_stream_t t0 = s0 ? (tn_stream_t)s0 : stream, t1 = s1 ? (tn_stream_t)s1 : stream;
+    rc0 = tn_weights_bwd(at(TRO_E0), at(TRO_D0), at(TRO_W0), d_weights0, N, S0, dd0, t0);
+    if (!rc0) rc0 = tn_prop_density_bwd(prop0, o, d, at(TRO_E0), dd0, N, S0, prop_workspace0, d_origins, d_directions, t0);
+    rc1 = tn_weights_bwd(at(TRO_E1), at(TRO_D1), at(TRO_W1), d_weights1, N, S1, dd1, t1);
+    if (!rc1) rc1 = tn_prop_density_bwd(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, d_origins, d_directions, t1);
+  }
+  rc = tn_field_bwd(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, d_origins, d_directions, stream);
+  if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
+  return rc ? rc : (rc0 ? rc0 : rc1);
+}

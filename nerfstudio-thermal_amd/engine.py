@@ -22,6 +22,9 @@ from .netparams import field_params, prop_params
 # timing experiments: TN_FUSE_SMALL=0 runs the small operators through one entry point per reference seam (tn_weights_fwd, tn_composite_fwd,
 # tn_clip_depth, tn_pixel_losses, tn_proposal_losses, tn_pose_apply_fwd/bwd, tn_camera_reg) instead of the fused launches
 _FUSE = os.environ.get("TN_FUSE_SMALL", "1") != "0"
+# TN_ONE_CALL_BWD=0: the backward of a branch as the individual entry points (render_bwd, weights_bwd, prop_density_bwd x2, field_bwd on torch
+# side streams) instead of tn_render_rays_train_bwd (test / A-B aid: the two must agree)
+_ONE_CALL_BWD = os.environ.get("TN_ONE_CALL_BWD", "1") != "0"
 
 
 @dataclass
@@ -51,6 +54,7 @@ class Branch:
     depth: Tensor
     expected_depth: Tensor
     prop_grad: bool
+    fwd_buf: Optional[Tensor] = None  # the one buffer of tn_render_rays_train (fused training forward): what tn_render_rays_train_bwd reads
 
 
 def exp_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> float:
@@ -140,7 +144,7 @@ class RenderEngine:
                       for S, lv in zip(self.counts, r["levels"])]
             return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
                           rgb_samples=r["rgb_samples"], comp=r["rgb"], accumulation=r["accumulation"], depth=r["depth"],
-                          expected_depth=r["expected_depth"], prop_grad=prop_grad)
+                          expected_depth=r["expected_depth"], prop_grad=prop_grad, fwd_buf=r["buf"])
         first = None
         if training and pose is not None:
             if _FUSE:  # pose correction and the level-0 bins are independent: one launch
@@ -359,6 +363,15 @@ class RenderEngine:
             d_d = Z[("d_d", sfx)] if want_pos else None
             dws = grads_w[sfx]
             dc = d_comp_t if sfx else d_comp
+            if _FUSE and _ONE_CALL_BWD and not pipelined and br.fwd_buf is not None and getattr(self, "scatter_events", None) is None:
+                # the whole backward of the branch as ONE call of the C ABI (tn_render_rays_train_bwd): renderer backward, field backward with
+                # d position and table scatter, both proposal networks on the library's companion streams -- the launches below, enqueued
+                # by the library in the same order per stream
+                ops.render_rays_train_bwd(props, fld, br.fwd_buf, br.origins, br.directions, cam, self.counts, dc,
+                                          [dws[0] if br.prop_grad else None, dws[1] if br.prop_grad else None, dws[2]], d_dens_extra[sfx], d_o, d_d,
+                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx))
+                br._d_o, br._d_d = d_o, d_d
+                continue
             if _FUSE:
                 d_rgb, d_dens = ops.render_bwd(lv[2].e_bins, lv[2].density, br.rgb_samples, lv[2].weights, dc, dws[2])
             else:

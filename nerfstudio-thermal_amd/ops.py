@@ -684,8 +684,53 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
         b = 2 + 5 * i
         levels.append({"s_bins": v(b, N, S + 1), "e_bins": v(b + 1, N, S + 1), "density": v(b + 2, N, S), "weights": v(b + 3, N, S), "median": v(b + 4, N, 1)})
     levels.append({"s_bins": v(12, N, S2 + 1), "e_bins": v(13, N, S2 + 1), "density": v(14, N, S2), "weights": v(15, N, S2), "median": v(19, N, 1)})
-    return {"origins": v(0, N, 3) if pose is not None else origins, "directions": v(1, N, 3) if pose is not None else directions, "levels": levels,
+    return {"buf": buf, "origins": v(0, N, 3) if pose is not None else origins, "directions": v(1, N, 3) if pose is not None else directions, "levels": levels,
             "rgb_samples": v(16, N, S2, Cc), "rgb": v(17, N, Cc), "accumulation": v(18, N, 1), "depth": v(19, N, 1), "expected_depth": v(20, N, 1)}
+
+
+def _prop_ws(device, num_points: int, tag: str) -> Tensor:
+    need = int(_lib.load().tn_prop_workspace_bytes(num_points))
+    key = (str(device), tag)
+    ws = _PROP_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _PROP_WS[key] = ws
+    return ws
+
+
+_BWD_TMP: dict = {}
+
+
+def render_rays_train_bwd(props: Sequence[PropNetParams], fld: FieldParams, fwd_buf: Tensor, origins: Tensor, directions: Tensor, cam: Tensor,
+                          counts: Sequence[int], d_comp: Tensor, d_weights: Sequence[Optional[Tensor]], d_density_extra: Optional[Tensor],
+                          d_origins: Optional[Tensor], d_directions: Optional[Tensor], tag: str = "main", side_tags=("side0", "side1")) -> None:
+    """The training backward of one branch in ONE library call (tn_render_rays_train_bwd): renderer backward, field backward (+ d position, table
+    scatter) and -- when d_weights[0] / d_weights[1] are given -- both proposal networks' backward on the library's companion streams.
+    fwd_buf: the buffer ops.render_rays_train returned ("buf"); origins / directions: its pose-corrected rays; d_weights = [level0, level1, fine]."""
+    N = origins.shape[0]
+    S0, S1, S2 = (int(c) for c in counts)
+    Cc = fld.num_channels
+    lib = _lib.load()
+    dev = origins.device
+    need = int(lib.tn_render_rays_train_bwd_tmp_floats(N, S0, S1, S2, Cc))
+    key = (str(dev), tag)
+    tmp = _BWD_TMP.get(key)
+    if tmp is None or tmp.numel() < need:
+        tmp = _BWD_TMP[key] = torch.empty(need, device=dev)
+    ws = fld.workspace(N * S2, True, tag)
+    prop_grad = d_weights[0] is not None
+    p0 = props[0].cstruct(need_grad=True) if prop_grad else None
+    p1 = props[1].cstruct(need_grad=True) if prop_grad else None
+    f = fld.cstruct(need_grad=True)
+    w0 = _prop_ws(dev, N * S0, side_tags[0]) if prop_grad else None
+    w1 = _prop_ws(dev, N * S1, side_tags[1]) if prop_grad else None
+    check(lib.tn_render_rays_train_bwd(C.byref(p0) if prop_grad else None, C.byref(p1) if prop_grad else None, C.byref(f), _f32(origins, "origins", (N, 3)),
+                                       _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)), N, S0, S1, S2, C.c_void_p(fwd_buf.data_ptr()),
+                                       _f32(d_comp, "d_comp", (N, Cc)), _f32(d_weights[0], "d_weights0", (N, S0), True), _f32(d_weights[1], "d_weights1", (N, S1), True),
+                                       _f32(d_weights[2], "d_weights2", (N, S2)), _f32(d_density_extra, "d_density_extra", (N, S2), True),
+                                       C.c_void_p(ws.data_ptr()), C.c_void_p(w0.data_ptr()) if prop_grad else None, C.c_void_p(w1.data_ptr()) if prop_grad else None,
+                                       C.c_void_p(tmp.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
+                                       _stream()), "tn_render_rays_train_bwd")
 
 
 _RENDER_SCRATCH: dict = {}

@@ -450,3 +450,38 @@ def test_density_after_training(golden_dir, mode):
         frac = float((cerr > DENS_TOL).float().mean())
         assert frac <= max(0.03, 3.0 * sens_frac), (s, "chain", frac, sens_frac)
         assert float(cerr.max()) <= max(1e-3, 10.0 * sens), (s, "chain", float(cerr.max()), sens)
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_render_rays_train_bwd_is_the_launch_sequence(golden_dir, mode, monkeypatch):
+    """tn_render_rays_train_bwd (one call of the C ABI per branch: renderer backward, field backward with d position and table scatter, both
+    proposal networks on the library's companion streams) against the same backward made of the individual entry points on torch side streams
+    (TN_ONE_CALL_BWD=0): every loss and every gradient, on an iteration that updates the proposal networks and on one that does not.  Identical
+    up to the order of the float atomics (weight-gradient block sums, d origins / d directions)."""
+    from nerfstudio_thermal_amd import engine as E
+
+    gi, o, d, cam = dev_inputs(golden_dir, "tiny")
+    img, is_th = gi["image"].to(DEV), gi["is_thermal"].to(DEV)
+    jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+
+    def grads(one_call, prop_update):
+        monkeypatch.setattr(E, "_ONE_CALL_BWD", one_call)
+        _, _, arena, eng = build(mode, "tiny")
+        if not prop_update:  # make the sampler skip the proposal networks' gradient this iteration (ray_samplers.py:591)
+            eng.sampler_step, eng.steps_since_update = 2000, 0
+        arena.zero_grad()
+        out, br = eng.get_outputs(o, d, cam, True, jit, jit_t)
+        assert br[""].prop_grad == prop_update
+        losses = eng.loss_and_backward(out, br, cam, img, is_th)
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in losses.items()}, arena.grads.clone()
+
+    for prop_update in (True, False):
+        la, ga = grads(True, prop_update)
+        lb, gb = grads(False, prop_update)
+        assert la.keys() == lb.keys()
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]) + 1e-12, (k, la[k], lb[k])
+        assert torch.equal(ga == 0, gb == 0)  # same zero pattern
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
