@@ -451,7 +451,7 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     api = args.path == "model-api"
-    assert not (api and world > 1), "--path model-api is a single-GPU measurement (multi-GPU runs use the fused step with the overlapped exchange)"
+    ddp = None
 
     if api:
         from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
@@ -459,6 +459,11 @@ def main():
         cfg, arena, model = build_model(device, mode=args.mode, nerf_samples=args.nerf_samples)
         eng = model.engine
         optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam if args.api_optimizer == "hip" else torch.optim.Adam)
+        if world > 1:
+            # the reference's multi-GPU wrap (pipelines/base_pipeline.py:281-283); its reducer all-reduces the gradients over RCCL during backward
+            from torch.nn.parallel import DistributedDataParallel as DDP
+
+            ddp = DDP(model, device_ids=[local], find_unused_parameters=True)
     else:
         cfg, arena, eng = build_engine(device, mode=args.mode, nerf_samples=args.nerf_samples)
     rays = args.rays
@@ -469,7 +474,7 @@ def main():
     # N > 1: the gradient all-reduce (RCCL) is issued per level range of the main table while the backward is still running
     make_hook = lambda w: (OverlappedGradReducer(w) if args.dp_chunks < 0 else OverlappedGradReducer(w, level_chunks=args.dp_chunks)  # noqa: E731
                            if args.dp_chunks > 0 else GradAllReducer(w))
-    hook = make_hook(world) if world > 1 else None
+    hook = make_hook(world) if (world > 1 and not api) else None  # (the drop-in path exchanges through DistributedDataParallel instead)
     if hook is not None and args.dp_adam_per_range:
         hook.adam_per_range = True
     if args.force_dp and world == 1:
@@ -499,9 +504,15 @@ def main():
 
             scaler = DeviceGradScaler(device, num_groups=len(arena.optimised_groups))
 
+    if not api:
+        # TN_OVERLAP_ADAM=1: the field groups' Adam launch on a side stream beside the next step's pixel + proposal sampling.  Measured
+        # (profiles/r03_experiments.md): 1.09 -> 1.67 ms/step -- with a second queue active across the step boundary nearly every kernel of the
+        # step runs 1.5-5x longer, whatever the Adam grid -- so it stays off.
+        eng.overlap_adam = os.environ.get("TN_OVERLAP_ADAM", "0") == "1"
+
     def run(step):
         if api:
-            return one_step_api(model, optimizers, cam_t, cache, rays, step, scaler)
+            return one_step_api(model, optimizers, cam_t, cache, rays, step, scaler, call=ddp)
         return one_step(eng, cam_t, cache, rays, step, hook, scaler)
 
     step = 0

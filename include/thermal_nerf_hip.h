@@ -279,7 +279,9 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
  * Everything later stages need goes into ONE buffer `out` (256-byte aligned); tn_render_rays_train_layout fills offsets[] (floats) with the
  * position of: 0 origins 1 directions (pose-corrected; unused when pose_adjustment is NULL) | 2 s_bins0 3 e_bins0 4 density0 5 weights0
  * 6 median0 | 7..11 the same for level 1 | 12 s_bins2 13 e_bins2 14 density2 15 weights2 | 16 rgb_samples [N,S2,C] 17 comp [N,C]
- * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS. */
+ * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
+ * wait_event_before_field: NULL, or a hipEvent_t that `stream` waits for right before the field's first read of its parameters -- a trainer
+ * that runs the previous iteration's Adam launch over the field on another stream lets it overlap the proposal sampling this way. */
 #define TN_RENDER_TRAIN_OFFSETS 23
 int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
 int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
@@ -287,7 +289,7 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
                          const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                          int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                          const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace, float* out,
-                         tn_stream_t stream);
+                         void* wait_event_before_field, tn_stream_t stream);
 
 /* The TRAINING backward of one branch as ONE call, the counterpart of tn_render_rays_train: everything autograd runs behind d(composite) and
  * d(weights) in ThermalNerfactoModel's training step (models/thermal_nerfacto.py:403-489 backwards; cameras/rays.py:128-150,
@@ -388,6 +390,8 @@ int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float
  *    step -= found_inf);  lr_finals / sched_max_steps (HOST arrays or NULL) + sched_step: when given, lrs[k] is lr_init and the kernel
  *    evaluates the reference's ExponentialDecayScheduler (engine/schedulers.py:109-141) at sched_step - skipped[lag_index] (lag_index = -1:
  *    no lag): the trainer does not step the schedulers in an iteration whose scale dropped (engine/trainer.py:491-495).
+ *    zero_grads != 0: the launch CONSUMES the gradients of its ranges -- sets them to zero behind the read, also when the step is skipped --
+ *    (`grads` is then written): the optimizers.zero_grad_some() of the next iteration (engine/trainer.py:463-467) without a fill launch.
  *  - tn_grad_scaler_update is GradScaler.update() on the device (backoff / growth of *scale, growth tracker) and adds 1 to *lag (may be NULL)
  *    when any of the num_flags entries of found_inf is set; clear_found_inf != 0 zero-fills found_inf afterwards (ready for the next step). */
 int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream);
@@ -398,7 +402,7 @@ int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, f
                             const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                             const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                             const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
-                            int32_t lag_index, int32_t count_skip, tn_stream_t stream);
+                            int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream);
 int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
                           double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);

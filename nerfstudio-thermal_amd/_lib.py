@@ -92,7 +92,7 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_rays_train_layout": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _i32]),
     "tn_render_rays_train": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32,
-                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
@@ -107,7 +107,7 @@ SIGNATURES = {
     "tn_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _d, _d, _d, _d, _p]),
     "tn_adam_step_ranges": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _d, _d, _d, _p]),
     "tn_grad_nonfinite": (C.c_int, [_p, _i64, _p, _p]),
-    "tn_adam_step_ranges_amp": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _p]),
+    "tn_adam_step_ranges_amp": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p]),
     "tn_grad_nonfinite_ranges": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _p]),
     "tn_grad_scaler_update": (C.c_int, [_p, _p, _p, _i32, _p, _d, _d, _i32, _i32, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),

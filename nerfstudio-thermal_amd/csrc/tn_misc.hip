@@ -875,16 +875,22 @@ struct AdamRangesAmp {
 };
 __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
                                   double beta1, double beta2, float eps, const float* __restrict__ inv_scale, const float* __restrict__ found_inf,
-                                  int32_t* __restrict__ skipped, int count_skip) {
+                                  int32_t* __restrict__ skipped, int count_skip, int zero_g) {
   const int k = blockIdx.y;
   const int fl = r.flag[k];
+  float* gz = const_cast<float*>(g);  // zero_g: the gradients are consumed (set to zero behind the read): no zero-fill launch before the next backward
   // schedule lag = iterations so far in which the scale dropped; maintained by tn_grad_scaler_update AFTER this launch (stream order)
   const int lag = (skipped != nullptr && r.lag_index >= 0) ? skipped[r.lag_index] : 0;
+  const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
   if (found_inf != nullptr && found_inf[fl] != 0.0f) {  // uniform over the range's blocks
     if (count_skip && skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&skipped[fl], 1);
+    if (zero_g) {  // the skipped step still consumes its (non-finite) gradients
+      for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(gz + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - n4 * 4) gz[off + n4 * 4 + threadIdx.x] = 0.0f;
+    }
     return;
   }
-  const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
   if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) return;
   __shared__ float s_ns, s_bc;
   if (threadIdx.x == 0) {
@@ -930,6 +936,7 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
     p4[i] = pp;
     __builtin_nontemporal_store(mm4, reinterpret_cast<v4f*>(m4) + i);
     __builtin_nontemporal_store(vv4, reinterpret_cast<v4f*>(v4) + i);
+    if (zero_g) { const v4f z = {0.f, 0.f, 0.f, 0.f}; __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(gz + off) + i); }
   }
   const int tail = (int)(n - n4 * 4);
   if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
@@ -937,6 +944,7 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
     float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
     ADAM1(pp, gg, mm, vv)
     p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_g) gz[i] = 0.0f;
   }
 #undef ADAM1
 }
@@ -944,7 +952,7 @@ extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float*
                                        const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                                        const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                                        const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
-                                       int32_t lag_index, int32_t count_skip, tn_stream_t stream) {
+                                       int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream) {
   if (num_ranges == 0) return TN_OK;
   TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges_amp: null pointer");
   TN_REQUIRE(num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES, "tn_adam_step_ranges_amp: %d ranges (at most %d)", num_ranges, TN_ADAM_MAX_RANGES);
@@ -972,7 +980,7 @@ extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float*
   r.lag_index = lag_index;
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256), 256 * 16));
   hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
-                     found_inf, skipped, (int)count_skip);
+                     found_inf, skipped, (int)count_skip, (int)zero_grads);
   TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
   return TN_OK;
 }

@@ -103,7 +103,7 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
                                     const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                                     int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                     const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
-                                    float* out, tn_stream_t stream) {
+                                    float* out, void* wait_event_before_field, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -136,6 +136,12 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
   if ((rc = tn_weights_resample(at(TRO_E1), at(TRO_D1), at(TRO_S1), S1, anneal, lin_pdf2, jitter2, nears, fars, N, S2, at(TRO_W1), at(TRO_M1), at(TRO_S2),
                                 at(TRO_E2), stream)))
     return rc;
+  if (wait_event_before_field != nullptr) {
+    // the previous iteration's Adam launch over the field's parameters may still be running on another stream (it overlaps the proposal
+    // sampling above, which only reads the proposal networks): the field's first read of its parameters waits for it here
+    hipError_t e = hipStreamWaitEvent(tn_s(stream), reinterpret_cast<hipEvent_t>(wait_event_before_field), 0);
+    TN_REQUIRE(e == hipSuccess, "tn_render_rays_train: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+  }
   if ((rc = tn_field_pack_weights(field, field_workspace, stream))) return rc;
   if ((rc = tn_field_fwd(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, stream))) return rc;
   return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),

@@ -99,6 +99,16 @@ class RenderEngine:
         self.steps_since_update = 0
         self.sampler_step = 0
         self.adam_step_count = 0
+        # The fused step's optimiser launch CONSUMES the gradients (zero behind the read): no arena-wide zero-fill at the start of the next
+        # step.  `_grads_clean` says the arena's gradient buffer is known to be zero.
+        self._grads_clean = False
+        # overlap_adam: the Adam launch over the FIELD groups (470 MB of streaming traffic, ~65 us) runs on a side stream and overlaps the
+        # next step's pixel sampling + proposal sampling (which read the proposal networks and the poses only); the field's forward waits for
+        # it (tn_render_rays_train's wait event).  OFF: measured 1.09 -> 1.67 ms per step on MI355X / ROCm 7 -- with the second queue active
+        # across the step boundary almost every kernel of the step runs 1.5-5x longer (also with the Adam grid capped at 256 blocks; the same
+        # two launches on ONE stream cost nothing) -- see profiles/r03_experiments.md.  Kept as an option for runtimes where it pays.
+        self.overlap_adam = False
+        self._adam_event = None
 
     def _side_stream(self, i: int = 0):
         side = self.__dict__.setdefault("_side", {})
@@ -112,6 +122,12 @@ class RenderEngine:
         if pool is None:
             pool = self.__dict__["_rand"] = ops.UniformPool(self.device)
         return pool
+
+    def sync_params(self) -> None:
+        """Make the current stream wait for a still-running optimiser launch of the previous train_step (overlap_adam)."""
+        ev, self._adam_event = self._adam_event, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     # ---------------------------------------------------------------- sampler schedule
     def update_schedule(self, step: int) -> float:
@@ -133,13 +149,14 @@ class RenderEngine:
 
     # ---------------------------------------------------------------- forward of one branch
     def render_branch(self, props, fld, pose, frozen, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
-                      training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main") -> Branch:
+                      training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main", wait_event=None) -> Branch:
         o_in, d_in = origins, directions
         if training and _FUSE:
             # the whole training forward of the branch as ONE call of the C ABI (tn_render_rays_train): the library enqueues the eight
             # launches itself and every result is a view of one allocation -- the host side of a step is what bounds small batches and the
             # drop-in path
-            r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag)
+            r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag,
+                                      wait_event=wait_event)
             levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=lv["median"])
                       for S, lv in zip(self.counts, r["levels"])]
             return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
@@ -232,11 +249,16 @@ class RenderEngine:
         if training and jitters is None:
             jitters = list(self._uniforms().take((3, N)).unbind(0))
         updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
+        wait_ev = None
+        if training and _FUSE:
+            wait_ev, self._adam_event = self._adam_event, None  # the field's forward (inside tn_render_rays_train) waits for the pending Adam launch
+        else:
+            self.sync_params()
         if not training and _FUSE:
             b = self.render_branch_eval(self.props, self.field, origins, directions, cam, nears, fars, self.anneal)
         else:
             b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
-                                   jitters, prop_grad=updated)
+                                   jitters, prop_grad=updated, wait_event=wait_ev)
         self.last_updated = bool(updated)  # did the proposal networks of the RGB sampler get gradients in this forward?
         if updated:  # eval renders included, as ProposalNetworkSampler.generate_ray_samples does (ray_samplers.py:612-613)
             self.steps_since_update = 0
@@ -288,6 +310,7 @@ class RenderEngine:
         c = self.cfg
         N = image.shape[0]
         dev = self.device
+        self._grads_clean = False  # this call accumulates into the arena's gradient buffer
         b = branches[""]
         bt = branches.get("_thermal")
         C = b.comp.shape[1]
@@ -523,25 +546,50 @@ class RenderEngine:
             if lr_overrides and gname in lr_overrides:
                 lr = lr_overrides[gname]
             hyper[gname] = (self.group_steps[gname], lr)
-        if grad_scaler is not None and grad_scaler.enabled:
-            assert ranges is None, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
+        if ranges is None:
+            # One launch for every stepped group (two with overlap_adam), through the entry point that keeps every decision on the device:
+            #   * the launch CONSUMES the gradients (zero behind the read): the next step starts without a zero-fill of the arena;
+            #   * with a grad scaler: per-group non-finite check, skip / bias-correction / LR-schedule lag on the device, scale update.
+            scaler = grad_scaler if (grad_scaler is not None and grad_scaler.enabled) else None
             names = list(hyper)
             gidx = {g: i for i, g in enumerate(a.optimised_groups)}
-            # GradScaler decides per optimiser = per parameter group: one flag per group, all groups checked in one launch
-            grad_scaler.check_ranges(a.grads, [a.group_range[g] for g in names], [gidx[g] for g in names])
-            sched = None
-            rng = [a.group_range[g] + hyper[g] for g in names]
-            if scheduled and not lr_overrides:  # schedule on the device: lr_init + (lr_final, max_steps), evaluated at count - lag
-                rng = [a.group_range[g] + (hyper[g][0], OPTIMIZERS[g][0]) for g in names]
-                sched = [(OPTIMIZERS[g][1], OPTIMIZERS[g][2]) for g in names]
-            ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, eps=1e-15, found_inf=grad_scaler.found_inf,
-                                     flags=[gidx[g] for g in names], skipped=grad_scaler.skipped, lag_index=grad_scaler.lag_index, count_skip=True,
-                                     schedule=sched, sched_step=self.adam_step_count - 1)
-            grad_scaler.update()
+            if scaler is not None:  # GradScaler decides per optimiser = per parameter group: one flag per group, all groups checked in one launch
+                scaler.check_ranges(a.grads, [a.group_range[g] for g in names], [gidx[g] for g in names])
+            on_device_lr = scaler is not None and scheduled and not lr_overrides
+
+            def launch(groups):
+                if not groups:
+                    return
+                if on_device_lr:  # lr_init + (lr_final, max_steps), evaluated at count - lag on the device
+                    rng = [a.group_range[g] + (hyper[g][0], OPTIMIZERS[g][0]) for g in groups]
+                    sched = [(OPTIMIZERS[g][1], OPTIMIZERS[g][2]) for g in groups]
+                else:
+                    rng, sched = [a.group_range[g] + hyper[g] for g in groups], None
+                ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, eps=1e-15,
+                                         found_inf=scaler.found_inf if scaler is not None else None, flags=[gidx[g] for g in groups] if scaler is not None else None,
+                                         skipped=scaler.skipped if scaler is not None else None, lag_index=scaler.lag_index if scaler is not None else -1,
+                                         count_skip=scaler is not None, schedule=sched, sched_step=self.adam_step_count - 1, zero_grads=True)
+
+            # the stepped groups' gradients are consumed; a skipped group (proposal networks on an iteration without their gradient) wrote none
+            self._grads_clean = True
+            if self.overlap_adam:
+                big = [g for g in names if g.startswith("fields")]
+                launch([g for g in names if not g.startswith("fields")])
+                main, side = torch.cuda.current_stream(), self._side_stream(5)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    launch(big)
+                    if scaler is not None:
+                        scaler.update()  # behind BOTH launches (it clears the flags they read): the side stream waited for the first
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                self._adam_event = ev
+            else:
+                launch(names)
+                if scaler is not None:
+                    scaler.update()
             return
-        if ranges is None:  # every group at once: one launch
-            ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [a.group_range[g] + hyper[g] for g in hyper], eps=1e-15)
-            return
+        assert grad_scaler is None or not grad_scaler.enabled, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
         for lo, hi in ranges:  # each range lies inside one optimiser group (Adam is element-wise: any partition of a group is the same update)
             gname = next(g for g in a.optimised_groups if a.group_range[g][0] <= lo and hi <= a.group_range[g][1])
             if gname not in hyper:
@@ -554,6 +602,7 @@ class RenderEngine:
         """What Trainer.save_checkpoint stores beside the model (engine/trainer.py:424-447: "optimizers" = torch.optim.Adam.state_dict()
         per parameter group, "schedulers" = LambdaLR.state_dict()), read out of the arena: state[i] = {step, exp_avg, exp_avg_sq} for the i-th
         parameter of the group in get_param_groups() order.  Plus the sampler's update counters, which the reference loses on resume."""
+        self.sync_params()
         a = self.arena
         steps = getattr(self, "group_steps", {})
         opt, sched = {}, {}
@@ -600,7 +649,9 @@ class RenderEngine:
         self.set_anneal_for_step(step)
         if grad_scaler is not None:
             grad_scaler.begin_step()
-        self.arena.zero_grad()
+        if not self._grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
+            self.sync_params()
+            self.arena.zero_grad()
         out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
             # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)

@@ -645,9 +645,10 @@ _TRAIN_LAYOUTS: dict = {}
 
 def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Optional[Tensor], frozen: Optional[Tensor], origins: Tensor,
                       directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor, counts: Sequence[int], anneal: float,
-                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main"):
+                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main", wait_event=None):
     """The training forward of one branch in ONE library call (tn_render_rays_train): pose correction, proposal sampling with jitter, field
     (activations kept in the field's workspace `tag`), weights, renderers.  Every result is a view of one allocation.
+    wait_event: a torch.cuda.Event the stream waits for right before the field's first parameter read (the previous step's Adam, see engine).
     -> dict(origins, directions [N,3]; levels: 3 x dict(s_bins, e_bins, density, weights, median); rgb_samples [N,S2,C]; rgb [N,C];
     accumulation, depth, expected_depth [N,1])."""
     N = origins.shape[0]
@@ -671,7 +672,8 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
                                    _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S0, S1, S2, float(anneal),
                                    _ray_scalar(jit[0], "jitter", N, True), _ray_scalar(jit[1], "jitter", N, True), _ray_scalar(jit[2], "jitter", N, True),
                                    _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"), _f32(_lin_table("pdf", S2, dev), "u2"),
-                                   C.c_void_p(ws.data_ptr()), C.c_void_p(buf.data_ptr()), _stream()), "tn_render_rays_train")
+                                   C.c_void_p(ws.data_ptr()), C.c_void_p(buf.data_ptr()),
+                                   C.c_void_p(wait_event.cuda_event) if wait_event is not None else None, _stream()), "tn_render_rays_train")
 
     def v(slot, *shape):
         n = 1
@@ -948,12 +950,13 @@ def grad_nonfinite_ranges(grads: Tensor, ranges, flags, found_inf: Tensor) -> No
 
 def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, ranges, beta1: float = 0.9, beta2: float = 0.999,
                          eps: float = 1e-15, inv_scale: Optional[Tensor] = None, found_inf: Optional[Tensor] = None, flags=None,
-                         skipped: Optional[Tensor] = None, lag_index: int = -1, count_skip: bool = False, schedule=None, sched_step: int = 0) -> None:
+                         skipped: Optional[Tensor] = None, lag_index: int = -1, count_skip: bool = False, schedule=None, sched_step: int = 0,
+                         zero_grads: bool = False) -> None:
     """adam_step_ranges with GradScaler's skip / unscale decision on the device (no host sync): see tn_adam_step_ranges_amp.
     found_inf: float device tensor with one entry per parameter group; flags: the entry of each range (default 0); skipped: int32 device
     tensor (per-group skip counts, and the schedule lag at lag_index).
     schedule: None, or one (lr_final, max_steps) per range: the range's lr is then lr_init and the exponential-decay schedule is evaluated on the
-    device at sched_step - skipped[lag_index]."""
+    device at sched_step - skipped[lag_index].  zero_grads: the launch consumes the gradients (zero behind the read, skipped steps included)."""
     n = len(ranges)
     if n == 0:
         return
@@ -975,7 +978,7 @@ def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg
                                               _f32(inv_scale, "inv_scale", (1,), True) if inv_scale is not None else None,
                                               _f32(found_inf, "found_inf", None, True) if found_inf is not None else None, fl, nflags,
                                               C.c_void_p(skipped.data_ptr()) if skipped is not None else None, int(lag_index), 1 if count_skip else 0,
-                                              _stream()), "tn_adam_step_ranges_amp")
+                                              1 if zero_grads else 0, _stream()), "tn_adam_step_ranges_amp")
 
 
 def grad_scaler_update(scale: Tensor, growth_tracker: Tensor, found_inf: Tensor, lag: Optional[Tensor], growth_factor: float, backoff_factor: float,
