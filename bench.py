@@ -585,19 +585,8 @@ def main():
                     "note": "BASELINE.md 3.4 figure (median of per-step HIP-event times, first 2 skipped; max over ranks); `value` follows --steps"}
 
     if rank == 0:
-        rows = kernel_roofline(eng, cam_t, idx)
-        if args.ops:
-            for name, ms, nbytes in rows:
-                print(f"{name:60s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s algorithmic", file=sys.stderr)
-        name, ms, nbytes = next(r for r in rows if r[0] == DOMINANT)
-        achieved = nbytes / (ms * 1e-3) / 1e9
-        pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
-        traffic = None
-        if pmc is not None and all(k in pmc for k in PMC_KEYS.get(name, ["?"])):
-            traffic = sum(pmc[k]["traffic_bytes"] for k in PMC_KEYS[name])
-        upd = updates / max(args.steps, 1)
-        step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
-        step_gbs = step_bytes / (dt / args.steps) / 1e9
+        # (measured BEFORE the stand-alone launches below, so that the LAST launches of every kernel in a rocprofv3 trace of this command are the
+        # stand-alone ones: scripts/rocpd_stats.py --tail 10 then reproduces roofline.avg_launch_ms, the all-launch mean the in-step figure)
         # the same launch pair INSIDE the step (HIP events on the launch stream around the scatter phase, 20 extra steps): what runs beside it
         # (k_field_dpos; on update steps the proposal networks' backward on the side streams) shares the chip with it
         in_step = None
@@ -613,6 +602,19 @@ def main():
                 in_step = {"mean_ms": float(np.mean([t for t, _ in tms])),
                            "mean_ms_update_steps": float(np.mean([t for t, u in tms if u])) if any(u for _, u in tms) else None,
                            "mean_ms_other_steps": float(np.mean([t for t, u in tms if not u])) if any(not u for _, u in tms) else None}
+        rows = kernel_roofline(eng, cam_t, idx)
+        if args.ops:
+            for name, ms, nbytes in rows:
+                print(f"{name:60s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s algorithmic", file=sys.stderr)
+        name, ms, nbytes = next(r for r in rows if r[0] == DOMINANT)
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
+        traffic = None
+        if pmc is not None and all(k in pmc for k in PMC_KEYS.get(name, ["?"])):
+            traffic = sum(pmc[k]["traffic_bytes"] for k in PMC_KEYS[name])
+        upd = updates / max(args.steps, 1)
+        step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
+        step_gbs = step_bytes / (dt / args.steps) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
                     "avg_launch_ms_in_step": None if in_step is None else in_step["mean_ms"], "in_step": in_step,

@@ -196,14 +196,16 @@ int tn_field_bwd(const TnField* field, const float* origins, const float* direct
 /* The same backward in phases, for data-parallel training: the table gradient of a level range is final as soon as its scatter has run,
  * so the caller can start that range's all-reduce (DDP's bucketed reducer, pipelines/base_pipeline.py:281-283) while the next range is
  * scattered.  phases is a bit set; tn_field_bwd == all three with levels [0, num_levels):
- *   TN_BWD_MLP      MLP backward + weight/bias/embedding gradients (the GEMMs are enqueued on a library-owned companion stream)
- *   TN_BWD_SCATTER  table gradient (+ d_origins/d_directions contribution) of levels [level_begin, level_end); needs TN_BWD_MLP done
- *   TN_BWD_JOIN     make `stream` wait for the companion stream; required before the MLP gradients or the workspace are used again 
+ *   TN_BWD_MLP      MLP backward + weight/bias/embedding gradients (one launch) and, when d_origins is given, d position from the forward's saved
+ *                   d enc / d offset (k_field_dpos); with TN_BWD_FORK_DPOS that second launch goes to a library-owned companion stream
+ *                   beside the scatter -- worth it only when other streams are busy anyway (a second active queue costs more than it hides)
+ *   TN_BWD_SCATTER  table gradient of levels [level_begin, level_end); needs TN_BWD_MLP done
+ *   TN_BWD_JOIN     make `stream` wait for the companion stream; required before d_origins / d_directions or the workspace are used again
  *   TN_BWD_SCATTER_BIN / TN_BWD_SCATTER_FOLD  the same scatter in its two passes: BIN writes the (slot, value) records of ALL levels once
  *                   (+ the d_origins/d_directions contribution); FOLD sums the records of levels [level_begin, level_end) into the table
  *                   gradient.  One BIN, then one FOLD per exchanged level range, costs the same as a single TN_BWD_SCATTER over all levels;
  *                   TN_BWD_SCATTER per range repeats the per-sample work of the bin pass for every range. */
-enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN = 8, TN_BWD_SCATTER_FOLD = 16 };
+enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN = 8, TN_BWD_SCATTER_FOLD = 16, TN_BWD_FORK_DPOS = 32 };
 int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                        const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                        float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream);

@@ -320,7 +320,9 @@ __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int6
 // The default path is atomic-free ("binned", tn_scatter.hip): contributions are written once as (slot, value) records into buckets of
 // 2^TN_BIN_SLICE_LOG2 consecutive table slots and summed per bucket in LDS.  Scratch per level: room for 16 records per sample (twice the
 // 8 corners: the hash spreads the records evenly, coarse levels are merged before they are written) plus slack for small batches.
+#ifndef TN_BIN_SLICE_LOG2
 #define TN_BIN_SLICE_LOG2 12
+#endif
 #define TN_BIN_MAX_SLICES 256
 #define TN_BIN_COUNT_STRIDE 16  // words reserved per bucket counter (one 64-B line each)
 static inline int64_t tn_bin_level_records(int64_t P) { return 16 * P + TN_BIN_MAX_SLICES * 1032; }

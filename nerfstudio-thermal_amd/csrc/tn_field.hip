@@ -1068,7 +1068,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   const bool dens_only = d_rgb == nullptr;  // backward of tn_field_density_fwd(training): no colour path at all
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
-  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) == 0 && phases != 0,
+  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD | TN_BWD_FORK_DPOS)) == 0 && phases != 0,
              "tn_field_bwd: bad phase set %d", phases);
   TN_REQUIRE(!((phases & TN_BWD_SCATTER) && (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD))), "tn_field_bwd: TN_BWD_SCATTER and its two halves exclude each other");
   if (phases & (TN_BWD_SCATTER | TN_BWD_SCATTER_FOLD))
@@ -1099,7 +1099,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     if (d_origins != nullptr) {
       // d position from the saved d enc / d offset (75 MB read) on the companion stream, beside the table scatter: the bin pass
       // runs without a d-position path of its own (which gathered the 8 x 16 corners of every sample again: 414 MB of the entry point's traffic)
-      hipStream_t side = tn_fork(st);
+      // Forked to the companion stream only when the caller says other streams are busy anyway (TN_BWD_FORK_DPOS: the proposal networks'
+      // backward runs beside this one).  On a step where the main stream is alone, a second active queue costs more than the ~25 us it hides:
+      // measured 0.845 (forked) vs 0.815 ms (in line) per non-update step, 1.24 vs 1.39 ms per update step when nothing forks.
+      hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
       const int64_t tiles = tn_cdiv(P, 32);
       hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
                          ws.g_enc, ws.jac, N, S, d_origins, d_directions);

@@ -205,7 +205,9 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
     rc1 = tn_weights_bwd(at(TRO_E1), at(TRO_D1), at(TRO_W1), d_weights1, N, S1, dd1, t1);
     if (!rc1) rc1 = tn_prop_density_bwd(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, d_origins, d_directions, t1);
   }
-  rc = tn_field_bwd(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, d_origins, d_directions, stream);
+  // (d position forks to its companion stream only when the proposal networks' backward keeps other queues busy anyway)
+  rc = tn_field_bwd_phase(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, d_origins, d_directions,
+                          TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | (prop_grad ? TN_BWD_FORK_DPOS : 0), 0, field->grid.num_levels, stream);
   if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
   return rc ? rc : (rc0 ? rc0 : rc1);
 }

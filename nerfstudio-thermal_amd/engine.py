@@ -426,7 +426,7 @@ class RenderEngine:
             if pipelined:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
-                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
+                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP | ph.TN_BWD_FORK_DPOS)
                 T2 = 2 * 2**fld.log2_hashmap_size
                 t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
                 P = N * self.counts[-1]
