@@ -16,8 +16,23 @@ struct PropK {
   float *gw0, *gb0, *gw1, *gb1;
 };
 
-__global__ void __launch_bounds__(256) k_prop_fwd(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                  const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ density) {
+// The 193 weights as rows of 12 floats per hidden unit, [w0[j][0..9] | b0[j] | w1[j]], staged in LDS once per block and read as three
+// broadcast ds_read_b128 per hidden unit (all lanes one address: no bank conflicts).  Read through the kernel's pointers they end up as
+// ~200 scalar registers the compiler spills into VGPR lanes: 698 v_readlane per sample made the kernel VALU-bound (45 us at level 0).
+#define PROP_WROW 12
+__device__ __forceinline__ void prop_stage_weights(const PropK& net, float* s_w) {  // s_w: PH * PROP_WROW + 4 floats, 16-B aligned
+  for (int t = threadIdx.x; t < PH * PROP_WROW; t += blockDim.x) {
+    const int j = t / PROP_WROW, k = t - j * PROP_WROW;
+    s_w[t] = k < PF ? net.w0[j * PF + k] : (k == PF ? net.b0[j] : net.w1[j]);
+  }
+  if (threadIdx.x == 0) s_w[PH * PROP_WROW] = net.b1[0];
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                     const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ density) {
+  __shared__ __attribute__((aligned(16))) float s_w[PH * PROP_WROW + 4];
+  prop_stage_weights(net, s_w);
   int64_t P = N * (int64_t)S;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t ray = i / S;
@@ -33,14 +48,23 @@ __global__ void __launch_bounds__(256) k_prop_fwd(PropK net, const float* __rest
       enc[2 * l] = v.x;
       enc[2 * l + 1] = v.y;
     }
-    float out = net.b1[0];
-#pragma unroll
+    float out = s_w[PH * PROP_WROW];
+#pragma unroll 4
     for (int j = 0; j < PH; ++j) {
-      float a = net.b0[j];
-#pragma unroll
-      for (int k = 0; k < PF; ++k) a = fmaf(net.w0[j * PF + k], enc[k], a);
-      a = fmaxf(a, 0.0f);
-      out = fmaf(net.w1[j], a, out);
+      const float4 wa = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW), wb = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW + 4),
+                   wc = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW + 8);
+      float a = wc.z;
+      a = fmaf(wa.x, enc[0], a);
+      a = fmaf(wa.y, enc[1], a);
+      a = fmaf(wa.z, enc[2], a);
+      a = fmaf(wa.w, enc[3], a);
+      a = fmaf(wb.x, enc[4], a);
+      a = fmaf(wb.y, enc[5], a);
+      a = fmaf(wb.z, enc[6], a);
+      a = fmaf(wb.w, enc[7], a);
+      a = fmaf(wc.x, enc[8], a);
+      a = fmaf(wc.y, enc[9], a);
+      out = fmaf(wc.w, fmaxf(a, 0.0f), out);
     }
     density[i] = c.sel ? expf(out) : 0.0f * expf(out);  // exp(x) * selector (0*inf = nan kept as torch would)
   }
@@ -64,139 +88,174 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// k_prop_bwd_mlp (1 lane = 1 sample): recompute the forward, then  d_out = g * exp(clamp(out,-15,15)) * sel  (trunc_exp backward),
-//   d a_j = d_out*w1_j*[a_j>0],  d enc_k = sum_j d a_j w0_jk  -> ws_denc for the table scatter (tn_scatter.hip), and the WEIGHT GRADIENTS
-//   dW0 = dA^T ENC, db0 = sum dA, dW1 = dOUT^T H, db1 = sum dOUT in the same kernel:
-//   a wave transposes its 64 samples' dA [64][16] and ENC [64][16: cols 0-9 enc, col 10 = 1 -> the bias column] through LDS and feeds them
-//   to v_mfma_f32_16x16x4_f32 (K = samples): written sample-major, the operand of k-step t is the LINEAR read lds[64 t + lane] (lane l holds
-//   row/col l % 16 of sample 4 t + l / 16), so the transpose costs 8 ds_write_b128 + 32 ds_read_b32 per 64 samples.  The accumulators
-//   (2 x 4 registers) persist over the wave's grid-stride loop; one block-level sum in LDS and one atomic burst per block close the kernel.
-//   Before: 65 floats per sample written to HBM (273 MB at level 0) and read back by a separate batched GEMM launch on a companion stream.
+// k_prop_bwd_mlp: recompute the forward, then  d_out = g * exp(clamp(out,-15,15)) * sel  (trunc_exp backward),
+//   d a_j = d_out*w1_j*[a_j>0],  d enc_k = sum_j d a_j w0_jk  -> ws_denc (level-major) for the table scatter (tn_scatter.hip), and the WEIGHT
+//   GRADIENTS dW0 = dA^T ENC, db0 = sum dA, dW1 = dOUT^T H, db1 = sum dOUT in the same kernel (layout and products: see the kernel).
+//   History: round 1 wrote 65 floats per sample to HBM for a separate batched GEMM; round 2 fused the weight gradients (MFMA, K = samples) but
+//   kept the MLP on the vector ALU with 193 wave-uniform weights in VGPRs (248 registers, 2 waves per SIMD) and closed with 1024 atomics per
+//   weight: 105 us per launch on average, 57 of them that burst.  Now 56 us.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                      const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
-                                                      float* __restrict__ ws_denc, uint32_t* __restrict__ zero_ptr, int zero_words) {
-  __shared__ float lds[4][2][64 * 16];  // per wave: operand A, operand B (8 KB)
+// k_prop_bwd_mlp, all three matrix products on v_mfma_f32_16x16x4_f32 (D[i][n] = sum_k A[i][k] B[k][n]; lane l supplies A[l % 16][l / 16] and
+// B[l / 16][l % 16], register r of lane l receives D[4 (l / 16) + r][l % 16]).  With g = l / 16, j = l % 16, and the wave's 64 samples in four
+// blocks c of 16:
+//   stage   lane = sample writes its row E[s] = [enc(10) | 1 | 0] (row stride 20 floats) and dd[s] = d_density * selector
+//   forward T_c[s][j] = sum_f E[16 c + s][f] W0aug[j][f]   A = E (read from LDS), B = the weights: 3 registers per lane hold [w0 | b0] for good.
+//           Lane (g, j) receives the pre-activations of hidden unit j for the samples 16 c + 4 g + r, r = 0..3.
+//   out     = b1 + sum_j w1[j] relu(T[s][j]): a butterfly over the 16 lanes of a row (DPP), every lane of the row ends up with the sum
+//   d_out   = dd * exp(clamp(out)),  dA[s][j] = [T > 0] d_out w1[j]  -- in the registers of lane (g, j), which is exactly operand B of
+//   weights G[f][j] += sum_s E[s][f] dA[s][j]   A = E^T read from LDS in the sample order the registers have (16 c + 4 g + r); row 10 = db0
+//   d enc   X_c[f][s] = sum_j W0[j][f] dA[16 c + s][j]   K = j now: dA goes through LDS once ([j][s], row stride 80, over E's space), A = 4 registers
+//           of weights.  Lane (g, s) receives features 4 g .. 4 g + 3 = levels 2 g, 2 g + 1 of sample 16 c + s: stored level-major (128-B runs).
+//   dW1[j], db1: per-lane sums over the loop, added up over the four rows g at the end.
+// The weights live in 8 registers per lane instead of 193 wave-uniform values (which the compiler kept in VGPRs: 248 of them, 2 waves per SIMD).
+#define PB_RS 20   // floats per row of E: the 16 lanes of a row group read 16 rows at one column -> banks 20 n + g: 2 lanes per bank (the floor for 64 lanes)
+#define PB_RS2 80  // floats per row of dA^T: ds_write_b128 at 80 j + 16 c + 4 g and ds_read_b32 at 80 (4 t + g) + n are both conflict-free
+#define PB_WAVE_FLOATS (64 * PB_RS + 64)
+#define PB_WAVE_SYNC()                                    \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+__device__ __forceinline__ float prop_row_sum(float x) {  // sum over the 16 lanes of a DPP row, result in every lane
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));  // row_mirror
+  return x;
+}
+
+// One block of 16 waves per CU (4 per SIMD): the kernel ends with one atomic per weight and block, and atomics on one 64-B line execute one after
+// the other (~25 ns each).  With 1024 blocks of 4 waves that burst was 57 of the kernel's 105 us.
+#define PB_THREADS 1024
+__global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                               const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
+                                                               float* __restrict__ ws_denc, uint32_t* __restrict__ zero_ptr, int zero_words) {
+  __shared__ __attribute__((aligned(16))) float lds[(PB_THREADS / 64) * PB_WAVE_FLOATS];
   tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the scatter that follows on this stream
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float* bufA = lds[wv][0];
-  float* bufB = lds[wv][1];
-  int64_t P = N * (int64_t)S;
-  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  float sum_dout = 0.0f;
-  // every wave of the grid makes the same number of trips (inactive lanes contribute zeros): the wave-level LDS hand-over below needs all lanes
-  for (int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64; base < P; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = base + lane;
-    const bool live = i < P;
-    const int64_t ic = live ? i : P - 1;
-    int64_t ray = ic / S;
-    int s = (int)(ic - ray * S);
-    const float* o = origins + ray * 3;
-    const float* d = directions + ray * 3;
-    const float* eb = e_bins + ray * (S + 1) + s;
-    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
-    float enc[PF];
+  const int g = lane >> 4, j = lane & 15;
+  float* E = lds + wv * PB_WAVE_FLOATS;
+  float* DA = E;  // dA^T takes E's place once the weight-gradient product has read E
+  float* DD = E + 64 * PB_RS;
+  float wf[3], wb[4];
 #pragma unroll
-    for (int l = 0; l < PL; ++l) {
-      float2 v = tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
-      enc[2 * l] = v.x;
-      enc[2 * l + 1] = v.y;
-    }
-    float a[PH];
-    float out = net.b1[0];
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      float t = net.b0[j];
-#pragma unroll
-      for (int k = 0; k < PF; ++k) t = fmaf(net.w0[j * PF + k], enc[k], t);
-      a[j] = t;
-      out = fmaf(net.w1[j], fmaxf(t, 0.0f), out);
-    }
-    float d_out = (live && c.sel) ? d_density[ic] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;
-    float denc[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) denc[k] = 0.0f;
-    float da[PH], hh[PH];
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      hh[j] = fmaxf(a[j], 0.0f);
-      da[j] = (a[j] > 0.0f) ? d_out * net.w1[j] : 0.0f;
-#pragma unroll
-      for (int k = 0; k < PF; ++k) denc[k] = fmaf(da[j], net.w0[j * PF + k], denc[k]);
-    }
-    if (live) {
-      *reinterpret_cast<float4*>(ws_denc + i * 16 + 0) = make_float4(denc[0], denc[1], denc[2], denc[3]);
-      *reinterpret_cast<float4*>(ws_denc + i * 16 + 4) = make_float4(denc[4], denc[5], denc[6], denc[7]);
-      *reinterpret_cast<float4*>(ws_denc + i * 16 + 8) = make_float4(denc[8], denc[9], 0.0f, 0.0f);
-    }
-    sum_dout += d_out;
-    // ---- dW0 | db0: A = dA [sample][16], B = [enc(10) | 1 | 0...] [sample][16]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bufA + lane * 16 + 4 * q) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-    *reinterpret_cast<float4*>(bufB + lane * 16 + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
-    *reinterpret_cast<float4*>(bufB + lane * 16 + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
-    *reinterpret_cast<float4*>(bufB + lane * 16 + 8) = make_float4(enc[8], enc[9], 1.0f, 0.0f);
-    *reinterpret_cast<float4*>(bufB + lane * 16 + 12) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bufA[64 * t + lane], bufB[64 * t + lane], acc0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- dW1: A = [d_out | 0 ...] (row 0 of a 16-row operand), B = H [sample][16]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(bufB + lane * 16 + 4 * q) = make_float4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
-    bufA[lane] = d_out;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      float av = (lane & 15) == 0 ? bufA[4 * t + (lane >> 4)] : 0.0f;
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bufB[64 * t + lane], acc1, 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  for (int t = 0; t < 3; ++t) {  // forward operand B[k = feature 4 t + g][n = hidden j]
+    const int f = 4 * t + g;
+    wf[t] = f < PF ? net.w0[j * PF + f] : (f == PF ? net.b0[j] : 0.0f);
   }
-  // ---- block-level sum (plain LDS adds, one wave per turn: ds_add_f32 is lane-serialised on gfx950), then one atomic burst per block.
-  // accumulator register r of lane l = entry [4 (l / 16) + r][l % 16] of the 16x16 result
-  __syncthreads();
-  float* red = &lds[0][0][0];  // [0..255] dW0|db0 tile, [256..271] dW1 (row 0 of its tile), [272] db1
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum_dout += __shfl_xor(sum_dout, o, 64);
-  for (int w = 0; w < 4; ++w) {
-    if (wv == w) {
+  for (int t = 0; t < 4; ++t) wb[t] = j < PF ? net.w0[(4 * t + g) * PF + j] : 0.0f;  // d enc operand A[i = feature j][k = hidden 4 t + g]
+  const float w1j = net.w1[j], b1 = net.b1[0];
+  int64_t P = N * (int64_t)S;
+  f32x4_t G = {0.f, 0.f, 0.f, 0.f};
+  float dw1 = 0.0f, sum_dout = 0.0f;
+  for (int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64; base < P; base += (int64_t)gridDim.x * blockDim.x) {
+    {
+      const int64_t i = base + lane;
+      const bool live = i < P;
+      const int64_t ic = live ? i : P - 1;
+      int64_t ray = ic / S;
+      int s = (int)(ic - ray * S);
+      const float* o = origins + ray * 3;
+      const float* d = directions + ray * 3;
+      const float* eb = e_bins + ray * (S + 1) + s;
+      Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+      const float dd = (live && c.sel) ? d_density[ic] : 0.0f;
+      float enc[PF];
+#pragma unroll
+      for (int l = 0; l < PL; ++l) {
+        float2 v = tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
+        enc[2 * l] = v.x;
+        enc[2 * l + 1] = v.y;
+      }
+      *reinterpret_cast<float4*>(E + lane * PB_RS + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
+      *reinterpret_cast<float4*>(E + lane * PB_RS + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
+      *reinterpret_cast<float4*>(E + lane * PB_RS + 8) = make_float4(enc[8], enc[9], 1.0f, 0.0f);
+      DD[lane] = dd;
+    }
+    PB_WAVE_SYNC();
+    // ---- forward: pre-activations of hidden unit j for the samples 16 c + 4 g + r
+    f32x4_t T[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(E[(16 * c + j) * PB_RS + 4 * t + g], wf[t], acc, 0, 0, 0);
+      T[c] = acc;
+    }
+    float da[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 dd4 = *reinterpret_cast<const float4*>(DD + 16 * c + 4 * g);
+      const float ddr[4] = {dd4.x, dd4.y, dd4.z, dd4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int idx = (4 * (lane >> 4) + r) * 16 + (lane & 15);
-        red[idx] = (w == 0 ? 0.0f : red[idx]) + acc0[r];
+        const float h = fmaxf(T[c][r], 0.0f);
+        const float out = b1 + prop_row_sum(w1j * h);
+        const float d_out = ddr[r] != 0.0f ? ddr[r] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;  // trunc_exp backward
+        sum_dout += d_out;
+        dw1 = fmaf(d_out, h, dw1);
+        da[c][r] = T[c][r] > 0.0f ? d_out * w1j : 0.0f;
       }
-      if (lane < 16) red[256 + lane] = (w == 0 ? 0.0f : red[256 + lane]) + acc1[0];  // row 0 = register 0 of lanes 0..15
-      if (lane == 0) red[272] = (w == 0 ? 0.0f : red[272]) + sum_dout;
     }
-    __syncthreads();
+    // ---- dW0 | db0 (transposed: [feature][hidden]): K = the wave's 64 samples, in the order the registers hold them
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = E[(16 * c + 4 * g + r) * PB_RS + j];
+        G = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 12 ? e : 0.0f, da[c][r], G, 0, 0, 0);  // (columns 12..15 of a row are the next row's padding)
+      }
+    PB_WAVE_SYNC();  // every lane is done with E
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(DA + j * PB_RS2 + 16 * c + 4 * g) = make_float4(da[c][0], da[c][1], da[c][2], da[c][3]);
+    PB_WAVE_SYNC();
+    // ---- d enc of sample 16 c + j, features 4 g .. 4 g + 3
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4_t X = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) X = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[t], DA[(4 * t + g) * PB_RS2 + 16 * c + j], X, 0, 0, 0);
+      const int64_t is = base + 16 * c + j;
+      if (is < P && g < 3) {  // level-major [PL][P] float2: 16 lanes write 128 consecutive bytes (the bin pass reads them the same way)
+        *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g) * P + is) * 2) = make_float2(X[0], X[1]);
+        if (g < 2) *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g + 1) * P + is) * 2) = make_float2(X[2], X[3]);
+      }
+    }
+    PB_WAVE_SYNC();  // dA^T has been read: the next trip may write E
   }
+  // ---- block-level sum: every wave leaves its partial sums in its own LDS region, 273 threads add them up, one atomic per weight and block.
+  // register r of lane (g, j) = G[feature 4 g + r][hidden j]
+  dw1 += __shfl_xor(dw1, 16, 64);
+  dw1 += __shfl_xor(dw1, 32, 64);
+  sum_dout += __shfl_xor(sum_dout, 16, 64);  // (the 16 lanes of a row hold the same sum: rows, not lanes, are added)
+  sum_dout += __shfl_xor(sum_dout, 32, 64);
   {
-    int j = threadIdx.x >> 4, k = threadIdx.x & 15;
-    float v = red[threadIdx.x];
+    float* mine = E;  // [0..255] [feature][hidden] tile (rows 0..9 dW0^T, row 10 db0), [256..271] dW1, [272] db1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[(4 * g + r) * 16 + j] = G[r];
+    if (lane < 16) mine[256 + lane] = dw1;
+    if (lane == 0) mine[272] = sum_dout;
+  }
+  __syncthreads();
+  if (threadIdx.x < 273) {
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < PB_THREADS / 64; ++w) v += lds[w * PB_WAVE_FLOATS + threadIdx.x];
+    const int f = threadIdx.x >> 4, h = threadIdx.x & 15;
     if (v != 0.0f) {
-      if (k < PF) atomicAdd(net.gw0 + j * PF + k, v);
-      else if (k == PF) atomicAdd(net.gb0 + j, v);
-    }
-    if (threadIdx.x < 16) {
-      float u = red[256 + threadIdx.x];
-      if (u != 0.0f) atomicAdd(net.gw1 + threadIdx.x, u);
-    }
-    if (threadIdx.x == 16) {
-      float u = red[272];
-      if (u != 0.0f) atomicAdd(net.gb1, u);
+      if (f < PF) atomicAdd(net.gw0 + h * PF + f, v);
+      else if (f == PF) atomicAdd(net.gb0 + h, v);
+      else if (f == 16) atomicAdd(net.gw1 + h, v);
+      else if (threadIdx.x == 272) atomicAdd(net.gb1, v);
     }
   }
 }
 
-// d enc [P][16], then the scatter's scratch (256-B aligned)
+// d enc (level-major [5][P] float2; the region keeps its [P][16] size), then the scatter's scratch (256-B aligned)
 static inline int64_t prop_scratch_offset(int64_t P) { return ((P * 16 * (int64_t)sizeof(float) + 1024 + 255) / 256) * 256; }
 
 extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
@@ -220,15 +279,16 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, net->gw0, net->gb0, net->gw1, net->gb1};
   int64_t P = N * (int64_t)S;
   float* ws_denc = reinterpret_cast<float*>(workspace);
-  // 1024 blocks: every wave makes ~4 trips at level 0 (1 M samples), so the weight-gradient accumulators are flushed 1024 times, not 16 384
-  // (same-line global atomics serialise at ~25 ns each)
-  int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 1024);
+  // one block per CU: every wave makes ~4 trips at level 0 (1 M samples) and the weight gradients are flushed 256 times
+  int grid = (int)std::min<int64_t>(tn_cdiv(P, PB_THREADS), 256);
+  const int threads = PB_THREADS;
   hipStream_t st = tn_s(stream);
   void* scratch = reinterpret_cast<char*>(workspace) + prop_scratch_offset(P);
   uint32_t* zp;
   int zw;
   tn_grid_scatter_counters(net->grid, P, scratch, &zp, &zw);
-  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(256), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw);
+  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(threads), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
-  return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, 16, N, S, d_origins, d_directions, scratch, st, nullptr, zw > 0);
+  return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, TN_LD_LEVEL_MAJOR, N, S, d_origins, d_directions, scratch, st, nullptr,
+                                zw > 0);
 }
