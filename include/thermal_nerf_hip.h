@@ -204,8 +204,12 @@ int tn_field_bwd(const TnField* field, const float* origins, const float* direct
  *   TN_BWD_SCATTER_BIN / TN_BWD_SCATTER_FOLD  the same scatter in its two passes: BIN writes the (slot, value) records of ALL levels once
  *                   (+ the d_origins/d_directions contribution); FOLD sums the records of levels [level_begin, level_end) into the table
  *                   gradient.  One BIN, then one FOLD per exchanged level range, costs the same as a single TN_BWD_SCATTER over all levels;
- *                   TN_BWD_SCATTER per range repeats the per-sample work of the bin pass for every range. */
-enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN = 8, TN_BWD_SCATTER_FOLD = 16, TN_BWD_FORK_DPOS = 32 };
+ *                   TN_BWD_SCATTER per range repeats the per-sample work of the bin pass for every range.
+ *   TN_BWD_COUNTERS_CLEAN  with TN_BWD_SCATTER (whole grid) or TN_BWD_SCATTER_BIN in a call WITHOUT TN_BWD_MLP: the caller vouches that the
+ *                   TN_BWD_MLP phase of this workspace and batch has run since the workspace's last scatter.  That launch leaves the bin
+ *                   pass's bucket counters zeroed; without the flag a phase-by-phase backward pays a memset launch for them. */
+enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN = 8, TN_BWD_SCATTER_FOLD = 16, TN_BWD_FORK_DPOS = 32,
+       TN_BWD_COUNTERS_CLEAN = 64 };
 int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                        const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                        float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream);

@@ -17,7 +17,7 @@ TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
 TN_LOSS_LINES = 64
 TN_RENDER_TRAIN_OFFSETS = 23
-TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD, TN_BWD_FORK_DPOS = 1, 2, 4, 8, 16, 32
+TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD, TN_BWD_FORK_DPOS, TN_BWD_COUNTERS_CLEAN = 1, 2, 4, 8, 16, 32, 64
 
 _p = C.c_void_p
 _i32 = C.c_int32

@@ -1068,7 +1068,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   const bool dens_only = d_rgb == nullptr;  // backward of tn_field_density_fwd(training): no colour path at all
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_field_bwd: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_bwd: bad N=%lld S=%d", (long long)N, S);
-  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD | TN_BWD_FORK_DPOS)) == 0 && phases != 0,
+  TN_REQUIRE((phases & ~(TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD | TN_BWD_FORK_DPOS | TN_BWD_COUNTERS_CLEAN)) == 0 && phases != 0,
              "tn_field_bwd: bad phase set %d", phases);
   TN_REQUIRE(!((phases & TN_BWD_SCATTER) && (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD))), "tn_field_bwd: TN_BWD_SCATTER and its two halves exclude each other");
   if (phases & (TN_BWD_SCATTER | TN_BWD_SCATTER_FOLD))
@@ -1114,15 +1114,16 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   float* sc_dd = nullptr;
   if (phases & TN_BWD_SCATTER) {
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
-    // (counters zeroed by the MLP phase only when this call runs both and covers the whole grid in one scatter)
-    const bool cz = (phases & TN_BWD_MLP) && level_begin == 0 && level_end == field->grid.num_levels;
+    // (counters zeroed by the MLP phase: this call runs both, or the caller vouches for it -- and the scatter covers the whole grid in one go)
+    const bool cz = (phases & (TN_BWD_MLP | TN_BWD_COUNTERS_CLEAN)) && level_begin == 0 && level_end == field->grid.num_levels;
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
                                 nullptr, cz);
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");
     if (phases & TN_BWD_SCATTER_BIN)
-      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st);
+      rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
+                               (phases & (TN_BWD_MLP | TN_BWD_COUNTERS_CLEAN)) != 0);
     if (rc == TN_OK && (phases & TN_BWD_SCATTER_FOLD)) rc = tn_grid_scatter_fold(field->grid, P, ws.scatter, level_begin, level_end, st);
   }
   if (phases & TN_BWD_JOIN) tn_join_all(st);

@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
 //           summed in registers on the coarser levels (segmented wave scan); the surviving (slot, value) records are ranked per bucket
 //           (bucket = 2^TN_BIN_SLICE_LOG2 consecutive slots of one level) with LDS counters, staged in LDS in bucket order, and copied out
 //           as contiguous runs into the buckets' global arrays (one returning integer atomic per block, level and bucket reserves the run).
-//   pass 2  k_grid_fold: block = (bucket, chunk of its records): sums the records into an LDS image of the bucket's slots (slot locks + plain
-//           read-modify-write, see below), then adds the non-zero slots into the table gradient with coalesced plain read-modify-writes
+//   pass 2  k_grid_fold: block = (bucket, chunk of its records): sums the records into an LDS image of the bucket's slots (double-precision LDS
+//           atomic adds, see below), then adds the non-zero slots into the table gradient with coalesced plain read-modify-writes
 //           (atomics only when a bucket is split over several chunks).
 // A bucket that overflows its capacity (never on hashed levels with anything like a real batch) falls back to global atomics for the excess,
 // so the result is right for any input.  The sample position's gradient comes out of pass 1 (same corner gathers as the forward).
@@ -239,11 +239,10 @@ struct BinK {
   int nslices;       // buckets per level (power of two, <= TN_BIN_MAX_SLICES)
   uint32_t merge_mask;  // bit l: sum runs of same-cell neighbours at level l before writing
   // fold work items: a bucket's records are cut into chunks of chunk[l] records, one block each; level l owns blocks [blk0[l], blk0[l+1]).
-  // Coarse levels have few live slots per bucket and hundreds of records per slot: nearly every record of a pass finds its slot taken and
-  // falls back to the serialised LDS float atomic, so their buckets are cut into small chunks that spread over many CUs.
+  // Coarse levels have few live slots per bucket and hundreds of records per slot (same-address LDS atomics execute one after the other):
+  // their buckets are cut into smaller chunks that spread over more CUs.
   uint32_t chunk[TN_MAX_LEVELS];
   uint32_t blk0[TN_MAX_LEVELS + 1];
-  uint32_t sparse_mask;  // bit l: level l is sparse (float atomics in the fold instead of slot locks)
   unsigned long long* trace;  // TN_FOLD_TRACE diagnostics: per fold block {start, after load+zero, after passes, end} wall-clock stamps, or NULL
 };
 
@@ -461,15 +460,13 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
 #ifndef FOLD_THREADS
 #define FOLD_THREADS 512
 #endif
-// How the fold sums a bucket's records in LDS.  LDS float atomics are no way to do it: ds_add_f32 is serialised lane by lane on gfx950
-// (~3 cycles per ACTIVE lane + ~20 per instruction, conflicts or not: scripts/microbench/lds_atomic_rate.hip; integer LDS atomics take 5-11
-// cycles per wave-instruction).  Block-wide passes separated by barriers are no way either: a barrier interval costs ~1 us with 32 waves on
-// the CU whatever it contains (profiles/r02_scatter_alternatives.md).  So every slot has a LOCK bit (one integer atomic OR claims it): the
-// claimant adds its record with a plain LDS read-modify-write and releases the bit with an atomic AND.  A wave's LDS instructions execute in
-// order, so the release is ordered behind the write, and no barrier is needed between records: the waves run through their records
-// independently.  A record that finds its slot locked is retried after the wave's other records.  Buckets of the SPARSE levels (a few dozen
-// live slots hammered by thousands of records) would spin on their locks: they go through the float atomic instead, whose cost does not
-// depend on conflicts.
+// How the fold sums a bucket's records in LDS: in DOUBLE, with the LDS atomic add.  ds_add_f32 is executed lane by lane on gfx950 (~195
+// cycles per wave instruction, conflicts or not); ds_add_f64 is not: ~27 cycles per wave instruction on random slots, integer atomics 11-16
+// (scripts/microbench/lds_atomic_rate.hip).  Nothing comes back from the add, so a wave fires its records at the image without waiting for any
+// of them, and the table gradient receives the double sum rounded once (order-independent up to that rounding).  Rounds 2-3 used slot LOCKS
+// (integer atomic OR to claim, plain read-modify-write, atomic AND to release: three dependent LDS round trips per record, float atomics for
+// the contended coarse levels): 141 us for the main grid's 25 M records, where this takes 81.  Block-wide passes separated by barriers are no
+// way either: a barrier interval costs ~1 us with 32 waves on the CU whatever it contains (profiles/r02_scatter_alternatives.md).
 struct FoldRecs {
   uint32_t idp[4];  // slots of records (2u, 2u+1) as two 16-bit halves
   float2 vals[8];
@@ -495,20 +492,8 @@ __device__ __forceinline__ void fold_load(const uint16_t* __restrict__ ip, const
     if (rec + 1 < end && (vq.z != 0.0f || vq.w != 0.0f)) r.ok |= 2u << (2 * u);
   }
 }
-// claim the slot's lock bit; true = this lane holds it now
-__device__ __forceinline__ bool fold_claim(uint32_t* lock, uint32_t id) {
-  const uint32_t bit = 1u << (id & 31u);
-  return !(__hip_atomic_fetch_or(&lock[id >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit);
-}
-__device__ __forceinline__ void fold_add_release(float2* acc, uint32_t* lock, uint32_t id, float2 v) {
-  float2 a = acc[id];
-  a.x += v.x;
-  a.y += v.y;
-  acc[id] = a;
-  (void)__hip_atomic_fetch_and(&lock[id >> 5], ~(1u << (id & 31u)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, uint32_t first_block) {
-  extern __shared__ float s_mem[];  // [2 << slice_log2] sums, then [(1 << slice_log2) / 32] lock words
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];  // two double images of the bucket's slots: [1 << slice_log2] x, then y
   const uint32_t blk = first_block + blockIdx.x;  // a launch may cover the blocks of a level range only
   uint32_t l = 0;
 #pragma unroll 1
@@ -528,46 +513,35 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
   const bool split = count > chunk;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t slots = 1u << bk.slice_log2;
-  const uint32_t words = (slots + 31) / 32;
-  float2* acc = reinterpret_cast<float2*>(s_mem);
-  uint32_t* lock = reinterpret_cast<uint32_t*>(s_mem + 2 * slots);
   const size_t base = (size_t)l * bk.level_stride + (size_t)sl * bk.cap;  // multiple of 8 records
   const uint16_t* ip = bk.idx + base;
   const float2* vp = bk.val + base;
   const uint32_t mine = wave * 512 + 2 * lane;
+  double* ax = reinterpret_cast<double*>(s_mem);  // [slots] first component, then [slots] second component
+  double* ay = ax + slots;
+#define FOLD_FIRE(REC)                                                                      \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+    if (((REC).ok >> j) & 1u) {                                                               \
+      const uint32_t id = (REC).id(j);                                                        \
+      if ((REC).vals[j].x != 0.0f) unsafeAtomicAdd(&ax[id], (double)(REC).vals[j].x);         \
+      if ((REC).vals[j].y != 0.0f) unsafeAtomicAdd(&ay[id], (double)(REC).vals[j].y);         \
+    }                                                                                         \
+  }
   FoldRecs cur, nxt;
   fold_load(ip, vp, begin + mine, end, cur);  // in flight while the LDS image is cleared
   {
     float4* z = reinterpret_cast<float4*>(s_mem);
-    const uint32_t nf = 4 * slots + words, n4 = nf / 4;
-    for (uint32_t t = tid; t < n4; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t t = 4 * n4 + tid; t < nf; t += FOLD_THREADS) s_mem[t] = 0.0f;
+    for (uint32_t t = tid; t < slots; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);  // 4 floats = 16 B per slot
   }
   __syncthreads();
   if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk + 1] = wall_clock64();
-  const bool sparse = (bk.sparse_mask >> l) & 1u;
-  float* acc2 = s_mem + 2 * slots + words;  // second image: float atomics only (a float atomic racing a plain read-modify-write would be lost)
   for (uint32_t blk = begin + wave * 512; blk < end; blk += FOLD_THREADS * 8) {  // per wave: no barrier inside
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if ((cur.ok >> j) & 1u) {
-        const uint32_t id = cur.id(j);
-        if (!sparse && fold_claim(lock, id)) {
-          fold_add_release(acc, lock, id, cur.vals[j]);
-        } else {  // slot busy (or a sparse level, where it nearly always is): no spinning, the float atomic takes it
-          if (cur.vals[j].x != 0.0f) unsafeAtomicAdd(&acc2[2 * id], cur.vals[j].x);
-          if (cur.vals[j].y != 0.0f) unsafeAtomicAdd(&acc2[2 * id + 1], cur.vals[j].y);
-        }
-      }
-      if (j == 0) {
-        // the next 8 records: issued only now, AFTER this iteration's records have been waited for -- the compiler waits with vmcnt(0),
-        // so loads issued before that wait would be waited for too and the memory latency would be paid in every iteration
-        nxt.ok = 0;
-        if (blk + FOLD_THREADS * 8 < end) fold_load(ip, vp, blk + FOLD_THREADS * 8 + 2 * lane, end, nxt);
-      }
-    }
+    nxt.ok = 0;
+    if (blk + FOLD_THREADS * 8 < end) fold_load(ip, vp, blk + FOLD_THREADS * 8 + 2 * lane, end, nxt);
+    FOLD_FIRE(cur)
     cur = nxt;
   }
+#undef FOLD_FIRE
   __syncthreads();
   if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk + 2] = wall_clock64();
   float2* dst = g.grad + (size_t)l * g.tsize + ((size_t)sl << bk.slice_log2);
@@ -579,8 +553,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
       const uint32_t t = t0 + u * FOLD_THREADS + tid;
       nz[u] = false;
       if (t < slots) {
-        const float2 a1 = acc[t], a2 = reinterpret_cast<const float2*>(s_mem + 2 * slots + words)[t];
-        v[u] = make_float2(a1.x + a2.x, a1.y + a2.y);
+        v[u] = make_float2((float)ax[t], (float)ay[t]);
         nz[u] = v[u].x != 0.0f || v[u].y != 0.0f;  // untouched slots keep an exactly-zero gradient
         if (nz[u] && !split) cv[u] = dst[t];
       }
@@ -646,7 +619,7 @@ static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
 
 // TN_SCATTER_MODE: 1 = binned (default), 0 = atomics with dense replicas (the round-1 path; also what the dense data-parallel exchange uses)
 static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); return m; }
-static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 8192, 1024, 32768) & ~1023; return r; }
+static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 16384, 1024, 32768) & ~1023; return r; }
 static int merge_res() { static int r = env_int("TN_SCATTER_MERGE_RES", 256, 0, 1 << 20); return r; }
 
 // Layout of the binned scatter for (grid, P, scratch): a pure function of its arguments, so the bin pass and the fold launches of a phased
@@ -674,10 +647,9 @@ static int bin_plan(const TnGrid& grid, int64_t P, void* scratch, BinK& bk, uint
     // live slots of the level: (res+1)^3 cells hashed into 2^log2T slots; below half of the table the buckets are sparse and hot
     const double r1 = ceil((double)grid.res[l]) + 1.0;
     const double T = (double)(1ll << grid.log2_hashmap_size), live = std::min(r1 * r1 * r1, T);
-    // ... or so many samples per live slot that a slot's lock would nearly always be found taken (the proposal grids: 256 samples per ray)
+    // ... or there are very many samples per live slot (the proposal grids: 256 samples per ray): smaller chunks spread such buckets over more CUs
     const bool sparse = r1 * r1 * r1 < 0.5 * T || 8.0 * (double)P > 16.0 * live;
     bk.chunk[l] = sparse ? (uint32_t)fold_chunk_sparse() : 32768u;
-    if (sparse) bk.sparse_mask |= 1u << l;
     bk.blk0[l] = nblk;
     nblk += (uint32_t)(bk.nslices * tn_cdiv(bk.cap, bk.chunk[l]));
   }
@@ -734,10 +706,10 @@ int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level
   if (rc) return rc;
   GridK gk = make_gridk(grid);
   const uint32_t first_block = bk.blk0[level_begin], nblk = bk.blk0[level_end] - bk.blk0[level_begin];
-  const size_t shmem = ((size_t)(4u << bk.slice_log2) + (((1u << bk.slice_log2) + 31) / 32) + 1) * sizeof(float);
+  const size_t shmem = (size_t)(2u << bk.slice_log2) * sizeof(double);
   // per launch, not once per process: the attribute is per device (a process that drives a second GPU would otherwise fail the fold there)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(((4u << TN_BIN_SLICE_LOG2) + ((1u << TN_BIN_SLICE_LOG2) / 32) + 1) * sizeof(float)));
+                            (int)((2u << TN_BIN_SLICE_LOG2) * sizeof(double)));
   static int trace_on = env_int("TN_FOLD_TRACE", 0, 0, 1);
   static unsigned long long* trace_buf = nullptr;
   if (trace_on) {  // diagnostics only: synchronises and prints

@@ -444,7 +444,8 @@ class RenderEngine:
                 # remaining levels go range by range through the whole scatter instead: bin + fold per range)
                 two_step = nd == 0
                 if two_step:
-                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER_BIN)
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
+                                        ph.TN_BWD_SCATTER_BIN | ph.TN_BWD_COUNTERS_CLEAN)  # (the MLP phase above left the bucket counters zeroed)
                 for lb, le in dp.level_ranges(fld.num_levels - nd):
                     lb, le = lb + nd, le + nd
                     ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
@@ -474,7 +475,8 @@ class RenderEngine:
                     ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_SCATTER, 0, fld.num_levels)
+                    ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
+                                        ph.TN_BWD_SCATTER | ph.TN_BWD_COUNTERS_CLEAN, 0, fld.num_levels)
                     e1.record()
                     ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
                     ev.append((e0, e1, bool(br.prop_grad)))

@@ -20,7 +20,11 @@ __global__ void __launch_bounds__(1024) k(float* out, int reps, int active) {
     if (MODE == 0) { if ((int)(hash32(tid + r * 977u) & 63u) < active) unsafeAtomicAdd(&lds[a], 1.0f); }
     else if (MODE == 1) atomicAdd(reinterpret_cast<uint32_t*>(lds) + a, 1u);
     else if (MODE == 2) acc += atomicAdd(reinterpret_cast<uint32_t*>(lds) + a, 1u);
-    else { float v = lds[a]; lds[a] = v + 1.0f; }
+    else if (MODE == 3) { float v = lds[a]; lds[a] = v + 1.0f; }
+    else if (MODE == 4) unsafeAtomicAdd(reinterpret_cast<double*>(lds) + (a >> 1), 1.0);                          // ds_add_f64 on 8192 doubles
+    else if (MODE == 5) atomicAdd(reinterpret_cast<unsigned long long*>(lds) + (a >> 1), 1ull);                   // ds_add_u64
+    else if (MODE == 6) { unsafeAtomicAdd(&lds[a & ~1u], 1.0f); unsafeAtomicAdd(&lds[a | 1u], 1.0f); }            // the two components of a float2 slot
+    else if (MODE == 7) { unsafeAtomicAdd(reinterpret_cast<double*>(lds) + ((a >> 2) << 1), 1.0); unsafeAtomicAdd(reinterpret_cast<double*>(lds) + ((a >> 2) << 1) + 1, 1.0); }
   }
   __syncthreads();
   if (tid == 0) out[blockIdx.x] = lds[5] + (float)acc;
@@ -51,6 +55,11 @@ int main() {
     run<1, 1>("ds_add_u32 consecutive", out, threads);
     run<2, 0>("ds_add_rtn_u32 random", out, threads);
     run<2, 1>("ds_add_rtn_u32 consecutive", out, threads);
+    run<4, 0>("ds_add_f64 random", out, threads);
+    run<4, 1>("ds_add_f64 consecutive", out, threads);
+    run<5, 0>("ds_add_u64 random", out, threads);
+    run<6, 0>("2 x ds_add_f32 (float2 slot) random", out, threads);
+    run<7, 0>("2 x ds_add_f64 (double2 slot) random", out, threads);
     run<3, 0>("ds_read+ds_write random", out, threads);
     run<3, 1>("ds_read+ds_write consecutive", out, threads);
   }
