@@ -255,7 +255,8 @@ struct BinLevel {
   float wx[2], wy[2], wz[2];  // [0] floor corner, [1] ceil corner
   bool emit;
   int start;    // first lane of this lane's run (merge levels)
-  int maxlen;   // longest run of the wave (merge levels)
+  int maxlen;   // power of two >= the longest run of the wave, capped at 16 (merge levels): which steps of the scan are needed
+  bool cross;   // some run continues over a boundary between rows of 16 lanes (merge levels)
 };
 __device__ __forceinline__ void bin_level(const Contracted& c, float res, uint32_t mask, bool merge, bool live, int lane, BinLevel& b) {
   const float sx = c.px * res, sy = c.py * res, sz = c.pz * res;
@@ -272,22 +273,55 @@ __device__ __forceinline__ void bin_level(const Contracted& c, float res, uint32
   b.emit = live;
   b.start = lane;
   b.maxlen = 1;
+  b.cross = false;
   if (merge) {
     // runs of consecutive lanes in one cell (same floor corner, same on-lattice flags => same 8 slots)
     const uint32_t k1 = fx | (fy << 16);
     const uint32_t k2 = fz | ((ox == 0.0f) ? 1u << 16 : 0u) | ((oy == 0.0f) ? 1u << 17 : 0u) | ((oz == 0.0f) ? 1u << 18 : 0u);
-    const uint32_t p1 = __shfl_up(k1, 1, 64), p2 = __shfl_up(k2, 1, 64);
+    // the lane before: DPP wave_shr:1 (vector ALU; lane 0 keeps its own key, it is a head anyway)
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)k1, (int)k1, 0x138, 0xf, 0xf, false);
+    const uint32_t p2 = (uint32_t)__builtin_amdgcn_update_dpp((int)k2, (int)k2, 0x138, 0xf, 0xf, false);
     const bool head = (lane == 0) || (k1 != p1) || (k2 != p2) || !live;
     const unsigned long long H = __ballot(head);
     b.start = 63 - __clzll(H & (~0ull >> (63 - lane)));
     const bool tail = (lane == 63) || ((H >> (lane + 1)) & 1ull);
-    int m = lane - b.start + 1;
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) m = max(m, __shfl_xor(m, o2, 64));
-    b.maxlen = m;
+    // which scan steps any run of the wave needs (wave-uniform, from ballots: no cross-lane reduction)
+    const int back = lane - b.start;
+    b.maxlen = __ballot(back >= 8) ? 16 : (__ballot(back >= 4) ? 8 : (__ballot(back >= 2) ? 4 : (__ballot(back >= 1) ? 2 : 1)));
+    b.cross = (~H & 0x0001000100010000ull) != 0ull;
     b.emit = live && tail;
   }
 }
+// Sums of the 16 values over every run of same-cell lanes, delivered to the run's LAST lane: a segmented inclusive scan on the vector ALU
+// (DPP), not through ds_bpermute -- the 96 permutes per level of the shuffle version kept the CU's one LDS pipe busy for 47 us of the level-0
+// proposal grid's 164-us bin pass.  Rows of 16 lanes first (row_shr 1, 2, 4, 8; a source outside the row reads 0), then the carries across
+// the row boundaries as in the classic wave scan (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3), each addition only where
+// the lane's run reaches that far back.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float bin_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void bin_scan_step(float (&vx)[8], float (&vy)[8], bool take) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float tx = bin_dpp<CTRL, ROW_MASK>(vx[k]), ty = bin_dpp<CTRL, ROW_MASK>(vy[k]);
+    vx[k] += take ? tx : 0.0f;
+    vy[k] += take ? ty : 0.0f;
+  }
+}
+__device__ __forceinline__ void bin_run_sums(float (&vx)[8], float (&vy)[8], int lane, const BinLevel& b) {
+  const int back = lane - b.start;  // lanes of the run before this one
+  bin_scan_step<0x111, 0xf>(vx, vy, back >= 1);
+  if (b.maxlen > 2) bin_scan_step<0x112, 0xf>(vx, vy, back >= 2);
+  if (b.maxlen > 4) bin_scan_step<0x114, 0xf>(vx, vy, back >= 4);
+  if (b.maxlen > 8) bin_scan_step<0x118, 0xf>(vx, vy, back >= 8);
+  if (b.cross) {  // some run continues over a row boundary (wave-uniform)
+    bin_scan_step<0x142, 0xa>(vx, vy, (lane & 16) && b.start < (lane & 48));  // rows 1, 3 += lane 15 / 47 (sum of the run's part in the row before)
+    bin_scan_step<0x143, 0xc>(vx, vy, (lane & 32) && b.start < 32);            // rows 2, 3 += lane 31 (everything of the run in rows 0-1)
+  }
+}
+
 template <bool WANT_DPOS>
 __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                           const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
@@ -392,16 +426,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
       vx[k] = w * gv.x;
       vy[k] = w * gv.y;
     }
-    if (merge) {
-      for (int o2 = 1; o2 < b.maxlen; o2 <<= 1) {  // wave-uniform bound; the run's last lane ends up with the run's sums
-        const bool take = lane - o2 >= b.start;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float tx = __shfl_up(vx[k], o2, 64), ty = __shfl_up(vy[k], o2, 64);
-          if (take) { vx[k] += tx; vy[k] += ty; }
-        }
-      }
-    }
+    if (merge && b.maxlen > 1) bin_run_sums(vx, vy, lane, b);  // the run's last lane ends up with the run's sums
     if (b.emit) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
