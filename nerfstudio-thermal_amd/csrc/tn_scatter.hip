@@ -297,28 +297,28 @@ __device__ __forceinline__ void bin_level(const Contracted& c, float res, uint32
 // proposal grid's 164-us bin pass.  Rows of 16 lanes first (row_shr 1, 2, 4, 8; a source outside the row reads 0), then the carries across
 // the row boundaries as in the classic wave scan (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3), each addition only where
 // the lane's run reaches that far back.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float bin_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+template <int CTRL>
+__device__ __forceinline__ float bin_dpp(float v) {  // every row enabled, invalid source lanes read 0: folds into the consumer (v_fmac_f32_dpp)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-template <int CTRL, int ROW_MASK>
+template <int CTRL>
 __device__ __forceinline__ void bin_scan_step(float (&vx)[8], float (&vy)[8], bool take) {
+  const float m = take ? 1.0f : 0.0f;  // v += m * shifted(v): one instruction per value (the sums stay exact: m is 0 or 1)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float tx = bin_dpp<CTRL, ROW_MASK>(vx[k]), ty = bin_dpp<CTRL, ROW_MASK>(vy[k]);
-    vx[k] += take ? tx : 0.0f;
-    vy[k] += take ? ty : 0.0f;
+    vx[k] = __builtin_fmaf(bin_dpp<CTRL>(vx[k]), m, vx[k]);
+    vy[k] = __builtin_fmaf(bin_dpp<CTRL>(vy[k]), m, vy[k]);
   }
 }
 __device__ __forceinline__ void bin_run_sums(float (&vx)[8], float (&vy)[8], int lane, const BinLevel& b) {
   const int back = lane - b.start;  // lanes of the run before this one
-  bin_scan_step<0x111, 0xf>(vx, vy, back >= 1);
-  if (b.maxlen > 2) bin_scan_step<0x112, 0xf>(vx, vy, back >= 2);
-  if (b.maxlen > 4) bin_scan_step<0x114, 0xf>(vx, vy, back >= 4);
-  if (b.maxlen > 8) bin_scan_step<0x118, 0xf>(vx, vy, back >= 8);
+  bin_scan_step<0x111>(vx, vy, back >= 1);
+  if (b.maxlen > 2) bin_scan_step<0x112>(vx, vy, back >= 2);
+  if (b.maxlen > 4) bin_scan_step<0x114>(vx, vy, back >= 4);
+  if (b.maxlen > 8) bin_scan_step<0x118>(vx, vy, back >= 8);
   if (b.cross) {  // some run continues over a row boundary (wave-uniform)
-    bin_scan_step<0x142, 0xa>(vx, vy, (lane & 16) && b.start < (lane & 48));  // rows 1, 3 += lane 15 / 47 (sum of the run's part in the row before)
-    bin_scan_step<0x143, 0xc>(vx, vy, (lane & 32) && b.start < 32);            // rows 2, 3 += lane 31 (everything of the run in rows 0-1)
+    bin_scan_step<0x142>(vx, vy, (lane & 16) && b.start < (lane & 48));  // rows 1, 3 += lane 15 / 47 (sum of the run's part in the row before)
+    bin_scan_step<0x143>(vx, vy, (lane & 32) && b.start < 32);            // rows 2, 3 += lane 31 (everything of the run in rows 0-1)
   }
 }
 
