@@ -925,10 +925,15 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
   }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     typedef float v4f __attribute__((ext_vector_type(4)));
-    float4 pp = p4[i];
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     v4f gg = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g4) + i);
     v4f mm4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m4) + i);
     v4f vv4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v4) + i);
+    // Entries that have never received a gradient (g, m and v all +0: on the coarse levels of a hash table most slots -- level 0 uses 4913 of
+    // 2^19) stay exactly as they are under Adam's arithmetic (m' = v' = 0, p' = p + step * 0 / eps = p): nothing to read further, nothing to write.
+    const v4u zb = __builtin_bit_cast(v4u, gg) | __builtin_bit_cast(v4u, mm4) | __builtin_bit_cast(v4u, vv4);
+    if ((zb.x | zb.y | zb.z | zb.w) == 0u) continue;
+    float4 pp = p4[i];
     ADAM1(pp.x, gg.x, mm4.x, vv4.x)
     ADAM1(pp.y, gg.y, mm4.y, vv4.y)
     ADAM1(pp.z, gg.z, mm4.z, vv4.z)

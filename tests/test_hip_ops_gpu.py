@@ -159,10 +159,10 @@ def sample_level(N, S, nears, fars):
     return s, orc.s_to_euclidean(s, nears, fars)
 
 
-@pytest.mark.parametrize("lvl,S", [(0, 256), (1, 96)])
-def test_prop_density_fwd_bwd(lvl, S):
+@pytest.mark.parametrize("lvl,S,N", [(0, 256, 128), (1, 96, 128), (0, 7, 37), (1, 3, 5)])
+def test_prop_density_fwd_bwd(lvl, S, N):
+    """(the last two cases: 259 and 15 points -- the tail of the backward kernel's 64-sample MFMA tiles, and fewer points than one 16-sample block)"""
     ocfg, params, cfg, arena = setup_pair()
-    N = 128
     r = rays(N)
     nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
     s, e = sample_level(N, S, nears, fars)
@@ -721,6 +721,40 @@ def test_adam_matches_torch_optim():
         assert torch.equal(x, y)
     with pytest.raises(RuntimeError):
         ops.adam_step_ranges(b[0], grad, b[1], b[2], [(2, 10, 1, 1e-3)])  # offsets must be multiples of 4
+
+
+def test_adam_untouched_entries_are_skipped_exactly():
+    """k_adam_ranges_amp leaves entries with g = m = v = +0 alone (no read of p, no write).  That must be indistinguishable from doing the
+    arithmetic: bit for bit against k_adam_ranges (the same arithmetic without the shortcut) and against torch.optim.Adam to its usual 2e-6,
+    over several steps with blocks of never-touched entries, entries whose gradient is zero in one step but whose moments are not (they must
+    still move), a -0.0 gradient (not skipped: it is computed like any other), and zero_grads."""
+    n = 4096 + 12
+    p0 = torch.from_numpy(synth.uniform("ap0", (n,), seed=SEED))
+    ref_p = p0.clone().to(DEV).requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-2, eps=1e-15)
+    hp, m, v = g(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    fp, fm, fv = g(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)  # the full arithmetic on every entry
+    dead = torch.zeros(n, dtype=torch.bool)
+    dead[64:1024] = True  # whole float4 groups and whole cache lines never touched
+    dead[2000:2003] = True  # part of a float4 group
+    for step in range(1, 5):
+        grad = torch.from_numpy(synth.uniform(f"agz{step}", (n,), seed=SEED)) * 1e-3
+        grad[dead] = 0.0
+        if step == 2:
+            grad[1100:1300] = 0.0  # moments are non-zero here from step 1: these entries still move
+            grad[1400] = -0.0
+        ref_p.grad = g(grad).clone()
+        opt.step()
+        ops.adam_step_ranges(fp, g(grad), fm, fv, [(0, n, step, 1e-2)])
+        hg = g(grad).clone()
+        ops.adam_step_ranges_amp(hp, hg, m, v, [(0, n, step, 1e-2)], zero_grads=True)
+        assert torch.equal(hp, fp) and torch.equal(m, fm) and torch.equal(v, fv), step
+        assert md(hp, ref_p.detach()) <= 2e-6, step
+        assert not hg.any(), "the launch consumes the gradients"
+        assert torch.equal(hp.cpu()[dead], p0[dead])
+        if step == 2:
+            assert (hp.cpu()[1100:1300] != before[1100:1300]).all(), "zero gradient, non-zero moments: the entry still moves"
+        before = hp.cpu().clone()
 
 
 def test_empty_single_and_eval_chunk_sizes():
