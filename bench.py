@@ -620,7 +620,7 @@ def main():
                     "avg_launch_ms_in_step": None if in_step is None else in_step["mean_ms"], "in_step": in_step,
                     "frac_in_step": None if in_step is None else nbytes / (in_step["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "the main grid's scatter entry point = k_grid_bin + k_grid_fold as the field backward calls it (d position comes from "
-                            "k_field_dpos); both passes run on the LDS unit, not on HBM (profiles/r02_scatter_alternatives.md)",
+                            "k_field_dpos); the bin pass is bound by instruction issue, the fold streams its records into double-precision LDS atomics",
                     "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows},
                     # SURVEY 8d's whole-step figure: (N x bytes_ray + bytes_step) / t_step against the HBM peak
                     "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "proposal_update_fraction": upd}}

@@ -247,7 +247,9 @@ struct BinK {
 };
 
 #define BIN_THREADS 256
+#ifndef BIN_MAX_COUNTERS
 #define BIN_MAX_COUNTERS 1024  // (levels handled by one block) x (buckets per level)
+#endif
 
 // corner slots of one level + run structure of the wave (which lanes write: the last lane of every run of same-cell samples)
 struct BinLevel {

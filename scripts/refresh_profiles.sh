@@ -22,14 +22,15 @@ b n1_96samples --nerf-samples 96 --no-cpu-baseline
 b n1_splat_1080p --workload splat
 python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1rank_latency.json
 rm -rf gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep
+# (the last 20 steps of a fused / separate run are the in-step measurement, which issues the backward phase by phase: the timelines show steps of the timed region)
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_a.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_dp -o dp -- python3 bench.py --force-dp --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_dp.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_sep -o sep -- python3 bench.py --mode separate --rays 8192 --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_sep.log 2>&1
 python scripts/rocpd_stats.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/bench_n1_kernel_stats.csv --split-grid --tail 10 > gpurun_out/$R/bench_n1_kernel_stats_tail.txt 2>&1
-python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --step-from-end 4 > /dev/null 2> gpurun_out/$R/timeline.err
-python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline_update_step.md --step-from-end 5 > /dev/null 2>> gpurun_out/$R/timeline.err
+python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --step-from-end 26 > /dev/null 2> gpurun_out/$R/timeline.err
+python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline_update_step.md --step-from-end 25 > /dev/null 2>> gpurun_out/$R/timeline.err
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_dp -name '*.db' | head -1) gpurun_out/$R/dp_timeline.md --step-from-end 4 > /dev/null 2>> gpurun_out/$R/timeline.err
-python scripts/rocpd_timeline.py $(find gpurun_out/prof_sep -name '*.db' | head -1) gpurun_out/$R/separate_timeline.md --step-from-end 4 > /dev/null 2>> gpurun_out/$R/timeline.err
+python scripts/rocpd_timeline.py $(find gpurun_out/prof_sep -name '*.db' | head -1) gpurun_out/$R/separate_timeline.md --step-from-end 25 > /dev/null 2>> gpurun_out/$R/timeline.err
 find gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep -name '*.db' -delete
 for f in gpurun_out/$R/bench_*.json; do python - <<PY
 import json
