@@ -205,10 +205,8 @@ def kernel_roofline(eng, cam_t, idx):
     d_o, d_d = torch.zeros_like(o), torch.zeros_like(d)
     grids = [("prop0 grid", eng.props[0], lv[0]), ("prop1 grid", eng.props[1], lv[1]), ("main grid", eng.field, lv[2])]
     for name, net, L in grids:
-        ld = 16 if net.num_levels == 5 else 32
-        g_enc = torch.randn((N * L.S, ld), device=o.device) * 1e-3
-        if net.num_levels != 5:  # the main field's backward hands its d enc over level-major
-            g_enc = g_enc.reshape(N * L.S, net.num_levels, 2).permute(1, 0, 2).contiguous()
+        # level-major [L][P] float2, as the backward kernels of all three grids hand their d enc over
+        g_enc = (torch.randn((N * L.S, net.num_levels, 2), device=o.device) * 1e-3).permute(1, 0, 2).contiguous()
         # as the step calls it: the proposal grids' scatter also yields d position; the main field's does not (k_field_dpos does, beside it)
         dpos = (d_o, d_d) if net.num_levels == 5 else (None, None)
         ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,

@@ -24,9 +24,8 @@ for _ in range(R):
 torch.cuda.synchronize()
 for net, L in ((eng.props[0], lv[0]), (eng.props[1], lv[1]), (eng.field, lv[2])):
     N, S = L.e_bins.shape[0], L.e_bins.shape[1] - 1
-    g_enc = torch.randn((N * S, 16 if net.num_levels == 5 else 32), device=dev) * 1e-3
-    if net.num_levels != 5:  # the main field's backward hands its d enc over level-major
-        g_enc = g_enc.reshape(N * S, net.num_levels, 2).permute(1, 0, 2).contiguous()
+    # level-major [L][P] float2, as the backward kernels of all three grids hand their d enc over
+    g_enc = (torch.randn((N * S, net.num_levels, 2), device=dev) * 1e-3).permute(1, 0, 2).contiguous()
     # the proposal grids' scatter computes d position itself; the main field's does not (k_field_dpos does, from the saved d enc / d offset)
     with_dpos = net.num_levels == 5
     for _ in range(R):

@@ -20,9 +20,8 @@ for name, net, L in (("prop0", eng.props[0], lv[0]), ("prop1", eng.props[1], lv[
     if name not in which:
         continue
     N, S = L.e_bins.shape[0], L.e_bins.shape[1] - 1
-    g_enc = torch.randn((N * S, 16 if net.num_levels == 5 else 32), device=dev) * 1e-3
-    if net.num_levels != 5:  # the main field's backward hands its d enc over level-major
-        g_enc = g_enc.reshape(N * S, net.num_levels, 2).permute(1, 0, 2).contiguous()
+    # level-major [L][P] float2, as the backward kernels of all three grids hand their d enc over
+    g_enc = (torch.randn((N * S, net.num_levels, 2), device=dev) * 1e-3).permute(1, 0, 2).contiguous()
     ms = bench.time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions, L.e_bins, g_enc, None, None))
     ms2 = bench.time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions, L.e_bins, g_enc, d_o, d_d))
     print(f"{name}: {ms*1e3:.1f} us without d position, {ms2*1e3:.1f} us with   [{os.environ.get('TN_FOLD_DBG','0')}]")
