@@ -246,7 +246,9 @@ struct BinK {
   unsigned long long* trace;  // TN_FOLD_TRACE diagnostics: per fold block {start, after load+zero, after passes, end} wall-clock stamps, or NULL
 };
 
-#define BIN_THREADS 256
+#ifndef BIN_THREADS
+#define BIN_THREADS 512  // 256: 198 us for the main grid, 512: 172 us (half the reservations, runs twice as long); 384 / 640 / 768 / 1024: 190 / 204 / 192 / 177 us
+#endif
 #ifndef BIN_MAX_COUNTERS
 #define BIN_MAX_COUNTERS 1024  // (levels handled by one block) x (buckets per level)
 #endif
