@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
       for (int r = 0; r < 4; ++r) {
         const float h = fmaxf(T[c][r], 0.0f);
         const float out = b1 + prop_row_sum(w1j * h);
-        const float d_out = ddr[r] != 0.0f ? ddr[r] * expf(fminf(fmaxf(out, -15.0f), 15.0f)) : 0.0f;  // trunc_exp backward
+        const float d_out = ddr[r] * expf(fminf(fmaxf(out, -15.0f), 15.0f));  // trunc_exp backward (the clamped exp is finite: 0 stays 0, no branch)
         sum_dout += d_out;
         dw1 = fmaf(d_out, h, dw1);
         da[c][r] = T[c][r] > 0.0f ? d_out * w1j : 0.0f;
