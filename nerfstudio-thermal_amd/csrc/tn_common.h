@@ -82,13 +82,18 @@ __device__ __forceinline__ float tn_s_to_euclid(float x, float s_near, float s_f
 }
 
 // SpacedSampler / UniformLinDispPiecewiseSampler bins of every ray (model_components/ray_samplers.py:78-128,225-248) as a grid-stride body
+// i / d for a flat work-item index: a 64-bit division is ~150 instructions on this machine, a 32-bit one ~25.  `total` (wave-uniform) bounds i.
+__device__ __forceinline__ int64_t tn_div_index(int64_t i, int64_t d, int64_t total) {
+  return total < (1ll << 31) ? (int64_t)((uint32_t)i / (uint32_t)d) : i / d;
+}
+
 // (bid / nblk stand in for blockIdx.x / gridDim.x: tn_spaced_bins launches it alone, tn_pose_spaced_bins as one slice of a launch)
 __device__ __forceinline__ void tn_spaced_bins_body(const float* __restrict__ lin_bins, const float* __restrict__ jitter,
                                                     const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
                                                     float* __restrict__ s_bins, float* __restrict__ e_bins, int bid, int nblk) {
   int64_t total = N * (int64_t)(S + 1);
   for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
-    int64_t ray = i / (S + 1);
+    int64_t ray = tn_div_index(i, S + 1, total);
     int j = (int)(i - ray * (S + 1));
     float b = lin_bins[j];
     if (jitter != nullptr) {
@@ -302,11 +307,11 @@ __device__ __forceinline__ float tn_wave_incl_rscan(float v, int lane) {
 // scatter-add feeds on.  Any N is handled (the last group may hold fewer than 4 rays).
 __device__ __forceinline__ void tn_patch_order(int64_t i, int64_t N, int S, int64_t& ray, int& s) {
   int64_t per = 4 * (int64_t)S;
-  int64_t g = i / per;
+  int64_t g = tn_div_index(i, per, N * (int64_t)S);
   int w = (int)(i - g * per);
   int64_t r0 = g * 4;
   int nr = (N - r0) < 4 ? (int)(N - r0) : 4;
-  s = w / nr;
+  s = nr == 4 ? (w >> 2) : w / nr;
   ray = r0 + (w - s * nr);
 }
 

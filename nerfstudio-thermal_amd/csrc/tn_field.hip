@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __re
     int64_t p = tile * 32 + (lane & 31);
     const bool live = p < N * (int64_t)S;
     if (!live) p = N * (int64_t)S - 1;  // whole tiles are written (fragment order): the lanes past the end repeat the last sample
-    int64_t ray = p / S;
+    int64_t ray = tn_div_index(p, S, N * (int64_t)S);
     int s = (int)(p - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ or
       dz += gv.x * j0.z + gv.y * j1.y + gv.z * j2.x + gv.w * j2.w;
     }
     dx += __shfl_xor(dx, 32, 64); dy += __shfl_xor(dy, 32, 64); dz += __shfl_xor(dz, 32, 64);
-    const int64_t ray = pc / S;
+    const int64_t ray = tn_div_index(pc, S, P);
     const int s = (int)(pc - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
     const int64_t p = tile * TILE + j;
     const bool valid = p < P;
     const int64_t pc = valid ? p : P - 1;
-    const int64_t ray = pc / S;
+    const int64_t ray = tn_div_index(pc, S, P);
     const int s = (int)(pc - ray * S);
     // ---------------- contraction + 8 levels x 8 corners for this lane's half of the levels
     const float* o = origins + ray * 3;

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
   prop_stage_weights(net, s_w);
   int64_t P = N * (int64_t)S;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t ray = i / S;
+    int64_t ray = tn_div_index(i, S, P);
     int s = (int)(i - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
       const int64_t i = base + lane;
       const bool live = i < P;
       const int64_t ic = live ? i : P - 1;
-      int64_t ray = ic / S;
+      int64_t ray = tn_div_index(ic, S, P);
       int s = (int)(ic - ray * S);
       const float* o = origins + ray * 3;
       const float* d = directions + ray * 3;
