@@ -165,13 +165,26 @@ def time_ms(fn, iters=10, warmup=2):
 
 # bench row -> kernels of profiles/r03_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
 DOMINANT = "scatter(main grid)"  # the launch pair with the largest share of the step (every step; the proposal grids' only on update steps)
+# kernel name + points of the launch; the key in the PMC file also carries the grid's y extent (level groups: "k_grid_bin<false> 196608x4"),
+# which changes with the block size of the bin pass -- matched by prefix
 PMC_KEYS = {
-    "scatter(main grid)": ["k_grid_bin<false> 196608x2", "k_grid_fold 196608x2"],
-    "scatter(prop0 grid)": ["k_grid_bin<true> 1048576x1", "k_grid_fold 1048576x1"],
-    "scatter(prop1 grid)": ["k_grid_bin<true> 393216x1", "k_grid_fold 393216x1"],
-    "k_prop_fwd(level0)": ["k_prop_fwd 1048576x1"],
-    "k_prop_fwd(level1)": ["k_prop_fwd 393216x1"],
+    "scatter(main grid)": ["k_grid_bin<false> 196608x", "k_grid_fold 196608x"],
+    "scatter(prop0 grid)": ["k_grid_bin<true> 1048576x", "k_grid_fold 1048576x"],
+    "scatter(prop1 grid)": ["k_grid_bin<true> 393216x", "k_grid_fold 393216x"],
+    "k_prop_fwd(level0)": ["k_prop_fwd 1048576x"],
+    "k_prop_fwd(level1)": ["k_prop_fwd 393216x"],
 }
+
+
+def pmc_lookup(pmc, prefixes):
+    """the PMC entries of a bench row (one per kernel of the entry point), or None when one is missing"""
+    out = []
+    for pre in prefixes:
+        hit = [v for k, v in pmc.items() if k.startswith(pre)]
+        if len(hit) != 1:
+            return None
+        out.append(hit[0])
+    return out
 
 
 def load_pmc():
@@ -608,8 +621,10 @@ def main():
         achieved = nbytes / (ms * 1e-3) / 1e9
         pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
         traffic = None
-        if pmc is not None and all(k in pmc for k in PMC_KEYS.get(name, ["?"])):
-            traffic = sum(pmc[k]["traffic_bytes"] for k in PMC_KEYS[name])
+        if pmc is not None and pmc_lookup(pmc, PMC_KEYS.get(name, ["?"])) is not None:
+            traffic = sum(v["traffic_bytes"] for v in pmc_lookup(pmc, PMC_KEYS[name]))
+        elif pmc is not None:
+            why = f"profiles/r03_pmc.json holds no (single) entry for {PMC_KEYS.get(name)}"
         upd = updates / max(args.steps, 1)
         step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
         step_gbs = step_bytes / (dt / args.steps) / 1e9
@@ -622,10 +637,11 @@ def main():
                     "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows},
                     # SURVEY 8d's whole-step figure: (N x bytes_ray + bytes_step) / t_step against the HBM peak
                     "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "proposal_update_fraction": upd}}
-        if pmc is None:
+        if traffic is None:
             roofline["traffic_unavailable"] = why
-        else:
-            roofline["traffic_all_kernels"] = {n: sum(pmc[k]["traffic_bytes"] for k in ks) for n, ks in PMC_KEYS.items() if all(k in pmc for k in ks)}
+        if pmc is not None:
+            roofline["traffic_all_kernels"] = {n: sum(v["traffic_bytes"] for v in pmc_lookup(pmc, ks)) for n, ks in PMC_KEYS.items()
+                                               if pmc_lookup(pmc, ks) is not None}
             roofline["mfma_busy_frac"] = {k.split(" ")[0]: v["mfma_busy_frac"] for k, v in pmc.items()
                                           if k.split(" ")[0] in ("k_field_fwd_fused<true>", "k_field_bwd_fused<false>") and "mfma_busy_frac" in v}
             roofline["pmc_source"] = "profiles/r03_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
