@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 300  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 301  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024

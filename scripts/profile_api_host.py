@@ -28,3 +28,4 @@ for _ in range(100):
     bench.one_step_api(model, opt, cam_t, cache, 4096, step, scaler); step += 1
 pr.disable(); torch.cuda.synchronize()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:8000])

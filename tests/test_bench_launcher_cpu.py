@@ -36,3 +36,26 @@ def test_single_rank_needs_no_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["spawned_by_bench"] is False
+
+
+def test_pmc_figures_are_only_quoted_for_the_kernels_they_were_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/r03_pmc.json: refused when its source hash is not the hash of csrc/ as it stands, and a bench row
+    finds its kernels by name + point count whatever the launch's y extent (the bin pass's level groups change with its block size)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    pmc = {"k_grid_bin<false> 196608x4": {"traffic_bytes": 220e6}, "k_grid_fold 196608x4": {"traffic_bytes": 260e6},
+           "k_grid_bin<true> 1048576x1": {"traffic_bytes": 1.0}, "k_grid_fold 1048576x1": {"traffic_bytes": 2.0}}
+    hit = bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(main grid)"])
+    assert hit is not None and sum(v["traffic_bytes"] for v in hit) == 480e6
+    assert bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(prop1 grid)"]) is None  # not measured: no figure, never a guess
+    pmc["k_grid_fold 196608x2"] = {"traffic_bytes": 1.0}
+    assert bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(main grid)"]) is None  # two candidates (stale + fresh entry): ambiguous, refused
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps({"source_hash": "0" * 16, "kernels": pmc}))
+    monkeypatch.setattr(bench, "PMC_JSON", str(f))
+    got, why = bench.load_pmc()
+    assert got is None and "measured on kernel sources" in why
+    f.write_text(json.dumps({"source_hash": bench.source_hash(), "kernels": pmc}))
+    got, why = bench.load_pmc()
+    assert got == pmc and why is None
