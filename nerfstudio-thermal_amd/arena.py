@@ -131,6 +131,14 @@ class ParamArena:
     def grad_view(self, name: str) -> torch.Tensor:
         return self._view(self.grads, name)
 
+    def grad_ptr(self, name: str) -> int:
+        """device address of a parameter's slice of the gradient buffer (to recognise a `.grad` that aliases it without building a view)"""
+        base = self.__dict__.get("_grad_ptr_base")
+        if base != self.grads.data_ptr():
+            self._grad_ptr_base = base = self.grads.data_ptr()
+            self._grad_ptrs = {n: base + 4 * off for n, (off, _) in self.layout.items()}
+        return self._grad_ptrs[name]
+
     def names(self) -> List[str]:
         return list(self.layout.keys())
 

@@ -157,8 +157,8 @@ class _RenderFn(torch.autograd.Function):
         if ctx.accumulating:
             for n in ctx.names:
                 g = params[n].grad
-                view = arena.grad_view(n)
-                if g is not None and g.data_ptr() != view.data_ptr():
+                if g is not None and g.data_ptr() != arena.grad_ptr(n):
+                    view = arena.grad_view(n)
                     detached[n] = view.clone()
                     view.zero_()
         d_od = {}
@@ -171,6 +171,19 @@ class _RenderFn(torch.autograd.Function):
             d_o = torch.zeros((N, 3), device=dev) if pose is not None else None
             d_d = torch.zeros((N, 3), device=dev) if pose is not None else None
             dw2 = (g_w[2][..., 0].contiguous() if g_w[2] is not None else z(lv[2].weights))  # read only (tn_render_bwd)
+            both, neither = g_w[0] is not None and g_w[1] is not None, g_w[0] is None and g_w[1] is None
+            if br.fwd_buf is not None and (neither or (both and br.prop_grad)):
+                # the whole backward of the branch as ONE call of the C ABI (tn_render_rays_train_bwd), exactly as the fused step issues it
+                # (engine.loss_and_backward): renderer backward, the density loss's own gradient added, both proposal networks on the
+                # library's companion streams, field backward with d position and table scatter
+                pg = both and br.prop_grad
+                ops.render_rays_train_bwd(props, fld, br.fwd_buf, br.origins, br.directions, cam, eng.counts,
+                                          (g_comp.contiguous() if g_comp is not None else z(br.comp)),
+                                          [g_w[0][..., 0].contiguous() if pg else None, g_w[1][..., 0].contiguous() if pg else None, dw2],
+                                          g_dens[..., 0].contiguous() if g_dens is not None else None, d_o, d_d,
+                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx))
+                d_od[sfx] = (d_o, d_d)
+                continue
             d_rgb, d_dens = ops.render_bwd(lv[2].e_bins, lv[2].density, br.rgb_samples, lv[2].weights,
                                            (g_comp.contiguous() if g_comp is not None else z(br.comp)), dw2)
             if g_dens is not None:
@@ -226,14 +239,14 @@ class _RenderFn(torch.autograd.Function):
         pg = []
         for n in ctx.names:
             p = params[n]
-            view = arena.grad_view(n)
-            aliased = p.grad is not None and p.grad.data_ptr() == view.data_ptr()
+            aliased = p.grad is not None and p.grad.data_ptr() == arena.grad_ptr(n)
             if n in detached:
+                view = arena.grad_view(n)
                 own = view.clone()
                 view.add_(detached[n])  # the arena keeps the running total
                 pg.append(own if n in live else None)
-            else:
-                pg.append(view if (n in live and not aliased) else None)
+            else:  # (a FRESH view object per step: autograd adopts a gradient it holds the only reference to, and copies one it does not)
+                pg.append(arena.grad_view(n) if (n in live and not aliased) else None)
         return (None, None, None, None, None, None, None, *pg)
 
 
@@ -429,7 +442,7 @@ class ThermalNerfactoModel(nn.Module):
     def _grads_alias_arena(self) -> bool:
         for n in self._param_names:
             g = self._params[n].grad
-            if g is not None and g.data_ptr() == self.arena.grad_view(n).data_ptr():
+            if g is not None and g.data_ptr() == self.arena.grad_ptr(n):
                 return True
         return False
 
