@@ -426,7 +426,10 @@ class RenderEngine:
             if pipelined:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
-                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP | ph.TN_BWD_FORK_DPOS)
+                # (d position beside the scatter only when the proposal networks' backward keeps other queues busy anyway: alone it stretches
+                # the bin pass by more than it hides, as in the plain step)
+                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
+                                    ph.TN_BWD_MLP | (ph.TN_BWD_FORK_DPOS if br.prop_grad else 0))
                 T2 = 2 * 2**fld.log2_hashmap_size
                 t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
                 P = N * self.counts[-1]
