@@ -430,6 +430,16 @@ class RenderEngine:
                 # the bin pass by more than it hides, as in the plain step)
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
                                     ph.TN_BWD_MLP | (ph.TN_BWD_FORK_DPOS if br.prop_grad else 0))
+                if _FUSE and pose is not None and not br.prop_grad:
+                    # Nothing else adds to d origins / d directions on a step without a proposal update: the pose gradient (+ the loss sums and
+                    # the camera regulariser) can be finished NOW, and with it everything behind the table in the arena is final -- MLP
+                    # weights, embedding, pose.  Their exchange goes out here, hidden behind the scatter, instead of as one more collective
+                    # behind the last table range (~35-50 us between the last fold and the optimiser, whatever the number of ranks).
+                    co = c.camera_optimizer_thermal if sfx else c.camera_optimizer
+                    ops.pose_bwd_finish(pose, frozen, cam, br.directions_in, d_o, d_d, pose_grad, co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale,
+                                        L[12:13] if sfx else L[11:12], Lp, L)
+                    br._pose_done = True
+                    dp.reduce_range(self.arena.layout["field.mlp_base.model.0.hash_table"][0] + self._table_floats(fld), self._camera_hi())
                 T2 = 2 * 2**fld.log2_hashmap_size
                 t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
                 P = N * self.counts[-1]
@@ -501,6 +511,9 @@ class RenderEngine:
             pose = self.pose_thermal if sfx else self.pose
             if pose is None:
                 continue
+            if getattr(br, "_pose_done", False):  # finished early (data-parallel schedule, step without a proposal update)
+                finished = True
+                continue
             pose_grad = self.pose_thermal_grad if sfx else self.pose_grad
             frozen = self.frozen_thermal if sfx else self.frozen_rgb
             co = c.camera_optimizer_thermal if sfx else c.camera_optimizer
@@ -523,6 +536,13 @@ class RenderEngine:
         if self.separate and self.pose_thermal is not None:
             losses["camera_opt_regularizer_thermal"] = L[12]
         return losses
+
+    def _table_floats(self, fld) -> int:
+        return fld.num_levels * 2 * 2**fld.log2_hashmap_size
+
+    def _camera_hi(self) -> int:
+        """end of the shared-mode live range behind the main table: field embedding + MLPs, then the camera optimiser's pose"""
+        return self.arena.group_range["camera_opt"][1]
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,

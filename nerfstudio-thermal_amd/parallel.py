@@ -105,6 +105,7 @@ class OverlappedGradReducer:
         self._arena = None
         self._avg = None
         self._after = {}
+        self._pieces = {}
 
     def level_ranges(self, num_levels: int) -> List[Tuple[int, int]]:
         if isinstance(self.level_chunks, int):
@@ -132,6 +133,7 @@ class OverlappedGradReducer:
         self._arena = arena
         self._ranges = []
         self._after = {}
+        self._pieces = {}
 
     def side_group(self):
         if isinstance(self._side_group, str):  # "auto": every rank reaches this at the same point of the same schedule (collective call)
@@ -150,6 +152,11 @@ class OverlappedGradReducer:
         if hi <= lo:
             return
         self._ranges.append((lo, hi))
+        # one collective, handed to the optimiser group by group (a range may run over a group boundary: MLP weights + pose behind the table)
+        cuts = sorted({b for g in self._arena.optimised_groups for b in self._arena.group_range[g]})
+        pts = [lo] + [c for c in cuts if lo < c < hi] + [hi]
+        if len(pts) > 2:
+            self._pieces[len(self._ranges) - 1] = list(zip(pts[:-1], pts[1:]))
         self._issue(self._arena.grads[lo:hi], self.side_group() if side else None)
 
     def reduce_tensor(self, tensor, covers: Tuple[int, int], after) -> None:
@@ -182,7 +189,7 @@ class OverlappedGradReducer:
                 merged[-1].append((a, b))
             else:
                 merged.append([(a, b)])
-        parts = {}
+        parts = dict(self._pieces)
         for grp in merged:
             self.reduce_range(grp[0][0], grp[-1][1])
             parts[len(self._ranges) - 1] = grp
