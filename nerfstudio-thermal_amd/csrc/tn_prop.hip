@@ -97,21 +97,23 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // k_prop_bwd_mlp, all three matrix products on v_mfma_f32_16x16x4_f32 (D[i][n] = sum_k A[i][k] B[k][n]; lane l supplies A[l % 16][l / 16] and
-// B[l / 16][l % 16], register r of lane l receives D[4 (l / 16) + r][l % 16]).  With g = l / 16, j = l % 16, and the wave's 64 samples in four
+// B[l / 16][l % 16], register r of lane l receives D[4 (l / 16) + r][l % 16]).  With g = l / 16, n = l % 16, and the wave's 64 samples in four
 // blocks c of 16:
-//   stage   lane = sample writes its row E[s] = [enc(10) | 1 | 0] (row stride 20 floats) and dd[s] = d_density * selector
-//   forward T_c[s][j] = sum_f E[16 c + s][f] W0aug[j][f]   A = E (read from LDS), B = the weights: 3 registers per lane hold [w0 | b0] for good.
-//           Lane (g, j) receives the pre-activations of hidden unit j for the samples 16 c + 4 g + r, r = 0..3.
-//   out     = b1 + sum_j w1[j] relu(T[s][j]): a butterfly over the 16 lanes of a row (DPP), every lane of the row ends up with the sum
-//   d_out   = dd * exp(clamp(out)),  dA[s][j] = [T > 0] d_out w1[j]  -- in the registers of lane (g, j), which is exactly operand B of
-//   weights G[f][j] += sum_s E[s][f] dA[s][j]   A = E^T read from LDS in the sample order the registers have (16 c + 4 g + r); row 10 = db0
-//   d enc   X_c[f][s] = sum_j W0[j][f] dA[16 c + s][j]   K = j now: dA goes through LDS once ([j][s], row stride 80, over E's space), A = 4 registers
-//           of weights.  Lane (g, s) receives features 4 g .. 4 g + 3 = levels 2 g, 2 g + 1 of sample 16 c + s: stored level-major (128-B runs).
-//   dW1[j], db1: per-lane sums over the loop, added up over the four rows g at the end.
-// The weights live in 8 registers per lane instead of 193 wave-uniform values (which the compiler kept in VGPRs: 248 of them, 2 waves per SIMD).
-#define PB_RS 20   // floats per row of E: the 16 lanes of a row group read 16 rows at one column -> banks 20 n + g: 2 lanes per bank (the floor for 64 lanes)
-#define PB_RS2 80  // floats per row of dA^T: ds_write_b128 at 80 j + 16 c + 4 g and ds_read_b32 at 80 (4 t + g) + n are both conflict-free
-#define PB_WAVE_FLOATS (64 * PB_RS + 64)
+//   stage   lane = sample writes its row E[s] = [enc(10) | 1 | 0] (row stride 12 floats) and dd[s] = d_density * selector
+//   forward T_c[j][s] = sum_f W0aug[j][f] E[16 c + s][f]   A = the weights (3 registers per lane hold [w0 | b0] for good), B = E from LDS.
+//           Lane (g, n) receives the pre-activations of the hidden units 4 g + r, r = 0..3, of sample 16 c + n.
+//   out     = b1 + sum_j w1[j] relu(T[j][s]): 4 terms in the lane, then the four rows g are added (two cross-row exchanges)
+//   d_out   = dd * exp(clamp(out)) (one exp per sample and row),  dA[j][s] = [T > 0] d_out w1[j]  -- in the registers of lane (g, n), which is
+//           exactly operand B of
+//   d enc   X_c[f][s] = sum_j W0[j][f] dA[j][16 c + s]   K = j = 4 g + r: straight from the registers, A = 4 registers of weights.  Lane (g, n)
+//           receives features 4 g .. 4 g + 3 = levels 2 g, 2 g + 1 of sample 16 c + n: stored level-major (128-B runs).
+//   weights G[f][j] += sum_s E[s][f] dA[j][s]   K = s: dA goes through LDS once ([s][j] rows of 16 floats) and comes back with the samples on
+//           the k index, beside E^T; row 10 = db0
+//   dW1[j], db1: per-lane sums over the loop, added up over the lanes at the end.
+// The weights live in 11 registers per lane instead of 193 wave-uniform values (which the compiler kept in VGPRs: 248 of them, 2 waves per SIMD).
+#define PB_RS 12   // floats per row of E ([enc(10) | 1 | 0]): 16 rows read at one column -> banks 12 n + g: every bank twice (the floor for 64 lanes)
+#define PB_RS2 16  // floats per row of dA: ds_write_b128 at 16 s + 4 g and ds_read_b32 at 16 (4 t + g) + n are both conflict-free
+#define PB_WAVE_FLOATS (64 * PB_RS + 64 * PB_RS2 + 64)
 #define PB_WAVE_SYNC()                                    \
   do {                                                    \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -136,22 +138,25 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
   __shared__ __attribute__((aligned(16))) float lds[(PB_THREADS / 64) * PB_WAVE_FLOATS];
   tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the scatter that follows on this stream
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int g = lane >> 4, j = lane & 15;
+  const int g = lane >> 4, n = lane & 15;
   float* E = lds + wv * PB_WAVE_FLOATS;
-  float* DA = E;  // dA^T takes E's place once the weight-gradient product has read E
-  float* DD = E + 64 * PB_RS;
-  float wf[3], wb[4];
+  float* DA = E + 64 * PB_RS;
+  float* DD = DA + 64 * PB_RS2;
+  float wf[3], wb[4], w1q[4];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {  // forward operand B[k = feature 4 t + g][n = hidden j]
+  for (int t = 0; t < 3; ++t) {  // forward operand A[i = hidden n][k = feature 4 t + g]
     const int f = 4 * t + g;
-    wf[t] = f < PF ? net.w0[j * PF + f] : (f == PF ? net.b0[j] : 0.0f);
+    wf[t] = f < PF ? net.w0[n * PF + f] : (f == PF ? net.b0[n] : 0.0f);
   }
 #pragma unroll
-  for (int t = 0; t < 4; ++t) wb[t] = j < PF ? net.w0[(4 * t + g) * PF + j] : 0.0f;  // d enc operand A[i = feature j][k = hidden 4 t + g]
-  const float w1j = net.w1[j], b1 = net.b1[0];
+  for (int r = 0; r < 4; ++r) {
+    wb[r] = n < PF ? net.w0[(4 * g + r) * PF + n] : 0.0f;  // d enc operand A[i = feature n][k = g <-> hidden 4 g + r] of k-step r
+    w1q[r] = net.w1[4 * g + r];
+  }
+  const float b1 = net.b1[0];
   int64_t P = N * (int64_t)S;
   f32x4_t G = {0.f, 0.f, 0.f, 0.f};
-  float dw1 = 0.0f, sum_dout = 0.0f;
+  float dw1[4] = {0.f, 0.f, 0.f, 0.f}, sum_dout = 0.0f;
   for (int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64; base < P; base += (int64_t)gridDim.x * blockDim.x) {
     {
       const int64_t i = base + lane;
@@ -177,67 +182,59 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
       DD[lane] = dd;
     }
     PB_WAVE_SYNC();
-    // ---- forward: pre-activations of hidden unit j for the samples 16 c + 4 g + r
-    f32x4_t T[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      // ---- forward: pre-activations of the hidden units 4 g + r of sample 16 c + n
+      f32x4_t T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(E[(16 * c + j) * PB_RS + 4 * t + g], wf[t], acc, 0, 0, 0);
-      T[c] = acc;
-    }
-    float da[4][4];
+      for (int t = 0; t < 3; ++t) T = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], E[(16 * c + n) * PB_RS + 4 * t + g], T, 0, 0, 0);
+      float part = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 dd4 = *reinterpret_cast<const float4*>(DD + 16 * c + 4 * g);
-      const float ddr[4] = {dd4.x, dd4.y, dd4.z, dd4.w};
+      for (int r = 0; r < 4; ++r) part = fmaf(w1q[r], fmaxf(T[r], 0.0f), part);
+      part += __shfl_xor(part, 16, 64);  // the four rows hold the four quarters of the hidden layer
+      part += __shfl_xor(part, 32, 64);
+      const float d_out = DD[16 * c + n] * expf(fminf(fmaxf(b1 + part, -15.0f), 15.0f));  // trunc_exp backward (the clamped exp is finite: 0 stays 0)
+      if (g == 0) sum_dout += d_out;  // (every row computes it: one of them counts)
+      float da[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float h = fmaxf(T[c][r], 0.0f);
-        const float out = b1 + prop_row_sum(w1j * h);
-        const float d_out = ddr[r] * expf(fminf(fmaxf(out, -15.0f), 15.0f));  // trunc_exp backward (the clamped exp is finite: 0 stays 0, no branch)
-        sum_dout += d_out;
-        dw1 = fmaf(d_out, h, dw1);
-        da[c][r] = T[c][r] > 0.0f ? d_out * w1j : 0.0f;
+        dw1[r] = fmaf(d_out, fmaxf(T[r], 0.0f), dw1[r]);
+        da[r] = T[r] > 0.0f ? d_out * w1q[r] : 0.0f;
       }
-    }
-    // ---- dW0 | db0 (transposed: [feature][hidden]): K = the wave's 64 samples, in the order the registers hold them
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = E[(16 * c + 4 * g + r) * PB_RS + j];
-        G = __builtin_amdgcn_mfma_f32_16x16x4f32(j < 12 ? e : 0.0f, da[c][r], G, 0, 0, 0);  // (columns 12..15 of a row are the next row's padding)
-      }
-    PB_WAVE_SYNC();  // every lane is done with E
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<float4*>(DA + j * PB_RS2 + 16 * c + 4 * g) = make_float4(da[c][0], da[c][1], da[c][2], da[c][3]);
-    PB_WAVE_SYNC();
-    // ---- d enc of sample 16 c + j, features 4 g .. 4 g + 3
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
+      // ---- d enc of sample 16 c + n, features 4 g .. 4 g + 3: K = hidden, k-step r <-> hidden 4 g + r, straight from the registers
       f32x4_t X = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 4; ++t) X = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[t], DA[(4 * t + g) * PB_RS2 + 16 * c + j], X, 0, 0, 0);
-      const int64_t is = base + 16 * c + j;
+      for (int r = 0; r < 4; ++r) X = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[r], da[r], X, 0, 0, 0);
+      const int64_t is = base + 16 * c + n;
       if (is < P && g < 3) {  // level-major [PL][P] float2: 16 lanes write 128 consecutive bytes (the bin pass reads them the same way)
         *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g) * P + is) * 2) = make_float2(X[0], X[1]);
         if (g < 2) *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g + 1) * P + is) * 2) = make_float2(X[2], X[3]);
       }
+      // dA[s][j] rows for the weight-gradient product
+      *reinterpret_cast<float4*>(DA + (16 * c + n) * PB_RS2 + 4 * g) = make_float4(da[0], da[1], da[2], da[3]);
     }
-    PB_WAVE_SYNC();  // dA^T has been read: the next trip may write E
+    PB_WAVE_SYNC();
+    // ---- dW0 | db0 (transposed: [feature][hidden]): K = the wave's 64 samples, four at a time
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float e = n < PB_RS ? E[(4 * t + g) * PB_RS + n] : 0.0f;
+      G = __builtin_amdgcn_mfma_f32_16x16x4f32(e, DA[(4 * t + g) * PB_RS2 + n], G, 0, 0, 0);
+    }
+    PB_WAVE_SYNC();  // E, dA and dd have been read: the next trip may write them
   }
   // ---- block-level sum: every wave leaves its partial sums in its own LDS region, 273 threads add them up, one atomic per weight and block.
-  // register r of lane (g, j) = G[feature 4 g + r][hidden j]
-  dw1 += __shfl_xor(dw1, 16, 64);
-  dw1 += __shfl_xor(dw1, 32, 64);
-  sum_dout += __shfl_xor(sum_dout, 16, 64);  // (the 16 lanes of a row hold the same sum: rows, not lanes, are added)
-  sum_dout += __shfl_xor(sum_dout, 32, 64);
+  // register r of lane (g, n) = G[feature 4 g + r][hidden n];  dw1[r] of lane (g, n) = this lane's samples' share of dW1[4 g + r]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dw1[r] = prop_row_sum(dw1[r]);
+  sum_dout = tn_wave_sum(sum_dout);
   {
     float* mine = E;  // [0..255] [feature][hidden] tile (rows 0..9 dW0^T, row 10 db0), [256..271] dW1, [272] db1
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mine[(4 * g + r) * 16 + j] = G[r];
-    if (lane < 16) mine[256 + lane] = dw1;
+    for (int r = 0; r < 4; ++r) mine[(4 * g + r) * 16 + n] = G[r];
+    if (n == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[256 + 4 * g + r] = dw1[r];
+    }
     if (lane == 0) mine[272] = sum_dout;
   }
   __syncthreads();
