@@ -82,6 +82,11 @@ const char* tn_last_error(void);
 int tn_version(void);
 /* bytes of device scratch tn_field_* need for `num_points` samples (packed weights + saved activations). */
 int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
+/* Work plan of the field's hash-grid gather (HashEncoding.pytorch_fwd, field_components/encodings.py:401-461), for tests and diagnostics.
+ * The gather is XCD-affine: workgroup b runs on XCD b % 8 and reads ONE level, so that a hashed level's table is served from that XCD's L2;
+ * XCD x runs level x for all samples, then level x + 8.  out [8][2][3] int32: item i of XCD x = {level (-1: unused), first chunk,
+ * chunk count}.  Returns the number of chunks per level (every level's chunks appear exactly once in the plan) or TN_EINVAL. */
+int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, int32_t* out);
 
 /* ---- N2  PatchPixelSampler.sample on a jagged image list + ground-truth gather (data/pixel_samplers.py:296-337 collate_image_dataset_batch_list,
  *          :389-441 PatchPixelSampler.sample_method without masks; what VanillaDataManager.next_train does on the host every step,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "tn_last_error": (C.c_char_p, []),
     "tn_version": (C.c_int, []),
     "tn_field_workspace_bytes": (_i64, [_i64, _i32]),
+    "tn_field_encode_plan": (_i32, [_p, _i64, _p]),
     "tn_prop_workspace_bytes": (_i64, [_i64]),
     "tn_sample_pixels": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "tn_raygen": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p]),

@@ -3,15 +3,16 @@
 //                                                              fields/thermal_nerfacto_field.py:91-99)
 //
 // Kernels:
-//   k_field_fwd_fused  gather + MFMA: one wave = 32 samples.  lane = (sample, half of the levels): contraction + selector + 8 levels x 8
-//                                     corners (all 64 fetches in flight at once) land directly in the D-layout of the first layer's B operand;
-//                                     then Linear(32,64) ReLU Linear(64,16) | head Linear(64 slots,64) ReLU Linear(64,64) ReLU Linear(64,C)
-//                                     sigmoid, every layer as v_mfma_f32_32x32x2_f32 on OUT^T = W . IN^T so that a layer's accumulator tile
-//                                     IS the next layer's B operand (no LDS round trip, no cross-lane traffic between layers).
+//   k_field_pos        streaming    : contracted position + selector of every sample, once
+//   k_field_encode_xcd gather       : XCD-affine and level-major -- block b runs on XCD b % 8 and gathers from ONE level, so that a hashed
+//                                     level's 4 MB table is served from that XCD's L2 while all samples visit it (thread = 4 samples)
+//   k_field_mlp_fwd    MFMA chain   : one wave = 32 samples: Linear(32,64) ReLU Linear(64,16) | head Linear(64 slots,64) ReLU Linear(64,64)
+//                                     ReLU Linear(64,C) sigmoid, every layer as v_mfma_f32_32x32x2_f32 on OUT^T = W . IN^T so that a layer's
+//                                     accumulator tile IS the next layer's B operand (no LDS round trip, no cross-lane traffic between layers).
 //   k_field_bwd_fused  MFMA chain   : dIN^T = W^T . dOUT^T with the same trick AND every weight gradient dW = dY^T X (operands transposed
 //                                     through per-wave LDS tiles), bias sums, appearance-embedding rows: one launch, one wave per SIMD
 //   k_field_dpos       streaming    : d position from d enc and the forward's saved d enc / d offset, beside the table scatter
-//   k_field_encode + k_field_density_only : the density-only evaluation (config 2's cross terms)
+//   k_field_density_only            : the first two layers alone: the density-only evaluation (config 2's cross terms)
 //   table-gradient scatter: tn_scatter.hip
 //
 // Register layout used everywhere ("D-layout" of v_mfma_f32_32x32x2_f32): lane = (j = lane&31 -> sample in the tile,
@@ -111,24 +112,30 @@ __global__ void k_field_pack(FieldK f, float* __restrict__ pack) {
 }
 
 // ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
+// Per-level tensors (enc, d enc / d offset, d enc) are LEVEL-MAJOR with a row stride of PT = samples rounded up to whole 32-sample tiles:
+// the XCD-affine encode writes one level at a time, the MFMA kernels read 8 levels per lane as coalesced float2 runs.
 // Saved activations are kept in FRAGMENT ORDER: [tile of 32 samples][m (32-feature tile)][g][lane] float4, where lane (j = sample, h) of
 // register group g holds features 32 m + 8 g + 4 h + {0..3} -- exactly what a wave holds in the D-layout, so every store / load instruction
-// of a wave moves one contiguous KiB (sample-major rows cost four 32-byte pieces per 128-byte line: 4x the L2 transactions; the training
-// forward writes 300 MB).  Nothing outside this file reads them.
+// of a wave moves one contiguous KiB (sample-major rows cost four 32-byte pieces per 128-byte line: 4x the L2 transactions).
+// Nothing outside this file reads them.
 struct FieldWs {
   float* pack;     // PACK_TOTAL_FLOATS
-  float* enc;      // [tiles][1][4][64] float4   hash encoding (32 features)
+  float* pos;      // [P] float4: contracted position in [0,1]^3 (masked) and the selector (k_field_pos)
+  float* enc;      // [16][PT] float2   hash encoding, level-major
   float* sel;      // [P]
+  float* sh;       // [rays][2][8]: SH16 of the ray's direction in D-layout order (entry [h][r] = sh[R(r,h)]); sized for S = 1
   // training only
   float* h1;       // [tiles][2][4][64] float4   relu(base layer 0)
-  float* hin;      // head input in slot space: sh16 | base_out16 | emb32
+  float* hin;      // [tiles][2][64] float4      the 16 base-MLP outputs (head-input slots 16..31; SH and the appearance embedding are per-ray:
+                   //                            the backward rebuilds them)
   float* hh1;      // relu(head layer 0)
   float* hh2;      // relu(head layer 1)
   float* y;        // [P][4]   sigmoid outputs (for the sigmoid derivative)
   float* g_enc;    // [16][P] float2  d enc, LEVEL-major (read by the table scatter's bin pass and k_field_dpos)
-  float* jac;      // res * d enc / d offset: 16 levels x 2 features x 3 axes per sample, [tile][q][k][lane] float4
-                   // (written by the training forward, read by k_field_dpos with the same lane mapping)
+  float* jac;      // res * d enc / d offset: [16 levels][3 axes][PT] float2 = (feature 0, feature 1) (written by the training encode, read by
+                   // k_field_dpos)
   void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
+  int64_t PT;      // row stride of the level-major tensors
   int64_t bytes;
 };
 static inline FieldWs ws_layout(void* base, int64_t P, int training) {
@@ -141,11 +148,14 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     return r;
   };
   const int64_t PT = tn_cdiv(P, 32) * 32;  // whole tiles
+  w.PT = PT;
   w.pack = take(PACK_TOTAL_FLOATS);
+  w.pos = take(P * 4);
   w.enc = take(PT * 32);
   w.sel = take(P);
+  w.sh = take(P * 16);
   if (training) {
-    w.h1 = take(PT * 64); w.hin = take(PT * 64); w.hh1 = take(PT * 64); w.hh2 = take(PT * 64); w.y = take(P * 4);
+    w.h1 = take(PT * 64); w.hin = take(PT * 16); w.hh1 = take(PT * 64); w.hh2 = take(PT * 64); w.y = take(P * 4);
     w.g_enc = take(P * 32);
     w.jac = take(PT * 96);
     w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
@@ -161,62 +171,156 @@ extern "C" int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training
   return ws_layout(nullptr, num_points, training).bytes;
 }
 
-// ---- encode ------------------------------------------------------------------------------------------------------------
-// thread = (sample p, half h): levels {4q + 2h, 4q + 2h + 1 : q = 0..3}  <->  features 8g + 4h + {0..3}, g = 0..3
-// JAC (training): also res * d enc / d offset per level and feature (6 floats per level -> jac[P][96]); the backward turns d enc into
-// d position with it (k_field_dpos) instead of gathering the 8 x 16 corners again inside the table-gradient scatter.
-template <bool JAC>
-__global__ void __launch_bounds__(256) k_field_encode(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                      const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ enc,
-                                                      float* __restrict__ sel, float* __restrict__ jac) {
-  int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    // lanes 0-31: h=0 of 32 consecutive samples, lanes 32-63: h=1 of the same samples (matches the MFMA tile layout)
-    int64_t tile = idx >> 6;
-    int lane = (int)(idx & 63);
-    int h = lane >> 5;
-    int64_t p = tile * 32 + (lane & 31);
-    const bool live = p < N * (int64_t)S;
-    if (!live) p = N * (int64_t)S - 1;  // whole tiles are written (fragment order): the lanes past the end repeat the last sample
-    int64_t ray = tn_div_index(p, S, N * (int64_t)S);
-    int s = (int)(p - ray * S);
+// ---- positions ---------------------------------------------------------------------------------------------------------
+// thread = sample: Frustums.get_positions + SceneContraction + (x+2)/4 + selector, once per sample (the encode below visits a sample once per
+// LEVEL and reads the 16 bytes written here instead of repeating two loads of the ray, the division by S and the contraction)
+__device__ __forceinline__ void sh16(float dx, float dy, float dz, float* c);
+__global__ void __launch_bounds__(256) k_field_pos(const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ e_bins,
+                                                   int64_t N, int S, float4* __restrict__ pos, float* __restrict__ sel, float* __restrict__ shtab) {
+  const int64_t P = N * (int64_t)S;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ray = tn_div_index(p, S, P);
+    const int s = (int)(p - ray * S);
     const float* o = origins + ray * 3;
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
-    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
-    if (h == 0 && live) sel[p] = c.sel ? 1.0f : 0.0f;
+    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+    const float m = c.sel ? 1.0f : 0.0f;
+    pos[p] = make_float4(c.px, c.py, c.pz, m);
+    sel[p] = m;
+    if (s == 0) {  // the ray's SH16 (a per-ray constant of the colour head's input), in the order the MFMA kernels' lanes hold it
+      float sh[16];
+      sh16(d[0], d[1], d[2], sh);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int l0 = 4 * q + 2 * h;
-      float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
-      if (JAC) {
-        float ja[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, jb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (l0 < g.L) a = tn_encode_level_jac(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize, ja);
-        if (l0 + 1 < g.L) b = tn_encode_level_jac(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize, jb);
-        // fragment order [tile][q][k][lane] float4: every store instruction of the wave writes one contiguous KiB (sample-major rows would be
-        // 48-byte pieces 384 B apart: the 75 MB cost 35 us that way)
-        v4f_t* jp = reinterpret_cast<v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;
-        const v4f_t j0 = {ja[0], ja[1], ja[2], ja[3]}, j1 = {ja[4], ja[5], jb[0], jb[1]}, j2 = {jb[2], jb[3], jb[4], jb[5]};
-        if (FRAG_NT) { __builtin_nontemporal_store(j0, jp); __builtin_nontemporal_store(j1, jp + 64); __builtin_nontemporal_store(j2, jp + 128); }
-        else { jp[0] = j0; jp[64] = j1; jp[128] = j2; }
-      } else {
-        if (l0 < g.L) a = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0], g.mask, (uint32_t)l0 * g.tsize);
-        if (l0 + 1 < g.L) b = tn_encode_level(g.table, c.px, c.py, c.pz, g.res[l0 + 1], g.mask, (uint32_t)(l0 + 1) * g.tsize);
-      }
-      reinterpret_cast<float4*>(enc)[(tile * 4 + q) * 64 + lane] = make_float4(a.x, a.y, b.x, b.y);  // fragment order
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) shtab[ray * 16 + hh * 8 + r] = sh[(r & 3) + 8 * (r >> 2) + 4 * hh];
+    }
+  }
+}
+
+// ---- encode, XCD-affine and level-major ------------------------------------------------------------------------------------
+// The 11 hashed levels of the default grid are 4 MB each: 46 MB that no L2 holds (4 MB per XCD), so a kernel in which every CU gathers from
+// every level runs at the chip's random-line rate beyond L2 (55-59 G lines/s: scripts/microbench/gather_rate.hip).  Workgroups are dealt to
+// the 8 XCDs round-robin by index, so block b runs on XCD b % 8: here it gathers from ONE level, and an XCD only ever sees the levels of its
+// own work list (EncSched: one hashed level at a time, in list order) -- the level's table stays in that XCD's L2 while all samples visit it.
+// scripts/microbench/encode_xcd.hip: 104 -> 67 us for 4096 x 48 samples against the lane = (sample, half of the levels) mapping.
+// A LANE PAIR per sample: the even lane fetches the four corners with x = ceil, the odd lane those with x = floor.  The two x neighbours of a
+// corner pair differ in the low bits of the hashed index only -- same 64-B line 7 times out of 8 -- and as adjacent lanes of ONE load
+// instruction they cost the texture path one line instead of two (67 -> 52 us in the microbenchmark).  The pair swaps one component per
+// corner over DPP and each lane interpolates ONE of the two features (a + b == b + a exactly, so the odd lane's x lerp  f3 ux + f0 ox  is the
+// reference's  f0 ox + f3 ux  bit for bit); outputs are level-major [L][PT] float2 = consecutive floats of the two lanes.
+// JAC (training): also res * d enc / d offset (3 floats per lane, planes [L][3 axes][PT] float2 = (feature 0, feature 1)): the backward turns
+// d enc into d position with it (k_field_dpos) instead of gathering the 8 x 16 corners again inside the table-gradient scatter.
+#ifndef ENC_PER
+#define ENC_PER 4        // samples per lane pair
+#endif
+#define ENC_CHUNK (128 * ENC_PER)  // samples per block
+#define ENC_MAX_ITEMS 2  // work items per XCD (TN_MAX_LEVELS / 8)
+static_assert(TN_MAX_LEVELS <= 8 * ENC_MAX_ITEMS, "encode plan");
+struct EncSched {
+  // XCD x runs its items in order; item i covers chunks [c0, c0 + first[i+1] - first[i]) of level `level`
+  int16_t level[8][ENC_MAX_ITEMS];
+  int32_t first[8][ENC_MAX_ITEMS + 1];  // prefix sum of the items' chunk counts: block q of XCD x belongs to the item with first[i] <= q < first[i+1]
+  int32_t c0[8][ENC_MAX_ITEMS];
+  int32_t blocks_per_xcd;               // max over x of first[x][last]
+};
+// Which XCD gathers which (level, chunk range): XCD x runs level x for all samples, then level x + 8.  With the default grid that leaves XCDs
+// 5-7 with two hashed levels and the others with one small + one hashed level.  Dealing the chunks out by cost instead (the levels' chunks on
+// one line, cut into 8 equal parts: every XCD one whole level plus pieces of others) was measured and LOST: 57.5 -> 58.8-63.0 us -- every
+// extra (XCD, level) pair is another 4 MB that an L2 has to fill from cold, and the launch is bound by L2 -> L1 line traffic, not by the
+// busiest XCD alone (profiles/r04_experiments.md).
+static EncSched make_enc_sched(const TnGrid& g, int64_t P) {
+  EncSched sc;
+  const int chunks = (int)tn_cdiv(P, ENC_CHUNK);
+  int mx = 0;
+  for (int x = 0; x < 8; ++x) {
+    int n = 0;
+    sc.first[x][0] = 0;
+    for (int l = x; l < g.num_levels && n < ENC_MAX_ITEMS; l += 8) {
+      sc.level[x][n] = (int16_t)l;
+      sc.c0[x][n] = 0;
+      sc.first[x][n + 1] = sc.first[x][n] + chunks;
+      ++n;
+    }
+    for (int i = n; i < ENC_MAX_ITEMS; ++i) { sc.level[x][i] = -1; sc.c0[x][i] = 0; sc.first[x][i + 1] = sc.first[x][n]; }
+    mx = sc.first[x][n] > mx ? sc.first[x][n] : mx;
+  }
+  sc.blocks_per_xcd = mx;
+  return sc;
+}
+template <bool JAC>
+__global__ void __launch_bounds__(256) k_field_encode_xcd(GridK g, EncSched sc, const float4* __restrict__ pos, int64_t P, int64_t PT,
+                                                          float* __restrict__ enc, float* __restrict__ jac) {
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  int item = 0;
+#pragma unroll
+  for (int i = 1; i < ENC_MAX_ITEMS; ++i) item += (q >= sc.first[x][i]) ? 1 : 0;
+  if (q >= sc.first[x][ENC_MAX_ITEMS]) return;
+  const int l = sc.level[x][item];
+  const int chunk = sc.c0[x][item] + (q - sc.first[x][item]);
+  const float res = g.res[l];
+  const uint32_t off = (uint32_t)l * g.tsize;
+  const int side = threadIdx.x & 1;  // 0: the corners with x = ceil and feature 0, 1: x = floor and feature 1
+  const int64_t base = (int64_t)chunk * ENC_CHUNK + (threadIdx.x >> 1);
+  float2 fv[ENC_PER][4];
+  float ox[ENC_PER], oy[ENC_PER], oz[ENC_PER];
+#pragma unroll
+  for (int u = 0; u < ENC_PER; ++u) {
+    int64_t p = base + u * 128;
+    if (p >= P) p = P - 1;
+    const float4 c = pos[p];
+    // tn_level_corners, this lane's half: slots 0..3 = (x, c, c) (x, f, c) (x, c, f) (x, f, f)  <->  f0|f3, f1|f2, f4|f7, f5|f6
+    const float sx = c.x * res, sy = c.y * res, sz = c.z * res;
+    const float fxf = floorf(sx), fyf = floorf(sy), fzf = floorf(sz);
+    const uint32_t xi = side ? (uint32_t)(int)fxf : (uint32_t)(int)ceilf(sx);
+    const uint32_t hcy = (uint32_t)(int)ceilf(sy) * TN_PRIME_Y, hfy = (uint32_t)(int)fyf * TN_PRIME_Y;
+    const uint32_t hcz = (uint32_t)(int)ceilf(sz) * TN_PRIME_Z, hfz = (uint32_t)(int)fzf * TN_PRIME_Z;
+    ox[u] = sx - fxf; oy[u] = sy - fyf; oz[u] = sz - fzf;
+    fv[u][0] = g.table[((xi ^ hcy ^ hcz) & g.mask) + off];
+    fv[u][1] = g.table[((xi ^ hfy ^ hcz) & g.mask) + off];
+    fv[u][2] = g.table[((xi ^ hcy ^ hfz) & g.mask) + off];
+    fv[u][3] = g.table[((xi ^ hfy ^ hfz) & g.mask) + off];
+  }
+#pragma unroll
+  for (int u = 0; u < ENC_PER; ++u) {
+    const int64_t p = base + u * 128;
+    const float ux = 1.0f - ox[u], uy = 1.0f - oy[u], uz = 1.0f - oz[u];
+    const float wk = side ? ux : ox[u], wr = side ? ox[u] : ux;  // weights of the kept corner (own x) and the received one (the partner's x)
+    float t[4], dk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float keep = side ? fv[u][k].y : fv[u][k].x, send = side ? fv[u][k].x : fv[u][k].y;
+      const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+      t[k] = keep * wk + recv * wr;                     // f03, f12, f47, f56 of this lane's feature
+      if (JAC) dk[k] = side ? recv - keep : keep - recv;  // f0 - f3, f1 - f2, f4 - f7, f5 - f6
+    }
+    const float f0312 = t[0] * oy[u] + t[1] * uy, f4756 = t[2] * oy[u] + t[3] * uy;
+    const float r = f0312 * oz[u] + f4756 * uz;
+    if (p >= P) continue;
+    enc[((int64_t)l * PT + p) * 2 + side] = r;
+    if (JAC) {
+      const float dx = (dk[0] * oy[u] + dk[1] * uy) * oz[u] + (dk[2] * oy[u] + dk[3] * uy) * uz;
+      const float dy = (t[0] - t[1]) * oz[u] + (t[2] - t[3]) * uz;
+      const float dz = f0312 - f4756;
+      float* jp = jac + ((int64_t)l * 3 * PT + p) * 2 + side;
+      __builtin_nontemporal_store(dx * res, jp);
+      __builtin_nontemporal_store(dy * res, jp + 2 * PT);
+      __builtin_nontemporal_store(dz * res, jp + 4 * PT);
     }
   }
 }
 
 // d position of every sample from d enc and the saved derivatives: dp_axis = sum_l sum_f g_enc[2l + f] * jac[l][f][axis]; then the
 // backward of contraction / frustum position and the per-ray sums into d origins / d directions (same arithmetic as the table scatter's
-// own d-position path, which stays for tn_hash_scatter and the proposal grids).  Lane mapping = k_field_encode's.
+// own d-position path, which stays for tn_hash_scatter and the proposal grids).  lane = (sample j of the tile, half h of the levels).
 __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ origins, const float* __restrict__ directions,
                                                     const float* __restrict__ e_bins, const float* __restrict__ g_enc, const float* __restrict__ jac,
-                                                    int64_t N, int S, float* __restrict__ d_origins, float* __restrict__ d_directions) {
+                                                    int64_t N, int S, int L, int64_t PT, float* __restrict__ d_origins, float* __restrict__ d_directions) {
   const int64_t P = N * (int64_t)S;
   const int64_t ntiles = tn_cdiv(P, 32);
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  typedef float v2f_t __attribute__((ext_vector_type(2)));
   for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * (blockDim.x >> 6)) {
     const int64_t p = tile * 32 + j;
     const bool live = p < P;
@@ -224,15 +328,26 @@ __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ or
     float dx = 0.f, dy = 0.f, dz = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float2 ga = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h) * 2 * P + 2 * pc);      // level-major [16][P] float2
-      const float2 gb = *reinterpret_cast<const float2*>(g_enc + (int64_t)(4 * q + 2 * h + 1) * 2 * P + 2 * pc);
-      const float4 gv = make_float4(ga.x, ga.y, gb.x, gb.y);
-      const v4f_t* jp = reinterpret_cast<const v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order, as the forward wrote it
-      const v4f_t j0 = FRAG_NT ? __builtin_nontemporal_load(jp) : jp[0], j1 = FRAG_NT ? __builtin_nontemporal_load(jp + 64) : jp[64],
-                  j2 = FRAG_NT ? __builtin_nontemporal_load(jp + 128) : jp[128];
-      dx += gv.x * j0.x + gv.y * j0.w + gv.z * j1.z + gv.w * j2.y;
-      dy += gv.x * j0.y + gv.y * j1.x + gv.z * j1.w + gv.w * j2.z;
-      dz += gv.x * j0.z + gv.y * j1.y + gv.z * j2.x + gv.w * j2.w;
+      float2 gl[2];
+      v2f_t jl[2][3];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int l = 4 * q + 2 * h + e;
+        if (l < L) {
+          gl[e] = *reinterpret_cast<const float2*>(g_enc + (int64_t)l * 2 * P + 2 * pc);  // level-major [16][P] float2
+          const v2f_t* jp = reinterpret_cast<const v2f_t*>(jac) + (int64_t)l * 3 * PT + pc;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) jl[e][k] = __builtin_nontemporal_load(jp + k * PT);
+        } else {
+          gl[e] = make_float2(0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) jl[e][k] = v2f_t{0.f, 0.f};
+        }
+      }
+      // plane k of a level = (d enc_0 / d o_k, d enc_1 / d o_k) * res
+      dx += gl[0].x * jl[0][0].x + gl[0].y * jl[0][0].y + gl[1].x * jl[1][0].x + gl[1].y * jl[1][0].y;
+      dy += gl[0].x * jl[0][1].x + gl[0].y * jl[0][1].y + gl[1].x * jl[1][1].x + gl[1].y * jl[1][1].y;
+      dz += gl[0].x * jl[0][2].x + gl[0].y * jl[0][2].y + gl[1].x * jl[1][2].x + gl[1].y * jl[1][2].y;
     }
     dx += __shfl_xor(dx, 32, 64); dy += __shfl_xor(dy, 32, 64); dz += __shfl_xor(dz, 32, 64);
     const int64_t ray = tn_div_index(pc, S, P);
@@ -344,25 +459,53 @@ __device__ __forceinline__ f32x16 load_frag(const float* __restrict__ base, int6
   }
   return v;
 }
-// the density logit = head-input slot 16 = tile 0, register group 2, half 0, component 0 of sample j
-__device__ __forceinline__ int64_t hin_logit_index(int64_t tile, int j) { return (((tile * 2 + 0) * 4 + 2) * 64 + j) * 4; }
+// the 16 base-MLP outputs of a tile (registers 0..7 of the Linear(64,16) accumulator: rows R(r,h) < 16) as [tile][2][lane] float4
+__device__ __forceinline__ void store_bo(float* __restrict__ base, int64_t tile, int lane, const f32x16& bo) {
+  v4f_t* b = reinterpret_cast<v4f_t*>(base) + tile * 128 + lane;
+  const v4f_t t0 = {bo[0], bo[1], bo[2], bo[3]}, t1 = {bo[4], bo[5], bo[6], bo[7]};
+  if (FRAG_NT) { __builtin_nontemporal_store(t0, b); __builtin_nontemporal_store(t1, b + 64); }
+  else { b[0] = t0; b[64] = t1; }
+}
+// the density logit = head-input slot 16 = base output row 0 = group 0, half 0, component 0 of sample j
+__device__ __forceinline__ int64_t hin_logit_index(int64_t tile, int j) { return (tile * 128 + j) * 4; }
+// level-major encoding -> the D-layout of the first layer's B operand: registers 4q .. 4q+3 = levels 4q + 2h (f0, f1), 4q + 2h + 1 (f0, f1)
+// (one 32-bit lane offset for all eight loads on top of wave-uniform bases: a 64-bit address per load costs the one-wave-per-SIMD backward
+// kernel 16 registers it does not have.  (2 PT + P) * 8 < 2^32 is checked on the host.)
+__device__ __forceinline__ f32x16 load_enc_lm(const float* __restrict__ enc, int64_t PT, int64_t pc, int h, int L) {
+  f32x16 v;
+  const uint32_t voff = (uint32_t)(((int64_t)(2 * h) * PT + pc) * 8);
+  const char* e = reinterpret_cast<const char*>(enc);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int l0 = 4 * q + 2 * h;
+    const char* b0 = e + (int64_t)(4 * q) * PT * 8;  // wave-uniform
+    const float2 a = l0 < L ? *reinterpret_cast<const float2*>(b0 + voff) : make_float2(0.f, 0.f);
+    const float2 b = l0 + 1 < L ? *reinterpret_cast<const float2*>(b0 + PT * 8 + voff) : make_float2(0.f, 0.f);
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = b.x; v[4 * q + 3] = b.y;
+  }
+  return v;
+}
 
-// ---- forward, one launch: 16-level gather + MLP chain (the fused gather + MLP) ---------------------------------------
-// k_field_fwd_fused = k_field_encode + k_field_mlp_fwd.  The lane mapping of the encode (lane = (sample j, half h): levels 4q + 2h, 4q + 2h + 1)
-// IS the D-layout of the first layer's B operand (registers 4q .. 4q+3 = features 8q + 4h + {0..3}), so the encoding goes from the gather
-// straight into the MFMA chain: no enc[P][32] round trip (25 MB written + read), one launch and one dependent boundary less.  Two blocks per
-// CU (two waves per SIMD): one wave's gather latency is covered by the other wave's 180 MFMAs.  TRAIN keeps what the backward needs
-// (enc for the first layer's weight gradient, d enc / d offset for d position, the activations).
+// ---- forward MLP chain ----------------------------------------------------------------------------------------------
+// The gather is k_field_encode_xcd's; this kernel is the chain alone.  Round 3 ran both in one launch (lane = (sample, half of the levels), the
+// encoding went from the gather straight into the first MFMA): 145 us at 4096 x 48 samples, of which the gather alone -- at the chip's
+// random-line rate beyond L2 -- is 104 us and the 224 MFMAs per tile 36 us: with two waves per SIMD the two hardly overlapped.  With the
+// XCD-affine encode (67 us) the chain reads 25 MB of encoding back and is bound by its MFMAs and, in training, its activation stores.
+// TRAIN keeps what the backward needs: relu(h1), the 16 base outputs, relu(hh1), relu(hh2), the sigmoid outputs.  SH16 and the appearance
+// embedding (48 of the 64 head-input slots) are per-ray constants: the backward rebuilds them (bit-identical: same code).
 #ifndef FWD_THREADS
 #define FWD_THREADS 256
 #endif
+// FWD_ABLATE (compile-time, timing diagnostics only -- the backward is wrong with it): 1 no activation stores
+#ifndef FWD_ABLATE
+#define FWD_ABLATE 0
+#endif
 template <bool TRAIN>
-__global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fused(GridK g, const float* __restrict__ pack, const float* __restrict__ origins,
-                                                            const float* __restrict__ directions, const float* __restrict__ e_bins,
+__global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ encs, int L,
+                                                            int64_t PT, const float* __restrict__ sels, const float* __restrict__ shtab,
                                                             const int64_t* __restrict__ cam_idx, const float* __restrict__ emb, int num_images,
                                                             int use_cam_emb, int64_t N, int S, int C, float* __restrict__ density,
-                                                            float* __restrict__ rgb, float* __restrict__ density_pre, float* __restrict__ encs,
-                                                            float* __restrict__ sels, float* __restrict__ jac, float* __restrict__ h1s,
+                                                            float* __restrict__ rgb, float* __restrict__ density_pre, float* __restrict__ h1s,
                                                             float* __restrict__ hins, float* __restrict__ hh1s, float* __restrict__ hh2s,
                                                             float* __restrict__ ys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_FWD_TOTAL floats
@@ -376,61 +519,18 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 #define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
+  f32x16 nin;  // the next tile's encoding, requested one tile ahead
+  if (wave < ntiles) {
+    const int64_t p0 = wave * TILE + j;
+    nin = load_enc_lm(encs, PT, p0 < P ? p0 : P - 1, h, L);
+  }
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t p = tile * TILE + j;
     const bool valid = p < P;
     const int64_t pc = valid ? p : P - 1;
     const int64_t ray = tn_div_index(pc, S, P);
-    const int s = (int)(pc - ray * S);
-    // ---------------- contraction + 8 levels x 8 corners for this lane's half of the levels
-    const float* o = origins + ray * 3;
-    const float* d = directions + ray * 3;
-    const float* eb = e_bins + ray * (S + 1) + s;
-    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
-    const float sl = c.sel ? 1.0f : 0.0f;
-    // all 64 corner fetches of the lane are issued before the first one is used: the wave pays the table's latency (L2 miss -> Infinity
-    // Cache for most of the 64 MB) once per tile, not once per level (hipcc otherwise waits level by level: 8 loads in flight per wave)
-    f32x16 in0;
-    LevelCorners lc[8];
-    float2 fv[8][8];
-#pragma unroll
-    for (int qi = 0; qi < 8; ++qi) {
-      const int l = 4 * (qi >> 1) + 2 * h + (qi & 1);
-      const int lcl = l < g.L ? l : g.L - 1;  // (levels beyond L read level L-1 and are zeroed below)
-      tn_level_corners(c.px, c.py, c.pz, g.res[lcl], g.mask, (uint32_t)lcl * g.tsize, lc[qi]);
-    }
-#pragma unroll
-    for (int qi = 0; qi < 8; ++qi)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) fv[qi][k] = g.table[lc[qi].idx[k]];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int l0 = 4 * q + 2 * h;
-      float2 a, b;
-      if (TRAIN) {
-        float ja[6], jb[6];
-        a = tn_level_interp_jac(fv[2 * q], lc[2 * q].ox, lc[2 * q].oy, lc[2 * q].oz, g.res[l0 < g.L ? l0 : g.L - 1], ja);
-        b = tn_level_interp_jac(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz, g.res[l0 + 1 < g.L ? l0 + 1 : g.L - 1], jb);
-        if (l0 >= g.L) { a = make_float2(0.f, 0.f); ja[0] = ja[1] = ja[2] = ja[3] = ja[4] = ja[5] = 0.0f; }
-        if (l0 + 1 >= g.L) { b = make_float2(0.f, 0.f); jb[0] = jb[1] = jb[2] = jb[3] = jb[4] = jb[5] = 0.0f; }
-        v4f_t* jp = reinterpret_cast<v4f_t*>(jac) + ((tile * 4 + q) * 3) * 64 + lane;  // fragment order (see k_field_encode)
-        const v4f_t j0 = {ja[0], ja[1], ja[2], ja[3]}, j1 = {ja[4], ja[5], jb[0], jb[1]}, j2 = {jb[2], jb[3], jb[4], jb[5]};
-        if (FRAG_NT) { __builtin_nontemporal_store(j0, jp); __builtin_nontemporal_store(j1, jp + 64); __builtin_nontemporal_store(j2, jp + 128); }
-        else { jp[0] = j0; jp[64] = j1; jp[128] = j2; }
-      } else {
-        a = tn_level_interp(fv[2 * q], lc[2 * q].ox, lc[2 * q].oy, lc[2 * q].oz);
-        b = tn_level_interp(fv[2 * q + 1], lc[2 * q + 1].ox, lc[2 * q + 1].oy, lc[2 * q + 1].oz);
-        if (l0 >= g.L) a = make_float2(0.f, 0.f);
-        if (l0 + 1 >= g.L) b = make_float2(0.f, 0.f);
-      }
-      in0[4 * q] = a.x; in0[4 * q + 1] = a.y; in0[4 * q + 2] = b.x; in0[4 * q + 3] = b.y;
-    }
-    if (TRAIN) {  // whole tiles: lanes past the end hold the (finite) values of the last sample, their gradients are zero
-      store_frag(encs, tile, 1, 0, lane, in0);
-      if (h == 0 && valid) sels[p] = sl;
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    const float sl = sels[pc];
+    const f32x16 in0 = nin;
     // ---------------- base MLP: Linear(32,64) ReLU Linear(64,16)
     f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
 #pragma unroll
@@ -438,9 +538,14 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
       a0 = MFMA(AF(0, 0, 0, r), in0[r], a0);
       a1 = MFMA(AF(0, 1, 0, r), in0[r], a1);
     }
+    {
+      const int64_t tn = tile + nwaves < ntiles ? tile + nwaves : tile;
+      const int64_t pn = tn * TILE + j;
+      nin = load_enc_lm(encs, PT, pn < P ? pn : P - 1, h, L);
+    }
     __builtin_amdgcn_sched_barrier(0);
     a0 = relu16(a0); a1 = relu16(a1);
-    if (TRAIN) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
+    if (TRAIN && !FWD_ABLATE) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
     f32x16 bo = bias_tile(lbias, 1, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
@@ -452,15 +557,15 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
       density[p] = expf(pre) * sl;  // average_init_density (=1.0) * trunc_exp(pre) * selector
       if (density_pre) density_pre[p] = pre;
     }
+    if (TRAIN && !FWD_ABLATE) store_bo(hins, tile, lane, bo);  // whole tiles: lanes past the end hold the (finite) values of the last sample
     // ---------------- head input in slot space: tile 0 = sh[R(r,h)] (r<8) | base_out rows (r>=8), tile 1 = embedding
-    float sh[16];
-    sh16(d[0], d[1], d[2], sh);
     f32x16 hi0, hi1;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      hi0[r] = h ? sh[RROW(r, 1)] : sh[RROW(r, 0)];
-      hi0[8 + r] = bo[r];
+    {
+      const float4 s0 = *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8), s1 = *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8 + 4);
+      hi0[0] = s0.x; hi0[1] = s0.y; hi0[2] = s0.z; hi0[3] = s0.w; hi0[4] = s1.x; hi0[5] = s1.y; hi0[6] = s1.z; hi0[7] = s1.w;
     }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) hi0[8 + r] = bo[r];
     {
       const float* ebp;
       if (use_cam_emb) {
@@ -475,7 +580,6 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
 #pragma unroll
         for (int q = 0; q < 4; ++q) hi1[4 * gq + q] = ebp[8 * gq + 4 * h + q];
     }
-    if (TRAIN) { store_frag(hins, tile, 2, 0, lane, hi0); store_frag(hins, tile, 2, 1, lane, hi1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 0
     f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
@@ -485,7 +589,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
     for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
-    if (TRAIN) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
+    if (TRAIN && !FWD_ABLATE) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
     // ---------------- head layer 1
     f32x16 d0 = bias_tile(lbias, 3, 0, h), d1 = bias_tile(lbias, 3, 1, h);
 #pragma unroll
@@ -494,7 +598,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
     for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
-    if (TRAIN) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
+    if (TRAIN && !FWD_ABLATE) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 2 + sigmoid
     f32x16 e = bias_tile(lbias, 4, 0, h);
@@ -516,7 +620,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_fwd_fu
 // density only (no head): cross-evaluated density2 / density2_thermal.  TRAIN keeps what the density-only backward needs: relu(layer 0) and
 // the density logit (in head-input slot 16, where the full forward leaves it).
 template <bool TRAIN>
-__global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __restrict__ pack, const float* __restrict__ enc,
+__global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __restrict__ pack, const float* __restrict__ enc, int L, int64_t PT,
                                                                const float* __restrict__ sel, int64_t P, float* __restrict__ density,
                                                                float* __restrict__ h1s, float* __restrict__ hins) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -533,7 +637,7 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
     int64_t p = tile * TILE + j;
     bool valid = p < P;
     int64_t pc = valid ? p : P - 1;
-    f32x16 in0 = load_frag(enc, tile, 1, 0, lane);
+    f32x16 in0 = load_enc_lm(enc, PT, pc, h, L);
     f32x16 a0 = bias_tile(lbias, 0, 0, h), a1 = bias_tile(lbias, 0, 1, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0 = MFMA(AF(0, 0, 0, r), in0[r], a0); a1 = MFMA(AF(0, 1, 0, r), in0[r], a1); }
@@ -647,6 +751,7 @@ struct FbSmall {
   float pre_logit, g_dens, sel_p;  // density logit (head-input slot 16), d density, selector
   float g3[4];                     // sigmoid backward (half 0 only)
   int cam;                         // camera of this lane's sample, -1 beyond the last sample
+  int ray;                         // ray of this lane's sample (the last ray beyond the last sample)
 };
 template <bool DENS_ONLY>
 __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int64_t P, int S, int C, int num_images, const float* __restrict__ hins,
@@ -661,10 +766,12 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int
   q.sel_p = sel[pc];
   q.g3[0] = q.g3[1] = q.g3[2] = q.g3[3] = 0.0f;
   q.cam = -1;
-  if (!DENS_ONLY && h == 0) {
-    const int64_t cam = cam_idx[pc / S];
+  q.ray = 0;
+  if (!DENS_ONLY) {
+    q.ray = (int)tn_div_index(pc, S, P);
+    const int64_t cam = cam_idx[q.ray];
     q.cam = valid ? ((cam < 0 || cam >= num_images) ? 0 : (int)cam) : -1;
-    if (valid) {
+    if (valid && h == 0) {
       const float4 y4 = *reinterpret_cast<const float4*>(ys + p * 4);
       const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
@@ -679,6 +786,7 @@ template <bool DENS_ONLY>
 __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_density,
                                                             const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
+                                                            const float* __restrict__ shtab, const float* __restrict__ emb, int L, int64_t PT,
                                                             const float* __restrict__ encs, const float* __restrict__ h1s,
                                                             const float* __restrict__ hins, const float* __restrict__ hh1s,
                                                             const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G,
@@ -766,12 +874,28 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0[r] = t0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = t1[r] > 0.0f ? dc1[r] : 0.0f; }
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 1: hh1
-      t0 = load_frag(hins, tile, 2, 0, lane); t1 = load_frag(hins, tile, 2, 1, lane);  // head-input slots: used after the next weight-gradient block
+      // head-input slots (X of head layer 0), rebuilt as the forward built them: sh | the 16 saved base outputs | the camera's embedding row.
+      // Only the base outputs stream from HBM: they are requested here, one weight-gradient block ahead; the two per-ray pieces are cache hits
+      // and are fetched behind that block (24 registers that do not stay live across it)
+      const v4f_t* bp = reinterpret_cast<const v4f_t*>(hins) + tile * 128 + lane;
+      const v4f_t hb0 = FRAG_NT ? __builtin_nontemporal_load(bp) : bp[0], hb1 = FRAG_NT ? __builtin_nontemporal_load(bp + 64) : bp[64];
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);  // d hw1 += gy_hh2^T hh1
       __builtin_amdgcn_sched_barrier(0);
       WAVE_LDS_SYNC();
-      lds_put_tile(bufY, j, h, 0, dc0); lds_put_tile(bufY, j, h, 1, dc1);  // dY of head layer 0: gy_hh1
+      {
+        const float* shp = shtab + (int64_t)sm.ray * 16 + h * 8;
+        const float4 sa = *reinterpret_cast<const float4*>(shp), sb = *reinterpret_cast<const float4*>(shp + 4);
+        const float* ebp = emb + (int64_t)(sm.cam < 0 ? 0 : sm.cam) * 32;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {  // (rows are 16-byte aligned: checked on the host)
+          const float4 e4 = *reinterpret_cast<const float4*>(ebp + 8 * gq + 4 * h);
+          t1[4 * gq] = e4.x; t1[4 * gq + 1] = e4.y; t1[4 * gq + 2] = e4.z; t1[4 * gq + 3] = e4.w;
+        }
+        lds_put_tile(bufY, j, h, 0, dc0); lds_put_tile(bufY, j, h, 1, dc1);  // dY of head layer 0: gy_hh1
+        t0[0] = sa.x; t0[1] = sa.y; t0[2] = sa.z; t0[3] = sa.w; t0[4] = sb.x; t0[5] = sb.y; t0[6] = sb.z; t0[7] = sb.w;
+        t0[8] = hb0.x; t0[9] = hb0.y; t0[10] = hb0.z; t0[11] = hb0.w; t0[12] = hb1.x; t0[13] = hb1.y; t0[14] = hb1.z; t0[15] = hb1.w;
+      }
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 0: head input slots
       s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
@@ -822,12 +946,17 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     *reinterpret_cast<float4*>(bufY + j * TSTR + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
     *reinterpret_cast<float4*>(bufY + j * TSTR + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
     lds_put_tile(bufX, j, h, 0, s0); lds_put_tile(bufX, j, h, 1, s1);      // X of base layer 1: h1
-    f32x16 e0 = load_frag(encs, tile, 1, 0, lane);                              // used after the next weight-gradient block + chain step
+#ifndef FB_E0_LATE
+#define FB_E0_LATE 0
+#endif
+    f32x16 e0;
+    if (!FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);                      // used after the next weight-gradient block + chain step
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 4)) wgrad_tile16(bufY, TSTR, 16, bufX, lane, acc1, bs1);  // d w1 += gy_bo^T h1
     __builtin_amdgcn_sched_barrier(0);
     // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
     f32x16 dh0 = zero16, dh1 = zero16;
+    if (FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);
 #pragma unroll
     for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
 #pragma unroll
@@ -982,14 +1111,34 @@ extern "C" int tn_field_pack_weights(const TnField* field, void* workspace, tn_s
   return TN_OK;
 }
 
+// the encode's work plan, for tests and diagnostics: out[x][i] = {level, first chunk, chunk count} of item i of XCD x (level -1: unused);
+// returns the number of chunks per level (a chunk = 128 * ENC_PER samples)
+extern "C" int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, int32_t* out) {
+  if (grid == nullptr || out == nullptr || num_points <= 0 || grid->num_levels < 1 || grid->num_levels > TN_MAX_LEVELS) return TN_EINVAL;
+  const EncSched sc = make_enc_sched(*grid, num_points);
+  for (int x = 0; x < 8; ++x)
+    for (int i = 0; i < ENC_MAX_ITEMS; ++i) {
+      int32_t* o = out + (x * ENC_MAX_ITEMS + i) * 3;
+      o[0] = sc.level[x][i]; o[1] = sc.c0[x][i]; o[2] = sc.first[x][i + 1] - sc.first[x][i];
+    }
+  return (int32_t)tn_cdiv(num_points, ENC_CHUNK);
+}
+
+// positions (one launch) + the XCD-affine encode (one launch); a training workspace also receives d enc / d offset for the backward
 static int launch_encode(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                          const FieldWs& ws, tn_stream_t stream) {
-  int64_t total = tn_cdiv(N * (int64_t)S, 32) * 64;
-  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 256 * 32);
-  if (ws.jac != nullptr)  // training workspace: keep d enc / d offset for the backward
-    hipLaunchKernelGGL(k_field_encode<true>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel, ws.jac);
+  const int64_t P = N * (int64_t)S;
+  hipLaunchKernelGGL(k_field_pos, dim3((unsigned)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16)), dim3(256), 0, tn_s(stream), origins, directions, e_bins, N, S,
+                     reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh);
+  TN_CHECK_LAUNCH("tn_field_fwd(positions)");
+  const EncSched sc = make_enc_sched(field->grid, P);
+  const unsigned grid = 8u * (unsigned)sc.blocks_per_xcd;
+  if (ws.jac != nullptr)
+    hipLaunchKernelGGL(k_field_encode_xcd<true>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), sc, reinterpret_cast<const float4*>(ws.pos), P,
+                       ws.PT, ws.enc, ws.jac);
   else
-    hipLaunchKernelGGL(k_field_encode<false>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), origins, directions, e_bins, N, S, ws.enc, ws.sel, nullptr);
+    hipLaunchKernelGGL(k_field_encode_xcd<false>, dim3(grid), dim3(256), 0, tn_s(stream), make_gridk(field->grid), sc, reinterpret_cast<const float4*>(ws.pos), P,
+                       ws.PT, ws.enc, nullptr);
   TN_CHECK_LAUNCH("tn_field_fwd(encode)");
   return TN_OK;
 }
@@ -1005,20 +1154,20 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
   if (N == 0) return TN_OK;
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, training);
-  // gather + MLP chain in one launch; 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
+  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
+  if (rc) return rc;
+  // the chain: 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
   const size_t shmem = PACK_FWD_TOTAL * sizeof(float);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), FWD_THREADS / 64), 512));
-  GridK gk = make_gridk(field->grid);
+  const int L = field->grid.num_levels;
   if (training) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_fwd_fused<true>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), gk, ws.pack, origins, directions, e_bins, camera_indices,
-                       field->emb, field->num_images, 1, N, S, field->num_channels, density, rgb, density_pre, ws.enc, ws.sel, ws.jac, ws.h1, ws.hin,
-                       ws.hh1, ws.hh2, ws.y);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_mlp_fwd<true>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), ws.pack, ws.enc, L, ws.PT, ws.sel, ws.sh, camera_indices,
+                       field->emb, field->num_images, 1, N, S, field->num_channels, density, rgb, density_pre, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_fwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_fwd_fused<false>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), gk, ws.pack, origins, directions, e_bins, camera_indices,
-                       field->emb, field->num_images, 0, N, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(k_field_mlp_fwd<false>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), ws.pack, ws.enc, L, ws.PT, ws.sel, ws.sh, camera_indices,
+                       field->emb, field->num_images, 0, N, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr, nullptr);
   }
   TN_CHECK_LAUNCH("tn_field_fwd");
   return TN_OK;
@@ -1038,10 +1187,10 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   size_t shmem = PACK_FWD_TOTAL * sizeof(float);
   if (training) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_density_only<true>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density, ws.h1, ws.hin);
+    hipLaunchKernelGGL(k_field_density_only<true>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, field->grid.num_levels, ws.PT, ws.sel, P, density, ws.h1, ws.hin);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_density_only<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_density_only<false>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, ws.sel, P, density, nullptr, nullptr);
+    hipLaunchKernelGGL(k_field_density_only<false>, dim3(mlp_grid(P)), dim3(256), shmem, tn_s(stream), ws.pack, ws.enc, field->grid.num_levels, ws.PT, ws.sel, P, density, nullptr, nullptr);
   }
   TN_CHECK_LAUNCH("tn_field_density_fwd");
   return TN_OK;
@@ -1089,11 +1238,11 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     if (dens_only) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<true>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
-                         C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+                         C, ws.sh, field->emb, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
-                         S, C, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+                         S, C, ws.sh, field->emb, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
     if (d_origins != nullptr) {
@@ -1105,7 +1254,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
       const int64_t tiles = tn_cdiv(P, 32);
       hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
-                         ws.g_enc, ws.jac, N, S, d_origins, d_directions);
+                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions);
       TN_CHECK_LAUNCH("tn_field_bwd(d position)");
     }
   }

@@ -58,3 +58,31 @@ def test_level_resolutions_match_reference_probe():
     assert ops.level_resolutions(16, 16, 2048) == [16, 22, 30, 42, 58, 80, 111, 153, 212, 294, 406, 561, 776, 1072, 1482, 2047]
     assert ops.level_resolutions(5, 16, 128) == [16, 26, 45, 76, 128]
     assert ops.level_resolutions(5, 16, 256) == [16, 32, 64, 128, 256]
+
+
+@pytest.mark.parametrize("points", [1, 511, 512, 3072, 4096 * 48, 640 * 480 // 4])
+@pytest.mark.parametrize("levels,log2t", [(16, 19), (16, 12), (5, 17), (1, 19), (9, 19)])
+def test_encode_plan_covers_every_level_chunk_once(lib, points, levels, log2t):
+    """The XCD-affine gather's work plan (host logic, no GPU): every chunk of every level appears exactly once, and an XCD only sees levels x, x + 8."""
+    import ctypes as C
+
+    from nerfstudio_thermal_amd import ops
+
+    g = _lib.TnGrid()
+    g.num_levels, g.log2_hashmap_size = levels, log2t
+    for i, r in enumerate(ops.level_resolutions(levels, 16, 2048)):
+        g.res[i] = float(r)
+    out = (C.c_int32 * (8 * 2 * 3))()
+    chunks = lib.tn_field_encode_plan(C.byref(g), points, out)
+    assert chunks == -(-points // 512)
+    covered = {l: 0 for l in range(levels)}
+    for x in range(8):
+        for i in range(2):
+            l, c0, cnt = out[(x * 2 + i) * 3: (x * 2 + i) * 3 + 3]
+            if l < 0:
+                assert cnt == 0
+                continue
+            assert l % 8 == x and c0 == covered[l] and cnt > 0
+            covered[l] += cnt
+    assert all(v == chunks for v in covered.values())
+    assert lib.tn_field_encode_plan(None, points, out) == -22
