@@ -145,11 +145,13 @@ int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, con
 int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
                         int32_t S, float* density, tn_stream_t stream);
 /* backward of the above: d_density [N,S] -> table/MLP gradients (accumulated) and, if non-NULL, d_origins/d_directions [N,3] (accumulated).
- * workspace: tn_prop_workspace_bytes(N*S) bytes of device scratch (operands of the MLP weight-gradient GEMMs). */
+ * workspace: tn_prop_workspace_bytes(N*S) bytes of device scratch (d enc for the table scatter + the scatter's records); workspace_bytes = the size
+ * of the buffer behind it: a shorter one is refused with TN_EINVAL (every workspace_bytes argument below works the same way -- the scratch of
+ * a backward pass is hundreds of MB, and a short buffer would be a device out-of-bounds write the callee could not see). */
 int64_t tn_prop_workspace_bytes(int64_t num_points);
 int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
-                        const float* d_density, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
-                        tn_stream_t stream);
+                        const float* d_density, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
+                        float* d_directions, tn_stream_t stream);
 
 /* ---- a9 (backward)  autograd of HashEncoding.pytorch_fwd (field_components/encodings.py:420-461) with respect to the table (and the sample
  *          position): trilinear scatter-add of g_enc [N*S, ld] (feature 2*level + f) into grid->table_grad; d_origins/d_directions optional.
@@ -161,7 +163,7 @@ int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float*
  *          contribution straight into table_grad with global float atomics (same result up to summation order, several times slower). */
 int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t num_levels);
 int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
-                    int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream);
+                    int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, int64_t workspace_bytes, tn_stream_t stream);
 
 /* ---- a11 RaySamples.get_weights (cameras/rays.py:128-150) and, optionally, DepthRenderer("median") of the same level
  *          (model_components/renderers.py:547-557; used for prop_depth_i, models/nerfacto.py:351-352). median_depth may be NULL. */
@@ -191,12 +193,12 @@ int tn_weights_resample(const float* e_bins_prev, const float* density_prev, con
  * tn_field_bwd consumes, so the same pointer must be passed to both. */
 int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t stream);
 int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
-                 int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
-                 tn_stream_t stream);
+                 int64_t N, int32_t S, int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb,
+                 float* density_pre, tn_stream_t stream);
 /* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated).
  * d_rgb = NULL: density-only backward of tn_field_density_fwd(training != 0) (see there). */
 int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
-                 const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins,
+                 const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
                  float* d_directions, tn_stream_t stream);
 /* The same backward in phases, for data-parallel training: the table gradient of a level range is final as soon as its scatter has run,
  * so the caller can start that range's all-reduce (DDP's bucketed reducer, pipelines/base_pipeline.py:281-283) while the next range is
@@ -217,7 +219,8 @@ enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN =
        TN_BWD_COUNTERS_CLEAN = 64 };
 int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                        const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
-                       float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream);
+                       int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end,
+                       tn_stream_t stream);
 /* Data-parallel exchange of the COARSE levels in dense form.  Levels whose (res+1)^3 cells are fewer than the table's slots are accumulated
  * in dense per-cell replicas anyway; their slice of the table gradient is almost all zeros (332 k possible non-zeros in 2.6 M slots for
  * levels 0-4 of the default grid), so a data-parallel run exchanges the per-cell sums (2.65 MB) instead of the table slice (20 MB):
@@ -228,15 +231,15 @@ int tn_field_bwd_phase(const TnField* field, const float* origins, const float* 
  *   tn_field_dense_fold(field, N*S, lb, le, dense_sum) hashes the sums into the table gradient (accumulating), as the plain scatter would have. */
 int64_t tn_field_dense_count(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end);
 int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                               void* workspace, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end, float* dense_sum,
-                               tn_stream_t stream);
+                               void* workspace, int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end,
+                               float* dense_sum, tn_stream_t stream);
 int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
                         tn_stream_t stream);
 /* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458): get_density without get_outputs.
  * training != 0 keeps what the backward needs in `workspace` (sized with tn_field_workspace_bytes(N*S, 1)); that backward is
  * tn_field_bwd / tn_field_bwd_phase with d_rgb = NULL: the colour head, its three weight gradients and the appearance embedding are skipped. */
 int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                         int32_t training, void* workspace, float* density, tn_stream_t stream);
+                         int32_t training, void* workspace, int64_t workspace_bytes, float* density, tn_stream_t stream);
 
 /* ---- a15/a16  RGBRenderer / RGBTRenderer (background "last_sample"), AccumulationRenderer, DepthRenderer median+expected
  *          (model_components/renderers.py:118-133,238-245,292-307,418-425,509,547-576).
@@ -279,7 +282,7 @@ int64_t tn_render_rays_eval_workspace_bytes(int64_t num_rays, int32_t S0, int32_
 int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
                         const float* directions, const int64_t* camera_indices, const float* nears, const float* fars, int64_t N,
                         int32_t S0, int32_t S1, int32_t S2, float anneal, const float* lin_spaced0, const float* lin_pdf1,
-                        const float* lin_pdf2, void* workspace, float* rgb, float* accumulation, float* depth_median,
+                        const float* lin_pdf2, void* workspace, int64_t workspace_bytes, float* rgb, float* accumulation, float* depth_median,
                         float* depth_expected, float* prop_depth0, float* prop_depth1, float* density, float* e_bins_out,
                         float* rgb_samples_out, tn_stream_t stream);
 
@@ -299,8 +302,8 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
                          const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
                          const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                          int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
-                         const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace, float* out,
-                         void* wait_event_before_field, tn_stream_t stream);
+                         const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
+                         int64_t field_workspace_bytes, float* out, void* wait_event_before_field, tn_stream_t stream);
 
 /* The TRAINING backward of one branch as ONE call, the counterpart of tn_render_rays_train: everything autograd runs behind d(composite) and
  * d(weights) in ThermalNerfactoModel's training step (models/thermal_nerfacto.py:403-489 backwards; cameras/rays.py:128-150,
@@ -316,8 +319,8 @@ int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, con
                              const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
                              const float* fwd_out, const float* d_comp, const float* d_weights0,
                              const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
-                             void* prop_workspace0, void* prop_workspace1, float* tmp, float* d_origins, float* d_directions,
-                             tn_stream_t stream);
+                             int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
+                             int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, tn_stream_t stream);
 
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */

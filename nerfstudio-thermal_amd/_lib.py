@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 301  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 302  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
@@ -69,31 +69,31 @@ SIGNATURES = {
     "tn_pose_apply_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "tn_spaced_bins": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_prop_density_fwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _i64, _i32, _p, _p]),
-    "tn_prop_density_bwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "tn_prop_density_bwd": (C.c_int, [C.POINTER(TnPropNet), _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _p]),
     "tn_hash_scatter_workspace_bytes": (_i64, [_i64, _i32]),
-    "tn_hash_scatter": (C.c_int, [C.POINTER(TnGrid), _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _p]),
+    "tn_hash_scatter": (C.c_int, [C.POINTER(TnGrid), _p, _p, _p, _p, _i32, _i64, _i32, _p, _p, _p, _i64, _p]),
     "tn_weights_fwd": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p]),
     "tn_weights_bwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p]),
     "tn_weights_resample": (C.c_int, [_p, _p, _p, _i32, _f, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "tn_pdf_resample": (C.c_int, [_p, _p, _i32, _f, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_field_pack_weights": (C.c_int, [C.POINTER(TnField), _p, _p]),
-    "tn_field_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p]),
-    "tn_field_bwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
-    "tn_field_bwd_phase": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "tn_field_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),
+    "tn_field_bwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _p]),
+    "tn_field_bwd_phase": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _i32, _i32, _i32, _p]),
     "tn_field_dense_count": (_i64, [C.POINTER(TnField), _i64, _i32, _i32]),
-    "tn_field_bwd_scatter_dense": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _p]),
+    "tn_field_bwd_scatter_dense": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _p]),
     "tn_field_dense_fold": (C.c_int, [C.POINTER(TnField), _i64, _i32, _i32, _p, _p]),
-    "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    "tn_field_density_fwd": (C.c_int, [C.POINTER(TnField), _p, _p, _p, _i64, _i32, _i32, _p, _i64, _p, _p]),
     "tn_minmax_init": (C.c_int, [_p, _p]),
     "tn_composite_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
     "tn_clip_depth": (C.c_int, [_p, _p, _i64, _p]),
     "tn_composite_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_render_rays_eval_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "tn_render_rays_eval": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _f,
-                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                                      _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_rays_train_layout": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _i32]),
     "tn_render_rays_train": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32,
-                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
@@ -114,7 +114,7 @@ SIGNATURES = {
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_shutdown": (C.c_int, []),
     "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
-    "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 13),
+    "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 7 + [_i64, _p, _i64, _p, _i64] + [_p] * 4),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
     "tn_splat_bin": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p]),

@@ -112,6 +112,10 @@ class ParamArena:
         self.device = torch.device(device)
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        # True while the gradient buffer is known to be all zero (freshly allocated, zero_grad(), or consumed by an optimiser launch that zeroes
+        # behind its read).  EVERY writer outside those clears it -- the fused backward, the drop-in path's autograd nodes, gradients copied in
+        # by HipFusedAdam -- so that the fused step never starts on another path's leftovers.
+        self.grads_clean = True
         self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=self.device)
         ParamArena._arenas[:] = [r for r in ParamArena._arenas if r() is not None]
@@ -151,6 +155,7 @@ class ParamArena:
 
     def zero_grad(self) -> None:
         self.grads.zero_()
+        self.grads_clean = True
 
     def num_optimised(self) -> int:
         n = 0

@@ -1144,8 +1144,8 @@ static int launch_encode(const TnField* field, const float* origins, const float
 }
 
 extern "C" int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
-                            int64_t N, int32_t S, int32_t training, void* workspace, float* density, float* rgb, float* density_pre,
-                            tn_stream_t stream) {
+                            int64_t N, int32_t S, int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb,
+                            float* density_pre, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_fwd", false);
   if (rc) return rc;
@@ -1154,6 +1154,9 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
   if (N == 0) return TN_OK;
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, training);
+  TN_REQUIRE((2 * ws.PT + P) * 8 < (1ll << 32), "tn_field_fwd: batch too large for the 32-bit lane offsets of the level-major loads");
+  TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_fwd: workspace of %lld bytes, tn_field_workspace_bytes(%lld, %d) = %lld", (long long)workspace_bytes,
+             (long long)P, training, (long long)ws.bytes);
   rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
   if (rc) return rc;
   // the chain: 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
@@ -1174,7 +1177,7 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
 }
 
 extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                                    int32_t training, void* workspace, float* density, tn_stream_t stream) {
+                                    int32_t training, void* workspace, int64_t workspace_bytes, float* density, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_density_fwd", false);
   if (rc) return rc;
@@ -1182,6 +1185,9 @@ extern "C" int tn_field_density_fwd(const TnField* field, const float* origins, 
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_field_density_fwd: bad N=%lld S=%d", (long long)N, S);
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, training ? 1 : 0);
+  TN_REQUIRE((2 * ws.PT + P) * 8 < (1ll << 32), "tn_field_density_fwd: batch too large for the 32-bit lane offsets of the level-major loads");
+  TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_density_fwd: workspace of %lld bytes, tn_field_workspace_bytes(%lld, %d) = %lld", (long long)workspace_bytes,
+             (long long)P, training ? 1 : 0, (long long)ws.bytes);
   rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
   if (rc) return rc;
   size_t shmem = PACK_FWD_TOTAL * sizeof(float);
@@ -1209,7 +1215,8 @@ static TnGrid level_range_grid(const TnGrid& g, int level_begin, int level_end) 
 
 extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                                   const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
-                                  float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, tn_stream_t stream) {
+                                  int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end,
+                                  tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_bwd", true);
   if (rc) return rc;
@@ -1225,6 +1232,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
                level_end);
   int64_t P = N * (int64_t)S;
   FieldWs ws = ws_layout(workspace, P, 1);
+  // a short buffer would be a device out-of-bounds write (the scatter scratch alone is ~0.5 GB at 4096 rays): refused here
+  TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_bwd: workspace of %lld bytes, tn_field_workspace_bytes(%lld, 1) = %lld", (long long)workspace_bytes, (long long)P,
+             (long long)ws.bytes);
+  TN_REQUIRE((2 * ws.PT + P) * 8 < (1ll << 32), "tn_field_bwd: batch too large for the 32-bit lane offsets of the level-major loads");
   hipStream_t st = tn_s(stream);
   const int C = field->num_channels;
   if (phases & TN_BWD_MLP) {
@@ -1280,10 +1291,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
 }
 
 extern "C" int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
-                            const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
-                            tn_stream_t stream) {
+                            const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
+                            float* d_directions, tn_stream_t stream) {
   if (field == nullptr) return check_field(field, "tn_field_bwd", true);
-  return tn_field_bwd_phase(field, origins, directions, camera_indices, e_bins, d_density, d_rgb, N, S, workspace, d_origins, d_directions,
+  return tn_field_bwd_phase(field, origins, directions, camera_indices, e_bins, d_density, d_rgb, N, S, workspace, workspace_bytes, d_origins, d_directions,
                             TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN, 0, field->grid.num_levels, stream);
 }
 
@@ -1294,8 +1305,8 @@ extern "C" int64_t tn_field_dense_count(const TnField* field, int64_t num_points
 }
 
 extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                                          void* workspace, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end,
-                                          float* dense_sum, tn_stream_t stream) {
+                                          void* workspace, int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t level_begin,
+                                          int32_t level_end, float* dense_sum, tn_stream_t stream) {
   if (N == 0) return TN_OK;
   int rc = check_field(field, "tn_field_bwd_scatter_dense", true);
   if (rc) return rc;
@@ -1305,6 +1316,7 @@ extern "C" int tn_field_bwd_scatter_dense(const TnField* field, const float* ori
   TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= field->grid.num_levels, "tn_field_bwd_scatter_dense: bad level range [%d, %d)",
              level_begin, level_end);
   FieldWs ws = ws_layout(workspace, N * (int64_t)S, 1);
+  TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_bwd_scatter_dense: workspace of %lld bytes, needs %lld", (long long)workspace_bytes, (long long)ws.bytes);
   // (d position was produced by the MLP phase: k_field_dpos)
   return tn_grid_scatter_launch(level_range_grid(field->grid, level_begin, level_end), origins, directions, e_bins,
                                 ws.g_enc + (int64_t)level_begin * 2 * N * S, TN_LD_LEVEL_MAJOR, N, S, nullptr, nullptr, ws.scatter, tn_s(stream), dense_sum);

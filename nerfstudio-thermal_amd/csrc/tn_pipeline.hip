@@ -39,7 +39,7 @@ extern "C" int64_t tn_render_rays_eval_workspace_bytes(int64_t num_rays, int32_t
 extern "C" int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
                                    const float* directions, const int64_t* camera_indices, const float* nears, const float* fars, int64_t N,
                                    int32_t S0, int32_t S1, int32_t S2, float anneal, const float* lin_spaced0, const float* lin_pdf1,
-                                   const float* lin_pdf2, void* workspace, float* rgb, float* accumulation, float* depth_median,
+                                   const float* lin_pdf2, void* workspace, int64_t workspace_bytes, float* rgb, float* accumulation, float* depth_median,
                                    float* depth_expected, float* prop_depth0, float* prop_depth1, float* density, float* e_bins_out,
                                    float* rgb_samples_out, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
@@ -51,6 +51,9 @@ extern "C" int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop
   TN_REQUIRE(((uintptr_t)workspace % 256) == 0, "tn_render_rays_eval: workspace must be 256-byte aligned");
   const int C = field->num_channels;
   EvalWs w = eval_layout(workspace, N, S0, S1, S2, C);
+  TN_REQUIRE(workspace_bytes >= w.bytes, "tn_render_rays_eval: workspace of %lld bytes, tn_render_rays_eval_workspace_bytes = %lld", (long long)workspace_bytes,
+             (long long)w.bytes);
+  const int64_t field_ws_bytes = tn_field_workspace_bytes(N * (int64_t)S2, 0);
   float* e2 = e_bins_out ? e_bins_out : w.e2;
   float* rgb_s = rgb_samples_out ? rgb_samples_out : w.rgb_s;
   int rc;
@@ -62,7 +65,7 @@ extern "C" int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop
   if ((rc = tn_weights_resample(w.e1, w.d1, w.s1, S1, anneal, lin_pdf2, nullptr, nears, fars, N, S2, w.w1, prop_depth1, w.s2, e2, stream))) return rc;
   // field (mean appearance embedding at inference), then get_weights + the renderers
   if ((rc = tn_field_pack_weights(field, w.field_ws, stream))) return rc;
-  if ((rc = tn_field_fwd(field, origins, directions, camera_indices, e2, N, S2, 0, w.field_ws, density, rgb_s, nullptr, stream))) return rc;
+  if ((rc = tn_field_fwd(field, origins, directions, camera_indices, e2, N, S2, 0, w.field_ws, field_ws_bytes, density, rgb_s, nullptr, stream))) return rc;
   return tn_render_fwd(e2, density, rgb_s, N, S2, C, 0, w.w2, rgb, accumulation, depth_median, depth_expected, w.scratch, stream);
 }
 
@@ -103,7 +106,7 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
                                     const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                                     int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                     const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
-                                    float* out, void* wait_event_before_field, tn_stream_t stream) {
+                                    int64_t field_workspace_bytes, float* out, void* wait_event_before_field, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -143,7 +146,8 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
     TN_REQUIRE(e == hipSuccess, "tn_render_rays_train: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
   }
   if ((rc = tn_field_pack_weights(field, field_workspace, stream))) return rc;
-  if ((rc = tn_field_fwd(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, stream))) return rc;
+  if ((rc = tn_field_fwd(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, field_workspace_bytes, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, stream)))
+    return rc;
   return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
                        at(TRO_SCRATCH), stream);
 }
@@ -165,8 +169,8 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
                                         const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
                                         const float* fwd_out, const float* d_comp, const float* d_weights0,
                                         const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
-                                        void* prop_workspace0, void* prop_workspace1, float* tmp, float* d_origins, float* d_directions,
-                                        tn_stream_t stream) {
+                                        int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
+                                        int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, tn_stream_t stream) {
   if (N == 0) return TN_OK;
   TN_REQUIRE(field && origins && directions && camera_indices && fwd_out && d_comp && d_weights2 && field_workspace && tmp,
              "tn_render_rays_train_bwd: null pointer");
@@ -201,12 +205,12 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
     hipStream_t s0 = tn_fork_n(st, 1), s1 = tn_fork_n(st, 2);
     tn_stream_t t0 = s0 ? (tn_stream_t)s0 : stream, t1 = s1 ? (tn_stream_t)s1 : stream;
     rc0 = tn_weights_bwd(at(TRO_E0), at(TRO_D0), at(TRO_W0), d_weights0, N, S0, dd0, t0);
-    if (!rc0) rc0 = tn_prop_density_bwd(prop0, o, d, at(TRO_E0), dd0, N, S0, prop_workspace0, d_origins, d_directions, t0);
+    if (!rc0) rc0 = tn_prop_density_bwd(prop0, o, d, at(TRO_E0), dd0, N, S0, prop_workspace0, prop_workspace_bytes0, d_origins, d_directions, t0);
     rc1 = tn_weights_bwd(at(TRO_E1), at(TRO_D1), at(TRO_W1), d_weights1, N, S1, dd1, t1);
-    if (!rc1) rc1 = tn_prop_density_bwd(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, d_origins, d_directions, t1);
+    if (!rc1) rc1 = tn_prop_density_bwd(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, prop_workspace_bytes1, d_origins, d_directions, t1);
   }
   // (d position forks to its companion stream only when the proposal networks' backward keeps other queues busy anyway)
-  rc = tn_field_bwd_phase(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, d_origins, d_directions,
+  rc = tn_field_bwd_phase(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, field_workspace_bytes, d_origins, d_directions,
                           TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | (prop_grad ? TN_BWD_FORK_DPOS : 0), 0, field->grid.num_levels, stream);
   if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
   return rc ? rc : (rc0 ? rc0 : rc1);

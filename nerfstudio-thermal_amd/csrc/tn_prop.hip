@@ -261,8 +261,8 @@ extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
 }
 
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
-                                   const float* d_density, int64_t N, int32_t S, void* workspace, float* d_origins, float* d_directions,
-                                   tn_stream_t stream) {
+                                   const float* d_density, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
+                                   float* d_directions, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(net && origins && directions && e_bins && d_density && workspace, "tn_prop_density_bwd: null pointer");
   TN_REQUIRE(net->grid.table && net->grid.table_grad && net->w0 && net->b0 && net->w1 && net->b1 && net->gw0 && net->gb0 && net->gw1 && net->gb1,
@@ -272,6 +272,8 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   TN_REQUIRE(net->grid.log2_hashmap_size >= 1 && net->grid.log2_hashmap_size <= 24, "tn_prop_density_bwd: bad log2_hashmap_size");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_prop_density_bwd: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(((uintptr_t)workspace % 256) == 0, "tn_prop_density_bwd: workspace must be 256-byte aligned");
+  TN_REQUIRE(workspace_bytes >= tn_prop_workspace_bytes(N * (int64_t)S), "tn_prop_density_bwd: workspace of %lld bytes, tn_prop_workspace_bytes(%lld) = %lld",
+             (long long)workspace_bytes, (long long)(N * (int64_t)S), (long long)tn_prop_workspace_bytes(N * (int64_t)S));
   if (N == 0) return TN_OK;
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, net->gw0, net->gb0, net->gw1, net->gb1};
   int64_t P = N * (int64_t)S;

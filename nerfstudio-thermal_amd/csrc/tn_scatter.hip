@@ -876,12 +876,16 @@ extern "C" int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t n
 }
 
 extern "C" int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
-                               int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, tn_stream_t stream) {
+                               int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, int64_t workspace_bytes, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(grid != nullptr, "tn_hash_scatter: null grid");
   TN_REQUIRE(((uintptr_t)workspace % 256) == 0, "tn_hash_scatter: workspace must be 256-byte aligned");
   TN_REQUIRE((d_origins == nullptr) == (d_directions == nullptr), "tn_hash_scatter: d_origins and d_directions must both be given or both NULL");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_hash_scatter: bad N=%lld S=%d", (long long)N, S);
   TN_REQUIRE(grid->log2_hashmap_size >= 1 && grid->log2_hashmap_size <= 24, "tn_hash_scatter: bad log2_hashmap_size");
+  TN_REQUIRE(grid->num_levels >= 1 && grid->num_levels <= TN_MAX_LEVELS, "tn_hash_scatter: bad level count");
+  TN_REQUIRE(workspace == nullptr || workspace_bytes >= tn_scatter_scratch_bytes(N * (int64_t)S, grid->num_levels),
+             "tn_hash_scatter: workspace of %lld bytes, tn_hash_scatter_workspace_bytes(%lld, %d) = %lld", (long long)workspace_bytes, (long long)(N * (int64_t)S),
+             grid->num_levels, (long long)tn_scatter_scratch_bytes(N * (int64_t)S, grid->num_levels));
   return tn_grid_scatter_launch(*grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, workspace, tn_s(stream), nullptr);
 }

@@ -100,8 +100,7 @@ class RenderEngine:
         self.sampler_step = 0
         self.adam_step_count = 0
         # The fused step's optimiser launch CONSUMES the gradients (zero behind the read): no arena-wide zero-fill at the start of the next
-        # step.  `_grads_clean` says the arena's gradient buffer is known to be zero.
-        self._grads_clean = False
+        # step.  `arena.grads_clean` says the arena's gradient buffer is known to be zero (every writer of the buffer clears it).
         # overlap_adam: the Adam launch over the FIELD groups (470 MB of streaming traffic, ~65 us) runs on a side stream and overlaps the
         # next step's pixel sampling + proposal sampling (which read the proposal networks and the poses only); the field's forward waits for
         # it (tn_render_rays_train's wait event).  OFF: measured 1.09 -> 1.67 ms per step on MI355X / ROCm 7 -- with the second queue active
@@ -310,7 +309,7 @@ class RenderEngine:
         c = self.cfg
         N = image.shape[0]
         dev = self.device
-        self._grads_clean = False  # this call accumulates into the arena's gradient buffer
+        self.arena.grads_clean = False  # this call accumulates into the arena's gradient buffer
         b = branches[""]
         bt = branches.get("_thermal")
         C = b.comp.shape[1]
@@ -546,7 +545,7 @@ class RenderEngine:
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,
-                       grad_scaler=None) -> None:
+                       grad_scaler=None, skipped_have_no_grads: bool = False) -> None:
         """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307).
 
         torch.optim.Adam skips parameters whose .grad is None and advances its per-parameter step count (bias correction) only when it
@@ -595,8 +594,9 @@ class RenderEngine:
                                          skipped=scaler.skipped if scaler is not None else None, lag_index=scaler.lag_index if scaler is not None else -1,
                                          count_skip=scaler is not None, schedule=sched, sched_step=self.adam_step_count - 1, zero_grads=True)
 
-            # the stepped groups' gradients are consumed; a skipped group (proposal networks on an iteration without their gradient) wrote none
-            self._grads_clean = True
+            # the stepped groups' gradients are consumed.  A skipped group keeps whatever it holds: the buffer only counts as clean when the caller
+            # vouches that the skipped groups received no gradient (train_step: proposal networks on an iteration the sampler ran them under no_grad)
+            self.arena.grads_clean = (not skip_groups) or skipped_have_no_grads
             if self.overlap_adam:
                 big = [g for g in names if g.startswith("fields")]
                 launch([g for g in names if not g.startswith("fields")])
@@ -623,7 +623,7 @@ class RenderEngine:
             ops.adam_step(a.params[lo:hi], a.grads[lo:hi], a.exp_avg[lo:hi], a.exp_avg_sq[lo:hi], step, lr, eps=1e-15)
 
     # ---------------------------------------------------------------- checkpoint of the fused path's optimiser state
-    def optimizer_state_dict(self) -> Dict[str, object]:
+    def optimizer_state_dict(self, grad_scaler=None) -> Dict[str, object]:
         """What Trainer.save_checkpoint stores beside the model (engine/trainer.py:424-447: "optimizers" = torch.optim.Adam.state_dict()
         per parameter group, "schedulers" = LambdaLR.state_dict()), read out of the arena: state[i] = {step, exp_avg, exp_avg_sq} for the i-th
         parameter of the group in get_param_groups() order.  Plus the sampler's update counters, which the reference loses on resume."""
@@ -631,23 +631,36 @@ class RenderEngine:
         a = self.arena
         steps = getattr(self, "group_steps", {})
         opt, sched = {}, {}
-        for g in a.optimised_groups:
+        # With a grad scaler the host counters include the iterations the DEVICE skipped (inf / NaN gradients) and the schedule lag; what the
+        # reference Trainer would have written for the same history excludes them (torch's Adam `step` does not advance on a skipped step, the
+        # schedulers are not stepped when the scale dropped: engine/trainer.py:488-495) -- and so do the bias corrections / LR the next launch uses.
+        sc = grad_scaler.state_dict() if (grad_scaler is not None and getattr(grad_scaler, "enabled", True)) else None
+        lag = int(sc["schedule_lag"]) if sc else 0
+        epoch = max(self.adam_step_count - lag, 0)
+        for gi, g in enumerate(a.optimised_groups):
             lr0, lr_final, max_steps = OPTIMIZERS[g]
-            k = int(steps.get(g, 0))
+            k = int(steps.get(g, 0)) - (int(sc["skipped"][gi]) if sc else 0)
             state = {}
             if k > 0:
                 for i, name in enumerate(a.group_keys[g]):
                     state[i] = {"step": torch.tensor(float(k)), "exp_avg": a._view(a.exp_avg, name).detach().clone(),
                                 "exp_avg_sq": a._view(a.exp_avg_sq, name).detach().clone()}
-            opt[g] = {"state": state, "param_groups": [{"lr": exp_decay_lr(max(self.adam_step_count, 0), lr0, lr_final, max_steps), "betas": (0.9, 0.999),
+            opt[g] = {"state": state, "param_groups": [{"lr": exp_decay_lr(epoch, lr0, lr_final, max_steps), "betas": (0.9, 0.999),
                                                         "eps": 1e-15, "weight_decay": 0, "amsgrad": False, "initial_lr": lr0,
                                                         "params": list(range(len(a.group_keys[g])))}]}
-            sched[g] = {"last_epoch": self.adam_step_count, "_step_count": self.adam_step_count + 1, "base_lrs": [lr0]}
-        return {"optimizers": opt, "schedulers": sched,
-                "sampler": {"steps_since_update": self.steps_since_update, "step": self.sampler_step, "anneal": self.anneal}}
+            sched[g] = {"last_epoch": epoch, "_step_count": epoch + 1, "base_lrs": [lr0]}
+        out = {"optimizers": opt, "schedulers": sched,
+               "sampler": {"steps_since_update": self.steps_since_update, "step": self.sampler_step, "anneal": self.anneal}}
+        if sc:
+            # the counters themselves are folded into step / last_epoch above: a resumed scaler starts them at zero
+            out["scalers"] = {**sc, "skipped": [0] * len(sc["skipped"]), "schedule_lag": 0}
+        return out
 
-    def load_optimizer_state_dict(self, state: Dict[str, object]) -> None:
-        """Inverse of optimizer_state_dict; also accepts a checkpoint written by the reference Trainer (same layout, no "sampler" entry)."""
+    def load_optimizer_state_dict(self, state: Dict[str, object], grad_scaler=None) -> None:
+        """Inverse of optimizer_state_dict; also accepts a checkpoint written by the reference Trainer (same layout, no "sampler" entry; its
+        "scalers" entry is torch.amp.GradScaler's state_dict, which DeviceGradScaler.load_state_dict takes as it is)."""
+        if grad_scaler is not None and state.get("scalers"):
+            grad_scaler.load_state_dict(state["scalers"])
         a = self.arena
         self.group_steps = {}
         for g, od in state.get("optimizers", {}).items():
@@ -674,7 +687,7 @@ class RenderEngine:
         self.set_anneal_for_step(step)
         if grad_scaler is not None:
             grad_scaler.begin_step()
-        if not self._grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
+        if not self.arena.grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
             self.sync_params()
             self.arena.zero_grad()
         out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
@@ -691,12 +704,12 @@ class RenderEngine:
                 self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
             else:
                 grad_hook.finish(skip=idle)
-                self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler)
+                self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)
         else:
             losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
             if grad_hook is not None:
                 grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
             skip = () if branches[""].prop_grad else ("proposal_networks",)
-            self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler)
+            self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)
         self.step_cb(step)
         return losses

@@ -137,6 +137,7 @@ class _RenderFn(torch.autograd.Function):
         eng: RenderEngine = ctx.eng
         branches, cam = ctx.branches, ctx.cam
         arena = eng.arena
+        arena.grads_clean = False  # this node (and autograd, through the aliased .grad views) writes into the arena's gradient buffer
         params = dict(zip(ctx.names, ctx.params))
         dev = eng.device
         it = iter(grads)
@@ -567,11 +568,14 @@ class ThermalNerfactoModel(nn.Module):
         return ld
 
     # ------------------------------------------------------------------------------------------------ fused fast path
-    def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor], step: int, grad_hook=None, jitters=None, jitters_thermal=None):
-        """Trainer.train_iteration for this model without an autograd tape: callbacks + forward + losses + backward (+ all-reduce) + Adam."""
+    def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor], step: int, grad_hook=None, jitters=None, jitters_thermal=None,
+                        grad_scaler=None):
+        """Trainer.train_iteration for this model without an autograd tape: callbacks + forward + losses + backward (+ all-reduce) + Adam.
+        grad_scaler: optim.DeviceGradScaler -- the reference Trainer's GradScaler semantics (skip on inf / NaN, scale growth / backoff, LR-schedule
+        lag; engine/trainer.py:470-495) decided on the device -- or None."""
         cam = ray_bundle.camera_indices.reshape(-1).contiguous()
         return self.engine.train_step(ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous(), cam, batch["image"].to(self.device)[..., :3].contiguous(),
-                                      batch["is_thermal"].to(self.device).float().contiguous(), step, jitters, jitters_thermal, grad_hook)
+                                      batch["is_thermal"].to(self.device).float().contiguous(), step, jitters, jitters_thermal, grad_hook, grad_scaler=grad_scaler)
 
     # ------------------------------------------------------------------------------------------------ eval
     @torch.no_grad()

@@ -427,6 +427,11 @@ def prop_density_fwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_
     return out
 
 
+def _nbytes(t: Optional[Tensor]) -> int:
+    """size of a workspace tensor in bytes (the workspace_bytes argument behind every workspace pointer of the C ABI)"""
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 _PROP_WS: dict = {}
 
 
@@ -442,7 +447,7 @@ def prop_density_bwd(net: PropNetParams, origins: Tensor, directions: Tensor, e_
         _PROP_WS[key] = ws
     s = net.cstruct(need_grad=True)
     check(_lib.load().tn_prop_density_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
-                                          _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), N, S, C.c_void_p(ws.data_ptr()),
+                                          _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), N, S, C.c_void_p(ws.data_ptr()), _nbytes(ws),
                                           _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True), _stream()),
           "tn_prop_density_bwd")
 
@@ -464,7 +469,7 @@ def field_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
     pre = torch.empty((N, S), device=origins.device) if want_pre else None
     s = fld.cstruct()
     check(_lib.load().tn_field_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
-                                   _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()), _f32(dens, "density"),
+                                   _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()), _nbytes(ws), _f32(dens, "density"),
                                    _f32(rgb, "rgb"), _f32(pre, "pre", optional=True), _stream()), "tn_field_fwd")
     return dens, rgb, pre
 
@@ -480,7 +485,7 @@ def field_density_fwd(fld: FieldParams, origins: Tensor, directions: Tensor, e_b
         check(_lib.load().tn_field_pack_weights(C.byref(s), C.c_void_p(ws.data_ptr()), _stream()), "tn_field_pack_weights")
     dens = torch.empty((N, S), device=origins.device)
     check(_lib.load().tn_field_density_fwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
-                                           _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()),
+                                           _f32(e_bins, "e_bins", (N, S + 1)), N, S, 1 if training else 0, C.c_void_p(ws.data_ptr()), _nbytes(ws),
                                            _f32(dens, "density"), _stream()), "tn_field_density_fwd")
     return dens
 
@@ -493,7 +498,7 @@ def field_bwd(fld: FieldParams, origins: Tensor, directions: Tensor, cam: Tensor
     s = fld.cstruct(need_grad=True)
     check(_lib.load().tn_field_bwd(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)),
                                    _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)), _f32(d_rgb, "d_rgb", (N, S, fld.num_channels), True),
-                                   N, S, C.c_void_p(ws.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True),
+                                   N, S, C.c_void_p(ws.data_ptr()), _nbytes(ws), _f32(d_origins, "d_origins", (N, 3), True),
                                    _f32(d_directions, "d_directions", (N, 3), True), _stream()), "tn_field_bwd")
 
 
@@ -507,7 +512,7 @@ def field_bwd_phase(fld: FieldParams, origins: Tensor, directions: Tensor, cam: 
     s = fld.cstruct(need_grad=True)
     check(_lib.load().tn_field_bwd_phase(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
                                          _i64(cam, "camera_indices", (N,)), _f32(e_bins, "e_bins", (N, S + 1)), _f32(d_density, "d_density", (N, S)),
-                                         _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)), N, S, C.c_void_p(ws.data_ptr()),
+                                         _f32(d_rgb, "d_rgb", (N, S, fld.num_channels)), N, S, C.c_void_p(ws.data_ptr()), _nbytes(ws),
                                          _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
                                          phases, level_begin, level_end, _stream()), "tn_field_bwd_phase")
 
@@ -525,7 +530,7 @@ def field_bwd_scatter_dense(fld: FieldParams, origins: Tensor, directions: Tenso
     ws = fld.workspace(N * S, True, tag)
     s = fld.cstruct(need_grad=True)
     check(_lib.load().tn_field_bwd_scatter_dense(C.byref(s), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
-                                                 _f32(e_bins, "e_bins", (N, S + 1)), N, S, C.c_void_p(ws.data_ptr()),
+                                                 _f32(e_bins, "e_bins", (N, S + 1)), N, S, C.c_void_p(ws.data_ptr()), _nbytes(ws),
                                                  _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
                                                  level_begin, level_end, _f32(dense_sum, "dense_sum"), _stream()), "tn_field_bwd_scatter_dense")
 
@@ -558,7 +563,7 @@ def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashma
     g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
     check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),
                                       _f32(g_enc, "g_enc", None if level_major else (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
-                                      _f32(d_directions, "d_directions", (N, 3), True), C.c_void_p(ws.data_ptr()) if ws is not None else None,
+                                      _f32(d_directions, "d_directions", (N, 3), True), C.c_void_p(ws.data_ptr()) if ws is not None else None, _nbytes(ws),
                                       _stream()), "tn_hash_scatter")
 
 
@@ -614,7 +619,7 @@ def render_rays_eval(props: Sequence[PropNetParams], fld: FieldParams, origins: 
     check(lib.tn_render_rays_eval(C.byref(p0), C.byref(p1), C.byref(f), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)),
                                   _i64(cam, "camera_indices", (N,)), _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S0, S1, S2,
                                   float(anneal), _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"),
-                                  _f32(_lin_table("pdf", S2, dev), "u2"), C.c_void_p(ws.data_ptr()), _f32(out["rgb"], "rgb"), _f32(out["accumulation"], "acc"),
+                                  _f32(_lin_table("pdf", S2, dev), "u2"), C.c_void_p(ws.data_ptr()), _nbytes(ws), _f32(out["rgb"], "rgb"), _f32(out["accumulation"], "acc"),
                                   _f32(out["depth"], "depth"), _f32(out["expected_depth"], "exp"), _f32(out["prop_depth_0"], "pd0"),
                                   _f32(out["prop_depth_1"], "pd1"), _f32(out["density"], "density"), _f32(out["e_bins"], "e_bins"),
                                   _f32(out["rgb_samples"], "rgb_samples"), _stream()), "tn_render_rays_eval")
@@ -672,7 +677,7 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
                                    _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N), N, S0, S1, S2, float(anneal),
                                    _ray_scalar(jit[0], "jitter", N, True), _ray_scalar(jit[1], "jitter", N, True), _ray_scalar(jit[2], "jitter", N, True),
                                    _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"), _f32(_lin_table("pdf", S2, dev), "u2"),
-                                   C.c_void_p(ws.data_ptr()), C.c_void_p(buf.data_ptr()),
+                                   C.c_void_p(ws.data_ptr()), _nbytes(ws), C.c_void_p(buf.data_ptr()),
                                    C.c_void_p(wait_event.cuda_event) if wait_event is not None else None, _stream()), "tn_render_rays_train")
 
     def v(slot, *shape):
@@ -730,7 +735,8 @@ def render_rays_train_bwd(props: Sequence[PropNetParams], fld: FieldParams, fwd_
                                        _f32(directions, "directions", (N, 3)), _i64(cam, "camera_indices", (N,)), N, S0, S1, S2, C.c_void_p(fwd_buf.data_ptr()),
                                        _f32(d_comp, "d_comp", (N, Cc)), _f32(d_weights[0], "d_weights0", (N, S0), True), _f32(d_weights[1], "d_weights1", (N, S1), True),
                                        _f32(d_weights[2], "d_weights2", (N, S2)), _f32(d_density_extra, "d_density_extra", (N, S2), True),
-                                       C.c_void_p(ws.data_ptr()), C.c_void_p(w0.data_ptr()) if prop_grad else None, C.c_void_p(w1.data_ptr()) if prop_grad else None,
+                                       C.c_void_p(ws.data_ptr()), _nbytes(ws), C.c_void_p(w0.data_ptr()) if prop_grad else None, _nbytes(w0) if prop_grad else 0,
+                                       C.c_void_p(w1.data_ptr()) if prop_grad else None, _nbytes(w1) if prop_grad else 0,
                                        C.c_void_p(tmp.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
                                        _stream()), "tn_render_rays_train_bwd")
 

@@ -90,6 +90,7 @@ class HipFusedAdam(torch.optim.Optimizer):
                         continue  # torch.optim.Adam skips it too, and does not advance its step count
                     if g.data_ptr() != gptr:  # autograd kept its own buffer (e.g. two gradient sources were summed)
                         arena.grads[off:off + n].copy_(g.reshape(-1))
+                        arena.grads_clean = False
                     k = steps.get(id(p), 0) + 1
                     steps[id(p)] = k
                     if runs and runs[-1][0] is arena and runs[-1][3] == k and 0 <= off - runs[-1][2] < ParamArena.ALIGN:
@@ -237,6 +238,28 @@ class DeviceGradScaler:
     def schedule_lag(self) -> int:
         return int(self.skipped[self.num_groups].item())
 
+    def state_dict(self) -> Dict[str, object]:
+        """torch.amp.GradScaler.state_dict()'s keys (what Trainer.save_checkpoint stores under "scalers", engine/trainer.py:444) plus the two
+        device-side counters that GradScaler keeps implicitly in the optimisers / schedulers it did not step: per-group skipped steps and the
+        LR-schedule lag."""
+        sk = self.skipped.tolist()
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(self.growth_tracker.item()), "skipped": sk[:self.num_groups], "schedule_lag": sk[self.num_groups]}
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        """Accepts its own state_dict and a plain torch.amp.GradScaler one (no counters: a reference checkpoint's optimiser / scheduler state
+        already excludes the skipped steps)."""
+        if not state:
+            return
+        self.scale.fill_(float(state["scale"]))
+        self.growth_factor, self.backoff_factor = float(state["growth_factor"]), float(state["backoff_factor"])
+        self.growth_interval = int(state["growth_interval"])
+        self.growth_tracker.fill_(int(state.get("_growth_tracker", 0)))
+        sk = list(state.get("skipped", [0] * self.num_groups))[:self.num_groups]
+        sk += [0] * (self.num_groups - len(sk))
+        self.skipped.copy_(torch.tensor(sk + [int(state.get("schedule_lag", 0))], dtype=torch.int32))
+        self.found_inf.zero_()
+
 
 class ExponentialDecayLR:
     """ExponentialDecayScheduler without warm-up (engine/schedulers.py:109-141): lr(step) = exp(lerp(log lr_init, log lr_final, step/max_steps)).
@@ -324,9 +347,14 @@ class Optimizers:
                 by_arena.setdefault(id(r[0]), []).append(r)
             for rs in by_arena.values():
                 a = rs[0][0]
-                for i in range(0, len(rs), 8):
-                    ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [(r[1], (r[2] + 3) // 4 * 4, r[3], r[4]) for r in rs[i:i + 8]],
+                i = 0
+                while i < len(rs):  # chunks of <= 8 runs that share (beta1, beta2, eps), exactly as HipFusedAdam.step cuts them
+                    j = i + 1
+                    while j < len(rs) and j - i < 8 and rs[j][5:8] == rs[i][5:8]:
+                        j += 1
+                    ops.adam_step_ranges(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [(r[1], (r[2] + 3) // 4 * 4, r[3], r[4]) for r in rs[i:j]],
                                          beta1=rs[i][5], beta2=rs[i][6], eps=rs[i][7])
+                    i = j
             return
         for name, o in self.optimizers.items():
             max_norm = self.max_norm.get(name)

@@ -131,3 +131,38 @@ def pixel_batch(golden_dir):
         "num_rays": n,
         "ref": {k: torch.from_numpy(g[k]) for k in ("indices", "image", "is_thermal")},
     }
+
+
+_DSENS_CACHE = {}
+
+
+def oracle_density_sensitivity(golden_dir, mode="shared", size="tiny", ulps=1):
+    """Conditioning of the chained density: how far the ORACLE's own eval-mode density moves when its level-2 (field) sample bins move by `ulps`
+    fp32 ulps, up and down (no GPU involved).  After two PDF resamplings the field samples sit on a piecewise-linear hash grid whose tables are
+    deliberately high-variance in the synthetic weights: a 1-ulp shift of a sample changes the interpolated features, the 64-wide MLP amplifies
+    it, exp() turns it into density.  Returns per branch suffix {"max": max |d density|, "frac": share of samples that move by more than 1e-4,
+    "scale": max density}.  The chained GPU-vs-reference density bound is a stated multiple of this (tests/test_model_gpu.py)."""
+    key = (mode, size, ulps)
+    if key in _DSENS_CACHE:
+        return _DSENS_CACHE[key]
+    cfg = size_cfg(size, mode)
+    gi = golden_inputs(golden_dir, size)
+    params = make_params(cfg)
+    with torch.no_grad():
+        ref = orc.get_outputs(params, cfg, gi["origins"], gi["directions"], gi["camera_indices"], training=False)
+        res = {}
+        for sfx, prefix in (("", "field"), ("_thermal", "field_thermal")):
+            if f"density{sfx}" not in ref or (sfx and mode != "separate"):
+                continue
+            smp = ref["samples_list" + sfx][2]
+            worst = torch.zeros_like(ref[f"density{sfx}"])
+            for toward in (float("inf"), -float("inf")):
+                e2p = smp.e_bins
+                for _ in range(ulps):
+                    e2p = torch.nextafter(e2p, torch.tensor(toward))
+                moved = orc.Samples(s_bins=smp.s_bins, e_bins=e2p)
+                dp = orc.field_density(params, prefix, cfg, moved.positions(gi["origins"], gi["directions"]))[0]
+                worst = torch.maximum(worst, (dp - ref[f"density{sfx}"]).abs())
+            res[sfx] = {"max": float(worst.max()), "frac": float((worst > 1e-4).double().mean()), "scale": float(ref[f"density{sfx}"].max())}
+    _DSENS_CACHE[key] = res
+    return res

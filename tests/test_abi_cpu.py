@@ -86,3 +86,46 @@ def test_encode_plan_covers_every_level_chunk_once(lib, points, levels, log2t):
             covered[l] += cnt
     assert all(v == chunks for v in covered.values())
     assert lib.tn_field_encode_plan(None, points, out) == -22
+
+
+def test_short_workspaces_are_refused_before_any_launch(lib):
+    """ABI 302: every entry point that writes a workspace takes its size and answers TN_EINVAL to a short buffer (the scratch of a backward
+    pass is hundreds of MB: the callee used to trust the pointer).  Validation happens on the host before the first launch, so it runs here
+    without a device; the pointers only have to be non-NULL."""
+    import ctypes as C
+
+    from nerfstudio_thermal_amd import ops
+
+    buf = (C.c_float * 64)()
+    ptr = C.cast(buf, C.c_void_p)
+    fake = C.c_void_p(256 * 4096)  # a 256-byte aligned, non-NULL address that is never dereferenced
+    N, S = 64, 48
+    g = _lib.TnGrid()
+    g.table, g.table_grad, g.num_levels, g.log2_hashmap_size = ptr, ptr, 16, 19
+    for i, r in enumerate(ops.level_resolutions(16, 16, 2048)):
+        g.res[i] = float(r)
+    need = lib.tn_hash_scatter_workspace_bytes(N * S, 16)
+    assert need > 0
+    assert lib.tn_hash_scatter(C.byref(g), ptr, ptr, ptr, ptr, -1, N, S, None, None, fake, need - 1, None) == -22
+    assert b"workspace of" in lib.tn_last_error()
+    f = _lib.TnField()
+    f.grid = g
+    for name in _lib._FIELD_PTRS:
+        setattr(f, name, ptr)
+    f.num_channels, f.num_images = 4, 8
+    need = lib.tn_field_workspace_bytes(N * S, 1)
+    assert lib.tn_field_bwd(C.byref(f), ptr, ptr, ptr, ptr, ptr, ptr, N, S, fake, need - 1, None, None, None) == -22
+    assert b"tn_field_workspace_bytes" in lib.tn_last_error()
+    assert lib.tn_field_fwd(C.byref(f), ptr, ptr, ptr, ptr, N, S, 1, fake, 16, ptr, ptr, None, None) == -22
+    assert lib.tn_field_density_fwd(C.byref(f), ptr, ptr, ptr, N, S, 1, fake, 16, ptr, None) == -22
+    p = _lib.TnPropNet()
+    p.grid = g
+    p.grid.num_levels, p.grid.log2_hashmap_size = 5, 17
+    for name in ("w0", "b0", "w1", "b1", "gw0", "gb0", "gw1", "gb1"):
+        setattr(p, name, ptr)
+    need = lib.tn_prop_workspace_bytes(N * 256)
+    assert lib.tn_prop_density_bwd(C.byref(p), ptr, ptr, ptr, ptr, N, 256, fake, need - 1, None, None, None) == -22
+    assert b"tn_prop_workspace_bytes" in lib.tn_last_error()
+    need = lib.tn_render_rays_eval_workspace_bytes(N, 256, 96, 48, 4)
+    assert lib.tn_render_rays_eval(C.byref(p), C.byref(p), C.byref(f), ptr, ptr, ptr, ptr, ptr, N, 256, 96, 48, 1.0, ptr, ptr, ptr, fake, need - 1,
+                                   ptr, None, None, None, None, None, ptr, None, None, None) == -22

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden_file, golden_inputs, make_params, sample_indices, size_cfg, tiny_cfg
+from helpers import golden_file, golden_inputs, make_params, oracle_density_sensitivity, sample_indices, size_cfg, tiny_cfg
 from nerfstudio_thermal_amd import synth
 from nerfstudio_thermal_amd.arena import ParamArena
 import thermal_nerfacto_oracle as orc
@@ -35,15 +35,28 @@ def dev_inputs(golden_dir, size="tiny"):
 RGB_TOL, DENS_TOL, DEPTH_TOL = 1e-3, 1e-4, 1e-4
 
 
-def assert_density_chain(got, ref, what):
-    """Density after the WHOLE chain (two PDF resamplings feed the sample positions).  With the deliberately high-variance synthetic
-    tables the reference's own density moves by ~1.2e-4 when its sample bins move by ONE fp32 ulp (scripts/diag_chain.py, DESIGN.md
-    "conditioning"), so a chained max-abs of 1e-4 is below what the arithmetic defines: the chain is held to 1e-4 on >= 97% of the samples
-    and 1e-3 on all of them, and the strict 1e-4 bound is asserted where it is well posed -- on identical sample positions
-    (test_density_on_identical_samples below and tests/test_hip_ops_gpu.py::test_field_fwd_bwd)."""
+K_CHAIN = 6.0       # max |d density| of the chain <= K_CHAIN x the reference's own response to ONE ulp of its field sample bins
+U_CHAIN = 4         # share of samples above 1e-4 <= 1.5 x the reference's own share when EVERY field bin moves by U_CHAIN ulps
+
+
+def chain_sens(golden_dir, mode, size):
+    """the two oracle-only measurements the chained bound is derived from (helpers.oracle_density_sensitivity; no GPU involved)"""
+    return oracle_density_sensitivity(golden_dir, mode, size, 1), oracle_density_sensitivity(golden_dir, mode, size, U_CHAIN)
+
+
+def assert_density_chain(got, ref, what, sens1, sensU):
+    """Density after the WHOLE chain (two PDF resamplings feed the sample positions).  With the deliberately high-variance synthetic tables the
+    reference's own density moves by S1 = 1.2-1.5e-4 when its field sample bins move by ONE fp32 ulp (tests/test_conditioning_cpu.py measures it
+    on the oracle alone) and, when every bin moves by 4 ulps, by up to 3.2e-4 with 0.5-2.8 % of the samples above 1e-4 -- a chained max-abs of
+    1e-4 is below what the arithmetic defines.  The HIP sampler's field bins sit at a median of 1-2 ulps from the reference's, 85 % within 4,
+    95 % within 8 (test_sampler_bins_ulp_distance prints the histogram), so the chain is held to
+        max |err| <= K_CHAIN x S1        and        share(|err| > 1e-4) <= 1.5 x the oracle's share under +-U_CHAIN ulps;
+    the strict 1e-4 bound is asserted where it is well posed -- on identical sample positions (test_density_on_identical_samples below and
+    tests/test_hip_ops_gpu.py::test_field_fwd_bwd)."""
     err = (got.detach().cpu().double() - torch.as_tensor(ref).double()).abs()
-    assert float(err.max()) <= 1e-3, (what, float(err.max()))
-    assert float((err > DENS_TOL).double().mean()) <= 0.03, (what, float((err > DENS_TOL).double().mean()))
+    frac = float((err > DENS_TOL).double().mean())
+    assert float(err.max()) <= K_CHAIN * sens1["max"], (what, float(err.max()), sens1)
+    assert frac <= 1.5 * max(sensU["frac"], 2.0 / err.numel()), (what, frac, sensU)
 
 
 @pytest.mark.parametrize("size", ["tiny", "default", "default256"])  # "default": the reference at 16 x 2^19 / 5 x 2^17 tables, 64 rays
@@ -63,7 +76,11 @@ def test_eval_render_matches_reference_golden(golden_dir, mode, size):
         ref = g[f"eval/{k}"]
         assert tuple(out[k].shape) == ref.shape, (k, tuple(out[k].shape), ref.shape)
         if tol is None:
-            assert_density_chain(out[k], ref, k)
+            s1, su = chain_sens(golden_dir, mode, size)
+            # density2 / density2_thermal: a field on the OTHER branch's samples -- bounded by the larger of the two branches' responses
+            pick = (lambda sd: sd["_thermal" if k == "density_thermal" else ""]) if k in ("density", "density_thermal") else (
+                lambda sd: {"max": max(v["max"] for v in sd.values()), "frac": max(v["frac"] for v in sd.values())})
+            assert_density_chain(out[k], ref, k, pick(s1), pick(su))
         else:
             assert md(out[k], ref) <= tol, (k, md(out[k], ref))
     # discontinuous outputs (searchsorted at 0.5): allow a small fraction of rays to land on the neighbouring sample
@@ -89,7 +106,8 @@ def test_train_step_matches_reference_golden(golden_dir, mode, size):
         for i in range(3):
             assert outlier_fraction(lv[i].s_bins, g[f"train/sbins{s}_{i}"], 2e-6) <= 0.01, (s, i)
             assert outlier_fraction(lv[i].weights, g[f"train/weights{s}_{i}"], 1e-5) <= 0.01, (s, i)
-        assert_density_chain(out[f"density{s}"], g[f"train/density{s}"], f"density{s}")
+        s1, su = chain_sens(golden_dir, mode, size)
+        assert_density_chain(out[f"density{s}"], g[f"train/density{s}"], f"density{s}", s1[s], su[s])
         assert md(out[f"rgb{s}"], g[f"train/rgb{s}"]) <= RGB_TOL
         assert md(out[f"accumulation{s}"], g[f"train/accumulation{s}"]) <= 1e-4
     losses = eng.loss_and_backward(out, branches, cam, gi["image"].to(DEV), gi["is_thermal"].to(DEV))
@@ -223,7 +241,7 @@ def test_full_size_properties():
     assert md(half["rgbt"], out["rgbt"][: N // 2]) == 0.0
 
 
-def test_non_default_config_matches_oracle():
+def test_non_default_config_matches_oracle(golden_dir):
     """Everything the goldens pin is at the reference's default hyper-parameters; this runs a differently configured model (sample counts,
     planes, resolutions, loss multipliers) against the live oracle: eval render, train-mode forward, every loss term, one fused step."""
     from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
@@ -254,7 +272,9 @@ def test_non_default_config_matches_oracle():
     out, _ = eng.get_outputs(dev(ro), dev(rd), dev(cam), training=False)
     for key in ("rgb", "rgb_thermal", "accumulation"):
         assert float((out[key].cpu() - ref[key]).abs().max()) <= RGB_TOL, key
-    assert_density_chain(out["density"], ref["density"], "density")
+    # (no golden for this configuration: the default configuration's measured 1-ulp response stands in for its own)
+    s1, su = chain_sens(golden_dir, "shared", "tiny")
+    assert_density_chain(out["density"], ref["density"], "density", s1[""], su[""])
     # training forward + losses with injected jitters
     jit = [torch.from_numpy(j) for j in synth.synth_jitters(N, seed=77)]
     img, is_th = (torch.from_numpy(a) for a in synth.synth_gt(idx.numpy(), cams, seed=3))
@@ -485,3 +505,46 @@ def test_render_rays_train_bwd_is_the_launch_sequence(golden_dir, mode, monkeypa
             assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]) + 1e-12, (k, la[k], lb[k])
         assert torch.equal(ga == 0, gb == 0)  # same zero pattern
         assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), float((ga - gb).abs().max())
+
+
+def _ulp_distance(a, b):
+    """distance in fp32 ulps between two positive float tensors (their bit patterns are ordered like the values)"""
+    ai = torch.as_tensor(a).float().contiguous().view(torch.int32).long()
+    bi = torch.as_tensor(b).float().contiguous().view(torch.int32).long()
+    return (ai - bi).abs()
+
+
+@pytest.mark.parametrize("size", ["tiny", "default256"])
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_sampler_bins_ulp_distance(golden_dir, mode, size, capsys):
+    """How far the HIP sampler's bins sit from the REFERENCE's (train forward with the golden's injected jitter), in fp32 ulps of the euclidean
+    bins, level by level: level 0 must be exact up to one ulp (closed-form spacing), the two PDF resamplings add a few ulps each, and a handful
+    of bins per thousand land in a neighbouring CDF interval (searchsorted on a value within an ulp of a knot: the 'outliers' the bin tests
+    count).  The histogram is printed (pytest -s) and quoted in DESIGN.md section 4; the chained density bound K_CHAIN x S rests on it."""
+    g = golden_file(golden_dir, mode, size)
+    _, _, _, eng = build(mode, size)
+    gi, o, d, cam = dev_inputs(golden_dir, size)
+    jit = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to(DEV).reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+    eng.set_anneal_for_step(500)
+    _, branches = eng.get_outputs(o, d, cam, True, jit, jit_t)
+    edges = [0, 1, 2, 4, 8, 64]
+    checks = []
+    for sfx in ("", "_thermal") if mode == "separate" else ("",):
+        for i, lv in enumerate(branches[sfx].levels):
+            ref = g[f"train/ebins{sfx}_{i}"] if f"train/ebins{sfx}_{i}" in g.files else None
+            if ref is None:
+                continue
+            dist = _ulp_distance(lv.e_bins.detach().cpu(), ref).reshape(-1)
+            n = dist.numel()
+            hist = [int((dist == 0).sum())] + [int(((dist > lo) & (dist <= hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])] + [int((dist > edges[-1]).sum())]
+            with capsys.disabled():
+                print(f"\n[ulp distance of e_bins, {mode} {size} branch '{sfx}' level {i}] 0: {hist[0]}  1: {hist[1]}  2: {hist[2]}  3-4: {hist[3]}  5-8: {hist[4]}  "
+                      f"9-64: {hist[5]}  >64: {hist[6]}  of {n}")
+            checks.append((sfx, i, dist, hist))
+    for sfx, i, dist, hist in checks:
+        if i == 0:
+            assert int(dist.max()) <= 2, (sfx, i, int(dist.max()))
+        else:
+            assert float((dist <= 8).double().mean()) >= 0.90, (sfx, i, hist)
+            assert float((dist > 64).double().mean()) <= 0.02, (sfx, i, hist)

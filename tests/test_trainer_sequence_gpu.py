@@ -332,3 +332,66 @@ def test_load_torch_adam_checkpoint_with_idle_parameters(golden_dir):
     ref2.step()
     for p, a in zip(params, after_hip):
         assert float((p.detach() - a).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+def test_fused_checkpoint_carries_the_grad_scaler_state(golden_dir):
+    """Resume of the fused path after a skipped iteration (reference: Trainer.save_checkpoint stores "scalers": grad_scaler.state_dict(),
+    engine/trainer.py:444, restored at :408-419; torch's Adam `step` and the schedulers exclude the skipped iteration): the checkpoint written
+    after [clean, clean, inf, clean] carries scale / growth tracker, per-group steps WITHOUT the skipped one and last_epoch WITHOUT the lag, and a
+    model resumed from it takes the same next step as the one that kept running."""
+    from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+    mA, _, rb, batch, jit = _setup(golden_dir, "shared")
+    rays = (rb.origins.contiguous(), rb.directions.contiguous(), rb.camera_indices.reshape(-1).contiguous())
+    sA = DeviceGradScaler(DEV)
+    bad = batch["image"].clone()
+    bad[:, :] = float("inf")
+    for step in range(4):
+        mA.engine.train_step(*rays, bad if step == 2 else batch["image"], batch["is_thermal"], step, jit[0], jit[1], grad_scaler=sA)
+    ck = {"model": {k: v.clone() for k, v in mA.state_dict().items()}, **mA.engine.optimizer_state_dict(grad_scaler=sA)}
+    assert ck["scalers"]["scale"] == 32768.0 and ck["scalers"]["_growth_tracker"] == 1
+    # what the reference Trainer would have written for this history: 3 real field steps, 4 proposal steps, 3 scheduler steps
+    assert float(ck["optimizers"]["fields"]["state"][0]["step"]) == 3.0
+    assert float(ck["optimizers"]["proposal_networks"]["state"][0]["step"]) == 4.0
+    assert ck["schedulers"]["fields"]["last_epoch"] == 3
+    mB, _, _, _, _ = _setup(golden_dir, "shared")
+    sB = DeviceGradScaler(DEV)
+    mB.load_model(ck)
+    mB.engine.load_optimizer_state_dict(ck, grad_scaler=sB)
+    assert sB.get_scale() == 32768.0 and sB.schedule_lag() == 0 and int(sB.growth_tracker.item()) == 1
+    assert_same_training_state(_snapshot(mA), _snapshot(mB), "state right after loading the checkpoint", frac=0.0)
+    mA.engine.train_step(*rays, batch["image"], batch["is_thermal"], 4, jit[0], jit[1], grad_scaler=sA)
+    mB.engine.train_step(*rays, batch["image"], batch["is_thermal"], 4, jit[0], jit[1], grad_scaler=sB)
+    # one iteration from identical states: the same bias corrections (step 4 of the fields, 5 of the proposal networks) and the same LR (schedule at 3)
+    assert_same_training_state(_snapshot(mA), _snapshot(mB), "first step after the resume")
+    # a plain torch.amp.GradScaler state (a reference checkpoint) loads too
+    sC = DeviceGradScaler(DEV)
+    sC.load_state_dict(torch.amp.GradScaler("cuda", init_scale=1024.0).state_dict())
+    assert sC.get_scale() == 1024.0 and sC.schedule_lag() == 0
+
+
+def test_fused_step_after_a_drop_in_step_starts_from_zero_gradients(golden_dir):
+    """The fused step skips its zero-fill when the previous optimiser launch consumed the gradients.  A step on the drop-in path in between
+    writes into the same buffer (model._RenderFn.backward, autograd through the aliased .grad views) and its optimiser does not consume: the
+    arena's dirty bit must make the next fused step clear the buffer -- fused, drop-in, fused == the same three steps with explicit zero-fills."""
+    from nerfstudio_thermal_amd.optim import HipFusedAdam
+
+    mA, oA, rb, batch, jit = _setup(golden_dir, "shared", HipFusedAdam)
+    mB, oB, _, _, _ = _setup(golden_dir, "shared", HipFusedAdam)
+    rays = (rb.origins.contiguous(), rb.directions.contiguous(), rb.camera_indices.reshape(-1).contiguous())
+    for m, force in ((mA, False), (mB, True)):
+        opt = oA if m is mA else oB
+        m.engine.train_step(*rays, batch["image"], batch["is_thermal"], 0, jit[0], jit[1])
+        assert m.arena.grads_clean
+        _reference_train_iteration(m, opt, torch.amp.GradScaler("cuda", enabled=False), rb, batch, 1, False, jit)
+        assert not m.arena.grads_clean  # the drop-in step left its gradients in the buffer
+        if force:
+            m.arena.zero_grad()  # what the flag must trigger by itself in run A
+        m.engine.train_step(*rays, batch["image"], batch["is_thermal"], 2, jit[0], jit[1])
+    assert_same_training_state(_snapshot(mA), _snapshot(mB), "fused / drop-in / fused against the same with an explicit zero-fill")
+    # a manual optimiser step that skips a group which HAD gradients leaves the buffer dirty
+    mA.engine.train_step(*rays, batch["image"], batch["is_thermal"], 3, jit[0], jit[1])
+    out, br = mA.engine.get_outputs(*rays, True, jit[0], jit[1])
+    mA.engine.loss_and_backward(out, br, rays[2], batch["image"], batch["is_thermal"])
+    mA.engine.optimizer_step(skip_groups=("camera_opt",))
+    assert not mA.arena.grads_clean
