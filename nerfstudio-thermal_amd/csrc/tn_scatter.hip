@@ -327,7 +327,7 @@ __device__ __forceinline__ void bin_run_sums(float (&vx)[8], float (&vy)[8], int
 }
 
 template <bool WANT_DPOS>
-__global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+__global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                           const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
                                                           float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, BinK bk) {
   __shared__ uint32_t s_cnt[BIN_MAX_COUNTERS], s_loff[BIN_MAX_COUNTERS], s_gbase[BIN_MAX_COUNTERS];
@@ -351,25 +351,48 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
   const float st = eb[0], en = eb[1];
   const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
   const int nlev = (g.L - (int)blockIdx.y + level_groups - 1) / level_groups;  // levels of this block: blockIdx.y + li * level_groups
+  // The block is a chain of dependent latencies (a global load per level, the returning reservation atomics, ten barriers), not a
+  // throughput problem: 65 % of its wave-cycles were spent parked (profiles/r03_pmc_summary.md).  So every load whose address is known
+  // up front is issued up front -- d enc of ALL the block's levels here -- and the reservations below are waited for only after the first
+  // level has been staged.
+  constexpr int GVP = 5;
+  float2 gvp[GVP];
+#pragma unroll
+  for (int li = 0; li < GVP; ++li) {
+    const int l = blockIdx.y + li * level_groups;
+    gvp[li] = (live && li < nlev) ? *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p) : make_float2(0.f, 0.f);
+  }
   // ---- phase A: how many records this block sends to every bucket, one reservation per bucket for all levels at once (a returning global
   // atomic takes microseconds: inside the level loop it was the critical path)
   for (int t = tid; t < nlev * ns; t += BIN_THREADS) s_cnt[t] = 0;
   __syncthreads();
+  BinLevel bfirst;  // the first level's corners and run structure are kept for phase B (one of the nlev recomputations less)
 #pragma unroll 1
   for (int li = 0; li < nlev; ++li) {
     const int l = blockIdx.y + li * level_groups;
     BinLevel b;
     bin_level(c, g.res[l], g.mask, (bk.merge_mask >> l) & 1u, live, lane, b);
+    if (!WANT_DPOS && li == 0) bfirst = b;  // (the d-position variant has no registers to spare: 128 at four waves per SIMD)
     if (b.emit) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) atomicAdd(&s_cnt[li * ns + (b.idx[k] >> bk.slice_log2)], 1u);
     }
   }
   __syncthreads();
-  for (int li = tid >> 6; li < nlev; li += BIN_THREADS / 64) {  // one wave per level
+  // one wave per level: offsets of the buckets inside the staging area, and one returning global atomic per non-empty bucket reserves the run
+  // in the bucket's global array.  The atomics' results (gb) are NOT waited for here: they go to s_gbase after the first level's staging.
+  constexpr int GB = TN_BIN_MAX_SLICES / 64;
+  uint32_t gb[GB];
+  const int my_li = tid >> 6;  // the level this wave reserves for (if < nlev); further levels of blocks with more than 8 levels: the loop below
+#pragma unroll
+  for (int u = 0; u < GB; ++u) gb[u] = 0u;
+  for (int li = my_li; li < nlev; li += BIN_THREADS / 64) {
     const int l = blockIdx.y + li * level_groups;
     uint32_t run = 0;
-    for (int base = 0; base < ns; base += 64) {
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int base = u * 64;
+      if (base >= ns) break;
       const int sl = base + lane;
       const uint32_t cnt = sl < ns ? s_cnt[li * ns + sl] : 0u;
       uint32_t inc = cnt;
@@ -378,11 +401,14 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
         const uint32_t t = __shfl_up(inc, o2, 64);
         if (lane >= o2) inc += t;
       }
+      uint32_t r = 0u;
       if (sl < ns) {
         s_loff[li * ns + sl] = run + inc - cnt;
-        s_gbase[li * ns + sl] = cnt ? atomicAdd(&bk.count[((size_t)l * ns + sl) * bk.cstride], cnt) : 0u;
+        r = cnt ? atomicAdd(&bk.count[((size_t)l * ns + sl) * bk.cstride], cnt) : 0u;
         s_cnt[li * ns + sl] = 0;  // becomes the rank counter of phase B
       }
+      if (li == my_li) gb[u] = r;  // (first level of this wave: deferred)
+      else if (sl < ns) s_gbase[li * ns + sl] = r;
       run += __shfl(inc, 63, 64);
     }
     if (lane == 0) s_tot[li] = run;
@@ -397,10 +423,18 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
     const float res = g.res[l];
     const bool merge = (bk.merge_mask >> l) & 1u;
     BinLevel b;
-    bin_level(c, res, g.mask, merge, live, lane, b);
+    if (!WANT_DPOS && li == 0) b = bfirst;
+    else bin_level(c, res, g.mask, merge, live, lane, b);
     // row-major [P][ld], or level-major [L][P] float2 (TN_LD_LEVEL_MAJOR: the 64 lanes of a wave then read four runs of 16 consecutive float2
     // instead of 64 pieces of 8 bytes 128 B apart -- 114 MB fetched for the main grid's 25 MB of d enc)
-    const float2 gv = live ? *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p) : make_float2(0.f, 0.f);
+    float2 gv = make_float2(0.f, 0.f);
+    if (li < GVP) {
+#pragma unroll
+      for (int q = 0; q < GVP; ++q)
+        if (q == li) gv = gvp[q];
+    } else if (live) {
+      gv = *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p);
+    }
     if (WANT_DPOS) {
       // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
       const float2* tb = g.table + (size_t)l * g.tsize;
@@ -438,6 +472,13 @@ __global__ void __launch_bounds__(BIN_THREADS) k_grid_bin(GridK g, const float* 
         const uint32_t pos = s_loff[cidx] + atomicAdd(&s_cnt[cidx], 1u);
         s_idx[pos] = b.idx[k];
         s_val[pos] = make_float2(vx[k], vy[k]);
+      }
+    }
+    if (li == 0 && my_li < nlev) {  // the reservations of this wave's level have had the whole first level's staging to come back
+#pragma unroll
+      for (int u = 0; u < GB; ++u) {
+        const int sl = u * 64 + lane;
+        if (u * 64 < ns && sl < ns) s_gbase[my_li * ns + sl] = gb[u];
       }
     }
     __syncthreads();
