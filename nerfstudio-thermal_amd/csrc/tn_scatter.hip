@@ -330,7 +330,11 @@ template <bool WANT_DPOS>
 __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                           const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
                                                           float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, BinK bk) {
-  __shared__ uint32_t s_cnt[BIN_MAX_COUNTERS], s_loff[BIN_MAX_COUNTERS], s_gbase[BIN_MAX_COUNTERS];
+  // s_cnt: phase A: records per (level, bucket); phase B: next free staging position of the bucket (starts at the bucket's offset s_loff)
+  // s_dl: per (level, bucket) {delta, lim}: staged record j of the bucket goes to position j + delta of the level's global record array if
+  //       j < lim (delta = bucket * cap + reserved base - staging offset; lim = staging offset + room left in the bucket), else the bucket is full
+  __shared__ uint32_t s_cnt[BIN_MAX_COUNTERS], s_loff[BIN_MAX_COUNTERS];
+  __shared__ uint2 s_dl[BIN_MAX_COUNTERS];
   __shared__ uint32_t s_tot[TN_MAX_LEVELS];
   __shared__ uint32_t s_idx[BIN_THREADS * 8];
   __shared__ float2 s_val[BIN_THREADS * 8];
@@ -355,8 +359,9 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
   // throughput problem: 65 % of its wave-cycles were spent parked (profiles/r03_pmc_summary.md).  So every load whose address is known
   // up front is issued up front -- d enc of ALL the block's levels here -- and the reservations below are waited for only after the first
   // level has been staged.
-  constexpr int GVP = 5;
-  float2 gvp[GVP];
+  // (Not in the d-position variant: at four waves per SIMD it has 128 registers and spills with these prefetches -- measured 128 -> 131 us.)
+  constexpr int GVP = WANT_DPOS ? 0 : 5;
+  float2 gvp[GVP + 1];
 #pragma unroll
   for (int li = 0; li < GVP; ++li) {
     const int l = blockIdx.y + li * level_groups;
@@ -403,12 +408,13 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
       }
       uint32_t r = 0u;
       if (sl < ns) {
-        s_loff[li * ns + sl] = run + inc - cnt;
+        const uint32_t loff = run + inc - cnt;
+        s_loff[li * ns + sl] = loff;
         r = cnt ? atomicAdd(&bk.count[((size_t)l * ns + sl) * bk.cstride], cnt) : 0u;
-        s_cnt[li * ns + sl] = 0;  // becomes the rank counter of phase B
+        s_cnt[li * ns + sl] = loff;  // becomes the bucket's staging cursor of phase B
+        if (li != my_li) s_dl[li * ns + sl] = make_uint2((uint32_t)sl * bk.cap + r - loff, loff + (r < bk.cap ? bk.cap - r : 0u));
       }
       if (li == my_li) gb[u] = r;  // (first level of this wave: deferred)
-      else if (sl < ns) s_gbase[li * ns + sl] = r;
       run += __shfl(inc, 63, 64);
     }
     if (lane == 0) s_tot[li] = run;
@@ -468,8 +474,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
     if (b.emit) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int cidx = li * ns + (b.idx[k] >> bk.slice_log2);
-        const uint32_t pos = s_loff[cidx] + atomicAdd(&s_cnt[cidx], 1u);
+        const uint32_t pos = atomicAdd(&s_cnt[li * ns + (b.idx[k] >> bk.slice_log2)], 1u);
         s_idx[pos] = b.idx[k];
         s_val[pos] = make_float2(vx[k], vy[k]);
       }
@@ -478,20 +483,24 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int sl = u * 64 + lane;
-        if (u * 64 < ns && sl < ns) s_gbase[my_li * ns + sl] = gb[u];
+        if (u * 64 < ns && sl < ns) {
+          const uint32_t loff = s_loff[my_li * ns + sl], r = gb[u];
+          s_dl[my_li * ns + sl] = make_uint2((uint32_t)sl * bk.cap + r - loff, loff + (r < bk.cap ? bk.cap - r : 0u));
+        }
       }
     }
     __syncthreads();
     const uint32_t total = s_tot[li];
+    uint16_t* __restrict__ idx_l = bk.idx + (size_t)l * bk.level_stride;  // (wave-uniform bases + 32-bit record offsets: nslices * cap < 2^32)
+    float2* __restrict__ val_l = bk.val + (size_t)l * bk.level_stride;
     for (uint32_t j = tid; j < total; j += BIN_THREADS) {
       const uint32_t id = s_idx[j];
       const float2 v = s_val[j];
-      const uint32_t sl = id >> bk.slice_log2;
-      const uint32_t gpos = s_gbase[li * ns + sl] + (j - s_loff[li * ns + sl]);
-      if (gpos < bk.cap) {
-        const size_t at = (size_t)l * bk.level_stride + (size_t)sl * bk.cap + gpos;
-        bk.idx[at] = (uint16_t)(id & smask);
-        bk.val[at] = v;
+      const uint2 dl = s_dl[li * ns + (id >> bk.slice_log2)];
+      if (j < dl.y) {
+        const uint32_t at = j + dl.x;
+        idx_l[at] = (uint16_t)(id & smask);
+        val_l[at] = v;
       } else {  // bucket full: add straight into the gradient
         float* dst = reinterpret_cast<float*>(g.grad + (size_t)l * g.tsize + id);
         if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
