@@ -57,6 +57,10 @@ typedef struct TnGrid {
   int32_t num_levels;
   int32_t log2_hashmap_size;
   float res[TN_MAX_LEVELS]; /* floor(min_res * growth^l) as fp32, computed by the host exactly as the reference does */
+  /* NULL, or one float on the device that every table-gradient scatter of this grid sets to 1.0f when an entry of table_grad comes out inf / NaN
+   * (GradScaler's found_inf for the optimiser group that owns the table, engine/trainer.py:470-495 -> torch/amp/grad_scaler.py: raised by the
+   * kernel that writes the final value, so no separate pass over the 64 MB of table gradient is needed; never cleared by the scatter) */
+  float* nonfinite_flag;
 } TnGrid;
 
 /* HashMLPDensityField (fields/density_fields.py:34-118): 5 lvl x 2 feat -> Linear(10,16) ReLU Linear(16,1). */
@@ -371,6 +375,15 @@ int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, cons
                        const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                        const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
                        tn_stream_t stream);
+/* tn_pose_bwd_finish + GradScaler's non-finite check of what the table scatters do not see, in the same launch: found_inf[pose_flag] is raised
+ * when a contribution to the pose gradient is inf / NaN, and found_inf[flag_index[k]] when any of the `counts[k]` gradients at grads + offsets[k]
+ * is (up to 8 SMALL ranges -- MLP weights, embeddings: at most 4 M floats each; offsets / counts / flag_index are HOST arrays).  With
+ * TnGrid::nonfinite_flag on every grid this replaces tn_grad_nonfinite_ranges over the whole gradient arena. */
+int tn_pose_bwd_finish_check(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                             const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                             const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
+                             const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
+                             int32_t num_flags, float* found_inf, int32_t pose_flag, tn_stream_t stream);
 /* density L1 cross loss with the reference's detach asymmetry (models/thermal_nerfacto.py:328-344): loss += a*mean|x-y| with
  * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
 int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
@@ -419,6 +432,17 @@ int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, f
                             int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream);
 int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
                           double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream);
+/* tn_adam_step_ranges_amp + tn_grad_scaler_update(clear_found_inf = 1) in ONE launch: the last block of the Adam launch to finish performs
+ * GradScaler.update() -- every block has read found_inf / the schedule lag by then.  done_counter: TN_ADAM_DONE_WORDS zeroed uint32 on the device
+ * (left zero; the blocks count themselves in on 64 counters in 64 different 64-byte lines: same-line atomics execute one after the other). */
+#define TN_ADAM_DONE_WORDS (65 * 16)
+int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                   const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                   const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                                   const float* inv_scale, float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                                   int32_t lag_index, int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker,
+                                   uint32_t* done_counter, double growth_factor, double backoff_factor, int32_t growth_interval,
+                                   tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 /* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */
 int tn_shutdown(void);

@@ -33,6 +33,7 @@ class TnGrid(C.Structure):
         ("num_levels", _i32),
         ("log2_hashmap_size", _i32),
         ("res", _f * TN_MAX_LEVELS),
+        ("nonfinite_flag", _p),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "tn_sample_rays": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "tn_pose_spaced_bins": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "tn_pose_bwd_finish": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _f, _f, _f, _p, _p]),
+    "tn_pose_bwd_finish_check": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _f, _f, _f, _p, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p]),
     "tn_pose_apply_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "tn_pose_apply_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "tn_spaced_bins": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "tn_adam_step_ranges_amp": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p]),
     "tn_grad_nonfinite_ranges": (C.c_int, [_p, _i32, _p, _p, _p, _i32, _p, _p]),
     "tn_grad_scaler_update": (C.c_int, [_p, _p, _p, _i32, _p, _d, _d, _i32, _i32, _p]),
+    "tn_adam_step_ranges_amp_update": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _i32,
+                                                 _p, _p, _p, _d, _d, _i32, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_shutdown": (C.c_int, []),
     "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),

@@ -49,6 +49,7 @@ struct GridK {
   uint32_t mask;    // 2^log2T - 1
   uint32_t tsize;   // 2^log2T
   float res[TN_MAX_LEVELS];
+  float* nonfinite;  // TnGrid::nonfinite_flag
 };
 static inline GridK make_gridk(const TnGrid& g) {
   GridK k;
@@ -58,6 +59,7 @@ static inline GridK make_gridk(const TnGrid& g) {
   k.tsize = 1u << g.log2_hashmap_size;
   k.mask = k.tsize - 1u;
   for (int i = 0; i < TN_MAX_LEVELS; ++i) k.res[i] = g.res[i];
+  k.nonfinite = g.nonfinite_flag;
   return k;
 }
 

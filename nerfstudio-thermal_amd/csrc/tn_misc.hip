@@ -395,8 +395,9 @@ extern "C" int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* 
 //   dL/dv_m = f1 * skewpart(G)_m + f2 * ((G + G^T) v - 2 v tr G)_m + (<G,K> f1' + <G,K^2> f2') * dtheta/dn * 2 v_m
 __device__ __forceinline__ void pose_bwd_body(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
                                               const float* __restrict__ d_in, const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N,
-                                              int C, float* __restrict__ grad_pose, int bid, int nblk) {
+                                              int C, float* __restrict__ grad_pose, int bid, int nblk, float* __restrict__ nonfinite = nullptr) {
   int lane = tn_lane();
+  bool bad = false;  // a non-finite contribution makes the pose gradient non-finite (GradScaler's found_inf of the camera optimiser's group)
   int64_t stride = (int64_t)nblk * blockDim.x;
   int64_t iters = tn_cdiv(N, stride);
   for (int64_t it = 0; it < iters; ++it) {
@@ -448,13 +449,17 @@ __device__ __forceinline__ void pose_bwd_body(const float* __restrict__ pose, co
       for (int q = 0; q < 6; ++q) {
         float r = tn_wave_sum(out[q]);
         if (lane == 0 && r != 0.0f) atomicAdd(grad_pose + cam * 6 + q, r);
+        bad = bad || ((r - r) != 0.0f);
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < 6; ++q) {
         if (out[q] != 0.0f) atomicAdd(grad_pose + cam * 6 + q, out[q]);
+        bad = bad || ((out[q] - out[q]) != 0.0f);
+      }
     }
   }
+  if (nonfinite != nullptr && __any(bad) && lane == 0) *nonfinite = 1.0f;
 }
 
 __global__ void k_pose_bwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
@@ -554,6 +559,61 @@ extern "C" int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* f
   hipLaunchKernelGGL(k_pose_bwd_finish, dim3(nb + 1), dim3(256), 0, tn_s(stream), pose_adjustment, frozen, camera_indices, directions_in, d_origins,
                      d_directions, N, num_cameras, grad_pose, loss_lines, losses16, trans_pen, rot_pen, scale, reg_out);
   TN_CHECK_LAUNCH("tn_pose_bwd_finish");
+  return TN_OK;
+}
+
+#define TN_ADAM_MAX_RANGES 8  // ranges per launch of the multi-range entry points (Adam, non-finite checks)
+// tn_pose_bwd_finish + GradScaler's non-finite check of everything the table scatters do not see (tn_pose_bwd_finish_check): the pose gradient
+// through its contributions (this launch produces it), and up to TN_ADAM_MAX_RANGES small gradient ranges -- MLP weights, embeddings: final
+// by now -- in extra blocks, 4096 floats each.  Together with TnGrid::nonfinite_flag this replaces the pass of tn_grad_nonfinite_ranges over the
+// whole gradient arena (78 MB, 12 us on the serial chain of a step).
+struct SmallRanges { int64_t off[TN_ADAM_MAX_RANGES], cnt[TN_ADAM_MAX_RANGES]; int32_t flag[TN_ADAM_MAX_RANGES], first_block[TN_ADAM_MAX_RANGES + 1]; int32_t n; };
+__global__ void __launch_bounds__(256) k_pose_bwd_finish_check(const float* __restrict__ pose, const uint8_t* __restrict__ frozen,
+                                                               const int64_t* __restrict__ cam_idx, const float* __restrict__ d_in,
+                                                               const float* __restrict__ g_o, const float* __restrict__ g_d, int64_t N, int C,
+                                                               float* __restrict__ grad_pose, const float* __restrict__ lines, float* __restrict__ losses,
+                                                               float trans_pen, float rot_pen, float scale, float* __restrict__ reg_out, int pose_blocks,
+                                                               const float* __restrict__ grads, SmallRanges sr, float* __restrict__ found_inf, int pose_flag) {
+  const int b = blockIdx.x;
+  if (b < pose_blocks) { pose_bwd_body(pose, frozen, cam_idx, d_in, g_o, g_d, N, C, grad_pose, b, pose_blocks, found_inf + pose_flag); return; }
+  if (b == pose_blocks) { losses_finish_body<true>(lines, losses, pose, C, trans_pen, rot_pen, scale, reg_out, grad_pose); return; }
+  const int cb = b - pose_blocks - 1;
+  int k = 0;
+  for (int i = 1; i < sr.n; ++i)
+    if (cb >= sr.first_block[i]) k = i;
+  const int64_t lo = (int64_t)(cb - sr.first_block[k]) * 4096, hi = lo + 4096 < sr.cnt[k] ? lo + 4096 : sr.cnt[k];
+  const float* base = grads + sr.off[k];
+  bool bad = false;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const float x = base[i]; bad = bad || ((x - x) != 0.0f); }
+  if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[sr.flag[k]] = 1.0f;
+}
+extern "C" int tn_pose_bwd_finish_check(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                                        const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
+                                        const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
+                                        const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
+                                        int32_t num_flags, float* found_inf, int32_t pose_flag, tn_stream_t stream) {
+  TN_REQUIRE(pose_adjustment && camera_indices && directions_in && d_origins && d_directions && grad_pose && reg_out, "tn_pose_bwd_finish_check: null pointer");
+  TN_REQUIRE((loss_lines == nullptr) == (losses16 == nullptr), "tn_pose_bwd_finish_check: loss_lines and losses16 go together");
+  TN_REQUIRE(N >= 1 && num_cameras >= 1, "tn_pose_bwd_finish_check: bad N=%lld C=%d", (long long)N, num_cameras);
+  TN_REQUIRE(found_inf && num_flags >= 1 && pose_flag >= 0 && pose_flag < num_flags, "tn_pose_bwd_finish_check: bad found_inf / pose_flag");
+  TN_REQUIRE(num_ranges >= 0 && num_ranges <= TN_ADAM_MAX_RANGES && (num_ranges == 0 || (grads && offsets && counts && flag_index)),
+             "tn_pose_bwd_finish_check: bad range list");
+  SmallRanges sr{};
+  int nb = 0;
+  for (int k = 0; k < num_ranges; ++k) {
+    TN_REQUIRE(offsets[k] >= 0 && counts[k] >= 0 && counts[k] <= (1 << 22) && flag_index[k] >= 0 && flag_index[k] < num_flags,
+               "tn_pose_bwd_finish_check: bad range %d (the small ranges only: at most 4 M floats each)", k);
+    if (counts[k] == 0) continue;
+    sr.off[sr.n] = offsets[k]; sr.cnt[sr.n] = counts[k]; sr.flag[sr.n] = flag_index[k]; sr.first_block[sr.n] = nb;
+    nb += (int)tn_cdiv(counts[k], 4096);
+    ++sr.n;
+  }
+  sr.first_block[sr.n] = nb;
+  const unsigned pb = (unsigned)std::min<int64_t>(tn_cdiv(N, 256), 1024);
+  hipLaunchKernelGGL(k_pose_bwd_finish_check, dim3(pb + 1 + nb), dim3(256), 0, tn_s(stream), pose_adjustment, frozen, camera_indices, directions_in, d_origins,
+                     d_directions, N, num_cameras, grad_pose, loss_lines, losses16, trans_pen, rot_pen, scale, reg_out, (int)pb, grads, sr, found_inf,
+                     (int)pose_flag);
+  TN_CHECK_LAUNCH("tn_pose_bwd_finish_check");
   return TN_OK;
 }
 
@@ -720,7 +780,6 @@ __global__ void k_adam(float4* __restrict__ p, const float4* __restrict__ g, flo
   adam_body(p, g, m, v, n4, pt, gt, mt, vt, tail, b1, b2, omb1, omb2, neg_step, bc2_sqrt, eps);
 }
 // several ranges of the same arenas (one per optimiser group: own step count and learning rate) in one launch; blockIdx.y = range
-#define TN_ADAM_MAX_RANGES 8
 struct AdamRanges {
   int64_t off[TN_ADAM_MAX_RANGES], cnt[TN_ADAM_MAX_RANGES];
   float neg_step[TN_ADAM_MAX_RANGES], bc2_sqrt[TN_ADAM_MAX_RANGES];
@@ -873,9 +932,66 @@ struct AdamRangesAmp {
   int32_t sched_step;                     // scheduler steps on the host's count
   int32_t num_flags, lag_index;           // entries of found_inf; index of the schedule lag in skipped (-1: none)
 };
+// GradScaler.update() by the LAST block of the Adam launch to finish (tn_adam_step_ranges_amp_update): every block has read found_inf and the
+// schedule lag by the time it counts itself done, so the block that sees the full count may rewrite them -- one launch (4.6 us on the serial
+// chain of a step) less.  done: one zeroed uint32 on the device, left zero again.
+struct ScalerUpdate {
+  float* scale;             // NULL: no fused update
+  int32_t* growth_tracker;
+  uint32_t* done;
+  float growth_factor, backoff_factor;
+  int32_t growth_interval;
+};
+__device__ __forceinline__ void scaler_update_body(float* scale, int32_t* growth_tracker, float* found_inf, int num_flags, int32_t* lag, float growth_factor,
+                                                   float backoff_factor, int growth_interval, int clear) {
+  bool any = false;
+  for (int i = 0; i < num_flags; ++i) {
+    any = any || (found_inf[i] != 0.0f);
+    if (clear) found_inf[i] = 0.0f;  // ready for the next iteration: no separate zero-fill launch
+  }
+  if (any) {
+    *scale = *scale * backoff_factor;
+    *growth_tracker = 0;
+    if (lag != nullptr) *lag += 1;
+  } else {
+    const int successful = *growth_tracker + 1;
+    if (successful == growth_interval) {
+      const float ns = *scale * growth_factor;
+      if ((ns - ns) == 0.0f) *scale = ns;  // finite
+      *growth_tracker = 0;
+    } else {
+      *growth_tracker = successful;
+    }
+  }
+}
+// Counting the blocks in: atomics into ONE 64-byte line execute one after the other (~25 ns each), and the launch has up to 12 k blocks that
+// all finish at about the same time -- a single counter made the launch 4.5 x longer (0.3 ms of serialised atomics).  So the blocks count
+// themselves on 64 counters in 64 different lines (block b on line b mod 64), and the block that completes a line counts the LINE on a 65th.
+#define TN_DONE_WORDS (65 * 16)  // uint32 words of the done-counter buffer (all zero before the launch, all zero after it)
+// No fences: a device-scope release fence on gfx950 writes the XCD's whole L2 back (the launch has 300 MB of dirty lines: with one
+// __threadfence() per block it took 535 us instead of 67).  None is needed: what must be ordered is every block's READS of found_inf / the lag
+// before the updater's writes, and a block counts itself in only after its threads have USED those values (the barrier below); counters are
+// relaxed device-scope atomics, their resets and the update itself are consumed by later launches only.
+__device__ __forceinline__ void adam_block_done(const ScalerUpdate& su, float* found_inf, int num_flags, int32_t* skipped, int lag_index) {
+  if (su.scale == nullptr) return;
+  __syncthreads();  // every thread of the block has read what it needs of found_inf / skipped
+  if (threadIdx.x == 0) {
+    const uint32_t total = gridDim.x * gridDim.y, lb = blockIdx.y * gridDim.x + blockIdx.x, line = lb & 63u;
+    const uint32_t expect = total / 64u + ((line < (total & 63u)) ? 1u : 0u);
+    if (__hip_atomic_fetch_add(su.done + line * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == expect) {
+      __hip_atomic_store(su.done + line * 16u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t lines = total < 64u ? total : 64u;
+      if (__hip_atomic_fetch_add(su.done + 64u * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == lines) {
+        __hip_atomic_store(su.done + 64u * 16u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scaler_update_body(su.scale, su.growth_tracker, found_inf, num_flags, (skipped != nullptr && lag_index >= 0) ? skipped + lag_index : nullptr,
+                           su.growth_factor, su.backoff_factor, su.growth_interval, 1);
+      }
+    }
+  }
+}
 __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
-                                  double beta1, double beta2, float eps, const float* __restrict__ inv_scale, const float* __restrict__ found_inf,
-                                  int32_t* __restrict__ skipped, int count_skip, int zero_g) {
+                                  double beta1, double beta2, float eps, const float* __restrict__ inv_scale, float* __restrict__ found_inf,
+                                  int32_t* __restrict__ skipped, int count_skip, int zero_g, ScalerUpdate su) {
   const int k = blockIdx.y;
   const int fl = r.flag[k];
   float* gz = const_cast<float*>(g);  // zero_g: the gradients are consumed (set to zero behind the read): no zero-fill launch before the next backward
@@ -889,9 +1005,13 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
         reinterpret_cast<float4*>(gz + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - n4 * 4) gz[off + n4 * 4 + threadIdx.x] = 0.0f;
     }
+    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
     return;
   }
-  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) return;
+  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) {
+    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
+    return;
+  }
   __shared__ float s_ns, s_bc;
   if (threadIdx.x == 0) {
     const int sk = skipped ? skipped[fl] : 0;
@@ -952,12 +1072,13 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
     if (zero_g) gz[i] = 0.0f;
   }
 #undef ADAM1
+  adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
-extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
-                                       const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
-                                       const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
-                                       const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
-                                       int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream) {
+static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                               const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                               const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                               const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                               int32_t lag_index, int32_t count_skip, int32_t zero_grads, ScalerUpdate su, tn_stream_t stream) {
   if (num_ranges == 0) return TN_OK;
   TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges_amp: null pointer");
   TN_REQUIRE(num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES, "tn_adam_step_ranges_amp: %d ranges (at most %d)", num_ranges, TN_ADAM_MAX_RANGES);
@@ -985,9 +1106,30 @@ extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float*
   r.lag_index = lag_index;
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256), 256 * 16));
   hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
-                     found_inf, skipped, (int)count_skip, (int)zero_grads);
+                     const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su);
   TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
   return TN_OK;
+}
+extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                       const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                       const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                                       const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                                       int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream) {
+  return adam_ranges_amp_impl(params, grads, exp_avg, exp_avg_sq, num_ranges, offsets, counts, steps, lrs, lr_finals, sched_max_steps, sched_step, beta1, beta2,
+                              eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, ScalerUpdate{}, stream);
+}
+extern "C" int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                              const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                              const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
+                                              const float* inv_scale, float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
+                                              int32_t lag_index, int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker,
+                                              uint32_t* done_counter, double growth_factor, double backoff_factor, int32_t growth_interval,
+                                              tn_stream_t stream) {
+  TN_REQUIRE(found_inf && scale && growth_tracker && done_counter && growth_interval >= 1, "tn_adam_step_ranges_amp_update: bad scaler arguments");
+  TN_REQUIRE(num_ranges > 0, "tn_adam_step_ranges_amp_update: the fused scale update needs at least one range (use tn_grad_scaler_update otherwise)");
+  ScalerUpdate su{scale, growth_tracker, done_counter, (float)growth_factor, (float)backoff_factor, (int32_t)growth_interval};
+  return adam_ranges_amp_impl(params, grads, exp_avg, exp_avg_sq, num_ranges, offsets, counts, steps, lrs, lr_finals, sched_max_steps, sched_step, beta1, beta2,
+                              eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, su, stream);
 }
 
 // GradScaler.update() (torch/amp/grad_scaler.py -> amp_update_scale_cuda_kernel) for the fused step, one thread: backoff when any of the
@@ -995,25 +1137,7 @@ extern "C" int tn_adam_step_ranges_amp(float* params, const float* grads, float*
 // engine/trainer.py:491-495), growth after `growth_interval` clean iterations in a row.
 __global__ void k_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int num_flags, int32_t* lag, float growth_factor,
                                      float backoff_factor, int growth_interval, int clear) {
-  bool any = false;
-  for (int i = 0; i < num_flags; ++i) {
-    any = any || (found_inf[i] != 0.0f);
-    if (clear) found_inf[i] = 0.0f;  // ready for the next iteration: no separate zero-fill launch
-  }
-  if (any) {
-    *scale = *scale * backoff_factor;
-    *growth_tracker = 0;
-    if (lag != nullptr) *lag += 1;
-  } else {
-    const int successful = *growth_tracker + 1;
-    if (successful == growth_interval) {
-      const float ns = *scale * growth_factor;
-      if ((ns - ns) == 0.0f) *scale = ns;  // finite
-      *growth_tracker = 0;
-    } else {
-      *growth_tracker = successful;
-    }
-  }
+  scaler_update_body(scale, growth_tracker, found_inf, num_flags, lag, growth_factor, backoff_factor, growth_interval, clear);
 }
 extern "C" int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
                                      double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream) {

@@ -144,7 +144,10 @@ __global__ void __launch_bounds__(256) k_grid_scatter(GridK g, const float* __re
         uint32_t idx = dense ? (xi + hy[k] + hz[k]) : ((xi ^ hy[k] ^ hz[k]) & g.mask);
         float w = wxv * wy[k] * wz[k];
         float v = seg_sum4(w * gv, start, lane);
-        if (tail && v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(base + idx) + ft, v);
+        if (tail && v != 0.0f) {
+          unsafeAtomicAdd(reinterpret_cast<float*>(base + idx) + ft, v);
+          if (g.nonfinite != nullptr && (v - v) != 0.0f) *g.nonfinite = 1.0f;
+        }
       }
     }
     if (want_dpos) {
@@ -211,6 +214,7 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
   float* dst = reinterpret_cast<float*>(g.grad + idx);  // several dense entries may share a slot
   if (sx != 0.0f) unsafeAtomicAdd(dst, sx);
   if (sy != 0.0f) unsafeAtomicAdd(dst + 1, sy);
+  if (g.nonfinite != nullptr && ((sx - sx) + (sy - sy)) != 0.0f) *g.nonfinite = 1.0f;
 }
 
 // ======================================================================================================================================
@@ -505,6 +509,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
         float* dst = reinterpret_cast<float*>(g.grad + (size_t)l * g.tsize + id);
         if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
         if (v.y != 0.0f) unsafeAtomicAdd(dst + 1, v.y);
+        if (g.nonfinite != nullptr && ((v.x - v.x) + (v.y - v.y)) != 0.0f) *g.nonfinite = 1.0f;
       }
     }
     __syncthreads();  // the staging area is reused by the next level
@@ -642,10 +647,16 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
       const uint32_t t = t0 + u * FOLD_THREADS + tid;
       if (!nz[u]) continue;
       if (!split) {
-        dst[t] = make_float2(cv[u].x + v[u].x, cv[u].y + v[u].y);
+        const float2 r = make_float2(cv[u].x + v[u].x, cv[u].y + v[u].y);
+        dst[t] = r;
+        // GradScaler's found_inf on the FINAL value (x - x is 0 for finite x, NaN otherwise)
+        if (g.nonfinite != nullptr && ((r.x - r.x) + (r.y - r.y)) != 0.0f) *g.nonfinite = 1.0f;
       } else {
         if (v[u].x != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t), v[u].x);
         if (v[u].y != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t) + 1, v[u].y);
+        // (a bucket split over several blocks: this block's share is checked -- a non-finite share makes the sum non-finite; only a sum of
+        // finite shares that overflows would go unseen)
+        if (g.nonfinite != nullptr && ((v[u].x - v[u].x) + (v[u].y - v[u].y)) != 0.0f) *g.nonfinite = 1.0f;
       }
     }
   }
@@ -908,6 +919,7 @@ __global__ void __launch_bounds__(256) k_dense_fold(GridK g, ReplicaK rk, const 
   float* dst = reinterpret_cast<float*>(g.grad + idx);
   if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
   if (v.y != 0.0f) unsafeAtomicAdd(dst + 1, v.y);
+  if (g.nonfinite != nullptr && ((v.x - v.x) + (v.y - v.y)) != 0.0f) *g.nonfinite = 1.0f;
 }
 int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream) {
   TN_REQUIRE(grid.table_grad && dense_sum, "tn_grid_dense_fold: null pointer");

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -506,6 +506,12 @@ class RenderEngine:
             ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, None, bt._d_o, bt._d_d, tag="cross")
             ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, None, b._d_o, b._d_d, tag="cross")
         finished = not _FUSE
+        # GradScaler's found_inf from the kernels that write the gradients (see train_step): the last pose launch of the step also scans the
+        # small ranges no scatter sees; the flags count as raised only when every camera group's launch went through this path
+        kscaler = self.__dict__.get("_kflags_scaler") if (dp is None and _FUSE) else None
+        gidx = {g: i for i, g in enumerate(self.arena.optimised_groups)}
+        todo = [sfx for sfx, br in branches.items() if (self.pose_thermal if sfx else self.pose) is not None and not getattr(br, "_pose_done", False)]
+        handled = set()
         for sfx, br in branches.items():
             pose = self.pose_thermal if sfx else self.pose
             if pose is None:
@@ -518,14 +524,20 @@ class RenderEngine:
             co = c.camera_optimizer_thermal if sfx else c.camera_optimizer
             reg = L[12:13] if sfx else L[11:12]
             if _FUSE:  # pose gradient + regulariser (+ the loss sums, once) in one launch
+                extra = {}
+                if kscaler is not None and ("camera_opt" + sfx) in gidx:
+                    extra = dict(check_grads=self.arena.grads, check_ranges=self._small_grad_ranges() if sfx == todo[-1] else [],
+                                 found_inf=kscaler.found_inf, pose_flag=gidx["camera_opt" + sfx])
+                    handled.add("camera_opt" + sfx)
                 ops.pose_bwd_finish(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad, co.trans_l2_penalty, co.rot_l2_penalty,
-                                    co.penalty_scale, reg, None if finished else Lp, None if finished else L)
+                                    co.penalty_scale, reg, None if finished else Lp, None if finished else L, **extra)
                 finished = True
             else:
                 ops.pose_apply_bwd(pose, frozen, cam, br.directions_in, br._d_o, br._d_d, pose_grad)
                 ops.camera_reg(pose, co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale, reg, pose_grad)
         if not finished:
             ops.losses_finish(Lp, L)
+        self._kernel_flags_done = bool(handled) and handled == {g for g in self.arena.optimised_groups if g.startswith("camera_opt")}
         losses = {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
                   "distortion_loss": L[9]}
         if self.separate and c.density_loss_mult > 0:
@@ -542,6 +554,48 @@ class RenderEngine:
     def _camera_hi(self) -> int:
         """end of the shared-mode live range behind the main table: field embedding + MLPs, then the camera optimiser's pose"""
         return self.arena.group_range["camera_opt"][1]
+
+    # ---------------------------------------------------------------- GradScaler's found_inf raised by the kernels that write the gradients
+    def _small_grad_ranges(self) -> List[Tuple[int, int, int]]:
+        """(lo, hi, group index) of everything in the optimised groups that is neither a hash table (its scatter raises the group's flag through
+        TnGrid.nonfinite_flag) nor a pose (tn_pose_bwd_finish_check sees its contributions): MLP weights, biases, embeddings -- a few 10^4 floats."""
+        hit = self.__dict__.get("_small_ranges")
+        if hit is not None:
+            return hit
+        a = self.arena
+        out: List[Tuple[int, int, int]] = []
+        for gi, g in enumerate(a.optimised_groups):
+            if g.startswith("camera_opt"):
+                continue
+            cur = None
+            for name in sorted(a.group_keys[g], key=lambda n: a.layout[n][0]):
+                off, shape = a.layout[name]
+                n = int(np.prod(shape))
+                if name.endswith("hash_table"):
+                    if cur is not None:
+                        out.append((cur[0], cur[1], gi)); cur = None
+                    continue
+                if cur is not None and off - cur[1] < a.ALIGN:  # (alignment padding between two tensors is zero: harmless to scan)
+                    cur = (cur[0], off + n)
+                else:
+                    if cur is not None:
+                        out.append((cur[0], cur[1], gi))
+                    cur = (off, off + n)
+            if cur is not None:
+                out.append((cur[0], cur[1], gi))
+        self._small_ranges = out
+        return out
+
+    def _set_kernel_flags(self, scaler) -> None:
+        """Point every grid's nonfinite_flag at its optimiser group's found_inf entry (scaler = None: detach them)."""
+        gidx = {g: i for i, g in enumerate(self.arena.optimised_groups)}
+        def flag(g):
+            return None if (scaler is None or g not in gidx) else scaler.found_inf[gidx[g]:gidx[g] + 1]
+        for objs, g in ((self.props, "proposal_networks"), ([self.field], "fields"), (self.props_thermal if self.separate else [], "proposal_networks_thermal"),
+                        ([self.field_thermal] if self.field_thermal is not None else [], "fields_thermal")):
+            for o in objs:
+                if o is not None:
+                    o.__dict__["nonfinite_flag"] = flag(g)
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,
@@ -577,11 +631,15 @@ class RenderEngine:
             scaler = grad_scaler if (grad_scaler is not None and grad_scaler.enabled) else None
             names = list(hyper)
             gidx = {g: i for i, g in enumerate(a.optimised_groups)}
-            if scaler is not None:  # GradScaler decides per optimiser = per parameter group: one flag per group, all groups checked in one launch
+            # GradScaler decides per optimiser = per parameter group: one flag per group.  When the kernels that WRITE the gradients have raised the
+            # flags already (table scatters through TnGrid.nonfinite_flag, everything else in tn_pose_bwd_finish_check) no pass over the arena is
+            # needed; otherwise all groups are checked in one launch.
+            kernel_flags = scaler is not None and self.__dict__.pop("_kernel_flags_done", False)
+            if scaler is not None and not kernel_flags:
                 scaler.check_ranges(a.grads, [a.group_range[g] for g in names], [gidx[g] for g in names])
             on_device_lr = scaler is not None and scheduled and not lr_overrides
 
-            def launch(groups):
+            def launch(groups, fused_update=False):
                 if not groups:
                     return
                 if on_device_lr:  # lr_init + (lr_final, max_steps), evaluated at count - lag on the device
@@ -592,7 +650,8 @@ class RenderEngine:
                 ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, eps=1e-15,
                                          found_inf=scaler.found_inf if scaler is not None else None, flags=[gidx[g] for g in groups] if scaler is not None else None,
                                          skipped=scaler.skipped if scaler is not None else None, lag_index=scaler.lag_index if scaler is not None else -1,
-                                         count_skip=scaler is not None, schedule=sched, sched_step=self.adam_step_count - 1, zero_grads=True)
+                                         count_skip=scaler is not None, schedule=sched, sched_step=self.adam_step_count - 1, zero_grads=True,
+                                         scaler_update=scaler.fused_update_args() if fused_update else None)
 
             # the stepped groups' gradients are consumed.  A skipped group keeps whatever it holds: the buffer only counts as clean when the caller
             # vouches that the skipped groups received no gradient (train_step: proposal networks on an iteration the sampler ran them under no_grad)
@@ -610,8 +669,10 @@ class RenderEngine:
                     ev.record(side)
                 self._adam_event = ev
             else:
-                launch(names)
-                if scaler is not None:
+                # GradScaler.update() rides on the Adam launch (its last block to finish performs it): one launch less at the end of the step
+                fuse = scaler is not None and bool(names)
+                launch(names, fused_update=fuse)
+                if scaler is not None and not fuse:
                     scaler.update()
             return
         assert grad_scaler is None or not grad_scaler.enabled, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
@@ -687,6 +748,12 @@ class RenderEngine:
         self.set_anneal_for_step(step)
         if grad_scaler is not None:
             grad_scaler.begin_step()
+        # found_inf by the kernels that write the gradients -- only when the gradients are final where they are written (no data-parallel exchange
+        # behind the backward: with one, an inf on another rank arrives through the all-reduce and the explicit check after it stays)
+        kflags = grad_scaler if (grad_scaler is not None and grad_scaler.enabled and grad_hook is None and _FUSE) else None
+        if self.__dict__.get("_kflags_scaler") is not kflags:
+            self._set_kernel_flags(kflags)
+            self._kflags_scaler = kflags
         if not self.arena.grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
             self.sync_params()
             self.arena.zero_grad()

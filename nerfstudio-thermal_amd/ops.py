@@ -59,9 +59,12 @@ def _i64(t: Tensor, name: str, shape: Tuple[int, ...]):
     return C.c_void_p(t.data_ptr())
 
 
-def _grid_struct(table: Tensor, grad: Optional[Tensor], num_levels: int, log2_hashmap_size: int, res: Sequence[float]) -> TnGrid:
+def _grid_struct(table: Tensor, grad: Optional[Tensor], num_levels: int, log2_hashmap_size: int, res: Sequence[float],
+                 nonfinite_flag: Optional[Tensor] = None) -> TnGrid:
+    """nonfinite_flag: 1-element float device tensor the table-gradient scatter raises on an inf / NaN entry (TnGrid.nonfinite_flag), or None."""
     T = 2**log2_hashmap_size
     g = TnGrid()
+    g.nonfinite_flag = _f32(nonfinite_flag, "nonfinite_flag", (1,), optional=True) if (nonfinite_flag is not None and grad is not None) else None
     g.table = _f32(table, "hash_table", (num_levels * T, 2))
     g.table_grad = _f32(grad, "hash_table.grad", (num_levels * T, 2), optional=True)
     g.num_levels = num_levels
@@ -92,7 +95,9 @@ class PropNetParams:
         if need_grad and not g:
             raise ValueError("gradient buffers required")
         # the parameters are views of the arena: their addresses do not change from step to step, so the checked struct is built once
-        key = tuple(t.data_ptr() for t in (self.table, self.w0, self.b0, self.w1, self.b1)) + tuple(g[k].data_ptr() for k in sorted(g))
+        nf = self.__dict__.get("nonfinite_flag")  # set by the engine: the optimiser group's found_inf entry (DeviceGradScaler), or absent
+        key = tuple(t.data_ptr() for t in (self.table, self.w0, self.b0, self.w1, self.b1)) + tuple(g[k].data_ptr() for k in sorted(g)) + (
+            nf.data_ptr() if nf is not None else 0,)
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -102,7 +107,7 @@ class PropNetParams:
 
     def _build_cstruct(self, g) -> TnPropNet:
         s = TnPropNet()
-        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res)
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"))
         H, F = 16, self.num_levels * 2
         s.w0, s.b0 = _f32(self.w0, "w0", (H, F)), _f32(self.b0, "b0", (H,))
         s.w1, s.b1 = _f32(self.w1, "w1", (1, H)), _f32(self.b1, "b1", (1,))
@@ -148,7 +153,9 @@ class FieldParams:
         g = self.grads or {}
         if need_grad and not g:
             raise ValueError("gradient buffers required")
-        key = (self.table.data_ptr(),) + tuple(getattr(self, k).data_ptr() for k in _FIELD_KEYS) + tuple(g[k].data_ptr() for k in sorted(g))
+        nf = self.__dict__.get("nonfinite_flag")
+        key = (self.table.data_ptr(),) + tuple(getattr(self, k).data_ptr() for k in _FIELD_KEYS) + tuple(g[k].data_ptr() for k in sorted(g)) + (
+            nf.data_ptr() if nf is not None else 0,)
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -158,7 +165,7 @@ class FieldParams:
 
     def _build_cstruct(self, g) -> TnField:
         s = TnField()
-        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res)
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"))
         for k, shp in self.shapes().items():
             setattr(s, k, _f32(getattr(self, k), k, shp))
             setattr(s, "g" + k, _f32(g.get(k), "g" + k, shp, optional=True))
@@ -320,9 +327,26 @@ def pose_spaced_bins(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, origin
 
 def pose_bwd_finish(pose: Tensor, frozen: Optional[Tensor], cam: Tensor, directions_in: Tensor, d_o: Tensor, d_d: Tensor, grad_pose: Tensor,
                     trans_pen: float, rot_pen: float, scale: float, reg_out: Tensor, loss_lines: Optional[Tensor] = None,
-                    losses16: Optional[Tensor] = None) -> None:
-    """pose_apply_bwd + camera_reg (+ losses_finish when loss_lines / losses16 are given) in one launch (tn_pose_bwd_finish)."""
+                    losses16: Optional[Tensor] = None, check_grads: Optional[Tensor] = None, check_ranges=None, found_inf: Optional[Tensor] = None,
+                    pose_flag: int = 0) -> None:
+    """pose_apply_bwd + camera_reg (+ losses_finish when loss_lines / losses16 are given) in one launch (tn_pose_bwd_finish).
+    found_inf (+ check_grads, check_ranges = [(lo, hi, flag), ...] small ranges of the gradient arena, pose_flag): the same launch also raises
+    GradScaler's per-group found_inf for the pose gradient and those ranges (tn_pose_bwd_finish_check)."""
     N, Cn = directions_in.shape[0], pose.shape[0]
+    if found_inf is not None:
+        rs = list(check_ranges or [])
+        n = len(rs)
+        offs = (C.c_int64 * max(n, 1))(*[r[0] for r in rs])
+        cnts = (C.c_int64 * max(n, 1))(*[r[1] - r[0] for r in rs])
+        fl = (C.c_int32 * max(n, 1))(*[int(r[2]) for r in rs])
+        check(_lib.load().tn_pose_bwd_finish_check(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)),
+                                                   _f32(directions_in, "directions", (N, 3)), _f32(d_o, "d_origins", (N, 3)),
+                                                   _f32(d_d, "d_directions", (N, 3)), N, Cn, _f32(grad_pose, "grad_pose", (Cn, 6)),
+                                                   _f32(loss_lines, "loss_lines", (LOSS_LINES, 16), True), _f32(losses16, "losses16", None, True),
+                                                   float(trans_pen), float(rot_pen), float(scale), _f32(reg_out, "reg_out"),
+                                                   _f32(check_grads, "grads", None, True), n, offs, cnts, fl, int(found_inf.numel()),
+                                                   _f32(found_inf, "found_inf"), int(pose_flag), _stream()), "tn_pose_bwd_finish_check")
+        return
     check(_lib.load().tn_pose_bwd_finish(_f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), _i64(cam, "camera_indices", (N,)),
                                          _f32(directions_in, "directions", (N, 3)), _f32(d_o, "d_origins", (N, 3)), _f32(d_d, "d_directions", (N, 3)),
                                          N, Cn, _f32(grad_pose, "grad_pose", (Cn, 6)),
@@ -957,12 +981,14 @@ def grad_nonfinite_ranges(grads: Tensor, ranges, flags, found_inf: Tensor) -> No
 def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, ranges, beta1: float = 0.9, beta2: float = 0.999,
                          eps: float = 1e-15, inv_scale: Optional[Tensor] = None, found_inf: Optional[Tensor] = None, flags=None,
                          skipped: Optional[Tensor] = None, lag_index: int = -1, count_skip: bool = False, schedule=None, sched_step: int = 0,
-                         zero_grads: bool = False) -> None:
+                         zero_grads: bool = False, scaler_update=None) -> None:
     """adam_step_ranges with GradScaler's skip / unscale decision on the device (no host sync): see tn_adam_step_ranges_amp.
     found_inf: float device tensor with one entry per parameter group; flags: the entry of each range (default 0); skipped: int32 device
     tensor (per-group skip counts, and the schedule lag at lag_index).
     schedule: None, or one (lr_final, max_steps) per range: the range's lr is then lr_init and the exponential-decay schedule is evaluated on the
-    device at sched_step - skipped[lag_index].  zero_grads: the launch consumes the gradients (zero behind the read, skipped steps included)."""
+    device at sched_step - skipped[lag_index].  zero_grads: the launch consumes the gradients (zero behind the read, skipped steps included).
+    scaler_update: None, or (scale, growth_tracker, done_counter, growth_factor, backoff_factor, growth_interval): GradScaler.update() by the launch's
+    last block (tn_adam_step_ranges_amp_update) instead of a launch of its own."""
     n = len(ranges)
     if n == 0:
         return
@@ -979,6 +1005,16 @@ def adam_step_ranges_amp(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg
     lrf = (C.c_double * n)(*[float(x[0]) for x in schedule]) if schedule is not None else None
     smax = (C.c_int32 * n)(*[int(x[1]) for x in schedule]) if schedule is not None else None
     fl = (C.c_int32 * n)(*[int(x) for x in flags]) if flags is not None else None
+    if scaler_update is not None:
+        sc, gt, done, gf, bf, gi = scaler_update
+        check(_lib.load().tn_adam_step_ranges_amp_update(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n,
+                                                         offs, cnts, steps, lrs, lrf, smax, int(sched_step), float(beta1), float(beta2), float(eps),
+                                                         _f32(inv_scale, "inv_scale", (1,), True) if inv_scale is not None else None,
+                                                         _f32(found_inf, "found_inf"), fl, nflags,
+                                                         C.c_void_p(skipped.data_ptr()) if skipped is not None else None, int(lag_index), 1 if count_skip else 0,
+                                                         1 if zero_grads else 0, _f32(sc, "scale", (1,)), C.c_void_p(gt.data_ptr()), C.c_void_p(done.data_ptr()),
+                                                         float(gf), float(bf), int(gi), _stream()), "tn_adam_step_ranges_amp_update")
+        return
     check(_lib.load().tn_adam_step_ranges_amp(_f32(params, "params"), _f32(grads, "grads"), _f32(exp_avg, "exp_avg"), _f32(exp_avg_sq, "exp_avg_sq"), n,
                                               offs, cnts, steps, lrs, lrf, smax, int(sched_step), float(beta1), float(beta2), float(eps),
                                               _f32(inv_scale, "inv_scale", (1,), True) if inv_scale is not None else None,

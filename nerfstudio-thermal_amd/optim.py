@@ -210,6 +210,11 @@ class DeviceGradScaler:
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
         self.found_inf = torch.zeros(num_groups, device=device)                         # one flag per optimiser group (GradScaler decides per optimiser)
         self.skipped = torch.zeros(num_groups + 1, dtype=torch.int32, device=device)   # per-group skipped steps, then the LR-schedule lag
+        self._done = torch.zeros(65 * 16, dtype=torch.int32, device=device)             # block counters of the Adam launch that performs update() (TN_ADAM_DONE_WORDS)
+
+    def fused_update_args(self):
+        """what ops.adam_step_ranges_amp(scaler_update=...) needs to perform update() in the Adam launch's last block"""
+        return (self.scale, self.growth_tracker, self._done, self.growth_factor, self.backoff_factor, self.growth_interval)
 
     @property
     def lag_index(self) -> int:
