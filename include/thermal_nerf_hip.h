@@ -299,7 +299,10 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
  * 6 median0 | 7..11 the same for level 1 | 12 s_bins2 13 e_bins2 14 density2 15 weights2 | 16 rgb_samples [N,S2,C] 17 comp [N,C]
  * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
  * wait_event_before_field: NULL, or a hipEvent_t that `stream` waits for right before the field's first read of its parameters -- a trainer
- * that runs the previous iteration's Adam launch over the field on another stream lets it overlap the proposal sampling this way. */
+ * that runs the previous iteration's Adam launch over the field on another stream lets it overlap the proposal sampling this way.
+ * zero_fill: NULL, or zero_fill_bytes (multiple of 16) of 16-byte aligned device memory that the call clears on its way (inside the field's
+ * first launch): the caller's zero-initialised accumulators of the iteration -- loss sums, d(composite), d(weights), d origins / d directions --
+ * without a fill launch of their own. */
 #define TN_RENDER_TRAIN_OFFSETS 23
 int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
 int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
@@ -307,7 +310,8 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
                          const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                          int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                          const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
-                         int64_t field_workspace_bytes, float* out, void* wait_event_before_field, tn_stream_t stream);
+                         int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
+                         tn_stream_t stream);
 
 /* The TRAINING backward of one branch as ONE call, the counterpart of tn_render_rays_train: everything autograd runs behind d(composite) and
  * d(weights) in ThermalNerfactoModel's training step (models/thermal_nerfacto.py:403-489 backwards; cameras/rays.py:128-150,

@@ -95,7 +95,7 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_rays_train_layout": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _i32]),
     "tn_render_rays_train": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32,
-                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p]),
+                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),

@@ -83,8 +83,7 @@ __device__ __forceinline__ float bias_at(const FieldK& f, int layer, int o) {
   }
 }
 
-__global__ void k_field_pack(FieldK f, float* __restrict__ pack) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void field_pack_body(const FieldK& f, float* __restrict__ pack, int idx) {
   if (idx < PACK_FWD_FLOATS) {
     int layer = 0;
     while (layer < 4 && idx >= fwd_off(layer + 1)) ++layer;
@@ -110,6 +109,8 @@ __global__ void k_field_pack(FieldK f, float* __restrict__ pack) {
     pack[idx] = s / (float)f.num_images;
   }
 }
+__global__ void k_field_pack(FieldK f, float* __restrict__ pack) { field_pack_body(f, pack, blockIdx.x * blockDim.x + threadIdx.x); }
+#define PACK_BLOCKS ((PACK_FWD_TOTAL + 255) / 256)
 
 // ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
 // Per-level tensors (enc, d enc / d offset, d enc) are LEVEL-MAJOR with a row stride of PT = samples rounded up to whole 32-sample tiles:
@@ -174,11 +175,23 @@ extern "C" int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training
 // ---- positions ---------------------------------------------------------------------------------------------------------
 // thread = sample: Frustums.get_positions + SceneContraction + (x+2)/4 + selector, once per sample (the encode below visits a sample once per
 // LEVEL and reads the 16 bytes written here instead of repeating two loads of the ray, the division by S and the contraction)
+// PACK: the first PACK_BLOCKS blocks of the same launch rebuild the packed weights (tn_field_pack_weights: the parameters changed since the last
+// step) and every other block first clears `zero` (the step's accumulators: loss lines, d comp, d weights, d origins / d directions -- they are
+// needed long after this launch): what used to be three launches on the serial chain of a training step (pack 5 us, positions 5 us, fill 6 us).
 __device__ __forceinline__ void sh16(float dx, float dy, float dz, float* c);
-__global__ void __launch_bounds__(256) k_field_pos(const float* __restrict__ origins, const float* __restrict__ directions, const float* __restrict__ e_bins,
-                                                   int64_t N, int S, float4* __restrict__ pos, float* __restrict__ sel, float* __restrict__ shtab) {
+template <bool PACK>
+__global__ void __launch_bounds__(256) k_field_prep(FieldK f, float* __restrict__ pack, const float* __restrict__ origins,
+                                                    const float* __restrict__ directions, const float* __restrict__ e_bins, int64_t N, int S,
+                                                    float4* __restrict__ pos, float* __restrict__ sel, float* __restrict__ shtab,
+                                                    float4* __restrict__ zero, int64_t zero_n4) {
+  int bid = blockIdx.x, nblk = gridDim.x;
+  if (PACK) {
+    if (bid < PACK_BLOCKS) { field_pack_body(f, pack, bid * 256 + threadIdx.x); return; }
+    bid -= PACK_BLOCKS; nblk -= PACK_BLOCKS;
+  }
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)nblk * blockDim.x) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t P = N * (int64_t)S;
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t p = bid * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)nblk * blockDim.x) {
     const int64_t ray = tn_div_index(p, S, P);
     const int s = (int)(p - ray * S);
     const float* o = origins + ray * 3;
@@ -1125,11 +1138,20 @@ extern "C" int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, 
 }
 
 // positions (one launch) + the XCD-affine encode (one launch); a training workspace also receives d enc / d offset for the backward
+static FieldK make_fieldk(const TnField* f);
+struct FieldPrepExtra { bool pack; void* zero; int64_t zero_bytes; };
 static int launch_encode(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
-                         const FieldWs& ws, tn_stream_t stream) {
+                         const FieldWs& ws, tn_stream_t stream, FieldPrepExtra ex = FieldPrepExtra{false, nullptr, 0}) {
   const int64_t P = N * (int64_t)S;
-  hipLaunchKernelGGL(k_field_pos, dim3((unsigned)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16)), dim3(256), 0, tn_s(stream), origins, directions, e_bins, N, S,
-                     reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh);
+  const unsigned pb = (unsigned)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
+  float4* z = reinterpret_cast<float4*>(ex.zero);
+  const int64_t zn4 = ex.zero ? ex.zero_bytes / 16 : 0;
+  if (ex.pack)
+    hipLaunchKernelGGL(k_field_prep<true>, dim3(pb + PACK_BLOCKS), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
+                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4);
+  else
+    hipLaunchKernelGGL(k_field_prep<false>, dim3(pb), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
+                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4);
   TN_CHECK_LAUNCH("tn_field_fwd(positions)");
   const EncSched sc = make_enc_sched(field->grid, P);
   const unsigned grid = 8u * (unsigned)sc.blocks_per_xcd;
@@ -1146,6 +1168,13 @@ static int launch_encode(const TnField* field, const float* origins, const float
 extern "C" int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                             int64_t N, int32_t S, int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb,
                             float* density_pre, tn_stream_t stream) {
+  return tn_field_fwd_ex(field, origins, directions, camera_indices, e_bins, N, S, training, workspace, workspace_bytes, density, rgb, density_pre, 0, nullptr, 0,
+                         stream);
+}
+// tn_field_fwd with the weight packing (tn_field_pack_weights) and a zero-fill of `zero` riding in its first launch (csrc/tn_pipeline.hip)
+int tn_field_fwd_ex(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins, int64_t N, int32_t S,
+                    int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb, float* density_pre, int pack_first, void* zero,
+                    int64_t zero_bytes, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_fwd", false);
   if (rc) return rc;
@@ -1157,7 +1186,8 @@ extern "C" int tn_field_fwd(const TnField* field, const float* origins, const fl
   TN_REQUIRE((2 * ws.PT + P) * 8 < (1ll << 32), "tn_field_fwd: batch too large for the 32-bit lane offsets of the level-major loads");
   TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_fwd: workspace of %lld bytes, tn_field_workspace_bytes(%lld, %d) = %lld", (long long)workspace_bytes,
              (long long)P, training, (long long)ws.bytes);
-  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream);
+  TN_REQUIRE(zero == nullptr || (((uintptr_t)zero % 16) == 0 && zero_bytes % 16 == 0), "tn_field_fwd: the buffer to clear must be 16-byte aligned and sized");
+  rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream, FieldPrepExtra{pack_first != 0, zero, zero_bytes});
   if (rc) return rc;
   // the chain: 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
   const size_t shmem = PACK_FWD_TOTAL * sizeof(float);

@@ -64,8 +64,9 @@ extern "C" int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop
   if ((rc = tn_prop_density_fwd(prop1, origins, directions, w.e1, N, S1, w.d1, stream))) return rc;
   if ((rc = tn_weights_resample(w.e1, w.d1, w.s1, S1, anneal, lin_pdf2, nullptr, nears, fars, N, S2, w.w1, prop_depth1, w.s2, e2, stream))) return rc;
   // field (mean appearance embedding at inference), then get_weights + the renderers
-  if ((rc = tn_field_pack_weights(field, w.field_ws, stream))) return rc;
-  if ((rc = tn_field_fwd(field, origins, directions, camera_indices, e2, N, S2, 0, w.field_ws, field_ws_bytes, density, rgb_s, nullptr, stream))) return rc;
+  // (weight packing inside the field's first launch)
+  if ((rc = tn_field_fwd_ex(field, origins, directions, camera_indices, e2, N, S2, 0, w.field_ws, field_ws_bytes, density, rgb_s, nullptr, 1, nullptr, 0, stream)))
+    return rc;
   return tn_render_fwd(e2, density, rgb_s, N, S2, C, 0, w.w2, rgb, accumulation, depth_median, depth_expected, w.scratch, stream);
 }
 
@@ -106,7 +107,8 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
                                     const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                                     int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                     const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
-                                    int64_t field_workspace_bytes, float* out, void* wait_event_before_field, tn_stream_t stream) {
+                                    int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
+                                    tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -145,8 +147,9 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
     hipError_t e = hipStreamWaitEvent(tn_s(stream), reinterpret_cast<hipEvent_t>(wait_event_before_field), 0);
     TN_REQUIRE(e == hipSuccess, "tn_render_rays_train: hipStreamWaitEvent failed: %s", hipGetErrorString(e));
   }
-  if ((rc = tn_field_pack_weights(field, field_workspace, stream))) return rc;
-  if ((rc = tn_field_fwd(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, field_workspace_bytes, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, stream)))
+  // weight packing and the zero-fill of the caller's step accumulators ride in the field's first launch
+  if ((rc = tn_field_fwd_ex(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, field_workspace_bytes, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, 1,
+                            zero_fill, zero_fill_bytes, stream)))
     return rc;
   return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
                        at(TRO_SCRATCH), stream);

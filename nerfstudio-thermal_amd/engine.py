@@ -148,14 +148,15 @@ class RenderEngine:
 
     # ---------------------------------------------------------------- forward of one branch
     def render_branch(self, props, fld, pose, frozen, origins: Tensor, directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor,
-                      training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main", wait_event=None) -> Branch:
+                      training: bool, anneal: float, jitters: Optional[List[Tensor]], prop_grad: bool, tag: str = "main", wait_event=None,
+                      zero_fill: Optional[Tensor] = None) -> Branch:
         o_in, d_in = origins, directions
         if training and _FUSE:
             # the whole training forward of the branch as ONE call of the C ABI (tn_render_rays_train): the library enqueues the eight
             # launches itself and every result is a view of one allocation -- the host side of a step is what bounds small batches and the
             # drop-in path
             r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag,
-                                      wait_event=wait_event)
+                                      wait_event=wait_event, zero_fill=zero_fill)
             levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=lv["median"])
                       for S, lv in zip(self.counts, r["levels"])]
             return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
@@ -213,16 +214,34 @@ class RenderEngine:
             cache[key] = (torch.full((N,), near, device=self.device), torch.full((N,), self.cfg.far_plane, device=self.device))
         return cache[key]
 
-    def _zeros_many(self, shapes):
+    def _zeros_many(self, shapes, fill: bool = True):
         """Zero-initialised tensors carved out of ONE allocation (one fill kernel instead of one per tensor: at 2 ms per step the ~4.5 us
-        launch floor of every tiny kernel is visible).  Each view starts on a 256-byte boundary."""
+        launch floor of every tiny kernel is visible).  Each view starts on a 256-byte boundary.  fill=False: (views, flat) of an UNINITIALISED
+        allocation that somebody else clears (tn_render_rays_train's zero_fill: inside the field's first launch)."""
         sizes = [int(np.prod(s)) for s in shapes]
         offs, tot = [], 0
         for n in sizes:
             offs.append(tot)
             tot += (n + 63) // 64 * 64
-        flat = torch.zeros(tot, device=self.device)
-        return [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
+        flat = torch.zeros(tot, device=self.device) if fill else torch.empty(tot, device=self.device)
+        views = [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
+        return views if fill else (views, flat)
+
+    def _accumulator_spec(self, N: int, prop_grads: Dict[str, bool]):
+        """keys and shapes of the zero-initialised accumulators of one training iteration (loss_and_backward): the loss vector and its 64 lines,
+        then per branch d comp, d weights of the levels that take a gradient, d origins / d directions."""
+        zshapes, zkeys = [(16,), (ops.LOSS_LINES, 16)], [("L", ""), ("Lp", "")]
+        for sfx in [""] + (["_thermal"] if self.separate else []):
+            fld = self.field_thermal if sfx else self.field
+            zkeys.append(("d_comp", sfx)); zshapes.append((N, fld.num_channels))
+            zkeys.append(("dw2", sfx)); zshapes.append((N, self.counts[2]))
+            if prop_grads[sfx]:
+                for i in range(2):
+                    zkeys.append((f"dw{i}", sfx)); zshapes.append((N, self.counts[i]))
+            if (self.pose_thermal if sfx else self.pose) is not None:
+                zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
+                zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
+        return zkeys, zshapes
 
     @staticmethod
     def _branch_outputs(b: Branch, sfx: str, training: bool) -> Dict[str, object]:
@@ -241,8 +260,10 @@ class RenderEngine:
         return out
 
     def get_outputs(self, origins: Tensor, directions: Tensor, cam: Tensor, training: bool, jitters: Optional[List[Tensor]] = None,
-                    jitters_thermal: Optional[List[Tensor]] = None):
-        """ThermalNerfactoModel.get_outputs.  Returns (outputs dict with the reference's keys, branches for backward)."""
+                    jitters_thermal: Optional[List[Tensor]] = None, prealloc_accumulators: bool = False):
+        """ThermalNerfactoModel.get_outputs.  Returns (outputs dict with the reference's keys, branches for backward).
+        prealloc_accumulators (train_step): the iteration's zero-initialised accumulators are allocated here and cleared inside the field's
+        first launch of the forward (no fill launch of their own); loss_and_backward picks them up."""
         N = origins.shape[0]
         nears, fars = self._nears_fars(N, training)
         if training and jitters is None:
@@ -253,11 +274,17 @@ class RenderEngine:
             wait_ev, self._adam_event = self._adam_event, None  # the field's forward (inside tn_render_rays_train) waits for the pending Adam launch
         else:
             self.sync_params()
+        zero_fill = None
+        self._step_acc = None
+        if training and _FUSE and prealloc_accumulators:
+            keys, shapes = self._accumulator_spec(N, {"": bool(updated), "_thermal": True})
+            views, zero_fill = self._zeros_many(shapes, fill=False)
+            self._step_acc = (N, keys, dict(zip(keys, views)))
         if not training and _FUSE:
             b = self.render_branch_eval(self.props, self.field, origins, directions, cam, nears, fars, self.anneal)
         else:
             b = self.render_branch(self.props, self.field, self.pose, self.frozen_rgb, origins, directions, cam, nears, fars, training, self.anneal,
-                                   jitters, prop_grad=updated, wait_event=wait_ev)
+                                   jitters, prop_grad=updated, wait_event=wait_ev, zero_fill=zero_fill)
         self.last_updated = bool(updated)  # did the proposal networks of the RGB sampler get gradients in this forward?
         if updated:  # eval renders included, as ProposalNetworkSampler.generate_ray_samples does (ray_samplers.py:612-613)
             self.steps_since_update = 0
@@ -317,17 +344,13 @@ class RenderEngine:
         # every zero-initialised accumulator of the step comes out of one allocation / one fill (see _zeros_many)
         # L: 0 rgb 1 thermal 2 tv 3 cross 4 (scratch) 8 interlevel 9 distortion 10 density 11 camreg 12 camreg_thermal
         # Lp: the loss sums spread over LOSS_LINES 64-byte lines (ops.train_losses), added up into L by ops.losses_finish at the end
-        zshapes, zkeys = [(16,), (ops.LOSS_LINES, 16)], [("L", ""), ("Lp", "")]
-        for sfx, br in branches.items():
-            zkeys.append(("d_comp", sfx)); zshapes.append(tuple(br.comp.shape))
-            zkeys.append(("dw2", sfx)); zshapes.append(tuple(br.levels[2].weights.shape))
-            if br.prop_grad:
-                for i in range(2):
-                    zkeys.append((f"dw{i}", sfx)); zshapes.append(tuple(br.levels[i].weights.shape))
-            if (self.pose_thermal if sfx else self.pose) is not None:
-                zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
-                zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
-        Z = dict(zip(zkeys, self._zeros_many(zshapes)))
+        zkeys, zshapes = self._accumulator_spec(N, {sfx: bool(br.prop_grad) for sfx, br in branches.items()} | ({} if self.separate else {"_thermal": False}))
+        pre = self.__dict__.get("_step_acc")
+        self._step_acc = None
+        if pre is not None and pre[0] == N and pre[1] == zkeys:  # allocated by get_outputs(prealloc_accumulators=True), cleared by the forward
+            Z = pre[2]
+        else:
+            Z = dict(zip(zkeys, self._zeros_many(zshapes)))
         L, Lp = Z[("L", "")], Z[("Lp", "")]
         d_comp = Z[("d_comp", "")]
         # the pixel terms ride in the first branch's loss launch (ops.train_losses(pixel=...)): one launch instead of two back to back
@@ -757,7 +780,7 @@ class RenderEngine:
         if not self.arena.grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
             self.sync_params()
             self.arena.zero_grad()
-        out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal)
+        out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal, prealloc_accumulators=True)
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
             # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)
             grad_hook.begin(self.arena)

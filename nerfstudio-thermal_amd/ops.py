@@ -674,10 +674,11 @@ _TRAIN_LAYOUTS: dict = {}
 
 def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Optional[Tensor], frozen: Optional[Tensor], origins: Tensor,
                       directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor, counts: Sequence[int], anneal: float,
-                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main", wait_event=None):
+                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main", wait_event=None, zero_fill: Optional[Tensor] = None):
     """The training forward of one branch in ONE library call (tn_render_rays_train): pose correction, proposal sampling with jitter, field
     (activations kept in the field's workspace `tag`), weights, renderers.  Every result is a view of one allocation.
     wait_event: a torch.cuda.Event the stream waits for right before the field's first parameter read (the previous step's Adam, see engine).
+    zero_fill: a float tensor (whole multiples of 4 elements, 16-byte aligned) the call clears inside the field's first launch.
     -> dict(origins, directions [N,3]; levels: 3 x dict(s_bins, e_bins, density, weights, median); rgb_samples [N,S2,C]; rgb [N,C];
     accumulation, depth, expected_depth [N,1])."""
     N = origins.shape[0]
@@ -702,7 +703,8 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
                                    _ray_scalar(jit[0], "jitter", N, True), _ray_scalar(jit[1], "jitter", N, True), _ray_scalar(jit[2], "jitter", N, True),
                                    _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"), _f32(_lin_table("pdf", S2, dev), "u2"),
                                    C.c_void_p(ws.data_ptr()), _nbytes(ws), C.c_void_p(buf.data_ptr()),
-                                   C.c_void_p(wait_event.cuda_event) if wait_event is not None else None, _stream()), "tn_render_rays_train")
+                                   C.c_void_p(wait_event.cuda_event) if wait_event is not None else None,
+                                   C.c_void_p(zero_fill.data_ptr()) if zero_fill is not None else None, _nbytes(zero_fill), _stream()), "tn_render_rays_train")
 
     def v(slot, *shape):
         n = 1
