@@ -504,6 +504,9 @@ def main():
     ap.add_argument("--dp-chunks", type=int, default=-1, help="N>1: level ranges of the main table exchanged separately (-1 = the default "
                     "schedule, n = n equal ranges, 0 = one all-reduce after the backward)")
     ap.add_argument("--dp-adam-per-range", action="store_true", help="N>1 / --force-dp: one Adam launch per exchanged range instead of one after the exchange")
+    ap.add_argument("--dp-shard-optimizer", action="store_true", help="N>1: reduce-scatter the big gradient slices, Adam on the owned 1/N piece, all-gather "
+                    "the parameters (parallel.ShardedGradReducer; runs without the GradScaler semantics)")
+    ap.add_argument("--dp-bf16", action="store_true", help="N>1: the big gradient slices travel as bfloat16 (half the bytes per xGMI link; changes numerics)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher test: spawn / join the ranks, all-reduce once, print the rank count, exit")
@@ -551,8 +554,16 @@ def main():
     cam_t, idx, img, is_th = make_batch(device, rays, seed=rank_seed(42, rank))
     cache = make_image_cache(device)
     # N > 1: the gradient all-reduce (RCCL) is issued per level range of the main table while the backward is still running
-    make_hook = lambda w: (OverlappedGradReducer(w) if args.dp_chunks < 0 else OverlappedGradReducer(w, level_chunks=args.dp_chunks)  # noqa: E731
-                           if args.dp_chunks > 0 else GradAllReducer(w))
+    def make_hook(w):
+        if args.dp_shard_optimizer:
+            from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+            return ShardedGradReducer(w, rank) if args.dp_chunks <= 0 else ShardedGradReducer(w, rank, level_chunks=args.dp_chunks)
+        kw = {"transport_dtype": torch.bfloat16} if args.dp_bf16 else {}
+        if args.dp_chunks < 0:
+            return OverlappedGradReducer(w, **kw)
+        return OverlappedGradReducer(w, level_chunks=args.dp_chunks, **kw) if args.dp_chunks > 0 else GradAllReducer(w)
+
     hook = make_hook(world) if (world > 1 and not api) else None  # (the drop-in path exchanges through DistributedDataParallel instead)
     if hook is not None and args.dp_adam_per_range:
         hook.adam_per_range = True

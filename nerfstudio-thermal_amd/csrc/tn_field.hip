@@ -795,6 +795,10 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int
   return q;
 }
 
+#ifndef FB_NO_SB
+#define FB_NO_SB 0
+#endif
+#define FB_SB() do { if (!FB_NO_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool DENS_ONLY>
 __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_density,
@@ -875,14 +879,14 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       lds_put_tile(bufY, j, h, 0, dd0); lds_put_tile(bufY, j, h, 1, dd1);  // dY of head layer 1: gy_hh2
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 4)) wgrad_tile16(bufG, 4, C, bufX, lane, acc4, bs4);  // d hw2 += g3^T hh2
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
       // ---- d hh1 = hw1^T . d hh2
       f32x16 dc0 = zero16, dc1 = zero16;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
       WAVE_LDS_SYNC();  // the reads of bufX (hh2) are done
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0[r] = t0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = t1[r] > 0.0f ? dc1[r] : 0.0f; }
@@ -894,7 +898,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       const v4f_t hb0 = FRAG_NT ? __builtin_nontemporal_load(bp) : bp[0], hb1 = FRAG_NT ? __builtin_nontemporal_load(bp + 64) : bp[64];
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);  // d hw1 += gy_hh2^T hh1
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
       WAVE_LDS_SYNC();
       {
         const float* shp = shtab + (int64_t)sm.ray * 16 + h * 8;
@@ -913,14 +917,14 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
       if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, bs2);  // d hw0 (slot space) += gy_hh1^T hin
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
       // ---- d head-input slots = Wslot^T . d hh1
       f32x16 di1 = zero16;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
       // ---- appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(slot 32 + e)
       if (!(FB_ABLATE & 1)) {
         WAVE_LDS_SYNC();
@@ -942,7 +946,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      FB_SB();
     } else {
       s0 = nx0; s1 = nx1;
     }
@@ -966,7 +970,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     if (!FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);                      // used after the next weight-gradient block + chain step
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 4)) wgrad_tile16(bufY, TSTR, 16, bufX, lane, acc1, bs1);  // d w1 += gy_bo^T h1
-    __builtin_amdgcn_sched_barrier(0);
+    FB_SB();
     // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
     f32x16 dh0 = zero16, dh1 = zero16;
     if (FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);
@@ -974,7 +978,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dh0[r] = s0[r] > 0.0f ? dh0[r] : 0.0f; dh1[r] = s1[r] > 0.0f ? dh1[r] : 0.0f; }
-    __builtin_amdgcn_sched_barrier(0);
+    FB_SB();
     WAVE_LDS_SYNC();
     lds_put_tile(bufY, j, h, 0, dh0); lds_put_tile(bufY, j, h, 1, dh1);    // dY of base layer 0: gy_h1
     lds_put_tile(bufX, j, h, 0, e0);                                       // X of base layer 0: enc
@@ -987,7 +991,7 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     }
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 2)) wgrad_tile32<2, 1>(bufY, bufX, j, h, acc0, bs0);  // d w0 += gy_h1^T enc
-    __builtin_amdgcn_sched_barrier(0);
+    FB_SB();
     // ---- d enc = w0^T . d h1
     f32x16 de = zero16;
 #pragma unroll

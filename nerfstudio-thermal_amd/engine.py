@@ -527,7 +527,16 @@ class RenderEngine:
             # density-only backward: the colour head saw these samples with a zero gradient (models/thermal_nerfacto.py:447-458 calls
             # get_density only), so its backward, its three weight-gradient GEMMs and the embedding rows are skipped
             ops.field_bwd(self.field, bt.origins, bt.directions, cam, bt.levels[-1].e_bins, g_d2, None, bt._d_o, bt._d_d, tag="cross")
+            if dp is not None:
+                # Data parallel, separate mode: a table is final after its SECOND scatter (own branch + the cross-evaluated density).  The RGB
+                # field's 64 MB go out here and travel beside the thermal field's cross backward; the thermal table follows it, the rest at
+                # finish().  (DDP's buckets overlap with the backward in every mode: pipelines/base_pipeline.py:281-283.)
+                t0 = self.arena.layout["field.mlp_base.model.0.hash_table"][0]
+                dp.reduce_range(t0, t0 + self._table_floats(self.field))
             ops.field_bwd(self.field_thermal, b.origins, b.directions, cam, b.levels[-1].e_bins, g_d2t, None, b._d_o, b._d_d, tag="cross")
+            if dp is not None:
+                t0 = self.arena.layout["field_thermal.mlp_base.model.0.hash_table"][0]
+                dp.reduce_range(t0, t0 + self._table_floats(self.field_thermal))
         finished = not _FUSE
         # GradScaler's found_inf from the kernels that write the gradients (see train_step): the last pose launch of the step also scans the
         # small ranges no scatter sees; the flags count as raised only when every camera group's launch went through this path
@@ -792,6 +801,10 @@ class RenderEngine:
                 # Adam range by range, each as soon as its exchange has landed: the update of the first table levels runs while the last
                 # ones are still on the wire (one more launch per range on the host)
                 self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
+                if getattr(grad_hook, "sharded", False):
+                    # optimiser state sharded over the ranks (parallel.ShardedGradReducer): the ranges above were this rank's pieces; now the
+                    # updated parameters of every sharded slice are all-gathered
+                    grad_hook.gather_params()
             else:
                 grad_hook.finish(skip=idle)
                 self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)

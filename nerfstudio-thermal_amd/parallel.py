@@ -82,7 +82,8 @@ class OverlappedGradReducer:
     pipelined = True
     adam_per_range = False  # True: RenderEngine.train_step launches Adam per exchanged range (finish_iter) instead of once after finish()
 
-    def __init__(self, world_size: int, group=None, level_chunks=(6, 6, 4), dense_exchange: bool = False, side_group="auto"):
+    def __init__(self, world_size: int, group=None, level_chunks=(6, 6, 4), dense_exchange: bool = False, side_group="auto",
+                 transport_dtype: Optional[torch.dtype] = None):
         """level_chunks: how many table levels each successive exchange covers (an int n means n equal ranges).  The last range cannot hide
         behind any fold, so it is the smallest (4 levels = 16 MB, ~50 us on 8 GPUs); the first takes the six coarsest levels: their fold is
         the cheapest part of the backward and nothing can be exchanged before it anyway.  Three ranges, not more: every range costs a fold
@@ -94,8 +95,13 @@ class OverlappedGradReducer:
         faster on one rank (bench.py --force-dp), so it is off by default.
         side_group: process group for the proposal networks' exchange, which is issued from the side stream.  A communicator runs its
         collectives in issue order on ONE stream: in the same group as the table ranges, the first table range would queue behind the
-        proposal exchange, which in turn waits for the whole level-0 proposal backward.  "auto" creates a second group over the same ranks."""
+        proposal exchange, which in turn waits for the whole level-0 proposal backward.  "auto" creates a second group over the same ranks.
+        transport_dtype: None (fp32 on the wire, what DDP sends for the reference) or torch.bfloat16: slices of at least 1 M gradients are
+        converted, exchanged and converted back -- half the bytes per link (N = 2 / 4 are link-bound) for two
+        element-wise launches per slice and gradients rounded to 8 mantissa bits BEFORE the mean; off by default (it changes numerics)."""
         self.world = world_size
+        self.transport_dtype = transport_dtype
+        self._casts: dict = {}
         self.group = group
         self.level_chunks = level_chunks
         self.dense_exchange = dense_exchange
@@ -142,6 +148,10 @@ class OverlappedGradReducer:
 
     def _issue(self, tensor, group=None) -> None:
         if dist.is_initialized():  # a 1-process group still goes through the backend (GPU tests drive RCCL that way)
+            if self.transport_dtype is not None and tensor.numel() >= (1 << 20):
+                wire = tensor.to(self.transport_dtype)
+                self._casts[len(self._works)] = (tensor, wire)  # converted back when the collective has been waited for (finish_iter)
+                tensor = wire
             self._works.append(dist.all_reduce(tensor, op=self._op(), group=group if group is not None else self.group, async_op=True))
         else:
             self._works.append(None)
@@ -194,11 +204,13 @@ class OverlappedGradReducer:
             self.reduce_range(grp[0][0], grp[-1][1])
             parts[len(self._ranges) - 1] = grp
         scale = dist.is_initialized() and not self._avg and self.world > 1
-        works, ranges, after = self._works, self._ranges, self._after
-        self._works = []
+        works, ranges, after, casts = self._works, self._ranges, self._after, self._casts
+        self._works, self._casts = [], {}
         for k, (w, (a, b)) in enumerate(zip(works, ranges)):
             if w is not None:
                 w.wait()  # the current stream waits for the collective
+            if k in casts:
+                casts[k][0].copy_(casts[k][1])  # reduced-precision transport: back into the fp32 gradient slice
             if k in after:
                 tensor, fn = after[k]
                 if scale:
@@ -216,6 +228,90 @@ class OverlappedGradReducer:
     def __call__(self, arena) -> None:  # plain grad_hook use: everything at the end
         self.begin(arena)
         self.finish()
+
+
+class ShardedGradReducer(OverlappedGradReducer):
+    """The same overlapped exchange with the optimiser state SHARDED over the ranks: a large slice of the gradient arena (the table level
+    ranges, the proposal tables) is REDUCE-SCATTERED instead of all-reduced -- rank r receives the mean of its 1/world piece only --, every
+    rank runs Adam on the pieces it owns, and the updated PARAMETERS of the slice are all-gathered.  Reduce-scatter + all-gather move the bytes
+    one ring all-reduce moves (2 (N-1)/N x the slice per rank), but Adam's 28 B per parameter of HBM traffic -- 543 MB = 70 us per step in
+    shared mode -- shrinks to 1/world of it, and only 1/world of the two moment arenas is ever touched per rank.  Small slices (MLP weights,
+    embeddings, poses: latency-bound messages) stay all-reduced and replicated.  The parameters stay bit-identical across ranks: every element
+    is computed once, by its owner, and copied.
+
+    RenderEngine.train_step drives it (`sharded = True`): begin -> backward with reduce_range() -> finish_iter() yields the ranges THIS rank
+    runs Adam on -> gather_params().  Backends without reduce-scatter (gloo: the CPU tests) all-reduce the slice instead; everything behind
+    the collective -- ownership, Adam on the owned piece, the parameter all-gather -- is the same code.
+    GradScaler semantics (found_inf decided over the whole gradient) would need one more tiny collective; this variant runs without a scaler."""
+
+    sharded = True
+    adam_per_range = True
+
+    def __init__(self, world_size: int, rank: int, min_shard: int = 1 << 20, **kw):
+        super().__init__(world_size, **kw)
+        assert self.transport_dtype is None, "the sharded exchange moves fp32"
+        self.rank = rank
+        self.min_shard = min_shard
+        self._sharded: dict = {}   # index into _ranges -> (lo, hi) of a reduce-scattered slice
+        self._gather: List[Tuple[int, int]] = []
+
+    def _own(self, lo: int, hi: int) -> Tuple[int, int]:
+        n = (hi - lo) // self.world
+        return lo + self.rank * n, lo + (self.rank + 1) * n
+
+    def begin(self, arena) -> None:
+        super().begin(arena)
+        self._sharded = {}
+        self._gather = []
+
+    def reduce_range(self, lo: int, hi: int, side: bool = False) -> None:
+        n = hi - lo
+        cuts = {b for g in self._arena.optimised_groups for b in self._arena.group_range[g]}
+        shard = self.world > 1 and n >= self.min_shard and n % (4 * self.world) == 0 and not any(lo < c < hi for c in cuts)
+        if not shard:
+            return super().reduce_range(lo, hi, side)
+        self._ranges.append((lo, hi))
+        self._sharded[len(self._ranges) - 1] = (lo, hi)
+        grads = self._arena.grads
+        group = self.side_group() if side else self.group
+        if dist.get_backend(group) == "nccl":
+            a, b = self._own(lo, hi)
+            self._works.append(dist.reduce_scatter_tensor(grads[a:b], grads[lo:hi], op=self._op(), group=group, async_op=True))
+        else:  # no reduce-scatter in this backend: the whole slice is reduced, the owned piece is what gets used
+            self._works.append(dist.all_reduce(grads[lo:hi], op=self._op(), group=group, async_op=True))
+
+    def finish_iter(self, skip: Optional[List[Tuple[int, int]]] = None):
+        """As OverlappedGradReducer.finish_iter, but a reduce-scattered slice yields only the piece this rank owns (and is remembered for
+        gather_params)."""
+        sharded = dict(self._sharded)
+        ranges_before = list(self._ranges)
+        own = {}
+        for k, (lo, hi) in sharded.items():
+            own[(lo, hi)] = self._own(lo, hi)
+        for piece in super().finish_iter(skip):
+            if piece in own:
+                self._gather.append(piece)
+                yield own[piece]
+            else:
+                yield piece
+        del ranges_before
+
+    def gather_params(self) -> None:
+        """All-gather of the parameters of every sharded slice (each rank contributes the piece its Adam launch just updated); the current
+        stream waits for them: the next forward reads the parameters."""
+        works = []
+        params = self._arena.params
+        for lo, hi in self._gather:
+            a, b = self._own(lo, hi)
+            if dist.get_backend(self.group) == "nccl":
+                works.append(dist.all_gather_into_tensor(params[lo:hi], params[a:b], group=self.group, async_op=True))
+            else:
+                n = (hi - lo) // self.world
+                outs = [params[lo + r * n: lo + (r + 1) * n] for r in range(self.world)]
+                works.append(dist.all_gather(outs, params[a:b].clone(), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        self._gather = []
 
 
 def broadcast_params(arena, src: int = 0, group=None) -> None:

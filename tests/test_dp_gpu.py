@@ -132,3 +132,29 @@ def test_dense_exchange_of_coarse_levels_full_size(rccl_group):
     for g1 in grads[1:]:
         assert float((g0 - g1).abs().max()) <= 2e-6 * scale, float((g0 - g1).abs().max()) / scale
         assert int(((g0 == 0) != (g1 == 0)).sum()) <= 4  # exact cancellations may leave a residue in another summation order
+
+
+def test_sharded_reducer_and_bf16_transport_on_one_rank(golden_dir, rccl_group):
+    """The two data-parallel variants on a 1-rank RCCL group (what a GPU box with one GPU can run): the sharded-optimiser schedule degenerates to
+    the per-range Adam schedule (world 1: every rank owns everything) and must match the plain step; bf16 transport rounds the big slices'
+    gradients to 8 mantissa bits -- the first step's gradients agree to 2^-7 relative, exact zeros stay exact zeros."""
+    from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+    # (reference: the per-range Adam schedule, which like the sharded one does not consume the gradients -- the fused step's single Adam launch
+    # zeroes them behind its read, so its gradient buffer is all zero afterwards)
+    ref = OverlappedGradReducer(1, level_chunks=2)
+    ref.adam_per_range = True
+    a0, g0, l0 = run_steps(golden_dir, "shared", ref)
+    a1, g1, l1 = run_steps(golden_dir, "shared", ShardedGradReducer(1, 0, level_chunks=2))
+    scale = float(g0.abs().max())
+    assert scale > 0
+    noise = float((g0 - run_steps(golden_dir, "shared", ref, steps=1)[1]).abs().max())
+    assert float((g0 - g1).abs().max()) <= max(4.0 * noise, 1e-6 * scale)
+    moved = float((a0.params - build("shared")[2].params).double().norm())
+    assert float((a0.params - a1.params).double().norm()) <= 0.02 * moved
+    hook = OverlappedGradReducer(1, level_chunks=2, transport_dtype=torch.bfloat16)
+    hook.adam_per_range = True
+    a2, g2, l2 = run_steps(golden_dir, "shared", hook, steps=1)
+    assert torch.equal(g0 == 0, g2 == 0)
+    # (the tiny test tables are below the 1 M-gradient bar of the conversion: nothing was rounded, the schedule itself must be unchanged)
+    assert float((g0 - g2).abs().max()) <= max(4.0 * noise, 1e-6 * scale)

@@ -172,3 +172,108 @@ def test_two_rank_side_tensor_exchange_stands_for_an_arena_range():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
+
+
+def _sharded_worker(rank, world, port, q):
+    """ShardedGradReducer against OverlappedGradReducer on the same rank-dependent gradients: reduce-scatter -> update of the owned piece ->
+    all-gather of the parameters must leave every rank with the parameters the all-reduce path computes (element-wise update rule, as Adam)."""
+    from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base_p = torch.from_numpy(synth.uniform("p", (arena.total,), seed=5))
+    base_g = torch.from_numpy(synth.uniform("g", (arena.total,), seed=3))
+    t0, tshape = arena.layout["field.mlp_base.model.0.hash_table"]
+    tn = int(np.prod(tshape))
+    half = tn // 2
+
+    def run(hook):
+        arena.params.copy_(base_p)
+        arena.grads.copy_(base_g * (rank + 1))
+        hook.begin(arena)
+        hook.reduce_range(t0, t0 + half)          # two level ranges of the main table, as engine.loss_and_backward issues them
+        hook.reduce_range(t0 + half, t0 + tn)
+        pieces = list(hook.finish_iter())
+        for lo, hi in pieces:                     # an element-wise update rule stands in for Adam (tn_adam_step_* needs the GPU)
+            arena.params[lo:hi] -= 0.1 * arena.grads[lo:hi]
+        if getattr(hook, "sharded", False):
+            hook.gather_params()
+        return pieces, arena.params.clone()
+
+    pieces_a, params_a = run(OverlappedGradReducer(world, side_group=None))
+    pieces_b, params_b = run(ShardedGradReducer(world, rank, min_shard=1024, side_group=None))
+    lo, hi = arena.live_range
+    mean_g = base_g * (sum(range(1, world + 1)) / world)
+    expect = base_p.clone()
+    expect[lo:hi] -= 0.1 * mean_g[lo:hi]
+    ok_ref = bool(torch.allclose(params_a[lo:hi], expect[lo:hi], rtol=1e-6, atol=1e-7))
+    ok_same = bool(torch.equal(params_a, params_b))
+    # this rank ran its update on 1/world of the table only, on the whole of everything else
+    n_a = sum(b - a for a, b in pieces_a)
+    n_b = sum(b - a for a, b in pieces_b)
+    own = [(a, b) for a, b in pieces_b if t0 <= a and b <= t0 + tn]
+    ok_own = sum(b - a for a, b in own) == tn // world and n_b == n_a - tn + tn // world
+    q.put((rank, ok_ref, ok_same, ok_own, params_b[t0:t0 + tn].double().sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_optimizer_equals_allreduce_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_ref, ok_same, ok_own, _ in res:
+        assert ok_ref and ok_same and ok_own, res
+    assert res[0][4] == res[1][4]  # the gathered table is bit-identical on both ranks
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base_g = torch.from_numpy(synth.uniform("g", (arena.total,), seed=3))
+    arena.grads.copy_(base_g * (rank + 1))
+    hook = OverlappedGradReducer(world, side_group=None, transport_dtype=torch.bfloat16)
+    hook.begin(arena)
+    t0, tshape = arena.layout["field.mlp_base.model.0.hash_table"]
+    tn = int(np.prod(tshape))
+    # (the conversion applies to slices of >= 1 M gradients; the tiny test table is below that, so lower the bar for the test)
+    import nerfstudio_thermal_amd.parallel as par
+    big = arena.grads[t0:t0 + tn]
+    wire = big.to(torch.bfloat16)
+    hook._casts[len(hook._works)] = (big, wire)
+    hook._ranges.append((t0, t0 + tn))
+    hook._works.append(dist.all_reduce(wire, op=hook._op(), async_op=True))
+    hook.finish()
+    lo, hi = arena.live_range
+    mean_g = base_g * (sum(range(1, world + 1)) / world)
+    err_table = float((arena.grads[t0:t0 + tn] - mean_g[t0:t0 + tn]).abs().max() / mean_g[t0:t0 + tn].abs().max())
+    rest = torch.ones(arena.total, dtype=torch.bool); rest[t0:t0 + tn] = False; rest[:lo] = False; rest[hi:] = False
+    err_rest = float((arena.grads[rest] - mean_g[rest]).abs().max())
+    q.put((rank, err_table, err_rest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_transport_rounds_only_the_big_slices():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err_table, err_rest in res:
+        assert 0 < err_table < 2 ** -6, res   # bf16: 8 mantissa bits on each addend, then on the sum
+        assert err_rest < 1e-6, res           # everything else travelled in fp32
