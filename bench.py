@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 RAYS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def source_hash() -> str:
@@ -163,7 +163,7 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# bench row -> kernels of profiles/r03_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
+# bench row -> kernels of profiles/r04_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
 DOMINANT = "scatter(main grid)"  # the launch pair with the largest share of the step (every step; the proposal grids' only on update steps)
 # kernel name + points of the launch; the key in the PMC file also carries the grid's y extent (level groups: "k_grid_bin<false> 196608x4"),
 # which changes with the block size of the bin pass -- matched by prefix
@@ -190,11 +190,11 @@ def pmc_lookup(pmc, prefixes):
 def load_pmc():
     """PMC figures measured by scripts/pmc_passes.sh, or (None, why) when they were taken on other kernel sources than the ones running."""
     if not os.path.exists(PMC_JSON):
-        return None, "no profiles/r03_pmc.json"
+        return None, "no profiles/r04_pmc.json"
     with open(PMC_JSON) as f:
         j = json.load(f)
     if j.get("source_hash") != source_hash():
-        return None, f"profiles/r03_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
+        return None, f"profiles/r04_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
     return j["kernels"], None
 
 
@@ -711,7 +711,7 @@ def main():
         if pmc is not None and pmc_lookup(pmc, PMC_KEYS.get(name, ["?"])) is not None:
             traffic = sum(v["traffic_bytes"] for v in pmc_lookup(pmc, PMC_KEYS[name]))
         elif pmc is not None:
-            why = f"profiles/r03_pmc.json holds no (single) entry for {PMC_KEYS.get(name)}"
+            why = f"profiles/r04_pmc.json holds no (single) entry for {PMC_KEYS.get(name)}"
         upd = updates / max(args.steps, 1)
         step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
         step_gbs = step_bytes / (dt / args.steps) / 1e9
@@ -730,8 +730,8 @@ def main():
             roofline["traffic_all_kernels"] = {n: sum(v["traffic_bytes"] for v in pmc_lookup(pmc, ks)) for n, ks in PMC_KEYS.items()
                                                if pmc_lookup(pmc, ks) is not None}
             roofline["mfma_busy_frac"] = {k.split(" ")[0]: v["mfma_busy_frac"] for k, v in pmc.items()
-                                          if k.split(" ")[0] in ("k_field_fwd_fused<true>", "k_field_bwd_fused<false>") and "mfma_busy_frac" in v}
-            roofline["pmc_source"] = "profiles/r03_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
+                                          if k.split(" ")[0] in ("k_field_mlp_fwd<true>", "k_field_bwd_fused<false>") and "mfma_busy_frac" in v}
+            roofline["pmc_source"] = "profiles/r04_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
         result = {
             "metric": "train rays/sec (4096-ray batch, 96 samples/ray)",
             "value": world * rays * args.steps / dt,

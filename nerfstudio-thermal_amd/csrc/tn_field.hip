@@ -963,17 +963,12 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     *reinterpret_cast<float4*>(bufY + j * TSTR + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
     *reinterpret_cast<float4*>(bufY + j * TSTR + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
     lds_put_tile(bufX, j, h, 0, s0); lds_put_tile(bufX, j, h, 1, s1);      // X of base layer 1: h1
-#ifndef FB_E0_LATE
-#define FB_E0_LATE 0
-#endif
-    f32x16 e0;
-    if (!FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);                      // used after the next weight-gradient block + chain step
+    f32x16 e0 = load_enc_lm(encs, PT, pc, h, L);                                // used after the next weight-gradient block + chain step
     WAVE_LDS_SYNC();
     if (!(FB_ABLATE & 4)) wgrad_tile16(bufY, TSTR, 16, bufX, lane, acc1, bs1);  // d w1 += gy_bo^T h1
     FB_SB();
     // ---- d h1 = w1^T . d base_out   (k-steps r<8: rows < 16)
     f32x16 dh0 = zero16, dh1 = zero16;
-    if (FB_E0_LATE) e0 = load_enc_lm(encs, PT, pc, h, L);
 #pragma unroll
     for (int r = 0; r < 8; ++r) { dh0 = MFMA(AB(1, 0, 0, r), dbo[r], dh0); dh1 = MFMA(AB(1, 1, 0, r), dbo[r], dh1); }
 #pragma unroll

@@ -1,5 +1,5 @@
 # copies what scripts/refresh_profiles.sh left under gpurun_out/<round>/ into profiles/<round>_* (run in the build container after the gpurun call)
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 for f in gpurun_out/$R/bench_*.json; do cp $f profiles/${R}_bench_$(basename $f | sed 's/^bench_//'); done
 cp gpurun_out/$R/bench_n1_kernel_stats.csv profiles/${R}_bench_n1_kernel_stats.csv

@@ -1,5 +1,5 @@
-# PMC passes + summary + a bench line:  gpurun --timeout 1200 -- 'bash scripts/gpu_pmc.sh r03'
-pfx=${1:-r03}
+# PMC passes + summary + a bench line:  gpurun --timeout 1200 -- 'bash scripts/gpu_pmc.sh r04'
+pfx=${1:-r04}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 bash scripts/pmc_passes.sh gpurun_out/pmc | tail -12

@@ -31,7 +31,9 @@ READ_SHAPE = {
     "k_grid_fold": "read16",            # (u32 slot pair + float4 value pair) per lane
     "k_field_bwd_fused": "read16", "k_field_dpos": "read16", "k_field_density_only": "read16",
     "k_grid_bin": "gather8",            # 8-B pieces: d enc per lane and level, the 8 corner fetches when it computes d position (64-B requests)
-    "k_field_fwd_fused": "gather8", "k_field_encode": "gather8", "k_prop_fwd": "gather8", "k_prop_bwd_mlp": "gather8",
+    "k_field_encode_xcd": "gather8", "k_prop_fwd": "gather8", "k_prop_bwd_mlp": "gather8",
+    "k_field_mlp_fwd": "read8",         # level-major encoding: 8 B per lane and level
+    "k_field_prep": "read8",
 }
 
 

@@ -1,7 +1,7 @@
-# Everything under profiles/r03_* in one gpurun call (tests, PMC passes, bench lines, kernel stats, timelines):
+# Everything under profiles/r04_* in one gpurun call (tests, PMC passes, bench lines, kernel stats, timelines):
 #   gpurun --timeout 1200 -- 'bash scripts/refresh_profiles.sh > gpurun_out/refresh.log 2>&1'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r03
+R=r04
 mkdir -p gpurun_out/$R
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/$R/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/$R/tests.log
 bash scripts/pmc_passes.sh gpurun_out/pmc | tail -12
@@ -10,20 +10,21 @@ last() { grep '^{' "$1" | tail -1 > "$1.tmp"; mv "$1.tmp" "$1"; }
 b() { out=gpurun_out/$R/bench_$1.json; shift; python bench.py "$@" > $out 2>/dev/null; last $out; }
 b n1_driver_invocation --steps 20 --warmup 5
 b n1_fused
-b n1_fused_200steps --no-cpu-baseline --steps 200 --warmup 60
+b n1_fused_200steps --no-cpu-baseline --no-extras --steps 200 --warmup 60
 b n1_separate_8192 --mode separate --rays 8192
 b n1_model_api --path model-api --no-cpu-baseline --steps 200 --warmup 60
 b n1_model_api_no_scaler --path model-api --no-grad-scaler --no-cpu-baseline --steps 200 --warmup 60
 b n1_model_api_torch_adam --path model-api --api-optimizer torch --no-cpu-baseline --steps 200 --warmup 60
-b n1_no_grad_scaler --no-grad-scaler --no-cpu-baseline
-b n1_force_dp --force-dp --no-cpu-baseline
+b n1_no_grad_scaler --no-grad-scaler --no-cpu-baseline --no-extras
+b n1_force_dp --force-dp --no-cpu-baseline --no-extras
+b n1_force_dp_sharded --force-dp --dp-shard-optimizer --no-grad-scaler --no-cpu-baseline --no-extras
 b n1_1024rays --rays 1024 --no-cpu-baseline
 b n1_96samples --nerf-samples 96 --no-cpu-baseline
 b n1_splat_1080p --workload splat
 python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1rank_latency.json
 rm -rf gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep
 # (the last 20 steps of a fused / separate run are the in-step measurement, which issues the backward phase by phase: the timelines show steps of the timed region)
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_a.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_a.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_dp -o dp -- python3 bench.py --force-dp --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_dp.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_sep -o sep -- python3 bench.py --mode separate --rays 8192 --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_sep.log 2>&1
 python scripts/rocpd_stats.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/bench_n1_kernel_stats.csv --split-grid --tail 10 > gpurun_out/$R/bench_n1_kernel_stats_tail.txt 2>&1
