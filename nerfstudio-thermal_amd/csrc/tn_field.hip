@@ -522,21 +522,21 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
                                                             float* __restrict__ hins, float* __restrict__ hh1s, float* __restrict__ hh2s,
                                                             float* __restrict__ ys) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // PACK_FWD_TOTAL floats
-  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
-  __syncthreads();
-  const float* lbias = lds + PACK_BIAS_OFF;
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
   const int64_t P = N * (int64_t)S;
   const int64_t ntiles = tn_cdiv(P, TILE);
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-#define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
-  f32x16 nin;  // the next tile's encoding, requested one tile ahead
+  f32x16 nin;  // the next tile's encoding, requested one tile ahead -- the first one before the weights are staged (a wave makes three trips)
   if (wave < ntiles) {
     const int64_t p0 = wave * TILE + j;
     nin = load_enc_lm(encs, PT, p0 < P ? p0 : P - 1, h, L);
   }
+  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
+  __syncthreads();
+  const float* lbias = lds + PACK_BIAS_OFF;
+#define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
   for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
     const int64_t p = tile * TILE + j;
     const bool valid = p < P;
