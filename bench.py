@@ -718,6 +718,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
                     "avg_launch_ms_in_step": None if in_step is None else in_step["mean_ms"], "in_step": in_step,
+                    "in_step_schedule": "phased backward: tn_field_bwd_phase(MLP) / HIP event / SCATTER / HIP event / JOIN in 20 EXTRA steps after the timed "
+                                        "region -- the timed `value` runs the one-call backward (tn_render_rays_train_bwd), which cannot take events",
                     "frac_in_step": None if in_step is None else nbytes / (in_step["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "the main grid's scatter entry point = k_grid_bin + k_grid_fold as the field backward calls it (d position comes from "
                             "k_field_dpos); the bin pass is bound by instruction issue, the fold streams its records into double-precision LDS atomics",
