@@ -422,8 +422,30 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
         step += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    opt_in = {}
+    if api:
+        # the same sequence with the opt-in host setting of nerfstudio_thermal_amd.configure_host(): autograd's nodes on the calling thread
+        import nerfstudio_thermal_amd as pkg
+
+        pkg.configure_host(single_thread_backward=True)
+        try:
+            for _ in range(warmup):
+                run(step)
+                step += 1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                run(step)
+                step += 1
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+        finally:
+            pkg.configure_host(single_thread_backward=False)
+        opt_in = {"single_thread_backward": {"ms_per_step": dt1 / steps * 1e3, "rays_per_s": rays * steps / dt1,
+                                             "note": "torch.autograd.set_multithreading_enabled(False) (nerfstudio_thermal_amd.configure_host, opt-in); "
+                                                     "ms_per_step above is with torch's defaults"}}
     name, ms, nbytes = next(r for r in kernel_roofline(eng, cam_t, idx) if r[0] == DOMINANT)
-    return {"workload": f"density_mode={mode}, {rays} rays, {nerf_samples} field samples, path {path}" + (" (autocast + torch.amp.GradScaler + HipFusedAdam: "
+    return {**opt_in, "workload": f"density_mode={mode}, {rays} rays, {nerf_samples} field samples, path {path}" + (" (autocast + torch.amp.GradScaler + HipFusedAdam: "
             "the reference Trainer's sequence, engine/trainer.py:455-499)" if api else " (device-side GradScaler)"),
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rays_per_s": rays * steps / dt, "proposal_update_fraction": upd / steps,
             "dominant_kernel": name, "dominant_kernel_ms": ms, "dominant_kernel_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -491,6 +513,8 @@ def main():
                     "reference Trainer's sequence forward -> get_metrics_dict -> get_loss_dict -> backward -> optimisers on ThermalNerfactoModel")
     ap.add_argument("--api-optimizer", default="hip", choices=["hip", "torch"], help="--path model-api: HipFusedAdam (one launch per group over the arena) or "
                     "torch.optim.Adam on the same parameters")
+    ap.add_argument("--api-single-thread-backward", action="store_true", help="--path model-api: nerfstudio_thermal_amd.configure_host() -- autograd runs the "
+                    "backward nodes on the calling thread (torch.autograd.set_multithreading_enabled(False)); an opt-in process setting, not torch's default")
     ap.add_argument("--no-grad-scaler", action="store_true", help="drop the GradScaler semantics of the reference Trainer (mixed_precision=True in thermal-nerfacto's "
                     "method config): fused path = no non-finite check / device-side skip (optim.DeviceGradScaler), model-api path = plain backward + step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -538,6 +562,10 @@ def main():
     if api:
         from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
 
+        if args.api_single_thread_backward:
+            import nerfstudio_thermal_amd as pkg
+
+            pkg.configure_host(single_thread_backward=True)
         cfg, arena, model = build_model(device, mode=args.mode, nerf_samples=args.nerf_samples)
         eng = model.engine
         optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam if args.api_optimizer == "hip" else torch.optim.Adam)
@@ -749,7 +777,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"thermal-nerfacto density_mode={args.mode} train step (pixel sampling+raygen+fwd+losses+bwd+allreduce+Adam), {rays} rays/GPU, "
                                    f"256/96 proposal + {args.nerf_samples} field samples, hash 16x2^19x2 + 2x(5x2^17x2), 8 cameras (4 RGB + 4 thermal)",
-                       "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam)" if api else ""),
+                       "rays_per_gpu": rays, "parallelism": f"dp{world}", "path": args.path + (f" ({args.api_optimizer} Adam" + (", single-thread backward" if args.api_single_thread_backward else "") + ")" if api else ""),
                        "grad_scaler": (None if scaler is None else ("torch.amp.GradScaler + autocast" if api else "device-side (optim.DeviceGradScaler)")),
                        "final_loss": final_loss},
             "rccl_ranks": rccl_ranks,

@@ -416,7 +416,7 @@ int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float
  *  - tn_grad_nonfinite sets *found_inf = 1 when any of `count` gradients is inf or NaN (it never clears it: zero-fill once per step).
  *  - tn_adam_step_ranges_amp is tn_adam_step_ranges with the decision on the device.  Range k belongs to group flag_index[k] (HOST array, NULL =
  *    all 0):  found_inf[flag] != 0 -> range k is not touched (parameters and both moments bit-identical) and, when count_skip != 0,
- *    skipped[flag] += 1;  inv_scale (device float or NULL): gradients are multiplied by *inv_scale as they are read;  skipped (device int32
+ *    skipped[flag] += 1 (once per flag and launch, however many ranges carry it);  inv_scale (device float or NULL): gradients are multiplied by *inv_scale as they are read;  skipped (device int32
  *    array or NULL): the bias corrections use steps[k] - skipped[flag], as torch's fused Adam keeps its step tensors (torch/optim/adam.py:
  *    step -= found_inf);  lr_finals / sched_max_steps (HOST arrays or NULL) + sched_step: when given, lrs[k] is lr_init and the kernel
  *    evaluates the reference's ExponentialDecayScheduler (engine/schedulers.py:109-141) at sched_step - skipped[lag_index] (lag_index = -1:

@@ -14,3 +14,17 @@ import os as _os
 # stream's kernels queued after it (bench.py --force-dp: 2.75 ms/step with 4 queues, 1.42 ms with 8; the single-GPU step does not care).
 # Must be in the environment before the first HIP call of the process; an explicit setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def configure_host(single_thread_backward: bool = True) -> None:
+    """OPT-IN process setting for a training process that drives the model through the reference Trainer's sequence (engine/trainer.py:455-499).
+    Nothing in the package calls this at import; the method plugin calls it when TN_SINGLE_THREAD_BACKWARD=1 is in the environment.
+
+    single_thread_backward: torch.autograd.set_multithreading_enabled(False) -- `loss.backward()` runs its nodes on the calling thread instead of
+    handing them to autograd's device thread.  This model's backward is two custom nodes that only enqueue kernels, so the second thread buys
+    nothing and the hand-over (wake-up, GIL traffic with the waiting caller) sits on the iteration's critical path: with the Trainer's two
+    `grad_scaler.get_scale()` host synchronisations per iteration the GPU idles exactly as long as the host needs to reach the backward launch.
+    Measured on MI355X, 4096 rays, autocast + GradScaler: 1.49 -> 1.27 ms per iteration (scripts/trace_api_host.py, ST_BWD=1)."""
+    import torch
+
+    torch.autograd.set_multithreading_enabled(not single_thread_backward)

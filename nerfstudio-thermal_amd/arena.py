@@ -133,7 +133,22 @@ class ParamArena:
         return self._view(self.params, name)
 
     def grad_view(self, name: str) -> torch.Tensor:
-        return self._view(self.grads, name)
+        """a FRESH view of the parameter's slice of the gradient buffer (one as_strided: the drop-in backward hands out ~30 of them per step)"""
+        spec = self.__dict__.get("_grad_view_spec")
+        if spec is None:
+            spec = self._grad_view_spec = {}
+            for n, (off, shape) in self.layout.items():
+                stride, k = [], 1
+                for d in reversed(shape):
+                    stride.append(k)
+                    k *= d
+                spec[n] = (tuple(shape), tuple(reversed(stride)), off)
+        shape, stride, off = spec[name]
+        return self.grads.as_strided(shape, stride, self.grads.storage_offset() + off)
+
+    def grad_ptrs(self) -> Dict[str, int]:
+        self.grad_ptr(next(iter(self.layout)))
+        return self._grad_ptrs
 
     def grad_ptr(self, name: str) -> int:
         """device address of a parameter's slice of the gradient buffer (to recognise a `.grad` that aliases it without building a view)"""

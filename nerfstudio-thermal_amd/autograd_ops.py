@@ -157,6 +157,9 @@ class LossSpec:
         self.camera_regs = camera_regs  # [(trans_pen, rot_pen, scale)] per pose parameter passed
 
 
+_LOSS_LAYOUTS: dict = {}
+
+
 class TrainLosses(torch.autograd.Function):
     """EVERY loss term of a training iteration (models/thermal_nerfacto.py:253-388) as one autograd node, through the same launches as the
     fused step (engine.RenderEngine.loss_and_backward): tn_train_losses per branch (distortion + both interlevel terms, the pixel terms in the
@@ -183,13 +186,17 @@ class TrainLosses(torch.autograd.Function):
             shapes.append(tuple(comp.shape))
             shapes += [tuple(w.shape[:2]) for w in ws]
         shapes += [tuple(d.shape) for d in dens] + [tuple(p.shape) for p in poses]
-        sizes = [int(torch.Size(s).numel()) for s in shapes]
-        offs, tot = [], 0
-        for n in sizes:
-            offs.append(tot)
-            tot += (n + 63) // 64 * 64
+        lay = _LOSS_LAYOUTS.get(tuple(shapes))
+        if lay is None:  # (the shapes of an iteration never change: offsets / strides computed once)
+            sizes = [int(torch.Size(s).numel()) for s in shapes]
+            offs, tot = [], 0
+            for n in sizes:
+                offs.append(tot)
+                tot += (n + 63) // 64 * 64
+            lay = _LOSS_LAYOUTS[tuple(shapes)] = (offs, sizes, [ops._contig_strides(tuple(s)) for s in shapes], tot)
+        offs, sizes, strides, tot = lay
         flat = torch.zeros(tot, device=dev)
-        bufs = [flat[o:o + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
+        bufs = [flat.as_strided(s, st, o) for o, s, st in zip(offs, shapes, strides)]
         L, Lp, grads = bufs[0], bufs[1], bufs[2:]
         gi = iter(grads)
         g_per = [(next(gi), [next(gi), next(gi), next(gi)]) for _ in per]
@@ -224,7 +231,7 @@ class TrainLosses(torch.autograd.Function):
         # the terms this iteration actually produced (a term that does not exist in this mode is never waited for in backward)
         ctx.live = [0, 1, 2, 3, 8, 9] + ([10] if dens else []) + [11 + k for k in range(len(poses))]
         ctx.n_inputs = 3 + len(ts)
-        ctx.flat, ctx.layout, ctx.nper = flat, (offs[2:], sizes[2:], shapes[2:]), [pg for _, _, pg, _, _ in per]
+        ctx.flat, ctx.layout, ctx.nper = flat, (offs[2:], shapes[2:], strides[2:]), [pg for _, _, pg, _, _ in per]
         ops.train_metrics(L, image.shape[0], spec.thermal_mult, [p.detach() for p in poses], L[16:24])
         outs = L.unbind(0)
         ctx.mark_non_differentiable(*(outs[i] for i in range(32) if i not in (0, 1, 2, 3, 8, 9, 10, 11, 12)))
@@ -237,7 +244,7 @@ class TrainLosses(torch.autograd.Function):
             return (None,) * ctx.n_inputs
         scaled = ctx.flat * g  # every gradient buffer at once (out of place: the loss values the caller holds live in the same allocation)
         out = [None, None, None]
-        gi = iter([scaled[o:o + n].view(*s) for o, n, s in zip(*ctx.layout)])
+        gi = iter([scaled.as_strided(s, st, o) for o, s, st in zip(*ctx.layout)])
         for pg in ctx.nper:
             out.append(next(gi))
             dws = [next(gi), next(gi), next(gi)]

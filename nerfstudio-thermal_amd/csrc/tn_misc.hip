@@ -918,6 +918,7 @@ extern "C" int tn_grad_nonfinite_ranges(const float* grads, int32_t num_ranges, 
 // Adam with the skip / unscale decision ON THE DEVICE: no host synchronisation between backward and optimiser step.  GradScaler decides per
 // OPTIMISER (torch/amp/grad_scaler.py: found_inf_per_device of that optimiser's gradients), i.e. per parameter group here:
 //   found_inf[flag[k]] != 0 -> range k is not touched (parameters and both moments stay bit-identical); if `count_skip`, skipped[flag[k]] += 1
+//                              (once per flag and launch: a group whose parameters form several ranges is one skipped step)
 //   inv_scale               -> gradients are multiplied by *inv_scale as they are read (GradScaler.step on not-yet-unscaled gradients)
 //   skipped[flag[k]]        -> steps of that group skipped so far: the bias corrections use (host step count - skipped), as torch's fused Adam
 //                              keeps its step tensors (torch/optim/adam.py _fused_adam: step -= found_inf)
@@ -999,7 +1000,11 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
   const int lag = (skipped != nullptr && r.lag_index >= 0) ? skipped[r.lag_index] : 0;
   const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
   if (found_inf != nullptr && found_inf[fl] != 0.0f) {  // uniform over the range's blocks
-    if (count_skip && skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&skipped[fl], 1);
+    if (count_skip && skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+      bool first = true;  // ONE count per group and launch, however many ranges of the launch carry the group's flag
+      for (int j = 0; j < k; ++j) first = first && r.flag[j] != fl;
+      if (first) atomicAdd(&skipped[fl], 1);
+    }
     if (zero_g) {  // the skipped step still consumes its (non-finite) gradients
       for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
         reinterpret_cast<float4*>(gz + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);

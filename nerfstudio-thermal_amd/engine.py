@@ -131,14 +131,17 @@ class RenderEngine:
     # ---------------------------------------------------------------- sampler schedule
     def update_schedule(self, step: int) -> float:
         c = self.cfg
-        return float(np.clip(np.interp(step, [0, c.proposal_warmup], [0, c.proposal_update_every]), 1, c.proposal_update_every))
+        # np.clip(np.interp(step, [0, warmup], [0, every]), 1, every) (models/nerfacto.py:283-288) in plain Python: ~15 us of numpy dispatch per call
+        w, e = float(c.proposal_warmup), float(c.proposal_update_every)
+        x = e if step >= w else (0.0 if step <= 0 else (e / w) * step)  # (slope first, as np.interp evaluates it: bit-identical)
+        return min(max(x, 1.0), e)
 
     def set_anneal_for_step(self, step: int) -> None:
         """set_anneal callback (models/nerfacto.py:271-281)."""
         c = self.cfg
         if not c.use_proposal_weight_anneal:
             return
-        frac = float(np.clip(step / c.proposal_weights_anneal_max_num_iters, 0, 1))
+        frac = min(max(step / c.proposal_weights_anneal_max_num_iters, 0.0), 1.0)
         b = c.proposal_weights_anneal_slope
         self.anneal = b * frac / ((b - 1) * frac + 1)
 

@@ -120,6 +120,9 @@ class _RenderFn(torch.autograd.Function):
         # caller fills that dict with this node's own outputs, and a node that reaches its outputs (directly or through the model) is a
         # reference cycle that only the cyclic garbage collector frees: ~30 MB of activations per iteration piled up until it ran.
         ctx.eng, ctx.branches, ctx.cam = eng, branches, cam
+        # outputs nobody differentiated arrive as None in backward, not as zero tensors: an iteration whose proposal networks ran without
+        # gradients then takes the one-call backward below instead of three fills and the launch-by-launch path
+        ctx.set_materialize_grads(False)
         ctx.names, ctx.params = model._param_names, params
         ctx.has_cross = bool(eng.separate and "density2" in out)
         tensors = []
@@ -138,7 +141,6 @@ class _RenderFn(torch.autograd.Function):
         branches, cam = ctx.branches, ctx.cam
         arena = eng.arena
         arena.grads_clean = False  # this node (and autograd, through the aliased .grad views) writes into the arena's gradient buffer
-        params = dict(zip(ctx.names, ctx.params))
         dev = eng.device
         it = iter(grads)
         N = cam.shape[0]
@@ -156,6 +158,7 @@ class _RenderFn(torch.autograd.Function):
         # from zero there and hand out only its own contribution
         detached = {}
         if ctx.accumulating:
+            params = dict(zip(ctx.names, ctx.params))
             for n in ctx.names:
                 g = params[n].grad
                 if g is not None and g.data_ptr() != arena.grad_ptr(n):
@@ -231,23 +234,32 @@ class _RenderFn(torch.autograd.Function):
         # (ray_samplers.py:591,605-610) and the thermal twins that shared mode never evaluates -- torch.optim.Adam skips a parameter whose
         # .grad is None, whereas a zero gradient would advance its step count and let it coast on its momentum.  None also for a parameter
         # whose .grad already IS the arena view (gradient accumulation): the kernels have added into it in place.
-        live = set()
-        for sfx, br in branches.items():
-            live.update(arena.group_keys["fields_thermal" if sfx else "fields"])
-            live.update(arena.group_keys["camera_opt_thermal" if sfx else "camera_opt"])
-            if br.prop_grad:
-                live.update(arena.group_keys["proposal_networks_thermal" if sfx else "proposal_networks"])
-        pg = []
-        for n in ctx.names:
-            p = params[n]
-            aliased = p.grad is not None and p.grad.data_ptr() == arena.grad_ptr(n)
+        key = tuple((sfx, bool(br.prop_grad)) for sfx, br in branches.items())
+        cache = arena.__dict__.setdefault("_live_index", {})
+        hit = cache.get(key)
+        if hit is None or hit[0] is not ctx.names:  # (positions in ctx.names of the parameters this kind of iteration differentiates)
+            live = set()
+            for sfx, pgrad in key:
+                live.update(arena.group_keys["fields_thermal" if sfx else "fields"])
+                live.update(arena.group_keys["camera_opt_thermal" if sfx else "camera_opt"])
+                if pgrad:
+                    live.update(arena.group_keys["proposal_networks_thermal" if sfx else "proposal_networks"])
+            hit = cache[key] = (ctx.names, [i for i, n in enumerate(ctx.names) if n in live])
+        names, plist = ctx.names, ctx.params
+        pg = [None] * len(names)
+        ptrs = arena.grad_ptrs()
+        for i in hit[1]:
+            n = names[i]
             if n in detached:
                 view = arena.grad_view(n)
-                own = view.clone()
-                view.add_(detached[n])  # the arena keeps the running total
-                pg.append(own if n in live else None)
-            else:  # (a FRESH view object per step: autograd adopts a gradient it holds the only reference to, and copies one it does not)
-                pg.append(arena.grad_view(n) if (n in live and not aliased) else None)
+                pg[i] = view.clone()
+                view.add_(detached.pop(n))  # the arena keeps the running total
+                continue
+            g = plist[i].grad
+            if g is None or g.data_ptr() != ptrs[n]:
+                pg[i] = arena.grad_view(n)  # (a FRESH view object per step: autograd adopts a gradient it holds the only reference to, and copies one it does not)
+        for n, prev in detached.items():  # (not differentiated this iteration: its slice just gets the previous micro-steps back)
+            arena.grad_view(n).add_(prev)
         return (None, None, None, None, None, None, None, *pg)
 
 
@@ -435,8 +447,13 @@ class ThermalNerfactoModel(nn.Module):
             nears, fars = eng._nears_fars(o.shape[0], True)
             for sfx, br in branches.items():
                 out[f"_prop_grad{sfx}"] = br.prop_grad  # the sampler ran this iteration's proposal networks with gradients (ray_samplers.py:591)
-                bundle = RayBundle(origins=br.origins, directions=br.directions, pixel_area=ray_bundle.pixel_area, camera_indices=ray_bundle.camera_indices,
-                                   nears=nears[:, None], fars=fars[:, None])
+
+                def bundle(br=br, cache=[]):  # built when a level is first used as a real RaySamples (the training loop reads the bins only)
+                    if not cache:
+                        cache.append(RayBundle(origins=br.origins, directions=br.directions, pixel_area=ray_bundle.pixel_area,
+                                               camera_indices=ray_bundle.camera_indices, nears=nears[:, None], fars=fars[:, None]))
+                    return cache[0]
+
                 out[f"ray_samples_list{sfx}"] = [LazyRaySamples(bundle, L.s_bins, L.e_bins, nears, fars) for L in br.levels]
         return out
 

@@ -132,10 +132,17 @@ class NearFarCollider(nn.Module):
         self.near_plane, self.far_plane, self.reset_near_plane = near_plane, far_plane, reset_near_plane
 
     def set_nears_and_fars(self, ray_bundle: RayBundle) -> RayBundle:
-        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+        """The two constants as [..., 1] tensors.  They depend on the batch shape only: built once per shape and handed out again (the
+        reference builds them per call with ones_like and two multiplications -- three launches in front of every forward); nothing on this
+        path writes into a bundle's nears / fars in place."""
         near = self.near_plane if (self.training or not self.reset_near_plane) else 0
-        ray_bundle.nears = ones * near
-        ray_bundle.fars = ones * self.far_plane
+        o = ray_bundle.origins
+        key = (tuple(o.shape[:-1]), o.device, o.dtype, float(near), float(self.far_plane))
+        hit = self.__dict__.get("_nf")
+        if hit is None or hit[0] != key:
+            ones = torch.ones_like(o[..., 0:1])
+            hit = self._nf = (key, ones * near, ones * self.far_plane)
+        ray_bundle.nears, ray_bundle.fars = hit[1], hit[2]
         return ray_bundle
 
     def forward(self, ray_bundle: RayBundle) -> RayBundle:

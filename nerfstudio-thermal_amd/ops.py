@@ -31,6 +31,20 @@ def level_resolutions(num_levels: int, min_res: int, max_res: int) -> List[float
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_STRIDES: dict = {}
+
+
+def _contig_strides(shape: Tuple[int, ...]) -> Tuple[int, ...]:
+    st = _STRIDES.get(shape)
+    if st is None:
+        out, k = [], 1
+        for d in reversed(shape):
+            out.append(k)
+            k *= d
+        st = _STRIDES[shape] = tuple(reversed(out))
+    return st
+
+
 def _stream() -> C.c_void_p:
     """torch's current stream as a raw hipStream_t (the private accessor costs ~0.3 us, torch.cuda.current_stream() ~10 us: a step makes
     ~50 launches)."""
@@ -706,11 +720,10 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
                                    C.c_void_p(wait_event.cuda_event) if wait_event is not None else None,
                                    C.c_void_p(zero_fill.data_ptr()) if zero_fill is not None else None, _nbytes(zero_fill), _stream()), "tn_render_rays_train")
 
-    def v(slot, *shape):
-        n = 1
-        for d in shape:
-            n *= d
-        return buf[off[slot]:off[slot] + n].view(*shape)
+    so = buf.storage_offset()
+
+    def v(slot, *shape):  # one as_strided per result (a slice + a view are two dispatcher calls, and a step hands out 22 of these)
+        return buf.as_strided(shape, _contig_strides(shape), so + off[slot])
 
     levels = []
     for i, S in enumerate((S0, S1)):

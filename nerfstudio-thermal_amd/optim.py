@@ -12,6 +12,7 @@ iterations where the sampler ran them under no_grad, model_components/ray_sample
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional
 
 import numpy as np
@@ -19,6 +20,8 @@ import torch
 
 from . import ops
 from .arena import ParamArena
+
+_FUSED_SCALER_STEP = os.environ.get("TN_FUSED_SCALER_STEP", "1") != "0"  # A/B switch (read once at import): 0 = one GradScaler.step() per optimiser
 
 
 class HipFusedAdam(torch.optim.Optimizer):
@@ -186,6 +189,23 @@ class HipFusedAdam(torch.optim.Optimizer):
                 self._steps[id(p)] = int(float(st["step"]))
                 st["step"] = torch.tensor(float(self._steps[id(p)]))
 
+def _cut_launches(work: list, max_ranges: int = 8) -> List[list]:
+    """work: ranges in optimiser order, each (flag, arena, lo, hi, step, lr, (beta1, beta2, eps)).  Launches of <= max_ranges consecutive ranges
+    over one arena with one (beta1, beta2, eps), cut at optimiser boundaries: an optimiser is split only when it alone exceeds a launch, so
+    that at most its LAST launch has to count a skipped step (the kernel counts once per flag and launch)."""
+    launches, i = [], 0
+    while i < len(work):
+        j = i + 1
+        while j < len(work) and j - i < max_ranges and work[j][1] is work[i][1] and work[j][6] == work[i][6]:
+            j += 1
+        if j < len(work) and work[j][0] == work[j - 1][0] and work[j - 1][0] != work[i][0]:
+            while work[j - 1][0] == work[j][0]:  # the launch would end inside an optimiser that did not start it: end it before that optimiser
+                j -= 1
+        launches.append(work[i:j])
+        i = j
+    return launches
+
+
 class DeviceGradScaler:
     """torch.amp.GradScaler's state machine (torch/amp/grad_scaler.py) for the FUSED step (RenderEngine.train_step), kept on the device: the
     reference Trainer runs every iteration through `grad_scaler.scale(loss).backward()`, `optimizer_scaler_step_some`, `grad_scaler.update()` and
@@ -276,8 +296,8 @@ class ExponentialDecayLR:
         self._apply()
 
     def _apply(self) -> None:
-        t = float(np.clip(self.last_epoch / self.max_steps, 0, 1))
-        lr = float(np.exp(np.log(self.lr_init) * (1 - t) + np.log(self.lr_final) * t))
+        t = min(max(self.last_epoch / self.max_steps, 0.0), 1.0)
+        lr = float(np.exp(np.log(self.lr_init) * (1 - t) + np.log(self.lr_final) * t))  # (numpy's exp / log: the LambdaLR of the reference evaluates them in numpy)
         for g in self.optimizer.param_groups:
             g["lr"] = lr
 
@@ -323,9 +343,80 @@ class Optimizers:
         for name in param_groups:
             self.optimizers[name].zero_grad()
 
+    def _amp_state(self, device):
+        """Device state of the fused GradScaler step, one entry per optimiser in dict order: found_inf (float32; cleared and raised every
+        iteration), a persistent 1-element view of each entry (what GradScaler.update() collects), the skipped-step counters (int32)."""
+        st = self.__dict__.get("_amp")
+        if st is None or st[0].device != device:
+            n = len(self.optimizers)
+            found = torch.zeros(n, dtype=torch.float32, device=device)
+            st = self._amp = (found, [found[i:i + 1] for i in range(n)], torch.zeros(n, dtype=torch.int32, device=device))
+        return st
+
+    def _fused_scaler_step(self, grad_scaler, names: List[str]) -> bool:
+        """torch.amp.GradScaler.step() for ALL the named optimisers in three launches instead of per optimiser: one non-finite check over every
+        gradient range (found_inf per optimiser: GradScaler decides optimiser by optimiser), one reciprocal of the scale, one Adam launch that
+        unscales while it reads and leaves an optimiser with a non-finite gradient untouched.  GradScaler's own bookkeeping is kept as its
+        step() keeps it (torch/amp/grad_scaler.py:360-470: stage = STEPPED, found_inf_per_device), so get_scale() / update() / state_dict()
+        behave as the reference Trainer expects (engine/trainer.py:488-495).  Per optimiser GradScaler.step() costs ~130 us of host time
+        (inspect.signature of step(), a foreach unscale pass with a dummy scale, the torch.optim step wrapper): 0.38 ms of a 1.5 ms iteration.
+        Returns False -- nothing done -- whenever the general path must run (another optimiser class, hooks, max_norm, unscale_() already
+        called, a GradScaler without the private fields read here)."""
+        if not isinstance(grad_scaler, torch.amp.GradScaler) or not grad_scaler.is_enabled() or self.max_norm or not _FUSED_SCALER_STEP:
+            return False
+        opts = [self.optimizers[n] for n in names]
+        if any(type(o) is not HipFusedAdam or o._optimizer_step_pre_hooks or o._optimizer_step_post_hooks for o in opts):
+            return False
+        try:
+            from torch.amp.grad_scaler import OptState
+
+            states, get_scale, check = grad_scaler._per_optimizer_states, grad_scaler._get_scale_async, grad_scaler._check_scale_growth_tracker
+        except (ImportError, AttributeError):
+            return False
+        live = [(n, o) for n, o in zip(names, opts) if any(p.grad is not None for g in o.param_groups for p in g["params"])]
+        if not live:
+            return True
+        if any(states[id(o)]["stage"] is not OptState.READY for _, o in live):
+            return False
+        check("step")  # (raises like GradScaler.step when scale() was never called)
+        index = self.__dict__.get("_opt_index")
+        if index is None or len(index) != len(self.optimizers):
+            index = self._opt_index = {n: i for i, n in enumerate(self.optimizers)}
+        device = next(iter(live[0][1]._where.values()))[0].params.device
+        found, views, skipped = self._amp_state(device)
+        found.zero_()
+        work = []  # (flag, arena, lo, hi, step, lr, (beta1, beta2, eps))
+        for n, o in live:
+            gi = index[n]
+            mine = skipped[gi:gi + 1]
+            if o._skipped is None or o._skipped.data_ptr() != mine.data_ptr():
+                if o._skipped is not None:
+                    mine.copy_(o._skipped)  # steps it skipped through its own step() so far
+                o._skipped = mine
+            work += [(gi, r[0], r[1], (r[2] + 3) // 4 * 4, r[3], r[4], tuple(r[5:8])) for r in o.collect_runs()]
+        # launches of <= 8 ranges over one arena with one (beta1, beta2, eps); an optimiser is never split over two launches that both count
+        # a skipped step (the kernel counts once per flag and launch)
+        launches = _cut_launches(work)
+        for ch in launches:
+            ops.grad_nonfinite_ranges(ch[0][1].grads, [(w[2], w[3]) for w in ch], [w[0] for w in ch], found)
+        inv = get_scale().to(torch.float32).reciprocal().reshape(1)
+        for k, ch in enumerate(launches):
+            a, (b1, b2, eps) = ch[0][1], ch[0][6]
+            last = k + 1 == len(launches) or launches[k + 1][0][0] != ch[-1][0]  # (an optimiser of > 8 ranges: only its last launch counts)
+            ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, [(w[2], w[3], w[4], w[5]) for w in ch], beta1=b1, beta2=b2, eps=eps,
+                                     inv_scale=inv, found_inf=found, flags=[w[0] for w in ch], skipped=skipped, count_skip=last)
+        for n, o in live:
+            st = states[id(o)]
+            st["found_inf_per_device"] = {device: views[index[n]]}
+            st["stage"] = OptState.STEPPED
+        return True
+
     def optimizer_scaler_step_some(self, grad_scaler, param_groups: List[str]) -> None:
         """engine/optimizers.py:160-173: unscale + clip when the group has a max_norm, then GradScaler.step -- which skips the optimiser when an
-        inf / NaN was found (on the device for HipFusedAdam, through found_inf.item() for torch.optim.Adam) -- for groups with any gradient."""
+        inf / NaN was found (on the device for HipFusedAdam, through found_inf.item() for torch.optim.Adam) -- for groups with any gradient.
+        HipFusedAdam optimisers without hooks / max_norm go out together (_fused_scaler_step)."""
+        if self._fused_scaler_step(grad_scaler, param_groups):
+            return
         for name in param_groups:
             optimizer = self.optimizers[name]
             max_norm = self.max_norm.get(name)

@@ -49,3 +49,10 @@ def _build():
 
 
 thermal_nerfacto_hip = _build()
+
+import os as _os  # noqa: E402
+
+if _os.environ.get("TN_SINGLE_THREAD_BACKWARD", "0") == "1":  # opt-in (see configure_host): the training process that loads this plugin
+    from . import configure_host as _configure_host
+
+    _configure_host(single_thread_backward=True)

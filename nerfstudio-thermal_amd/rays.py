@@ -137,7 +137,8 @@ class LazyRaySamples:
     only ever reads `s_bins` / `e_bins` from the entries of `ray_samples_list` (the loss kernels take the dense bins); building the full
     Frustums / RaySamples views for three levels costs ~60 tensor operations per iteration on the host, so they are built on demand."""
 
-    def __init__(self, bundle: RayBundle, s_bins: Tensor, e_bins: Tensor, nears: Tensor, fars: Tensor):
+    def __init__(self, bundle, s_bins: Tensor, e_bins: Tensor, nears: Tensor, fars: Tensor):
+        """bundle: the RayBundle of the level's rays, or a callable that builds it (the bundle's broadcast-on-construct is host time, too)."""
         self.s_bins, self.e_bins = s_bins, e_bins
         self._args = (bundle, nears, fars)
         self._real: Optional[RaySamples] = None
@@ -145,6 +146,8 @@ class LazyRaySamples:
     def materialize(self) -> RaySamples:
         if self._real is None:
             bundle, nears, fars = self._args
+            if not isinstance(bundle, RayBundle):
+                bundle = bundle()
             self._real = ray_samples_from_level(bundle, self.s_bins, self.e_bins, nears, fars)
         return self._real
 

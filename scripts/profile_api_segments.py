@@ -1,5 +1,6 @@
 """Host time of the drop-in path's step, segment by segment (perf_counter around the statements of bench.one_step_api, no device sync inside
-the loop, garbage collector frozen as in bench.py): where the ~1 ms of Python per step goes."""
+the loop, garbage collector frozen as in bench.py): where the ~1 ms of Python per step goes.  AMP=1: the reference Trainer's autocast +
+torch.amp.GradScaler sequence (engine/trainer.py:470-495) with its two get_scale() host synchronisations."""
 import functools, gc, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +17,8 @@ cache = bench.make_image_cache(dev)
 dm = bench._datamanager(model, cam_t, cache, 4096)
 cbs = model.get_training_callbacks()
 groups = list(opt.optimizers.keys())
+AMP = os.environ.get("AMP", "0") == "1"
+scaler = torch.amp.GradScaler("cuda") if AMP else None
 acc = {}
 def seg(name, t0):
     t = time.perf_counter(); acc[name] = acc.get(name, 0.0) + (t - t0); return t
@@ -26,13 +29,24 @@ def step(s, timed):
     opt.zero_grad_some(groups); t = seg("callbacks + zero_grad", t) if timed else t
     rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
     batch = {"image": im, "is_thermal": th}; t = seg("RayBundle", t) if timed else t
-    out = model(rb); t = seg("model(rb)", t) if timed else t
-    m = model.get_metrics_dict(out, batch); t = seg("get_metrics_dict", t) if timed else t
-    L = model.get_loss_dict(out, batch, m); t = seg("get_loss_dict", t) if timed else t
-    loss = functools.reduce(torch.add, L.values()); t = seg("sum of losses", t) if timed else t
-    loss.backward(); t = seg("backward", t) if timed else t
-    opt.optimizer_step_all(s); t = seg("optimizer_step_all", t) if timed else t
-    opt.scheduler_step_all(s); t = seg("scheduler_step_all", t) if timed else t
+    with torch.autocast(device_type="cuda", enabled=AMP):
+        out = model(rb); t = seg("model(rb)", t) if timed else t
+        m = model.get_metrics_dict(out, batch); t = seg("get_metrics_dict", t) if timed else t
+        L = model.get_loss_dict(out, batch, m); t = seg("get_loss_dict", t) if timed else t
+        loss = functools.reduce(torch.add, L.values()); t = seg("sum of losses", t) if timed else t
+    if not AMP:
+        loss.backward(); t = seg("backward", t) if timed else t
+        opt.optimizer_step_all(s); t = seg("optimizer_step_all", t) if timed else t
+        opt.scheduler_step_all(s); t = seg("scheduler_step_all", t) if timed else t
+    else:
+        sl = scaler.scale(loss); t = seg("scaler.scale(loss)", t) if timed else t
+        sl.backward(); t = seg("backward", t) if timed else t
+        opt.optimizer_scaler_step_some(scaler, groups); t = seg("optimizer_scaler_step_some", t) if timed else t
+        sc = scaler.get_scale(); t = seg("get_scale() #1 (host sync: waits for the step's kernels)", t) if timed else t
+        scaler.update(); t = seg("scaler.update()", t) if timed else t
+        if sc <= scaler.get_scale():
+            t = seg("get_scale() #2", t) if timed else t
+            opt.scheduler_step_all(s); t = seg("scheduler_step_all", t) if timed else t
     for cb in cbs: cb.run_callback_at_location(s, Loc.AFTER_TRAIN_ITERATION)
     seg("after callbacks", t) if timed else None
 s = 0

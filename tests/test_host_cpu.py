@@ -198,3 +198,34 @@ def test_uniform_pool_hands_out_fresh_disjoint_slices():
     torch.manual_seed(5)
     again = UniformPool("cpu", steps=4)
     assert all(torch.equal(a, again.take((3, 50))) for a in got)
+
+
+def test_fused_scaler_step_cuts_launches_at_optimiser_boundaries():
+    """optim._cut_launches: the launches of Optimizers._fused_scaler_step (torch.amp.GradScaler.step for every optimiser at once).  A skipped
+    step is counted once per flag and launch, so an optimiser may only be split when it alone exceeds a launch."""
+    from nerfstudio_thermal_amd.optim import _cut_launches
+
+    A, B = object(), object()
+    h, h2 = (0.9, 0.999, 1e-15), (0.9, 0.99, 1e-15)
+
+    def rng(flag, k, arena=A, hyper=h):
+        return [(flag, arena, 100 * i, 100 * i + 64, 1, 1e-2, hyper) for i in range(k)]
+
+    def flags(launches):
+        return [[w[0] for w in ch] for ch in launches]
+
+    # the normal case: one range per optimiser, one launch
+    assert flags(_cut_launches(rng(0, 1) + rng(1, 1) + rng(2, 1))) == [[0, 1, 2]]
+    # 3 + 3 + 3 ranges: the third optimiser does not fit behind the first two -> it starts the next launch whole
+    assert flags(_cut_launches(rng(0, 3) + rng(1, 3) + rng(2, 3))) == [[0] * 3 + [1] * 3, [2] * 3]
+    # an optimiser of 11 ranges is split (only its last launch counts), the next one rides with its tail
+    assert flags(_cut_launches(rng(0, 11) + rng(1, 2))) == [[0] * 8, [0] * 3 + [1] * 2]
+    # another arena / other betas start a launch of their own
+    assert flags(_cut_launches(rng(0, 2) + rng(1, 2, arena=B) + rng(2, 1, arena=B, hyper=h2))) == [[0, 0], [1, 1], [2]]
+    # every range goes out exactly once, in order
+    work = rng(0, 5) + rng(1, 9) + rng(2, 1) + rng(3, 7)
+    out = _cut_launches(work)
+    assert [w for ch in out for w in ch] == work and all(len(ch) <= 8 for ch in out)
+    for k, ch in enumerate(out[:-1]):  # a launch ends inside an optimiser only if that optimiser also started it
+        if out[k + 1][0][0] == ch[-1][0]:
+            assert ch[0][0] == ch[-1][0]

@@ -246,11 +246,15 @@ def test_growth_interval_and_partial_group_skip():
     assert float((p[n:] - ref6.param_groups[0]["params"][0].detach()).abs().max()) <= 2e-6  # group 1: 6 steps (one skipped)
 
 
-def test_distributed_data_parallel_wrap_single_rank(golden_dir):
+@pytest.mark.parametrize("single_thread_backward", [False, True])
+def test_distributed_data_parallel_wrap_single_rank(golden_dir, single_thread_backward):
     """pipelines/base_pipeline.py:281-283: DDP(model, device_ids=[local_rank], find_unused_parameters=True).  The parameters are views of one
     arena, the proposal networks get None gradients on non-update iterations and the thermal twins never get one in shared mode: the wrapped
-    model must take the same steps as the unwrapped one (1-rank RCCL group: the all-reduce is the identity)."""
+    model must take the same steps as the unwrapped one (1-rank RCCL group: the all-reduce is the identity).
+    single_thread_backward: the opt-in host setting nerfstudio_thermal_amd.configure_host() -- DDP's reducer hooks then run on the calling thread."""
     import torch.distributed as dist
+
+    import nerfstudio_thermal_amd as pkg
     from torch.nn.parallel import DistributedDataParallel as DDP
 
     from nerfstudio_thermal_amd.parallel import free_port
@@ -261,6 +265,7 @@ def test_distributed_data_parallel_wrap_single_rank(golden_dir):
         os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=0, world_size=1)
         created = True
+    pkg.configure_host(single_thread_backward=single_thread_backward)
     try:
         mA, oA, rb, batch, _ = _setup(golden_dir, "shared")
         mB, oB, _, _, _ = _setup(golden_dir, "shared")
@@ -280,6 +285,7 @@ def test_distributed_data_parallel_wrap_single_rank(golden_dir):
             assert_same_training_state(_snapshot(mA), _snapshot(mB), f"DistributedDataParallel-wrapped vs plain model, iteration {step}")
         assert seen_idle
     finally:
+        pkg.configure_host(single_thread_backward=False)
         if created:
             dist.destroy_process_group()
 
