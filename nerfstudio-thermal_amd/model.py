@@ -361,7 +361,11 @@ class ThermalNerfactoModel(nn.Module):
         self.density_loss = nn.L1Loss()
         self.psnr = _psnr
         # parameters in arena order: what _RenderFn receives / returns gradients for
-        self._param_names = list(self.arena.names())
+        # (only the optimised groups: the thermal twins that shared mode never evaluates would be ~30 more inputs of the autograd node, each
+        # of which costs host time per iteration and could only ever receive None)
+        opt = {n for g in self.arena.optimised_groups for n in self.arena.group_keys[g]}
+        self._param_names = [n for n in self.arena.names() if n in opt]
+        self._param_list = [self._params[n] for n in self._param_names]
 
     def _init_parameters(self) -> None:
         """The reference's initialisers: hash tables U(-1,1)*1e-3 (field_components/encodings.py:377-379), nn.Linear default
@@ -429,9 +433,8 @@ class ThermalNerfactoModel(nn.Module):
         if not grad_mode:
             out, branches = eng.get_outputs(o, d, cam, self.training, jitters, jitters_thermal)
         else:
-            params = [self._params[n] for n in self._param_names]
             holder: list = []
-            flat = _RenderFn.apply(self, holder, o, d, cam, jitters, jitters_thermal, *params)
+            flat = _RenderFn.apply(self, holder, o, d, cam, jitters, jitters_thermal, *self._param_list)
             out, branches = holder.pop()
             it = iter(flat)
             for sfx in branches:
@@ -458,9 +461,10 @@ class ThermalNerfactoModel(nn.Module):
         return out
 
     def _grads_alias_arena(self) -> bool:
-        for n in self._param_names:
-            g = self._params[n].grad
-            if g is not None and g.data_ptr() == self.arena.grad_ptr(n):
+        ptrs = self.arena.grad_ptrs()
+        for n, p in zip(self._param_names, self._param_list):
+            g = p.grad
+            if g is not None and g.data_ptr() == ptrs[n]:
                 return True
         return False
 

@@ -104,14 +104,20 @@ class PropNetParams:
     res: List[float]
     grads: Optional[dict] = None  # same keys -> gradient tensors
 
+    def __setattr__(self, name, value):  # a new tensor in any field: the checked C struct is rebuilt at the next call
+        self.__dict__.pop("_cs", None)
+        object.__setattr__(self, name, value)
+
     def cstruct(self, need_grad: bool = False) -> TnPropNet:
         g = self.grads or {}
         if need_grad and not g:
             raise ValueError("gradient buffers required")
         # the parameters are views of the arena: their addresses do not change from step to step, so the checked struct is built once
         nf = self.__dict__.get("nonfinite_flag")  # set by the engine: the optimiser group's found_inf entry (DeviceGradScaler), or absent
-        key = tuple(t.data_ptr() for t in (self.table, self.w0, self.b0, self.w1, self.b1)) + tuple(g[k].data_ptr() for k in sorted(g)) + (
-            nf.data_ptr() if nf is not None else 0,)
+        # (key: the table's addresses stand for all of them -- every tensor is a view of the same arena; assigning a field drops the cached
+        # struct, see __setattr__ -- 25 data_ptr() calls per struct and step were ~10 us each on the path to the two library calls)
+        gt = g.get("table")
+        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0)
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -161,6 +167,10 @@ class FieldParams:
         return {"w0": (64, 32), "b0": (64,), "w1": (16, 64), "b1": (16,), "hw0": (64, 63), "hb0": (64,), "hw1": (64, 64),
                 "hb1": (64,), "hw2": (C_, 64), "hb2": (C_,), "emb": (I, 32)}
 
+    def __setattr__(self, name, value):  # a new tensor in any field: the checked C struct is rebuilt at the next call
+        self.__dict__.pop("_cs", None)
+        object.__setattr__(self, name, value)
+
     def cstruct(self, need_grad: bool = False) -> TnField:
         if self.num_levels * 2 != 32:
             raise ValueError("the fused main-field kernels are built for 16 levels x 2 features")
@@ -168,8 +178,8 @@ class FieldParams:
         if need_grad and not g:
             raise ValueError("gradient buffers required")
         nf = self.__dict__.get("nonfinite_flag")
-        key = (self.table.data_ptr(),) + tuple(getattr(self, k).data_ptr() for k in _FIELD_KEYS) + tuple(g[k].data_ptr() for k in sorted(g)) + (
-            nf.data_ptr() if nf is not None else 0,)
+        gt = g.get("table")  # (as PropNetParams.cstruct: the table's addresses stand for the arena's; __setattr__ drops the cache)
+        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0)
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
