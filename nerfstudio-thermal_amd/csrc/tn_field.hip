@@ -119,6 +119,7 @@ __global__ void k_field_pack(FieldK f, float* __restrict__ pack) { field_pack_bo
 // register group g holds features 32 m + 8 g + 4 h + {0..3} -- exactly what a wave holds in the D-layout, so every store / load instruction
 // of a wave moves one contiguous KiB (sample-major rows cost four 32-byte pieces per 128-byte line: 4x the L2 transactions).
 // Nothing outside this file reads them.
+#define FIELD_MAX_IMAGES 4096  // cameras the per-camera sums of the training backward are sized for (1 MB of the workspace)
 struct FieldWs {
   float* pack;     // PACK_TOTAL_FLOATS
   float* pos;      // [P] float4: contracted position in [0,1]^3 (masked) and the selector (k_field_pos)
@@ -135,6 +136,7 @@ struct FieldWs {
   float* g_enc;    // [16][P] float2  d enc, LEVEL-major (read by the table scatter's bin pass and k_field_dpos)
   float* jac;      // res * d enc / d offset: [16 levels][3 axes][PT] float2 = (feature 0, feature 1) (written by the training encode, read by
                    // k_field_dpos)
+  float* cam_bias; // [FIELD_MAX_IMAGES][64]  head layer 0's bias gradient per camera (k_field_bwd_fused -> k_field_emb_finish); zero between uses
   void* scatter;   // scratch of the table-gradient scatter (tn_scatter_scratch_bytes)
   int64_t PT;      // row stride of the level-major tensors
   int64_t bytes;
@@ -159,9 +161,10 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     w.h1 = take(PT * 64); w.hin = take(PT * 16); w.hh1 = take(PT * 64); w.hh2 = take(PT * 64); w.y = take(P * 4);
     w.g_enc = take(P * 32);
     w.jac = take(PT * 96);
+    w.cam_bias = take((int64_t)FIELD_MAX_IMAGES * 64);
     w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
   } else {
-    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g_enc = w.jac = nullptr;
+    w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g_enc = w.jac = w.cam_bias = nullptr;
     w.scatter = nullptr;
   }
   w.bytes = off;
@@ -183,13 +186,15 @@ template <bool PACK>
 __global__ void __launch_bounds__(256) k_field_prep(FieldK f, float* __restrict__ pack, const float* __restrict__ origins,
                                                     const float* __restrict__ directions, const float* __restrict__ e_bins, int64_t N, int S,
                                                     float4* __restrict__ pos, float* __restrict__ sel, float* __restrict__ shtab,
-                                                    float4* __restrict__ zero, int64_t zero_n4) {
+                                                    float4* __restrict__ zero, int64_t zero_n4, float4* __restrict__ cam_bias, int cam_bias_n4) {
   int bid = blockIdx.x, nblk = gridDim.x;
   if (PACK) {
     if (bid < PACK_BLOCKS) { field_pack_body(f, pack, bid * 256 + threadIdx.x); return; }
     bid -= PACK_BLOCKS; nblk -= PACK_BLOCKS;
   }
   for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)nblk * blockDim.x) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the backward's per-camera sums start from zero (k_field_emb_finish leaves them zero again; this covers a fresh workspace)
+  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < cam_bias_n4; i += (int64_t)nblk * blockDim.x) cam_bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int64_t P = N * (int64_t)S;
   for (int64_t p = bid * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)nblk * blockDim.x) {
     const int64_t ray = tn_div_index(p, S, P);
@@ -681,11 +686,12 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
 //        sample-major with a 68-float row stride (conflict-free ds_write_b128 AND ds_read_b32),
 //     3. reads them back TRANSPOSED (lane = feature, k = sample) as the A / B operands of dW += dY^T X:
 //        v_mfma_f32_32x32x2_f32 for the 64-wide layers, v_mfma_f32_16x16x4_f32 for the two layers with <= 16 outputs (Linear(64,16), Linear(64,C)).
-//   Bias gradients are the lane sums of the A operands; the appearance-embedding rows are column sums of the tile's d(head input) with a
-//   running (camera, sum) pair per lane (any number of cameras; one 128-B atomic segment per camera change).
+//   Bias gradients are the lane sums of the A operands; the appearance-embedding rows are hw0[:, 31:63]^T times head layer 0's bias gradient
+//   restricted to the camera: running per-camera sums (lane = feature; up to FIELD_MAX_IMAGES cameras, two 128-B atomic segments per camera
+//   change) into cam_bias, multiplied by hw0 in k_field_emb_finish (one 64-thread block per camera behind this launch).
 //   Epilogue: the block's four waves add their accumulators in LDS (plain read-modify-write, one wave per turn) and ONE burst of float
 //   atomics per block goes to the gradient arena (256 blocks x 12.5 k floats).
-//   MFMA work per tile: chain 184 + weight gradients 160 (32x32x2) + 64 (16x16x4, half the cycles) -> 24 k cycles; 6 tiles per wave at 4096 rays.
+//   MFMA work per tile: chain 152 + weight gradients 160 (32x32x2) + 64 (16x16x4, half the cycles) -> 22.2 k cycles; 6 tiles per wave at 4096 rays.
 #define TSTR 68                       // LDS row stride (floats) of a [32 samples][<= 64 features] transposition tile
 #define FB_TILE_FLOATS (32 * TSTR)    // one tile buffer
 #define FB_WAVE_FLOATS (2 * FB_TILE_FLOATS + 128 + 32)  // dY tile, X tile, g3 [32][4], camera of each sample [32]
@@ -702,7 +708,7 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
 #define FB_RED_B4 12480
 #define FB_RED_B1 12496
 #define FB_RED_TOTAL 12512
-static_assert(FB_RED_TOTAL + 8 * 32 + 8 <= 4 * FB_WAVE_FLOATS, "block-sum area (+ the embedding merge) must fit in the per-wave buffers");
+static_assert(FB_RED_TOTAL + 4 * 64 + 8 <= 4 * FB_WAVE_FLOATS, "block-sum area (+ the embedding merge) must fit in the per-wave buffers");
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define WAVE_LDS_SYNC()                                   \
@@ -795,6 +801,24 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int
   return q;
 }
 
+// gemb[cam][e] += sum_f hw0[f][31 + e] * cam_bias[cam][f]  (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the
+// appearance embedding: fields/nerfacto_field.py:288-300, sh16 | geo15 | emb32), and cam_bias is left zero for the next backward.
+// One block per camera; the only writer of gemb on its stream at this point (plain read-modify-write).
+__global__ void __launch_bounds__(64) k_field_emb_finish(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb) {
+  __shared__ float sums[64];
+  const int cam = blockIdx.x, t = threadIdx.x;
+  const float v = cam_bias[(int64_t)cam * 64 + t];
+  sums[t] = v;
+  if (v != 0.0f) cam_bias[(int64_t)cam * 64 + t] = 0.0f;
+  __syncthreads();
+  if (__ballot(v != 0.0f) == 0ull) return;  // a camera without samples in this batch
+  const int e = t & 31, half = t >> 5;
+  float a = 0.0f;
+  for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
+  a += __shfl_xor(a, 32, 64);
+  if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
+}
+
 #ifndef FB_NO_SB
 #define FB_NO_SB 0
 #endif
@@ -803,7 +827,8 @@ template <bool DENS_ONLY>
 __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_density,
                                                             const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
-                                                            const float* __restrict__ shtab, const float* __restrict__ emb, int L, int64_t PT,
+                                                            const float* __restrict__ shtab, const float* __restrict__ emb,
+                                                            float* __restrict__ cam_bias, int L, int64_t PT,
                                                             const float* __restrict__ encs, const float* __restrict__ h1s,
                                                             const float* __restrict__ hins, const float* __restrict__ hh1s,
                                                             const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G,
@@ -837,10 +862,14 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) { acc4[b] = zero4; acc1[b] = zero4; }
-  // appearance-embedding rows: lane = (feature e = lane & 31, half = samples 16 half .. 16 half + 15 of the tile); running sum for one camera
+  // appearance-embedding rows.  The embedding is an INPUT of head layer 0 that is constant over a camera's samples, so its gradient is linear
+  // in that layer's pre-activation gradient:  gemb[cam][e] = sum_f hw0[f][31 + e] * (sum over the camera's samples of gy_hh1[.][f]).
+  // The inner sum is the layer's bias gradient restricted to the camera -- the lane sums the weight-gradient product forms anyway -- so the
+  // chain does not compute d(slots 32..63) at all (32 MFMAs per tile less) and no per-tile column sums are taken: lane = feature (32 h + j)
+  // keeps a running (camera, sum), flushed into cam_bias[camera][64] on a camera change; k_field_emb_finish multiplies by hw0 afterwards.
   int emb_cam = -1;
   float emb_sum = 0.0f;
-  // A wave walks a CONTIGUOUS slab of tiles: consecutive tiles share rays and cameras, so the running embedding sum is flushed (float atomics
+  // A wave walks a CONTIGUOUS slab of tiles: consecutive tiles share rays and cameras, so the running sum is flushed (float atomics
   // into the 128-B row of a camera) about once per camera change.  With tiles dealt round-robin every tile started a new camera and all
   // waves of the chip were adding into the rows of the same two cameras at any time: same-line atomics execute one after the other (~25 ns
   // each) -- 170 us of a 320 us kernel.
@@ -916,36 +945,44 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 0: head input slots
       s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
-      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, bs2);  // d hw0 (slot space) += gy_hh1^T hin
+      float tb[2] = {0.0f, 0.0f};  // this tile's share of the layer's bias gradient (lane (j, h): k-parity h of output 32a + j)
+      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, tb);  // d hw0 (slot space) += gy_hh1^T hin
+      bs2[0] += tb[0]; bs2[1] += tb[1];
       FB_SB();
-      // ---- d head-input slots = Wslot^T . d hh1
-      f32x16 di1 = zero16;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0); di1 = MFMA(AB(2, 1, 0, r), dc0[r], di1); }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0); di1 = MFMA(AB(2, 1, 1, r), dc1[r], di1); }
-      FB_SB();
-      // ---- appearance-embedding rows: gemb[cam][e] += sum over the camera's samples of d(slot 32 + e)
+      // ---- appearance-embedding rows (see emb_cam above): the tile's bias sums go to the running sums of its camera
       if (!(FB_ABLATE & 1)) {
-        WAVE_LDS_SYNC();
-        lds_put_tile(bufX, j, h, 0, di1);  // [32 samples][32 features]
-        WAVE_LDS_SYNC();
-        float ev[16];
-        int ec[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { ev[q] = bufX[(16 * h + q) * TSTR + j]; ec[q] = bufC[16 * h + q]; }  // every read in flight at once
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          if (ec[q] >= 0) {  // uniform over the half-wave; -1 beyond the last sample
-            if (ec[q] != emb_cam) {
-              if (emb_cam >= 0 && emb_sum != 0.0f) atomicAdd(G.gemb + (int64_t)emb_cam * 32 + j, emb_sum);
-              emb_cam = ec[q];
-              emb_sum = 0.0f;
+        const float tt0 = tb[0] + __shfl_xor(tb[0], 32, 64), tt1 = tb[1] + __shfl_xor(tb[1], 32, 64);  // all 32 samples of outputs j, 32 + j
+        const int cam0 = __builtin_amdgcn_readfirstlane(sm.cam);  // (lane 0's sample exists: tile * 32 < P)
+        if (__ballot(sm.cam >= 0 && sm.cam != cam0) == 0) {
+          if (cam0 != emb_cam) {
+            if (emb_cam >= 0 && emb_sum != 0.0f) atomicAdd(cam_bias + (int64_t)emb_cam * 64 + lane, emb_sum);
+            emb_cam = cam0;
+            emb_sum = 0.0f;
+          }
+          emb_sum += h ? tt1 : tt0;
+        } else {
+          // a camera boundary inside the tile (ray counts that are not a multiple of the tile): the tile's rows sample by sample; bufY still
+          // holds gy_hh1 [32 samples][64] and bufC the samples' cameras (-1 beyond the last sample)
+          for (int q = 0; q < 32; ++q) {
+            const int c = bufC[q];
+            if (c >= 0) {
+              if (c != emb_cam) {
+                if (emb_cam >= 0 && emb_sum != 0.0f) atomicAdd(cam_bias + (int64_t)emb_cam * 64 + lane, emb_sum);
+                emb_cam = c;
+                emb_sum = 0.0f;
+              }
+              emb_sum += bufY[q * TSTR + lane];
             }
-            emb_sum += ev[q];
           }
         }
       }
+      FB_SB();
+      // ---- d head-input slots 0..31 = Wslot^T . d hh1 (sh | base outputs: only the base outputs' rows are used below; slots 32..63, the
+      // embedding, take their gradient through cam_bias)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0);
       FB_SB();
     } else {
       s0 = nx0; s1 = nx1;
@@ -1009,24 +1046,24 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   __syncthreads();  // every wave is done with its tile buffers: the sums go there
   float* red = lds + PACK_BWD_FLOATS;
   if (!DENS_ONLY) {
-    // the eight half-waves' running embedding sums: merged per camera inside the block first (a block's slab of rays usually holds one or two
+    // the four waves' running per-camera sums: merged per camera inside the block first (a block's slab of rays usually holds one or two
     // cameras), so that the end of the kernel is not 2048 half-waves adding into the same few 128-B rows at once
-    float* esum = red + FB_RED_TOTAL;                          // [8][32]
-    int* ecam = reinterpret_cast<int*>(esum + 8 * 32);          // [8]
-    esum[(2 * wv + h) * 32 + j] = emb_sum;
-    if (j == 0) ecam[2 * wv + h] = (emb_cam >= 0) ? emb_cam : -1;
+    float* esum = red + FB_RED_TOTAL;                          // [4 waves][64 sums]
+    int* ecam = reinterpret_cast<int*>(esum + 4 * 64);          // [4]
+    esum[wv * 64 + lane] = emb_sum;
+    if (lane == 0) ecam[wv] = emb_cam;
     __syncthreads();
-    if (threadIdx.x < 32) {
-      for (int e = 0; e < 8; ++e) {
+    if (threadIdx.x < 64) {
+      for (int e = 0; e < 4; ++e) {
         const int cam = ecam[e];
         if (cam < 0) continue;
         bool first = true;
         for (int f = 0; f < e; ++f) first = first && (ecam[f] != cam);
         if (!first) continue;
         float tot = 0.0f;
-        for (int f = e; f < 8; ++f)
-          if (ecam[f] == cam) tot += esum[f * 32 + threadIdx.x];
-        if (tot != 0.0f) atomicAdd(G.gemb + (int64_t)cam * 32 + threadIdx.x, tot);
+        for (int f = e; f < 4; ++f)
+          if (ecam[f] == cam) tot += esum[f * 64 + threadIdx.x];
+        if (tot != 0.0f) atomicAdd(cam_bias + (int64_t)cam * 64 + threadIdx.x, tot);
       }
     }
   }
@@ -1144,13 +1181,15 @@ static int launch_encode(const TnField* field, const float* origins, const float
   const int64_t P = N * (int64_t)S;
   const unsigned pb = (unsigned)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
   float4* z = reinterpret_cast<float4*>(ex.zero);
+  float4* cb = reinterpret_cast<float4*>(ws.cam_bias);  // (training workspaces only)
+  const int cbn4 = ws.cam_bias ? std::min(field->num_images, FIELD_MAX_IMAGES) * 16 : 0;
   const int64_t zn4 = ex.zero ? ex.zero_bytes / 16 : 0;
   if (ex.pack)
     hipLaunchKernelGGL(k_field_prep<true>, dim3(pb + PACK_BLOCKS), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
-                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4);
+                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4, cb, cbn4);
   else
     hipLaunchKernelGGL(k_field_prep<false>, dim3(pb), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
-                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4);
+                       reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4, cb, cbn4);
   TN_CHECK_LAUNCH("tn_field_fwd(positions)");
   const EncSched sc = make_enc_sched(field->grid, P);
   const unsigned grid = 8u * (unsigned)sc.blocks_per_xcd;
@@ -1267,6 +1306,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   TN_REQUIRE((2 * ws.PT + P) * 8 < (1ll << 32), "tn_field_bwd: batch too large for the 32-bit lane offsets of the level-major loads");
   hipStream_t st = tn_s(stream);
   const int C = field->num_channels;
+  TN_REQUIRE(dens_only || !(phases & TN_BWD_MLP) || field->num_images <= FIELD_MAX_IMAGES,
+             "tn_field_bwd: %d cameras, the per-camera sums of the appearance embedding's gradient are sized for %d", field->num_images, FIELD_MAX_IMAGES);
   if (phases & TN_BWD_MLP) {
     // chain + every weight gradient in one launch (k_field_bwd_fused)
     const size_t shmem = FB_LDS_FLOATS * sizeof(float);
@@ -1278,11 +1319,13 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     if (dens_only) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<true>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
-                         C, ws.sh, field->emb, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+                         C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
-                         S, C, ws.sh, field->emb, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+                         S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+      // the appearance-embedding rows from the per-camera sums the launch above left in the workspace
+      hipLaunchKernelGGL(k_field_emb_finish, dim3(field->num_images), dim3(64), 0, st, ws.cam_bias, field->hw0, field->gemb);
     }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
     if (d_origins != nullptr) {

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -munsafe-fp-
 hipcc $FLAGS "$@" -c $file.hip -o ../build/${file}_$name.o
 objs=""
 for f in tn_misc tn_sampler tn_prop tn_field tn_scatter tn_splat tn_pipeline; do
-  if [ $f == $file ]; then objs="$objs ../build/${file}_$name.o"; else objs="$objs ../build/$f.o"; fi
+  if [ $f == ${FILE_REPLACES:-$file} ]; then objs="$objs ../build/${file}_$name.o"; else objs="$objs ../build/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../build/libtn_$name.so
 echo built libtn_$name.so
