@@ -13,6 +13,7 @@ b n1_fused
 b n1_fused_200steps --no-cpu-baseline --no-extras --steps 200 --warmup 60
 b n1_separate_8192 --mode separate --rays 8192
 b n1_model_api --path model-api --no-cpu-baseline --steps 200 --warmup 60
+b n1_model_api_single_thread_backward --path model-api --api-single-thread-backward --no-cpu-baseline --steps 200 --warmup 60
 b n1_model_api_no_scaler --path model-api --no-grad-scaler --no-cpu-baseline --steps 200 --warmup 60
 b n1_model_api_torch_adam --path model-api --api-optimizer torch --no-cpu-baseline --steps 200 --warmup 60
 b n1_no_grad_scaler --no-grad-scaler --no-cpu-baseline --no-extras
