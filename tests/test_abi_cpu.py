@@ -129,3 +129,16 @@ def test_short_workspaces_are_refused_before_any_launch(lib):
     need = lib.tn_render_rays_eval_workspace_bytes(N, 256, 96, 48, 4)
     assert lib.tn_render_rays_eval(C.byref(p), C.byref(p), C.byref(f), ptr, ptr, ptr, ptr, ptr, N, 256, 96, 48, 1.0, ptr, ptr, ptr, fake, need - 1,
                                    ptr, None, None, None, None, None, ptr, None, None, None) == -22
+
+
+def test_field_camera_cap_is_the_documented_one():
+    """include/thermal_nerf_hip.h documents TN_FIELD_MAX_IMAGES (cameras the backward's per-camera sums are sized for); the kernel source sizes
+    the workspace region with its own constant: they must be the same number."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "thermal_nerf_hip.h")).read()
+    src = open(os.path.join(root, "nerfstudio-thermal_amd", "csrc", "tn_field.hip")).read()
+    a = int(re.search(r"#define TN_FIELD_MAX_IMAGES (\d+)", hdr).group(1))
+    b = int(re.search(r"#define FIELD_MAX_IMAGES (\d+)", src).group(1))
+    assert a == b == 4096
