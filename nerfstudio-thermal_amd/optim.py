@@ -80,6 +80,8 @@ class HipFusedAdam(torch.optim.Optimizer):
                 if g is None or g.data_ptr() != gptr or steps.get(id(p), 0) != k0:
                     fast = False
                     break
+            if not fast and rows and any(p.grad is None for p, _, _, _, _ in rows):
+                self._partial_steps = True  # (see _sync_step_tensors: skipped steps are counted per optimiser, not per parameter)
             if fast:
                 k = k0 + 1
                 for row in rows:
@@ -142,7 +144,19 @@ class HipFusedAdam(torch.optim.Optimizer):
         return int(self._skipped.item()) if self._skipped is not None else 0
 
     def _sync_step_tensors(self) -> None:
+        """Skipped steps (GradScaler's found_inf, decided on the device) are counted per OPTIMISER -- one counter, as GradScaler decides per
+        optimiser -- and subtracted from every parameter's host step count here and in the kernel's bias correction.  torch.optim.Adam
+        subtracts per parameter (`step -= found_inf` for the parameters that took part in the call): the two agree whenever all parameters of
+        the optimiser receive their gradients together, which is how every optimiser of this model is used (one per parameter group).  An
+        optimiser that has stepped with only SOME of its parameters holding gradients and has skipped a step since cannot tell which
+        parameters the skip belongs to: that is reported instead of written silently into a checkpoint."""
         sk = self.num_skipped()  # the host-side counts include the skipped steps; torch's step tensors do not
+        if sk and getattr(self, "_partial_steps", False):
+            import warnings
+
+            warnings.warn("HipFusedAdam: steps were skipped on found_inf while only some parameters of the optimiser held gradients; the per-parameter "
+                          "`step` values written now subtract the skips from every parameter (torch.optim.Adam would subtract them only from the "
+                          "parameters that took part)", RuntimeWarning, stacklevel=3)
         if sk:
             for k in list(self._steps):
                 self._steps[k] = max(0, self._steps[k] - sk)
