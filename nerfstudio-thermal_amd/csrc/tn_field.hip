@@ -329,12 +329,46 @@ __global__ void __launch_bounds__(256) k_field_encode_xcd(GridK g, EncSched sc, 
   }
 }
 
+// gemb[cam][e] += sum_f hw0[f][31 + e] * cam_bias[cam][f]  (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the
+// appearance embedding: fields/nerfacto_field.py:288-300, sh16 | geo15 | emb32), and cam_bias is left zero for the next backward.  The per-camera
+// sums come from k_field_bwd_fused.  Threads 0..63 of a block work on one camera at a time (the block's other threads only take part in the
+// barriers); the only writer of gemb on its stream at this point (plain read-modify-write).  Rides at the head of k_field_dpos when that
+// kernel follows anyway, else runs as k_field_emb_finish.
+__device__ __forceinline__ void emb_finish_block(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images,
+                                                 float* sums /* 64 floats of LDS */) {
+  const int t = threadIdx.x;
+  for (int cam = blockIdx.x; cam < num_images; cam += gridDim.x) {  // (block-uniform trip count)
+    float v = 0.0f;
+    if (t < 64) {
+      v = cam_bias[(int64_t)cam * 64 + t];
+      sums[t] = v;
+      if (v != 0.0f) cam_bias[(int64_t)cam * 64 + t] = 0.0f;
+    }
+    __syncthreads();
+    if (t < 64 && __ballot(v != 0.0f) != 0ull) {  // (wave 0 as a whole; a camera without samples in this batch is skipped)
+      const int e = t & 31, half = t >> 5;
+      float a = 0.0f;
+      for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
+      a += __shfl_xor(a, 32, 64);
+      if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(64) k_field_emb_finish(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images) {
+  __shared__ float sums[64];
+  emb_finish_block(cam_bias, hw0, gemb, num_images, sums);
+}
+
 // d position of every sample from d enc and the saved derivatives: dp_axis = sum_l sum_f g_enc[2l + f] * jac[l][f][axis]; then the
 // backward of contraction / frustum position and the per-ray sums into d origins / d directions (same arithmetic as the table scatter's
 // own d-position path, which stays for tn_hash_scatter and the proposal grids).  lane = (sample j of the tile, half h of the levels).
 __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ origins, const float* __restrict__ directions,
                                                     const float* __restrict__ e_bins, const float* __restrict__ g_enc, const float* __restrict__ jac,
-                                                    int64_t N, int S, int L, int64_t PT, float* __restrict__ d_origins, float* __restrict__ d_directions) {
+                                                    int64_t N, int S, int L, int64_t PT, float* __restrict__ d_origins, float* __restrict__ d_directions,
+                                                    float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images) {
+  __shared__ float emb_sums[64];
+  if (cam_bias != nullptr) emb_finish_block(cam_bias, hw0, gemb, num_images, emb_sums);  // (the embedding rows of the MLP phase before this launch)
   const int64_t P = N * (int64_t)S;
   const int64_t ntiles = tn_cdiv(P, 32);
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -799,24 +833,6 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int j, int h, int
     }
   }
   return q;
-}
-
-// gemb[cam][e] += sum_f hw0[f][31 + e] * cam_bias[cam][f]  (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the
-// appearance embedding: fields/nerfacto_field.py:288-300, sh16 | geo15 | emb32), and cam_bias is left zero for the next backward.
-// One block per camera; the only writer of gemb on its stream at this point (plain read-modify-write).
-__global__ void __launch_bounds__(64) k_field_emb_finish(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb) {
-  __shared__ float sums[64];
-  const int cam = blockIdx.x, t = threadIdx.x;
-  const float v = cam_bias[(int64_t)cam * 64 + t];
-  sums[t] = v;
-  if (v != 0.0f) cam_bias[(int64_t)cam * 64 + t] = 0.0f;
-  __syncthreads();
-  if (__ballot(v != 0.0f) == 0ull) return;  // a camera without samples in this batch
-  const int e = t & 31, half = t >> 5;
-  float a = 0.0f;
-  for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
-  a += __shfl_xor(a, 32, 64);
-  if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
 }
 
 #ifndef FB_NO_SB
@@ -1324,8 +1340,10 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
                          S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
-      // the appearance-embedding rows from the per-camera sums the launch above left in the workspace
-      hipLaunchKernelGGL(k_field_emb_finish, dim3(field->num_images), dim3(64), 0, st, ws.cam_bias, field->hw0, field->gemb);
+      // the appearance-embedding rows from the per-camera sums the launch above left in the workspace: at the head of k_field_dpos when that
+      // launch follows, else a launch of their own
+      if (d_origins == nullptr)
+        hipLaunchKernelGGL(k_field_emb_finish, dim3(std::min(field->num_images, 1024)), dim3(64), 0, st, ws.cam_bias, field->hw0, field->gemb, field->num_images);
     }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
     if (d_origins != nullptr) {
@@ -1337,7 +1355,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
       const int64_t tiles = tn_cdiv(P, 32);
       hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
-                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions);
+                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions, dens_only ? nullptr : ws.cam_bias, field->hw0, field->gemb,
+                         field->num_images);
       TN_CHECK_LAUNCH("tn_field_bwd(d position)");
     }
   }
