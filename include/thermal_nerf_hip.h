@@ -453,6 +453,57 @@ int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp
                                    uint32_t* done_counter, double growth_factor, double backoff_factor, int32_t growth_interval,
                                    tn_stream_t stream);
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
+
+/* ---- Trainer.train_iteration (engine/trainer.py:455-499) for the shared-density model with a camera optimiser, as ONE call: what
+ * RenderEngine.train_step enqueues through five calls of this ABI, in the same order on the same streams, bit for bit --
+ *   tn_render_rays_train      forward of the branch (pose correction, proposal sampling, field, renderers); the accumulators in `acc` are cleared
+ *                             inside the field's first launch
+ *   tn_train_losses           pixel terms + distortion + both interlevel terms (value and gradient), sums spread over loss_lines
+ *   tn_render_rays_train_bwd  renderer backward, field backward (d position, table scatter), both proposal networks when prop_grad != 0
+ *   tn_pose_bwd_finish_check  pose gradient + camera regulariser + loss sums into losses16, GradScaler's found_inf for the pose and the small
+ *                             ranges no table scatter sees
+ *   tn_adam_step_ranges_amp_update   Adam over the stepped groups (skip / bias correction / LR schedule decided on the device), GradScaler.update()
+ * A host that drives training through this entry point spends one call (~0.11 ms of launch time) per iteration; through the Python binding the
+ * host side of an iteration drops from 0.39 to 0.22 ms (scripts/trace_fused_host.py, 1024 rays).  The iteration itself is GPU-bound at either
+ * batch size (0.44 ms at 1024 rays, 0.83 ms at 4096): the wall time does not change, the host thread is free for the other 0.2 ms.
+ * Every pointer is a device pointer unless it says HOST; buffers as the five entry points document them.
+ * `acc` (acc_bytes, 16-byte aligned, multiple of 16): ONE allocation holding losses16 [16], loss_lines [TN_LOSS_LINES][16], d_comp [N,C],
+ * d_weights2 [N,S2], d_weights0 [N,S0], d_weights1 [N,S1] (both only read when prop_grad != 0), d_origins, d_directions [N,3]; the call clears it. */
+#define TN_TRAIN_STEP_MAX_RANGES 8
+typedef struct TnTrainStep {
+  const TnPropNet* prop0; const TnPropNet* prop1; const TnField* field;  /* HOST structs, gradient pointers set */
+  /* the iteration's batch (datamanager.next_train): rays before the pose correction, ground truth */
+  const float* origins_in; const float* directions_in; const int64_t* camera_indices; const float* image; const float* is_thermal;
+  const float* nears; const float* fars;
+  int64_t N; int32_t S0, S1, S2;
+  /* camera optimiser */
+  const float* pose_adjustment; const uint8_t* frozen; int32_t num_cameras; float* grad_pose;
+  float trans_pen, rot_pen, pen_scale;
+  /* sampler */
+  float anneal; int32_t prop_grad;
+  const float* jitter0; const float* jitter1; const float* jitter2; const float* lin_spaced0; const float* lin_pdf1; const float* lin_pdf2;
+  /* buffers */
+  void* field_workspace; int64_t field_workspace_bytes;
+  void* prop_workspace0; int64_t prop_workspace_bytes0; void* prop_workspace1; int64_t prop_workspace_bytes1;
+  float* fwd_out;   /* tn_render_rays_train_layout: offsets[TN_RENDER_TRAIN_OFFSETS - 1] floats, 256-byte aligned */
+  float* bwd_tmp;   /* tn_render_rays_train_bwd_tmp_floats */
+  void* acc; int64_t acc_bytes;
+  float* losses16; float* loss_lines; float* d_comp; float* d_weights0; float* d_weights1; float* d_weights2; float* d_origins; float* d_directions;
+  /* loss multipliers (models/thermal_nerfacto.py:32-64, models/nerfacto.py:52-133) */
+  float thermal_mult, tv_mult, cross_mult, distortion_mult, interlevel_mult;
+  /* GradScaler's check of the small gradient ranges (tn_pose_bwd_finish_check) */
+  int32_t num_check; int64_t check_offsets[TN_TRAIN_STEP_MAX_RANGES]; int64_t check_counts[TN_TRAIN_STEP_MAX_RANGES];
+  int32_t check_flags[TN_TRAIN_STEP_MAX_RANGES]; int32_t pose_flag;
+  /* Adam + GradScaler.update (tn_adam_step_ranges_amp_update); num_ranges == 0: no optimiser launch */
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq;
+  int32_t num_ranges; int64_t offsets[TN_TRAIN_STEP_MAX_RANGES]; int64_t counts[TN_TRAIN_STEP_MAX_RANGES]; int32_t steps[TN_TRAIN_STEP_MAX_RANGES];
+  double lrs[TN_TRAIN_STEP_MAX_RANGES]; double lr_finals[TN_TRAIN_STEP_MAX_RANGES]; int32_t sched_max_steps[TN_TRAIN_STEP_MAX_RANGES];
+  int32_t flag_index[TN_TRAIN_STEP_MAX_RANGES]; int32_t sched_step;
+  double beta1, beta2, eps;
+  float* found_inf; int32_t num_flags; int32_t* skipped; int32_t lag_index;
+  float* scale; int32_t* growth_tracker; uint32_t* done_counter; double growth_factor, backoff_factor; int32_t growth_interval;
+} TnTrainStep;
+int tn_train_step(const TnTrainStep* step, tn_stream_t stream);
 /* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */
 int tn_shutdown(void);
 

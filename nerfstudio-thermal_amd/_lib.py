@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 302  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 303  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
@@ -47,6 +47,36 @@ _FIELD_PTRS = ("w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2",
 
 class TnField(C.Structure):
     _fields_ = [("grid", TnGrid)] + [(n, _p) for n in _FIELD_PTRS] + [("num_channels", _i32), ("num_images", _i32)]
+
+
+TN_TRAIN_STEP_MAX_RANGES = 8
+_R = TN_TRAIN_STEP_MAX_RANGES
+
+
+class TnTrainStep(C.Structure):
+    """The argument block of tn_train_step: field for field the struct of include/thermal_nerf_hip.h (tests/test_abi_cpu.py compares the two)."""
+    _fields_ = [
+        ("prop0", C.POINTER(TnPropNet)), ("prop1", C.POINTER(TnPropNet)), ("field", C.POINTER(TnField)),
+        ("origins_in", _p), ("directions_in", _p), ("camera_indices", _p), ("image", _p), ("is_thermal", _p), ("nears", _p), ("fars", _p),
+        ("N", _i64), ("S0", _i32), ("S1", _i32), ("S2", _i32),
+        ("pose_adjustment", _p), ("frozen", _p), ("num_cameras", _i32), ("grad_pose", _p),
+        ("trans_pen", _f), ("rot_pen", _f), ("pen_scale", _f),
+        ("anneal", _f), ("prop_grad", _i32),
+        ("jitter0", _p), ("jitter1", _p), ("jitter2", _p), ("lin_spaced0", _p), ("lin_pdf1", _p), ("lin_pdf2", _p),
+        ("field_workspace", _p), ("field_workspace_bytes", _i64),
+        ("prop_workspace0", _p), ("prop_workspace_bytes0", _i64), ("prop_workspace1", _p), ("prop_workspace_bytes1", _i64),
+        ("fwd_out", _p), ("bwd_tmp", _p), ("acc", _p), ("acc_bytes", _i64),
+        ("losses16", _p), ("loss_lines", _p), ("d_comp", _p), ("d_weights0", _p), ("d_weights1", _p), ("d_weights2", _p), ("d_origins", _p),
+        ("d_directions", _p),
+        ("thermal_mult", _f), ("tv_mult", _f), ("cross_mult", _f), ("distortion_mult", _f), ("interlevel_mult", _f),
+        ("num_check", _i32), ("check_offsets", _i64 * _R), ("check_counts", _i64 * _R), ("check_flags", _i32 * _R), ("pose_flag", _i32),
+        ("params", _p), ("grads", _p), ("exp_avg", _p), ("exp_avg_sq", _p),
+        ("num_ranges", _i32), ("offsets", _i64 * _R), ("counts", _i64 * _R), ("steps", _i32 * _R),
+        ("lrs", _d * _R), ("lr_finals", _d * _R), ("sched_max_steps", _i32 * _R), ("flag_index", _i32 * _R), ("sched_step", _i32),
+        ("beta1", _d), ("beta2", _d), ("eps", _d),
+        ("found_inf", _p), ("num_flags", _i32), ("skipped", _p), ("lag_index", _i32),
+        ("scale", _p), ("growth_tracker", _p), ("done_counter", _p), ("growth_factor", _d), ("backoff_factor", _d), ("growth_interval", _i32),
+    ]
 
 
 class TnSplatCamera(C.Structure):
@@ -116,6 +146,7 @@ SIGNATURES = {
     "tn_adam_step_ranges_amp_update": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _d, _d, _d, _p, _p, _p, _i32, _p, _i32, _i32, _i32,
                                                  _p, _p, _p, _d, _d, _i32, _p]),
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
+    "tn_train_step": (C.c_int, [C.POINTER(TnTrainStep), _p]),
     "tn_shutdown": (C.c_int, []),
     "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 7 + [_i64, _p, _i64, _p, _i64] + [_p] * 4),

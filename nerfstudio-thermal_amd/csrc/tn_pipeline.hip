@@ -218,3 +218,61 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
   if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
   return rc ? rc : (rc0 ? rc0 : rc1);
 }
+
+
+// tn_train_step: one training iteration of the shared-density model as ONE call (see the header): the five entry points RenderEngine.train_step
+// calls, in its order, on the caller's stream.  Nothing here launches a kernel of its own.
+extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
+  TN_REQUIRE(a != nullptr, "tn_train_step: null argument block");
+  if (a->N == 0) return TN_OK;
+  TN_REQUIRE(a->prop0 && a->prop1 && a->field && a->origins_in && a->directions_in && a->camera_indices && a->image && a->is_thermal && a->nears &&
+                 a->fars && a->fwd_out && a->bwd_tmp && a->acc && a->losses16 && a->loss_lines && a->d_comp && a->d_weights2,
+             "tn_train_step: null pointer");
+  TN_REQUIRE(a->pose_adjustment && a->grad_pose && a->d_origins && a->d_directions && a->num_cameras >= 1,
+             "tn_train_step: this entry point is the iteration WITH a camera optimiser (pose_adjustment, grad_pose, d_origins, d_directions)");
+  TN_REQUIRE(a->prop_grad == 0 || (a->d_weights0 && a->d_weights1 && a->prop_workspace0 && a->prop_workspace1),
+             "tn_train_step: prop_grad needs d_weights0 / d_weights1 and both proposal workspaces");
+  TN_REQUIRE(a->num_check >= 0 && a->num_check <= TN_TRAIN_STEP_MAX_RANGES && a->num_ranges >= 0 && a->num_ranges <= TN_TRAIN_STEP_MAX_RANGES,
+             "tn_train_step: at most %d ranges", TN_TRAIN_STEP_MAX_RANGES);
+  TN_REQUIRE(a->found_inf && a->num_flags >= 1 && a->scale && a->growth_tracker && a->done_counter && a->skipped,
+             "tn_train_step: the GradScaler state is part of the iteration (found_inf, scale, growth_tracker, done_counter, skipped)");
+  TN_REQUIRE(a->num_ranges == 0 || (a->params && a->grads && a->exp_avg && a->exp_avg_sq), "tn_train_step: null arena pointer");
+  const int C = a->field->num_channels;
+  TN_REQUIRE(C == 4, "tn_train_step: the shared-density model renders RGB + thermal from one field (4 channels), got %d", C);
+  int64_t off[TRO_COUNT];
+  train_layout(a->N, a->S0, a->S1, a->S2, C, off);
+  int rc;
+  if ((rc = tn_render_rays_train(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
+                                 a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
+                                 a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
+                                 a->acc_bytes, stream)))
+    return rc;
+  const float* out = a->fwd_out;
+  const float* sprop[2] = {out + off[TRO_S0], out + off[TRO_S1]};
+  const float* wprop[2] = {out + off[TRO_W0], out + off[TRO_W1]};
+  const int32_t Sprop[2] = {a->S0, a->S1};
+  float* dwprop[2] = {a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr};
+  const float* comp = out + off[TRO_COMP];
+  // pixel terms on the RGB columns / the thermal column of the one RGBT composite (models/thermal_nerfacto.py:425-428)
+  if ((rc = tn_train_losses(out + off[TRO_S2], out + off[TRO_W2], a->S2, 2, sprop, wprop, Sprop, dwprop, a->N, a->distortion_mult, a->interlevel_mult,
+                            a->d_weights2, comp, C, comp + 3, C, a->image, a->is_thermal, a->thermal_mult, a->tv_mult, a->cross_mult, a->d_comp, a->d_comp + 3,
+                            a->loss_lines, stream)))
+    return rc;
+  if ((rc = tn_render_rays_train_bwd(a->prop_grad ? a->prop0 : nullptr, a->prop_grad ? a->prop1 : nullptr, a->field, out + off[TRO_ORIGINS],
+                                     out + off[TRO_DIRECTIONS], a->camera_indices, a->N, a->S0, a->S1, a->S2, out, a->d_comp,
+                                     a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr, a->d_weights2, nullptr,
+                                     a->field_workspace, a->field_workspace_bytes, a->prop_grad ? a->prop_workspace0 : nullptr,
+                                     a->prop_grad ? a->prop_workspace_bytes0 : 0, a->prop_grad ? a->prop_workspace1 : nullptr,
+                                     a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, stream)))
+    return rc;
+  if ((rc = tn_pose_bwd_finish_check(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N,
+                                     a->num_cameras, a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11,
+                                     a->grads, a->num_check, a->check_offsets, a->check_counts, a->check_flags, a->num_flags, a->found_inf, a->pose_flag,
+                                     stream)))
+    return rc;
+  if (a->num_ranges == 0) return TN_OK;
+  return tn_adam_step_ranges_amp_update(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
+                                        a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,
+                                        a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter, a->growth_factor, a->backoff_factor,
+                                        a->growth_interval, stream);
+}

@@ -25,6 +25,8 @@ _FUSE = os.environ.get("TN_FUSE_SMALL", "1") != "0"
 # TN_ONE_CALL_BWD=0: the backward of a branch as the individual entry points (render_bwd, weights_bwd, prop_density_bwd x2, field_bwd on torch
 # side streams) instead of tn_render_rays_train_bwd (test / A-B aid: the two must agree)
 _ONE_CALL_BWD = os.environ.get("TN_ONE_CALL_BWD", "1") != "0"
+# TN_TRAIN_STEP_ONE_CALL=0: the fused step through its five library calls instead of tn_train_step (test / A-B aid: the two must agree)
+_ONE_CALL_STEP = os.environ.get("TN_TRAIN_STEP_ONE_CALL", "1") != "0"
 
 
 @dataclass
@@ -776,6 +778,51 @@ class RenderEngine:
         if smp:
             self.steps_since_update, self.sampler_step, self.anneal = int(smp["steps_since_update"]), int(smp["step"]), float(smp["anneal"])
 
+    def _train_step_one_call(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, jitters, scaler) -> Dict[str, Tensor]:
+        """The iteration of train_step (shared density, camera optimiser, device-side GradScaler, no data-parallel exchange) as ONE library call,
+        tn_train_step: what get_outputs + loss_and_backward + optimizer_step enqueue through five calls, with their bookkeeping done here.
+        The five-call path stays the reference (TN_TRAIN_STEP_ONE_CALL=0; tests/test_trainer_sequence_gpu.py compares the two)."""
+        a, c = self.arena, self.cfg
+        N = origins.shape[0]
+        call = self.__dict__.get("_step_call")
+        if call is None or call.scaler is not scaler or call.arena_tensors[1] is not a.grads:
+            co = c.camera_optimizer
+            gidx = {g: i for i, g in enumerate(a.optimised_groups)}
+            call = self._step_call = ops.TrainStepCall(
+                self.props, self.field, self.pose, self.frozen_rgb, self.pose_grad, (co.trans_l2_penalty, co.rot_l2_penalty, co.penalty_scale), self.counts,
+                (c.thermal_loss_mult, c.tv_pixel_loss_mult, c.cross_channel_loss_mult, c.distortion_loss_mult, c.interlevel_loss_mult),
+                (a.params, a.grads, a.exp_avg, a.exp_avg_sq), self._small_grad_ranges(), gidx["camera_opt"], scaler)
+            self._step_gidx = gidx
+        gidx = self._step_gidx
+        nears, fars = self._nears_fars(N, True)
+        if jitters is None:
+            jitters = list(self._uniforms().take((3, N)).unbind(0))
+        updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
+        keys, shapes = self._accumulator_spec(N, {"": bool(updated), "_thermal": False})
+        views, flat = self._zeros_many(shapes, fill=False)  # cleared inside the field's first launch
+        acc = {k[0]: v for k, v in zip(keys, views)}
+        # optimiser bookkeeping of optimizer_step: Adam step counts per group, LR schedule position (evaluated on the device at count - lag)
+        self.adam_step_count += 1
+        if not hasattr(self, "group_steps"):
+            self.group_steps = {}
+        ranges = []
+        for g in a.optimised_groups:
+            if g == "proposal_networks" and not updated:
+                continue  # ran under no_grad this iteration (ray_samplers.py:605-610): not stepped, keeps its step count
+            self.group_steps[g] = self.group_steps.get(g, 0) + 1
+            lr0, lr_final, max_steps = OPTIMIZERS[g]
+            lo, hi = a.group_range[g]
+            ranges.append((lo, hi, self.group_steps[g], lr0, lr_final, max_steps, gidx[g]))
+        a.grads_clean = False
+        call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count - 1)
+        a.grads_clean = True  # the Adam launch consumed the gradients of every group that received any
+        self.last_updated = bool(updated)
+        if updated:
+            self.steps_since_update = 0
+        L = acc["L"]
+        return {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
+                "distortion_loss": L[9], "camera_opt_regularizer": L[11]}
+
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
                    jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True, grad_scaler=None) -> Dict[str, Tensor]:
         """Trainer.train_iteration (engine/trainer.py:455-499) for this model: callbacks, forward, losses, backward, (all-reduce), Adam.
@@ -792,6 +839,12 @@ class RenderEngine:
         if not self.arena.grads_clean:  # (the previous step's optimiser launch consumed the gradients: nothing to fill)
             self.sync_params()
             self.arena.zero_grad()
+        if (_ONE_CALL_STEP and _FUSE and _ONE_CALL_BWD and kflags is not None and scheduled and not self.separate and self.pose is not None
+                and not self.overlap_adam and getattr(self, "scatter_events", None) is None
+                and self.field.num_channels == 4 and "camera_opt" in self.arena.optimised_groups):
+            losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler)
+            self.step_cb(step)
+            return losses
         out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal, prealloc_accumulators=True)
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
             # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)

@@ -744,6 +744,110 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
             "rgb_samples": v(16, N, S2, Cc), "rgb": v(17, N, Cc), "accumulation": v(18, N, 1), "depth": v(19, N, 1), "expected_depth": v(20, N, 1)}
 
 
+class TrainStepCall:
+    """One training iteration of the shared-density model as ONE library call (tn_train_step): the argument block is kept between iterations,
+    only what changes per iteration is written again.  RenderEngine.train_step builds one per (engine, scaler) and calls run() every step; the
+    five calls it replaces stay the reference for what it enqueues (tests/test_hip_ops_gpu.py)."""
+
+    def __init__(self, props: Sequence[PropNetParams], fld: FieldParams, pose: Tensor, frozen: Optional[Tensor], pose_grad: Tensor, penalties, counts,
+                 mults, arena_tensors, check_ranges, pose_flag: int, scaler, tags=("main", "side0", "side1")):
+        """penalties = (trans, rot, scale); mults = (thermal, tv, cross, distortion, interlevel); arena_tensors = (params, grads, exp_avg,
+        exp_avg_sq); check_ranges = [(lo, hi, flag)] small gradient ranges for GradScaler's check; scaler: optim.DeviceGradScaler."""
+        self.props, self.fld, self.pose, self.frozen, self.pose_grad = list(props), fld, pose, frozen, pose_grad
+        self.counts = tuple(int(c) for c in counts)
+        self.tags = tags
+        self.scaler = scaler
+        self.arena_tensors = arena_tensors
+        if fld.num_channels != 4 or len(check_ranges) > _lib.TN_TRAIN_STEP_MAX_RANGES:
+            raise ValueError("tn_train_step is the shared-density iteration (4 channels) with at most 8 small gradient ranges")
+        st = self.st = _lib.TnTrainStep()
+        Cn = pose.shape[0]
+        st.pose_adjustment, st.frozen, st.num_cameras = _f32(pose, "pose", (Cn, 6)), _u8(frozen, Cn), Cn
+        st.grad_pose = _f32(pose_grad, "grad_pose", (Cn, 6))
+        st.trans_pen, st.rot_pen, st.pen_scale = (float(x) for x in penalties)
+        st.S0, st.S1, st.S2 = self.counts
+        st.thermal_mult, st.tv_mult, st.cross_mult, st.distortion_mult, st.interlevel_mult = (float(x) for x in mults)
+        st.num_check = len(check_ranges)
+        for k, (lo, hi, fl) in enumerate(check_ranges):
+            st.check_offsets[k], st.check_counts[k], st.check_flags[k] = int(lo), int(hi - lo), int(fl)
+        st.pose_flag = int(pose_flag)
+        params, grads, m, v = arena_tensors
+        st.params, st.grads, st.exp_avg, st.exp_avg_sq = _f32(params, "params"), _f32(grads, "grads"), _f32(m, "exp_avg"), _f32(v, "exp_avg_sq")
+        st.beta1, st.beta2, st.eps = 0.9, 0.999, 1e-15
+        st.found_inf, st.num_flags = _f32(scaler.found_inf, "found_inf"), int(scaler.found_inf.numel())
+        st.skipped, st.lag_index = C.c_void_p(scaler.skipped.data_ptr()), int(scaler.lag_index)
+        sc, gt, done, gf, bf, gi = scaler.fused_update_args()
+        st.scale, st.growth_tracker, st.done_counter = _f32(sc, "scale", (1,)), C.c_void_p(gt.data_ptr()), C.c_void_p(done.data_ptr())
+        st.growth_factor, st.backoff_factor, st.growth_interval = float(gf), float(bf), int(gi)
+        self._N = -1
+        self._keep = None
+
+    def _for_batch(self, N: int, dev) -> None:
+        """what depends on the batch size only: layouts, workspaces, sampler tables"""
+        st, (S0, S1, S2) = self.st, self.counts
+        lib = _lib.load()
+        key = (N, S0, S1, S2, 4)
+        off = _TRAIN_LAYOUTS.get(key)
+        if off is None:
+            arr = (C.c_int64 * _lib.TN_RENDER_TRAIN_OFFSETS)()
+            check(lib.tn_render_rays_train_layout(N, S0, S1, S2, 4, arr, _lib.TN_RENDER_TRAIN_OFFSETS), "tn_render_rays_train_layout")
+            off = _TRAIN_LAYOUTS[key] = [int(x) for x in arr]
+        self.off = off
+        ws = self.fld.workspace(N * S2, True, self.tags[0])
+        w0, w1 = _prop_ws(dev, N * S0, self.tags[1]), _prop_ws(dev, N * S1, self.tags[2])
+        need = int(lib.tn_render_rays_train_bwd_tmp_floats(N, S0, S1, S2, 4))
+        tkey = (str(dev), self.tags[0])
+        tmp = _BWD_TMP.get(tkey)
+        if tmp is None or tmp.numel() < need:
+            tmp = _BWD_TMP[tkey] = torch.empty(need, device=dev)
+        lins = (_lin_table("spaced", S0, dev), _lin_table("pdf", S1, dev), _lin_table("pdf", S2, dev))
+        st.N = N
+        st.field_workspace, st.field_workspace_bytes = C.c_void_p(ws.data_ptr()), _nbytes(ws)
+        st.prop_workspace0, st.prop_workspace_bytes0 = C.c_void_p(w0.data_ptr()), _nbytes(w0)
+        st.prop_workspace1, st.prop_workspace_bytes1 = C.c_void_p(w1.data_ptr()), _nbytes(w1)
+        st.bwd_tmp = C.c_void_p(tmp.data_ptr())
+        st.lin_spaced0, st.lin_pdf1, st.lin_pdf2 = (_f32(t, "lin") for t in lins)
+        self._batch_keep = (ws, w0, w1, tmp, lins)
+        self._N = N
+
+    def run(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, nears: Tensor, fars: Tensor, anneal: float,
+            jitters: Sequence[Tensor], prop_grad: bool, acc_flat: Tensor, acc: dict, ranges, sched_step: int) -> Tensor:
+        """acc: name -> view of acc_flat for L [16], Lp [LOSS_LINES,16], d_comp, dw0, dw1 (prop_grad only), dw2, d_o, d_d.
+        ranges: [(lo, hi, adam step, lr_init, lr_final, max_steps, flag)] of the groups stepped this iteration.  -> the forward's buffer."""
+        N = origins.shape[0]
+        dev = origins.device
+        if N != self._N:
+            self._for_batch(N, dev)
+        st, (S0, S1, S2) = self.st, self.counts
+        # the structs' addresses must be the ones the library reads during THIS call: rebuilt only when a tensor of the networks moved
+        p0, p1, f = self.props[0].cstruct(need_grad=True), self.props[1].cstruct(need_grad=True), self.fld.cstruct(need_grad=True)
+        st.prop0, st.prop1, st.field = C.pointer(p0), C.pointer(p1), C.pointer(f)
+        st.origins_in, st.directions_in = _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3))
+        st.camera_indices = _i64(cam, "camera_indices", (N,))
+        st.image, st.is_thermal = _f32(image, "image", (N, 3)), _f32(is_thermal, "is_thermal", (N,))
+        st.nears, st.fars = _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N)
+        st.anneal, st.prop_grad = float(anneal), 1 if prop_grad else 0
+        st.jitter0, st.jitter1, st.jitter2 = (_ray_scalar(j, "jitter", N) for j in jitters)
+        buf = torch.empty(self.off[22], device=dev)
+        st.fwd_out = C.c_void_p(buf.data_ptr())
+        st.acc, st.acc_bytes = C.c_void_p(acc_flat.data_ptr()), _nbytes(acc_flat)
+        st.losses16, st.loss_lines = _f32(acc["L"], "losses16", (16,)), _f32(acc["Lp"], "loss_lines", (LOSS_LINES, 16))
+        st.d_comp, st.d_weights2 = _f32(acc["d_comp"], "d_comp", (N, 4)), _f32(acc["dw2"], "d_weights2", (N, S2))
+        st.d_weights0 = _f32(acc.get("dw0"), "d_weights0", (N, S0), optional=True) if prop_grad else None
+        st.d_weights1 = _f32(acc.get("dw1"), "d_weights1", (N, S1), optional=True) if prop_grad else None
+        st.d_origins, st.d_directions = _f32(acc["d_o"], "d_origins", (N, 3)), _f32(acc["d_d"], "d_directions", (N, 3))
+        if len(ranges) > _lib.TN_TRAIN_STEP_MAX_RANGES:
+            raise ValueError("at most 8 Adam ranges per iteration")
+        st.num_ranges = len(ranges)
+        for k, (lo, hi, step, lr0, lr1, ms, fl) in enumerate(ranges):
+            st.offsets[k], st.counts[k], st.steps[k] = int(lo), int(hi - lo), int(step)
+            st.lrs[k], st.lr_finals[k], st.sched_max_steps[k], st.flag_index[k] = float(lr0), float(lr1), int(ms), int(fl)
+        st.sched_step = int(sched_step)
+        self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters)  # alive until the next call replaces them
+        check(_lib.load().tn_train_step(C.byref(st), _stream()), "tn_train_step")
+        return buf
+
+
 def _prop_ws(device, num_points: int, tag: str) -> Tensor:
     need = int(_lib.load().tn_prop_workspace_bytes(num_points))
     key = (str(device), tag)

@@ -142,3 +142,45 @@ def test_field_camera_cap_is_the_documented_one():
     a = int(re.search(r"#define TN_FIELD_MAX_IMAGES (\d+)", hdr).group(1))
     b = int(re.search(r"#define FIELD_MAX_IMAGES (\d+)", src).group(1))
     assert a == b == 4096
+
+
+def test_train_step_struct_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of TnTrainStep (_lib.TnTrainStep) against the C compiler's layout of the header's struct: size and the offset of every
+    field (a field added on one side only, or in another order, would hand tn_train_step pointers in the wrong slots)."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    from nerfstudio_thermal_amd import _lib as L
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = [f[0] for f in L.TnTrainStep._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n  printf("%%zu\\n", sizeof(TnTrainStep));\n%s  return 0;\n}\n'
+                   % (os.path.join(root, "include", "thermal_nerf_hip.h"),
+                      "".join('  printf("%s %%zu\\n", offsetof(TnTrainStep, %s));\n' % (n, n) for n in names)))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert int(out[0]) == C.sizeof(L.TnTrainStep)
+    seen = {}
+    for line in out[1:]:
+        if line:
+            n, o = line.split()
+            seen[n] = int(o)
+    assert seen == {n: getattr(L.TnTrainStep, n).offset for n in names}
+    # and the header declares no field the mirror lacks
+    hdr = open(os.path.join(root, "include", "thermal_nerf_hip.h")).read()
+    body = hdr[hdr.index("typedef struct TnTrainStep {"):hdr.index("} TnTrainStep;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = set()
+    for stmt in body.split(";"):
+        stmt = stmt.replace("typedef struct TnTrainStep {", "").strip()
+        if not stmt:
+            continue
+        for part in stmt.split(","):
+            m = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip())
+            decl.add(m.group(1))
+    assert decl == set(names), (decl ^ set(names))

@@ -401,3 +401,44 @@ def test_fused_step_after_a_drop_in_step_starts_from_zero_gradients(golden_dir):
     mA.engine.loss_and_backward(out, br, rays[2], batch["image"], batch["is_thermal"])
     mA.engine.optimizer_step(skip_groups=("camera_opt",))
     assert not mA.arena.grads_clean
+
+
+def test_one_call_train_step_is_the_five_call_sequence(golden_dir, monkeypatch):
+    """tn_train_step (RenderEngine._train_step_one_call) against the same iteration through its five library calls (TN_TRAIN_STEP_ONE_CALL=0):
+    same rays, same jitter, same parameters -> the same losses (the forward and the loss kernels are deterministic up to the order of the
+    float atomics that add the 64 loss lines), the same training state after every iteration (compared from re-synchronised states, as the
+    other tests here do), the same sampler / optimiser bookkeeping; and a forced-inf iteration is skipped the same way."""
+    import nerfstudio_thermal_amd.engine as E
+    from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+    mA, _, rb, batch, jit = _setup(golden_dir, "shared")
+    mB, _, _, _, _ = _setup(golden_dir, "shared")
+    rays = (rb.origins.contiguous(), rb.directions.contiguous(), rb.camera_indices.reshape(-1).contiguous())
+    sA, sB = DeviceGradScaler(DEV), DeviceGradScaler(DEV)
+    bad = batch["image"].clone()
+    bad[:, :] = float("inf")
+    used = []
+    orig = E.RenderEngine._train_step_one_call
+    monkeypatch.setattr(E.RenderEngine, "_train_step_one_call", lambda self, *a, **k: (used.append(1), orig(self, *a, **k))[1])
+    for step in range(13):  # (covers iterations with and without a proposal update: the schedule thins out after the first ten)
+        img = bad if step == 6 else batch["image"]
+        mB.arena.params.copy_(mA.arena.params); mB.arena.exp_avg.copy_(mA.arena.exp_avg); mB.arena.exp_avg_sq.copy_(mA.arena.exp_avg_sq)
+        monkeypatch.setattr(E, "_ONE_CALL_STEP", True)
+        n0 = len(used)
+        lA = mA.engine.train_step(*rays, img, batch["is_thermal"], step, jit[0], None, grad_scaler=sA)
+        assert len(used) == n0 + 1  # the one-call path ran
+        monkeypatch.setattr(E, "_ONE_CALL_STEP", False)
+        lB = mB.engine.train_step(*rays, img, batch["is_thermal"], step, jit[0], None, grad_scaler=sB)
+        assert len(used) == n0 + 1
+        assert lA.keys() == lB.keys()
+        if step != 6:
+            for k in lA:
+                assert abs(float(lA[k]) - float(lB[k])) <= 1e-5 * abs(float(lB[k])) + 1e-12, (step, k, float(lA[k]), float(lB[k]))
+        assert_same_training_state(_snapshot(mA), _snapshot(mB), f"tn_train_step vs the five calls, iteration {step}")
+        eA, eB = mA.engine, mB.engine
+        assert (eA.last_updated, eA.steps_since_update, eA.adam_step_count, eA.group_steps) == (eB.last_updated, eB.steps_since_update, eB.adam_step_count,
+                                                                                               eB.group_steps)
+        assert sA.get_scale() == sB.get_scale() and sA.schedule_lag() == sB.schedule_lag()
+        assert [sA.num_skipped(i) for i in range(3)] == [sB.num_skipped(i) for i in range(3)]
+        assert mA.arena.grads_clean and float(mA.arena.grads.abs().max()) == 0.0  # the launch consumed the gradients
+    assert sA.get_scale() == 32768.0 and sA.schedule_lag() == 1
