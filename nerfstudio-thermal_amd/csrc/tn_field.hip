@@ -552,6 +552,10 @@ __device__ __forceinline__ f32x16 load_enc_lm(const float* __restrict__ enc, int
 #ifndef FWD_ABLATE
 #define FWD_ABLATE 0
 #endif
+// FWD_HEAD2_MFMA=1: the colour head's last layer as a 32x32x2 MFMA tile (round 3's form; A/B aid)
+#ifndef FWD_HEAD2_MFMA
+#define FWD_HEAD2_MFMA 0
+#endif
 template <bool TRAIN>
 __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ encs, int L,
                                                             int64_t PT, const float* __restrict__ sels, const float* __restrict__ shtab,
@@ -652,12 +656,33 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     d0 = relu16(d0); d1 = relu16(d1);
     if (TRAIN && !FWD_ABLATE) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- head layer 2 + sigmoid
-    f32x16 e = bias_tile(lbias, 4, 0, h);
+    // ---------------- head layer 2 + sigmoid.  Linear(64, C <= 4) on the VECTOR ALU: as a 32-row MFMA tile it spent 32 matrix instructions
+    // (2 064 cycles of the 14.4 k per tile) on 4 useful rows.  Lane (j, h) holds 32 of its sample's 64 inputs (tiles 0 / 1, registers r <->
+    // features 32 t + R(r, h)); the weights of the four outputs for that feature are lanes 32 h + 0..3 of the layer's forward fragment
+    // (Af[4][0][t][r][32 h + c] = W[c][32 t + R(r, h)]): one broadcast ds_read_b128 per (t, r), four FMAs, then the two halves are added.
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#if FWD_HEAD2_MFMA
+    {
+      f32x16 em = bias_tile(lbias, 4, 0, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) e = MFMA(AF(4, 0, 0, r), d0[r], e);
+      for (int r = 0; r < 16; ++r) em = MFMA(AF(4, 0, 0, r), d0[r], em);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) e = MFMA(AF(4, 0, 1, r), d1[r], e);
+      for (int r = 0; r < 16; ++r) em = MFMA(AF(4, 0, 1, r), d1[r], em);
+      e[0] = em[0]; e[1] = em[1]; e[2] = em[2]; e[3] = em[3];
+    }
+#else
+    {
+      const float* w4 = lds + fwd_off(4) + 32 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float4 wa = *reinterpret_cast<const float4*>(w4 + (r << 6)), wb = *reinterpret_cast<const float4*>(w4 + ((16 + r) << 6));
+        e[0] = fmaf(wa.x, d0[r], e[0]); e[1] = fmaf(wa.y, d0[r], e[1]); e[2] = fmaf(wa.z, d0[r], e[2]); e[3] = fmaf(wa.w, d0[r], e[3]);
+        e[0] = fmaf(wb.x, d1[r], e[0]); e[1] = fmaf(wb.y, d1[r], e[1]); e[2] = fmaf(wb.z, d1[r], e[2]); e[3] = fmaf(wb.w, d1[r], e[3]);
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) e[cc] = (e[cc] + __shfl_xor(e[cc], 32, 64)) + lbias[4 * 64 + cc];
+    }
+#endif
     if (valid && h == 0) {
       float y[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
