@@ -54,6 +54,14 @@ __host__ __device__ __forceinline__ constexpr int fwd_off(int l) {
 #define PACK_BWD_FLOATS PACK_FWD_FLOATS
 #define PACK_TOTAL_FLOATS (PACK_BWD_OFF + PACK_BWD_FLOATS)   // 29056 floats
 static_assert(PACK_FWD_TOTAL <= PACK_BWD_OFF, "pack layout");
+// Behind the fragments, in the same workspace region: the appearance embedding's share of the colour head's first layer, per camera --
+//   camhead[cam][f] = sum_e hw0[f][31 + e] * emb[cam][e]
+// The embedding is constant over a camera's samples, so the TRAINING forward starts head layer 0 from bias + camhead[cam] instead of running
+// the 32 embedding slots of every sample through the matrix cores (32 of the layer's 64 MFMAs per tile).  Rebuilt with the fragments.
+#define FIELD_MAX_IMAGES 4096  // cameras the per-camera tables are sized for (camhead here, the backward's per-camera sums: 1 MB each)
+#define PACK_CAMHEAD_OFF PACK_TOTAL_FLOATS
+#define PACK_REGION_FLOATS (PACK_TOTAL_FLOATS + FIELD_MAX_IMAGES * 64)
+static_assert(PACK_CAMHEAD_OFF % 64 == 0, "pack layout");
 
 // slot space of the colour head's first layer: [0,16) SH, [16,32) base-MLP output rows 0..15 (row 0 = density logit, weight 0),
 // [32,64) appearance embedding.  nn.Linear column for a slot (or -1):
@@ -83,6 +91,7 @@ __device__ __forceinline__ float bias_at(const FieldK& f, int layer, int o) {
   }
 }
 
+#define PACK_BLOCKS ((PACK_FWD_TOTAL + 255) / 256)
 __device__ __forceinline__ void field_pack_body(const FieldK& f, float* __restrict__ pack, int idx) {
   if (idx < PACK_FWD_FLOATS) {
     int layer = 0;
@@ -107,10 +116,22 @@ __device__ __forceinline__ void field_pack_body(const FieldK& f, float* __restri
     float s = 0.0f;
     for (int c = 0; c < f.num_images; ++c) s += f.emb[c * 32 + e];
     pack[idx] = s / (float)f.num_images;
+  } else if (idx >= PACK_BLOCKS * 256) {  // camhead: one thread per (camera, hidden unit)
+    const int q = idx - PACK_BLOCKS * 256;
+    const int ncam = f.num_images < FIELD_MAX_IMAGES ? f.num_images : FIELD_MAX_IMAGES;
+    if (q < ncam * 64) {
+      const float* w = f.hw0 + (q & 63) * 63 + 31;
+      const float* e = f.emb + (q >> 6) * 32;
+      float s = 0.0f;
+      for (int k = 0; k < 32; ++k) s = fmaf(w[k], e[k], s);
+      pack[PACK_CAMHEAD_OFF + q] = s;
+    }
   }
 }
 __global__ void k_field_pack(FieldK f, float* __restrict__ pack) { field_pack_body(f, pack, blockIdx.x * blockDim.x + threadIdx.x); }
-#define PACK_BLOCKS ((PACK_FWD_TOTAL + 255) / 256)
+static inline int pack_blocks(int num_images) {  // fragment blocks + one thread per (camera, hidden unit) of camhead
+  return PACK_BLOCKS + ((num_images < FIELD_MAX_IMAGES ? num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256;
+}
 
 // ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
 // Per-level tensors (enc, d enc / d offset, d enc) are LEVEL-MAJOR with a row stride of PT = samples rounded up to whole 32-sample tiles:
@@ -119,9 +140,8 @@ __global__ void k_field_pack(FieldK f, float* __restrict__ pack) { field_pack_bo
 // register group g holds features 32 m + 8 g + 4 h + {0..3} -- exactly what a wave holds in the D-layout, so every store / load instruction
 // of a wave moves one contiguous KiB (sample-major rows cost four 32-byte pieces per 128-byte line: 4x the L2 transactions).
 // Nothing outside this file reads them.
-#define FIELD_MAX_IMAGES 4096  // cameras the per-camera sums of the training backward are sized for (1 MB of the workspace)
 struct FieldWs {
-  float* pack;     // PACK_TOTAL_FLOATS
+  float* pack;     // PACK_REGION_FLOATS: forward / backward fragments, biases, mean embedding, then camhead
   float* pos;      // [P] float4: contracted position in [0,1]^3 (masked) and the selector (k_field_pos)
   float* enc;      // [16][PT] float2   hash encoding, level-major
   float* sel;      // [P]
@@ -152,7 +172,7 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
   };
   const int64_t PT = tn_cdiv(P, 32) * 32;  // whole tiles
   w.PT = PT;
-  w.pack = take(PACK_TOTAL_FLOATS);
+  w.pack = take(PACK_REGION_FLOATS);
   w.pos = take(P * 4);
   w.enc = take(PT * 32);
   w.sel = take(P);
@@ -189,8 +209,9 @@ __global__ void __launch_bounds__(256) k_field_prep(FieldK f, float* __restrict_
                                                     float4* __restrict__ zero, int64_t zero_n4, float4* __restrict__ cam_bias, int cam_bias_n4) {
   int bid = blockIdx.x, nblk = gridDim.x;
   if (PACK) {
-    if (bid < PACK_BLOCKS) { field_pack_body(f, pack, bid * 256 + threadIdx.x); return; }
-    bid -= PACK_BLOCKS; nblk -= PACK_BLOCKS;
+    const int pkb = PACK_BLOCKS + ((f.num_images < FIELD_MAX_IMAGES ? f.num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256;  // = pack_blocks()
+    if (bid < pkb) { field_pack_body(f, pack, bid * 256 + threadIdx.x); return; }
+    bid -= pkb; nblk -= pkb;
   }
   for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)nblk * blockDim.x) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // the backward's per-camera sums start from zero (k_field_emb_finish leaves them zero again; this covers a fresh workspace)
@@ -556,6 +577,10 @@ __device__ __forceinline__ f32x16 load_enc_lm(const float* __restrict__ enc, int
 #ifndef FWD_HEAD2_MFMA
 #define FWD_HEAD2_MFMA 0
 #endif
+// FWD_EMB_MFMA=1: the camera's embedding through the matrix cores in training too (A/B aid)
+#ifndef FWD_EMB_MFMA
+#define FWD_EMB_MFMA 0
+#endif
 template <bool TRAIN>
 __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ encs, int L,
                                                             int64_t PT, const float* __restrict__ sels, const float* __restrict__ shtab,
@@ -622,7 +647,20 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) hi0[8 + r] = bo[r];
-    {
+    f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
+    constexpr bool CAMHEAD = TRAIN && !FWD_EMB_MFMA;  // (the training launch is the one with per-camera embeddings: use_cam_emb == TRAIN)
+    if (CAMHEAD) {
+      // the camera's embedding enters head layer 0 as the per-camera vector camhead[cam] (built with the fragments): no MFMA for slots 32..63
+      int64_t cam = cam_idx[ray];
+      if (cam < 0 || cam >= num_images) cam = 0;
+      const float* chp = pack + PACK_CAMHEAD_OFF + cam * 64 + 4 * h;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 u0 = *reinterpret_cast<const float4*>(chp + 8 * gq), u1 = *reinterpret_cast<const float4*>(chp + 32 + 8 * gq);
+        c0[4 * gq] += u0.x; c0[4 * gq + 1] += u0.y; c0[4 * gq + 2] += u0.z; c0[4 * gq + 3] += u0.w;
+        c1[4 * gq] += u1.x; c1[4 * gq + 1] += u1.y; c1[4 * gq + 2] += u1.z; c1[4 * gq + 3] += u1.w;
+      }
+    } else {
       const float* ebp;
       if (use_cam_emb) {
         int64_t cam = cam_idx[ray];
@@ -638,11 +676,12 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 0
-    f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 0, r), hi0[r], c0); c1 = MFMA(AF(2, 1, 0, r), hi0[r], c1); }
+    if (!CAMHEAD) {  // (inference: the mean embedding goes through the matrix cores as before)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
+      for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
     if (TRAIN && !FWD_ABLATE) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
@@ -1196,7 +1235,7 @@ extern "C" int tn_field_pack_weights(const TnField* field, void* workspace, tn_s
   if (rc) return rc;
   TN_REQUIRE(workspace != nullptr, "tn_field_pack_weights: null workspace");
   FieldWs ws = ws_layout(workspace, 0, 0);
-  hipLaunchKernelGGL(k_field_pack, dim3((unsigned)tn_cdiv(PACK_FWD_TOTAL, 256)), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack);
+  hipLaunchKernelGGL(k_field_pack, dim3((unsigned)pack_blocks(field->num_images)), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack);
   TN_CHECK_LAUNCH("tn_field_pack_weights");
   return TN_OK;
 }
@@ -1226,7 +1265,7 @@ static int launch_encode(const TnField* field, const float* origins, const float
   const int cbn4 = ws.cam_bias ? std::min(field->num_images, FIELD_MAX_IMAGES) * 16 : 0;
   const int64_t zn4 = ex.zero ? ex.zero_bytes / 16 : 0;
   if (ex.pack)
-    hipLaunchKernelGGL(k_field_prep<true>, dim3(pb + PACK_BLOCKS), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
+    hipLaunchKernelGGL(k_field_prep<true>, dim3(pb + pack_blocks(field->num_images)), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
                        reinterpret_cast<float4*>(ws.pos), ws.sel, ws.sh, z, zn4, cb, cbn4);
   else
     hipLaunchKernelGGL(k_field_prep<false>, dim3(pb), dim3(256), 0, tn_s(stream), make_fieldk(field), ws.pack, origins, directions, e_bins, N, S,
@@ -1266,6 +1305,8 @@ int tn_field_fwd_ex(const TnField* field, const float* origins, const float* dir
   TN_REQUIRE(workspace_bytes >= ws.bytes, "tn_field_fwd: workspace of %lld bytes, tn_field_workspace_bytes(%lld, %d) = %lld", (long long)workspace_bytes,
              (long long)P, training, (long long)ws.bytes);
   TN_REQUIRE(zero == nullptr || (((uintptr_t)zero % 16) == 0 && zero_bytes % 16 == 0), "tn_field_fwd: the buffer to clear must be 16-byte aligned and sized");
+  TN_REQUIRE(!training || field->num_images <= FIELD_MAX_IMAGES, "tn_field_fwd: %d cameras, the per-camera tables of the training path are sized for %d",
+             field->num_images, FIELD_MAX_IMAGES);
   rc = launch_encode(field, origins, directions, e_bins, N, S, ws, stream, FieldPrepExtra{pack_first != 0, zero, zero_bytes});
   if (rc) return rc;
   // the chain: 2 blocks of FWD_THREADS per CU, each with its own 58.7 KB copy of the packed weights
