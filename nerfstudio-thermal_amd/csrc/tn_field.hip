@@ -181,7 +181,7 @@ static inline FieldWs ws_layout(void* base, int64_t P, int training) {
     w.h1 = take(PT * 64); w.hin = take(PT * 16); w.hh1 = take(PT * 64); w.hh2 = take(PT * 64); w.y = take(P * 4);
     w.g_enc = take(P * 32);
     w.jac = take(PT * 96);
-    w.cam_bias = take((int64_t)FIELD_MAX_IMAGES * 64);
+    w.cam_bias = take((int64_t)FIELD_MAX_IMAGES * 64 + 64);  // (+ the finishing launch's block counter, one 256-B line behind the sums)
     w.scatter = take(tn_scatter_scratch_bytes(P, TN_MAX_LEVELS) / 4);
   } else {
     w.h1 = w.hin = w.hh1 = w.hh2 = w.y = w.g_enc = w.jac = w.cam_bias = nullptr;
@@ -216,6 +216,7 @@ __global__ void __launch_bounds__(256) k_field_prep(FieldK f, float* __restrict_
   for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < zero_n4; i += (int64_t)nblk * blockDim.x) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   // the backward's per-camera sums start from zero (k_field_emb_finish leaves them zero again; this covers a fresh workspace)
   for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < cam_bias_n4; i += (int64_t)nblk * blockDim.x) cam_bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cam_bias_n4 > 0 && bid == 0 && threadIdx.x == 0) cam_bias[FIELD_MAX_IMAGES * 16] = make_float4(0.f, 0.f, 0.f, 0.f);  // the finishing launch's counter
   const int64_t P = N * (int64_t)S;
   for (int64_t p = bid * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)nblk * blockDim.x) {
     const int64_t ray = tn_div_index(p, S, P);
@@ -350,35 +351,65 @@ __global__ void __launch_bounds__(256) k_field_encode_xcd(GridK g, EncSched sc, 
   }
 }
 
-// gemb[cam][e] += sum_f hw0[f][31 + e] * cam_bias[cam][f]  (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the
-// appearance embedding: fields/nerfacto_field.py:288-300, sh16 | geo15 | emb32), and cam_bias is left zero for the next backward.  The per-camera
-// sums come from k_field_bwd_fused.  Threads 0..63 of a block work on one camera at a time (the block's other threads only take part in the
-// barriers); the only writer of gemb on its stream at this point (plain read-modify-write).  Rides at the head of k_field_dpos when that
-// kernel follows anyway, else runs as k_field_emb_finish.
-__device__ __forceinline__ void emb_finish_block(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images,
-                                                 float* sums /* 64 floats of LDS */) {
+// What the per-camera sums cam_bias[cam][f] = sum over the camera's samples of gy_hh1[.][f] (k_field_bwd_fused) stand for.  The appearance
+// embedding is an input of head layer 0 that is constant over a camera's samples, so both of its gradients are linear in those sums
+// (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the embedding: fields/nerfacto_field.py:288-300):
+//   gemb[cam][e]    += sum_f   hw0[f][31 + e] * cam_bias[cam][f]        job `cam` (threads 0..63 of a block)
+//   ghw0[f][31 + e] += sum_cam cam_bias[cam][f] * emb[cam][e]           jobs num_images .. num_images + 7 (256 of the 2048 entries each)
+// -- the fused kernel therefore neither computes d(head-input slots 32..63) nor the weight-gradient tile of those slots (64 MFMAs per tile less).
+// Jobs are dealt to the blocks of the launch round-robin; the last block to finish (one relaxed counter; every block's reads of cam_bias are
+// complete before it counts itself in) clears cam_bias and the counter for the next backward; blocks without a job do not take part.  The only writers of gemb and of those columns of
+// ghw0 on their stream at this point: plain read-modify-write.  Rides at the head of k_field_dpos when that launch follows, else k_field_emb_finish.
+__device__ __forceinline__ void emb_finish_jobs(float* __restrict__ cam_bias, uint32_t* __restrict__ counter, const float* __restrict__ hw0,
+                                                const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images,
+                                                float* sums /* 64 floats of LDS */, int* flag /* 1 int of LDS */) {
   const int t = threadIdx.x;
-  for (int cam = blockIdx.x; cam < num_images; cam += gridDim.x) {  // (block-uniform trip count)
-    float v = 0.0f;
-    if (t < 64) {
-      v = cam_bias[(int64_t)cam * 64 + t];
-      sums[t] = v;
-      if (v != 0.0f) cam_bias[(int64_t)cam * 64 + t] = 0.0f;
+  const int njobs = num_images + 8;
+  if ((int)blockIdx.x >= njobs) return;  // only the blocks with a job count themselves in (one same-address atomic each: ~25 ns apiece)
+  const unsigned workers = (unsigned)njobs < gridDim.x ? (unsigned)njobs : gridDim.x;
+  for (int job = blockIdx.x; job < njobs; job += gridDim.x) {  // (block-uniform trip count)
+    if (job < num_images) {
+      const int cam = job;
+      float v = 0.0f;
+      if (t < 64) {
+        v = cam_bias[(int64_t)cam * 64 + t];
+        sums[t] = v;
+      }
+      __syncthreads();
+      if (t < 64 && __ballot(v != 0.0f) != 0ull) {  // (wave 0 as a whole; a camera without samples in this batch is skipped)
+        const int e = t & 31, half = t >> 5;
+        float a = 0.0f;
+        for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
+        a += __shfl_xor(a, 32, 64);
+        if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
+      }
+      __syncthreads();
+    } else {
+      const int o = (job - num_images) * 256 + t;  // entry (f, e) of the embedding columns of d hw0
+      if (t < 256 && o < 2048) {
+        const int f = o >> 5, e = o & 31;
+        float a = 0.0f;
+        for (int cam = 0; cam < num_images; ++cam) {
+          const float b = cam_bias[(int64_t)cam * 64 + f];
+          if (b != 0.0f) a += b * emb[(int64_t)cam * 32 + e];
+        }
+        if (a != 0.0f) ghw0[f * 63 + 31 + e] += a;
+      }
     }
-    __syncthreads();
-    if (t < 64 && __ballot(v != 0.0f) != 0ull) {  // (wave 0 as a whole; a camera without samples in this batch is skipped)
-      const int e = t & 31, half = t >> 5;
-      float a = 0.0f;
-      for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
-      a += __shfl_xor(a, 32, 64);
-      if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
-    }
-    __syncthreads();
+  }
+  __syncthreads();  // every thread of the block has consumed what it read from cam_bias
+  if (t == 0) *flag = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == workers - 1) ? 1 : 0;
+  __syncthreads();
+  if (*flag) {
+    for (int i = t; i < num_images * 64; i += blockDim.x) cam_bias[i] = 0.0f;
+    if (t == 0) *counter = 0u;
   }
 }
-__global__ void __launch_bounds__(64) k_field_emb_finish(float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images) {
+__global__ void __launch_bounds__(256) k_field_emb_finish(float* __restrict__ cam_bias, uint32_t* __restrict__ counter, const float* __restrict__ hw0,
+                                                          const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images) {
   __shared__ float sums[64];
-  emb_finish_block(cam_bias, hw0, gemb, num_images, sums);
+  __shared__ int flag;
+  emb_finish_jobs(cam_bias, counter, hw0, emb, gemb, ghw0, num_images, sums, &flag);
 }
 
 // d position of every sample from d enc and the saved derivatives: dp_axis = sum_l sum_f g_enc[2l + f] * jac[l][f][axis]; then the
@@ -387,9 +418,12 @@ __global__ void __launch_bounds__(64) k_field_emb_finish(float* __restrict__ cam
 __global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ origins, const float* __restrict__ directions,
                                                     const float* __restrict__ e_bins, const float* __restrict__ g_enc, const float* __restrict__ jac,
                                                     int64_t N, int S, int L, int64_t PT, float* __restrict__ d_origins, float* __restrict__ d_directions,
-                                                    float* __restrict__ cam_bias, const float* __restrict__ hw0, float* __restrict__ gemb, int num_images) {
+                                                    float* __restrict__ cam_bias, uint32_t* __restrict__ fin_counter, const float* __restrict__ hw0,
+                                                    const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images) {
   __shared__ float emb_sums[64];
-  if (cam_bias != nullptr) emb_finish_block(cam_bias, hw0, gemb, num_images, emb_sums);  // (the embedding rows of the MLP phase before this launch)
+  __shared__ int emb_flag;
+  // (the embedding's gradients of the MLP phase before this launch, from its per-camera sums)
+  if (cam_bias != nullptr) emb_finish_jobs(cam_bias, fin_counter, hw0, emb, gemb, ghw0, num_images, emb_sums, &emb_flag);
   const int64_t P = N * (int64_t)S;
   const int64_t ntiles = tn_cdiv(P, 32);
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -789,12 +823,12 @@ __global__ void __launch_bounds__(256, 2) k_field_density_only(const float* __re
 //   change) into cam_bias, multiplied by hw0 in k_field_emb_finish (one 64-thread block per camera behind this launch).
 //   Epilogue: the block's four waves add their accumulators in LDS (plain read-modify-write, one wave per turn) and ONE burst of float
 //   atomics per block goes to the gradient arena (256 blocks x 12.5 k floats).
-//   MFMA work per tile: chain 152 + weight gradients 160 (32x32x2) + 64 (16x16x4, half the cycles) -> 22.2 k cycles; 6 tiles per wave at 4096 rays.
+//   MFMA work per tile: chain 152 + weight gradients 128 (32x32x2) + 64 (16x16x4, half the cycles) -> 20.2 k cycles; 6 tiles per wave at 4096 rays.
 #define TSTR 68                       // LDS row stride (floats) of a [32 samples][<= 64 features] transposition tile
 #define FB_TILE_FLOATS (32 * TSTR)    // one tile buffer
 #define FB_WAVE_FLOATS (2 * FB_TILE_FLOATS + 128 + 32)  // dY tile, X tile, g3 [32][4], camera of each sample [32]
 #define FB_LDS_FLOATS (PACK_BWD_FLOATS + 4 * FB_WAVE_FLOATS)
-// block-sum layout (floats, inside the per-wave region): W3 [64][64] | W2 [64 out][64 slots] | W0 [64][32] | W4 [16][64] | W1 [16][64] | b3 b2 b0 (64 each) | b4 b1 (16 each)
+// block-sum layout (floats, inside the per-wave region): W3 [64][64] | W2 [64 out][32 slots] (+ 2048 unused) | W0 [64][32] | W4 [16][64] | W1 [16][64] | b3 b2 b0 (64 each) | b4 b1 (16 each)
 #define FB_RED_W3 0
 #define FB_RED_W2 4096
 #define FB_RED_W0 8192
@@ -931,14 +965,15 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const f32x4v zero4 = {0, 0, 0, 0};
   // weight-gradient accumulators (whole kernel)
-  f32x16 acc3[2][2], acc2[2][2], acc0[2][1];
+  f32x16 acc3[2][2], acc2[2][1], acc0[2][1];
   f32x4v acc4[4], acc1[4];
   float bs3[2] = {0.f, 0.f}, bs2[2] = {0.f, 0.f}, bs0[2] = {0.f, 0.f}, bs4 = 0.f, bs1 = 0.f;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     acc0[a][0] = zero16;
+    acc2[a][0] = zero16;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) { acc3[a][b] = zero16; acc2[a][b] = zero16; }
+    for (int b = 0; b < 2; ++b) acc3[a][b] = zero16;
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) { acc4[b] = zero4; acc1[b] = zero4; }
@@ -1000,9 +1035,10 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dc0[r] = t0[r] > 0.0f ? dc0[r] : 0.0f; dc1[r] = t1[r] > 0.0f ? dc1[r] : 0.0f; }
       lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 1: hh1
-      // head-input slots (X of head layer 0), rebuilt as the forward built them: sh | the 16 saved base outputs | the camera's embedding row.
-      // Only the base outputs stream from HBM: they are requested here, one weight-gradient block ahead; the two per-ray pieces are cache hits
-      // and are fetched behind that block (24 registers that do not stay live across it)
+      // head-input slots 0..31 (X of head layer 0), rebuilt as the forward built them: sh | the 16 saved base outputs.  (Slots 32..63, the
+      // camera's embedding row, are not needed: their weight-gradient columns come out of the per-camera sums, emb_finish_jobs.)
+      // Only the base outputs stream from HBM: they are requested here, one weight-gradient block ahead; the per-ray piece is a cache hit
+      // and is fetched behind that block (8 registers that do not stay live across it)
       const v4f_t* bp = reinterpret_cast<const v4f_t*>(hins) + tile * 128 + lane;
       const v4f_t hb0 = FRAG_NT ? __builtin_nontemporal_load(bp) : bp[0], hb1 = FRAG_NT ? __builtin_nontemporal_load(bp + 64) : bp[64];
       WAVE_LDS_SYNC();
@@ -1012,21 +1048,15 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       {
         const float* shp = shtab + (int64_t)sm.ray * 16 + h * 8;
         const float4 sa = *reinterpret_cast<const float4*>(shp), sb = *reinterpret_cast<const float4*>(shp + 4);
-        const float* ebp = emb + (int64_t)(sm.cam < 0 ? 0 : sm.cam) * 32;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {  // (rows are 16-byte aligned: checked on the host)
-          const float4 e4 = *reinterpret_cast<const float4*>(ebp + 8 * gq + 4 * h);
-          t1[4 * gq] = e4.x; t1[4 * gq + 1] = e4.y; t1[4 * gq + 2] = e4.z; t1[4 * gq + 3] = e4.w;
-        }
         lds_put_tile(bufY, j, h, 0, dc0); lds_put_tile(bufY, j, h, 1, dc1);  // dY of head layer 0: gy_hh1
         t0[0] = sa.x; t0[1] = sa.y; t0[2] = sa.z; t0[3] = sa.w; t0[4] = sb.x; t0[5] = sb.y; t0[6] = sb.z; t0[7] = sb.w;
         t0[8] = hb0.x; t0[9] = hb0.y; t0[10] = hb0.z; t0[11] = hb0.w; t0[12] = hb1.x; t0[13] = hb1.y; t0[14] = hb1.z; t0[15] = hb1.w;
       }
-      lds_put_tile(bufX, j, h, 0, t0); lds_put_tile(bufX, j, h, 1, t1);    // X of head layer 0: head input slots
+      lds_put_tile(bufX, j, h, 0, t0);                                     // X of head layer 0: head input slots 0..31
       s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
       float tb[2] = {0.0f, 0.0f};  // this tile's share of the layer's bias gradient (lane (j, h): k-parity h of output 32a + j)
-      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc2, tb);  // d hw0 (slot space) += gy_hh1^T hin
+      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 1>(bufY, bufX, j, h, acc2, tb);  // d hw0 (slots 0..31) += gy_hh1^T hin
       bs2[0] += tb[0]; bs2[1] += tb[1];
       FB_SB();
       // ---- appearance-embedding rows (see emb_cam above): the tile's bias sums go to the running sums of its camera
@@ -1158,10 +1188,8 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
           const int o = 32 * a + RROW(r, h);
           if (!DENS_ONLY) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-              RED_PUT(FB_RED_W3 + o * 64 + 32 * b + j, acc3[a][b][r]);
-              RED_PUT(FB_RED_W2 + o * 64 + 32 * b + j, acc2[a][b][r]);
-            }
+            for (int b = 0; b < 2; ++b) RED_PUT(FB_RED_W3 + o * 64 + 32 * b + j, acc3[a][b][r]);
+            RED_PUT(FB_RED_W2 + o * 32 + j, acc2[a][0][r]);  // [64 out][32 slots]
           }
           RED_PUT(FB_RED_W0 + o * 32 + j, acc0[a][0][r]);
         }
@@ -1194,7 +1222,12 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
     if (v == 0.0f) continue;
     float* dst = nullptr;
     if (t < FB_RED_W2) { if (!DENS_ONLY) dst = G.ghw1 + t; }
-    else if (t < FB_RED_W0) { const int q = t - FB_RED_W2, col = slot_to_col(q & 63); if (!DENS_ONLY && col >= 0) dst = G.ghw0 + (q >> 6) * 63 + col; }
+    else if (t < FB_RED_W0) {  // d hw0, slots 0..31 (sh | base outputs): [64 out][32 slots] at the head of the region, the rest unused
+      const int q = t - FB_RED_W2;
+      if (q >= 64 * 32) continue;
+      const int col = slot_to_col(q & 31);
+      if (!DENS_ONLY && col >= 0) dst = G.ghw0 + (q >> 5) * 63 + col;
+    }
     else if (t < FB_RED_W4) dst = G.gw0 + (t - FB_RED_W0);
     else if (t < FB_RED_W1) { const int q = t - FB_RED_W4; if (!DENS_ONLY && (q >> 6) < C) dst = G.ghw2 + q; }
     else if (t < FB_RED_B3) dst = G.gw1 + (t - FB_RED_W1);
@@ -1409,7 +1442,9 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       // the appearance-embedding rows from the per-camera sums the launch above left in the workspace: at the head of k_field_dpos when that
       // launch follows, else a launch of their own
       if (d_origins == nullptr)
-        hipLaunchKernelGGL(k_field_emb_finish, dim3(std::min(field->num_images, 1024)), dim3(64), 0, st, ws.cam_bias, field->hw0, field->gemb, field->num_images);
+        hipLaunchKernelGGL(k_field_emb_finish, dim3(std::min(field->num_images + 8, 1024)), dim3(256), 0, st, ws.cam_bias,
+                           reinterpret_cast<uint32_t*>(ws.cam_bias + (int64_t)FIELD_MAX_IMAGES * 64), field->hw0, field->emb, field->gemb, field->ghw0,
+                           field->num_images);
     }
     TN_CHECK_LAUNCH("tn_field_bwd(mlp + weight gradients)");
     if (d_origins != nullptr) {
@@ -1421,7 +1456,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
       const int64_t tiles = tn_cdiv(P, 32);
       hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
-                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions, dens_only ? nullptr : ws.cam_bias, field->hw0, field->gemb,
+                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions, dens_only ? nullptr : ws.cam_bias,
+                         reinterpret_cast<uint32_t*>(ws.cam_bias + (int64_t)FIELD_MAX_IMAGES * 64), field->hw0, field->emb, field->gemb, field->ghw0,
                          field->num_images);
       TN_CHECK_LAUNCH("tn_field_bwd(d position)");
     }
