@@ -954,3 +954,40 @@ def test_device_data_manager_batches(golden_dir):
             for a, r in ((o, o_r), (d, d_r), (cam, cam_r), (img, img_r), (is_th, th_r)):
                 assert torch.equal(a, r), prefetch
         assert not torch.equal(got[0][2], got[1][2]) or not torch.equal(got[0][3], got[1][3])  # a new batch every call
+
+
+def test_field_fwd_bwd_many_cameras():
+    """The per-camera tables of the training path (camhead in the forward, the per-camera sums and their finishing jobs in the backward) with a
+    few hundred cameras in random order over the rays: every tile of 32 samples may hold a camera boundary, cameras without a ray in the batch
+    exist, the finishing jobs outnumber the eight embedding-column jobs, and a second backward on the same forward adds the same gradients again
+    (the sums are cleared by the finishing launch, not only by the next forward)."""
+    I = 300
+    ocfg, params, cfg, arena = setup_pair("shared", num_images=I, is_thermal_cam=tuple([0, 1] * (I // 2)))
+    N, S = 257, 48
+    r = rays(N)
+    gen = torch.Generator().manual_seed(5)
+    cam = torch.randint(0, I - 40, (N,), generator=gen)  # (the last 40 cameras see no ray)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    smp = orc.Samples(s_bins=s, e_bins=e)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    dens, geo, pre, enc = orc.field_density(p, "field", ocfg, smp.positions(r["origins"], r["directions"]))
+    rgb = orc.field_color(p, "field", ocfg, r["directions"], geo, cam, True)
+    fld = field_params(arena, "field", cfg, with_grads=True)
+    hd, hrgb, _ = ops.field_fwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), True, want_pre=True)
+    assert md(hd, dens[..., 0]) <= 1e-4 and md(hrgb, rgb) <= 1e-4
+    C = fld.num_channels
+    gd = torch.from_numpy(synth.uniform("gfd", (N, S, 1), seed=SEED))
+    gc = torch.from_numpy(synth.uniform("gfc", (N, S, C), seed=SEED))
+    ((dens * gd).sum() + (rgb * gc).sum()).backward()
+    arena.zero_grad()
+    k = orc.field_keys("field")
+    for rep in (1, 2):
+        ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), g(gd[..., 0]), g(gc), None, None)
+        for short in ("table", "w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
+            ref = p[k[short]].grad * rep
+            got = arena.grad_view(k[short])
+            scale = float(ref.abs().max())
+            assert md(got, ref) <= 3e-4 * scale, (rep, short, md(got, ref), scale)
+    gemb = arena.grad_view(k["emb"])
+    assert float(gemb[I - 40:].abs().max()) == 0.0  # cameras without a ray keep an exactly-zero embedding gradient
