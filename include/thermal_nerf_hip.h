@@ -302,13 +302,16 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
  * Everything later stages need goes into ONE buffer `out` (256-byte aligned); tn_render_rays_train_layout fills offsets[] (floats) with the
  * position of: 0 origins 1 directions (pose-corrected; unused when pose_adjustment is NULL) | 2 s_bins0 3 e_bins0 4 density0 5 weights0
  * 6 median0 | 7..11 the same for level 1 | 12 s_bins2 13 e_bins2 14 density2 15 weights2 | 16 rgb_samples [N,S2,C] 17 comp [N,C]
- * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
+ * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22, 23 the proposal levels' encodings [N*S0][10], [N*S1][10] (written
+ * only with save_prop_enc) | 24 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
+ * save_prop_enc != 0: the proposal networks take a gradient this iteration (ray_samplers.py:591): their encodings are kept in `out`, and
+ * tn_render_rays_train_bwd(prop_enc_saved != 0) reads them back instead of repeating the 40 table reads per sample -- the same values.
  * wait_event_before_field: NULL, or a hipEvent_t that `stream` waits for right before the field's first read of its parameters -- a trainer
  * that runs the previous iteration's Adam launch over the field on another stream lets it overlap the proposal sampling this way.
  * zero_fill: NULL, or zero_fill_bytes (multiple of 16) of 16-byte aligned device memory that the call clears on its way (inside the field's
  * first launch): the caller's zero-initialised accumulators of the iteration -- loss sums, d(composite), d(weights), d origins / d directions --
  * without a fill launch of their own. */
-#define TN_RENDER_TRAIN_OFFSETS 23
+#define TN_RENDER_TRAIN_OFFSETS 25
 int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
 int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
                          const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
@@ -316,7 +319,7 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
                          int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                          const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
                          int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
-                         tn_stream_t stream);
+                         int32_t save_prop_enc, tn_stream_t stream);
 
 /* The TRAINING backward of one branch as ONE call, the counterpart of tn_render_rays_train: everything autograd runs behind d(composite) and
  * d(weights) in ThermalNerfactoModel's training step (models/thermal_nerfacto.py:403-489 backwards; cameras/rays.py:128-150,
@@ -326,14 +329,16 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
  * d_density_extra [N,S2] or NULL (the density loss's gradient on this branch's density, separate mode).  The library enqueues tn_render_bwd,
  * then -- on two companion streams of `stream` -- tn_weights_bwd + tn_prop_density_bwd per proposal level, beside tn_field_bwd on `stream`, and
  * joins: same launches and results as those calls made one by one.  tmp: tn_render_rays_train_bwd_tmp_floats(...) floats of scratch;
- * prop_workspace_k: tn_prop_workspace_bytes(N*S_k) (may be NULL without d_weights).  d_origins / d_directions [N,3] accumulate (or both NULL). */
+ * prop_workspace_k: tn_prop_workspace_bytes(N*S_k) (may be NULL without d_weights).  d_origins / d_directions [N,3] accumulate (or both NULL).
+ * prop_enc_saved != 0: fwd_out holds the proposal levels' encodings (tn_render_rays_train(save_prop_enc != 0) on this buffer). */
 int64_t tn_render_rays_train_bwd_tmp_floats(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
 int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
                              const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
                              const float* fwd_out, const float* d_comp, const float* d_weights0,
                              const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
                              int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
-                             int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, tn_stream_t stream);
+                             int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
+                             tn_stream_t stream);
 
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */

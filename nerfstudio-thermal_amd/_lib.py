@@ -16,7 +16,7 @@ TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 1024
 TN_LOSS_LINES = 64
-TN_RENDER_TRAIN_OFFSETS = 23
+TN_RENDER_TRAIN_OFFSETS = 25
 TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD, TN_BWD_FORK_DPOS, TN_BWD_COUNTERS_CLEAN = 1, 2, 4, 8, 16, 32, 64
 
 _p = C.c_void_p
@@ -125,7 +125,7 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_rays_train_layout": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _p, _i32]),
     "tn_render_rays_train": (C.c_int, [C.POINTER(TnPropNet), C.POINTER(TnPropNet), C.POINTER(TnField), _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32,
-                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _p]),
+                                       _i32, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p]),
     "tn_render_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "tn_render_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "tn_distortion_loss": (C.c_int, [_p, _p, _i64, _i32, _f, _p, _p, _p]),
@@ -149,7 +149,7 @@ SIGNATURES = {
     "tn_train_step": (C.c_int, [C.POINTER(TnTrainStep), _p]),
     "tn_shutdown": (C.c_int, []),
     "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
-    "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 7 + [_i64, _p, _i64, _p, _i64] + [_p] * 4),
+    "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 7 + [_i64, _p, _i64, _p, _i64] + [_p] * 3 + [_i32, _p]),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "tn_splat_project": (C.c_int, [_p] * 9 + [_i64, _i32, _i32, _i32] + [_p] * 8 + [_i64, _p]),
     "tn_splat_bin": (C.c_int, [_p, _p, _i64, _p, _i64, _p, _p]),

@@ -65,6 +65,11 @@ static inline GridK make_gridk(const TnGrid& g) {
 
 // tn_field_fwd with tn_field_pack_weights (pack_first) and a zero-fill of `zero` (16-byte aligned, zero_bytes a multiple of 16; or NULL) riding
 // in its first launch: what tn_render_rays_eval / _train call (tn_field.hip)
+int tn_prop_density_fwd_ex(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                           float* density, float* enc_out, tn_stream_t stream);
+int tn_prop_density_bwd_ex(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, const float* d_density, int64_t N,
+                           int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins, float* d_directions, const float* saved_enc,
+                           tn_stream_t stream);
 int tn_field_fwd_ex(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins, int64_t N, int32_t S,
                     int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb, float* density_pre, int pack_first, void* zero,
                     int64_t zero_bytes, tn_stream_t stream);

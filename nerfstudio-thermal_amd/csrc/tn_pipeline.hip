@@ -79,7 +79,9 @@ enum {
   TRO_S0, TRO_E0, TRO_D0, TRO_W0, TRO_M0,                // level 0: s_bins, e_bins [N,S0+1], density, weights [N,S0], median depth [N]
   TRO_S1, TRO_E1, TRO_D1, TRO_W1, TRO_M1,                // level 1
   TRO_S2, TRO_E2, TRO_D2, TRO_W2,                        // level 2 (field)
-  TRO_RGB_SAMPLES, TRO_COMP, TRO_ACC, TRO_DEPTH, TRO_EXPECTED, TRO_SCRATCH, TRO_END,
+  TRO_RGB_SAMPLES, TRO_COMP, TRO_ACC, TRO_DEPTH, TRO_EXPECTED, TRO_SCRATCH,
+  TRO_PENC0, TRO_PENC1,                                  // [N*S0][10], [N*S1][10]: the proposal levels' encodings (written with save_prop_enc only)
+  TRO_END,
   TRO_COUNT
 };
 static void train_layout(int64_t N, int S0, int S1, int S2, int C, int64_t* off) {
@@ -91,6 +93,7 @@ static void train_layout(int64_t N, int S0, int S1, int S2, int C, int64_t* off)
   take(TRO_S2, N * (S2 + 1)); take(TRO_E2, N * (S2 + 1)); take(TRO_D2, N * S2); take(TRO_W2, N * S2);
   take(TRO_RGB_SAMPLES, N * (int64_t)S2 * C); take(TRO_COMP, N * C); take(TRO_ACC, N); take(TRO_DEPTH, N); take(TRO_EXPECTED, N);
   take(TRO_SCRATCH, TN_RENDER_SCRATCH_FLOATS);
+  take(TRO_PENC0, N * (int64_t)S0 * 10); take(TRO_PENC1, N * (int64_t)S1 * 10);
   off[TRO_END] = o;
 }
 
@@ -108,7 +111,7 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
                                     int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                     const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
                                     int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
-                                    tn_stream_t stream) {
+                                    int32_t save_prop_enc, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -133,11 +136,12 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
   } else if ((rc = tn_spaced_bins(lin_spaced0, jitter0, nears, fars, N, S0, at(TRO_S0), at(TRO_E0), stream))) {
     return rc;
   }
-  if ((rc = tn_prop_density_fwd(prop0, o, d, at(TRO_E0), N, S0, at(TRO_D0), stream))) return rc;
+  // save_prop_enc: the proposal networks take a gradient this iteration -- their encodings are kept for tn_render_rays_train_bwd
+  if ((rc = tn_prop_density_fwd_ex(prop0, o, d, at(TRO_E0), N, S0, at(TRO_D0), save_prop_enc ? at(TRO_PENC0) : nullptr, stream))) return rc;
   if ((rc = tn_weights_resample(at(TRO_E0), at(TRO_D0), at(TRO_S0), S0, anneal, lin_pdf1, jitter1, nears, fars, N, S1, at(TRO_W0), at(TRO_M0), at(TRO_S1),
                                 at(TRO_E1), stream)))
     return rc;
-  if ((rc = tn_prop_density_fwd(prop1, o, d, at(TRO_E1), N, S1, at(TRO_D1), stream))) return rc;
+  if ((rc = tn_prop_density_fwd_ex(prop1, o, d, at(TRO_E1), N, S1, at(TRO_D1), save_prop_enc ? at(TRO_PENC1) : nullptr, stream))) return rc;
   if ((rc = tn_weights_resample(at(TRO_E1), at(TRO_D1), at(TRO_S1), S1, anneal, lin_pdf2, jitter2, nears, fars, N, S2, at(TRO_W1), at(TRO_M1), at(TRO_S2),
                                 at(TRO_E2), stream)))
     return rc;
@@ -173,7 +177,8 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
                                         const float* fwd_out, const float* d_comp, const float* d_weights0,
                                         const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
                                         int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
-                                        int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, tn_stream_t stream) {
+                                        int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
+                                        tn_stream_t stream) {
   if (N == 0) return TN_OK;
   TN_REQUIRE(field && origins && directions && camera_indices && fwd_out && d_comp && d_weights2 && field_workspace && tmp,
              "tn_render_rays_train_bwd: null pointer");
@@ -208,9 +213,13 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
     hipStream_t s0 = tn_fork_n(st, 1), s1 = tn_fork_n(st, 2);
     tn_stream_t t0 = s0 ? (tn_stream_t)s0 : stream, t1 = s1 ? (tn_stream_t)s1 : stream;
     rc0 = tn_weights_bwd(at(TRO_E0), at(TRO_D0), at(TRO_W0), d_weights0, N, S0, dd0, t0);
-    if (!rc0) rc0 = tn_prop_density_bwd(prop0, o, d, at(TRO_E0), dd0, N, S0, prop_workspace0, prop_workspace_bytes0, d_origins, d_directions, t0);
+    if (!rc0)
+      rc0 = tn_prop_density_bwd_ex(prop0, o, d, at(TRO_E0), dd0, N, S0, prop_workspace0, prop_workspace_bytes0, d_origins, d_directions,
+                                   prop_enc_saved ? at(TRO_PENC0) : nullptr, t0);
     rc1 = tn_weights_bwd(at(TRO_E1), at(TRO_D1), at(TRO_W1), d_weights1, N, S1, dd1, t1);
-    if (!rc1) rc1 = tn_prop_density_bwd(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, prop_workspace_bytes1, d_origins, d_directions, t1);
+    if (!rc1)
+      rc1 = tn_prop_density_bwd_ex(prop1, o, d, at(TRO_E1), dd1, N, S1, prop_workspace1, prop_workspace_bytes1, d_origins, d_directions,
+                                   prop_enc_saved ? at(TRO_PENC1) : nullptr, t1);
   }
   // (d position forks to its companion stream only when the proposal networks' backward keeps other queues busy anyway)
   rc = tn_field_bwd_phase(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, field_workspace_bytes, d_origins, d_directions,
@@ -245,7 +254,7 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   if ((rc = tn_render_rays_train(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
                                  a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
                                  a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
-                                 a->acc_bytes, stream)))
+                                 a->acc_bytes, a->prop_grad ? 1 : 0, stream)))
     return rc;
   const float* out = a->fwd_out;
   const float* sprop[2] = {out + off[TRO_S0], out + off[TRO_S1]};
@@ -263,7 +272,7 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
                                      a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr, a->d_weights2, nullptr,
                                      a->field_workspace, a->field_workspace_bytes, a->prop_grad ? a->prop_workspace0 : nullptr,
                                      a->prop_grad ? a->prop_workspace_bytes0 : 0, a->prop_grad ? a->prop_workspace1 : nullptr,
-                                     a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, stream)))
+                                     a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, a->prop_grad ? 1 : 0, stream)))
     return rc;
   if ((rc = tn_pose_bwd_finish_check(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N,
                                      a->num_cameras, a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11,

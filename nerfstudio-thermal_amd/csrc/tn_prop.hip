@@ -29,8 +29,12 @@ __device__ __forceinline__ void prop_stage_weights(const PropK& net, float* s_w)
   __syncthreads();
 }
 
+// SAVE_ENC (training iterations in which the proposal networks take a gradient): the 10 encoding features of every sample are kept
+// ([P][10] floats, 40 B per lane: whole cache lines per wave) so that k_prop_bwd_mlp does not repeat the 40 gathers per sample.
+template <bool SAVE_ENC>
 __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
-                                                     const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ density) {
+                                                     const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ density,
+                                                     float* __restrict__ enc_out) {
   __shared__ __attribute__((aligned(16))) float s_w[PH * PROP_WROW + 4];
   prop_stage_weights(net, s_w);
   int64_t P = N * (int64_t)S;
@@ -47,6 +51,7 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
       float2 v = tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
       enc[2 * l] = v.x;
       enc[2 * l + 1] = v.y;
+      if (SAVE_ENC) *reinterpret_cast<float2*>(enc_out + i * PF + 2 * l) = v;
     }
     float out = s_w[PH * PROP_WROW];
 #pragma unroll 4
@@ -72,6 +77,11 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
 
 extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
                                    int32_t S, float* density, tn_stream_t stream) {
+  return tn_prop_density_fwd_ex(net, origins, directions, e_bins, N, S, density, nullptr, stream);
+}
+// enc_out: NULL, or [N*S][10] floats that receive the samples' encodings (for tn_prop_density_bwd_ex; csrc/tn_pipeline.hip)
+int tn_prop_density_fwd_ex(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+                           float* density, float* enc_out, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(net && origins && directions && e_bins && density, "tn_prop_density_fwd: null pointer");
   TN_REQUIRE(net->grid.table && net->w0 && net->b0 && net->w1 && net->b1, "tn_prop_density_fwd: null parameter pointer");
@@ -82,7 +92,10 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
   PropK k{make_gridk(net->grid), net->w0, net->b0, net->w1, net->b1, nullptr, nullptr, nullptr, nullptr};
   int64_t P = N * (int64_t)S;
   int grid = (int)std::min<int64_t>(tn_cdiv(P, 256), 256 * 16);
-  hipLaunchKernelGGL(k_prop_fwd, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, N, S, density);
+  if (enc_out != nullptr)
+    hipLaunchKernelGGL(k_prop_fwd<true>, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, N, S, density, enc_out);
+  else
+    hipLaunchKernelGGL(k_prop_fwd<false>, dim3(grid), dim3(256), 0, tn_s(stream), k, origins, directions, e_bins, N, S, density, enc_out);
   TN_CHECK_LAUNCH("tn_prop_density_fwd");
   return TN_OK;
 }
@@ -132,9 +145,13 @@ __device__ __forceinline__ float prop_row_sum(float x) {  // sum over the 16 lan
 // One block of 16 waves per CU (4 per SIMD): the kernel ends with one atomic per weight and block, and atomics on one 64-B line execute one after
 // the other (~25 ns each).  With 1024 blocks of 4 waves that burst was 57 of the kernel's 105 us.
 #define PB_THREADS 1024
+// HAVE_ENC: the forward of this iteration kept the samples' encodings (k_prop_fwd<true>): they are read back (40 B per lane) instead of
+// gathered again (40 table reads per sample: ~2/5 of this kernel) -- the same values, bit for bit.
+template <bool HAVE_ENC>
 __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
                                                                const float* __restrict__ e_bins, const float* __restrict__ d_density, int64_t N, int S,
-                                                               float* __restrict__ ws_denc, uint32_t* __restrict__ zero_ptr, int zero_words) {
+                                                               float* __restrict__ ws_denc, uint32_t* __restrict__ zero_ptr, int zero_words,
+                                                               const float* __restrict__ saved_enc) {
   __shared__ __attribute__((aligned(16))) float lds[(PB_THREADS / 64) * PB_WAVE_FLOATS];
   tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the scatter that follows on this stream
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -172,7 +189,8 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
       float enc[PF];
 #pragma unroll
       for (int l = 0; l < PL; ++l) {
-        float2 v = tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
+        const float2 v = HAVE_ENC ? *reinterpret_cast<const float2*>(saved_enc + ic * PF + 2 * l)
+                                  : tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
         enc[2 * l] = v.x;
         enc[2 * l + 1] = v.y;
       }
@@ -263,6 +281,12 @@ extern "C" int64_t tn_prop_workspace_bytes(int64_t num_points) {
 extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
                                    const float* d_density, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
                                    float* d_directions, tn_stream_t stream) {
+  return tn_prop_density_bwd_ex(net, origins, directions, e_bins, d_density, N, S, workspace, workspace_bytes, d_origins, d_directions, nullptr, stream);
+}
+// saved_enc: NULL, or what tn_prop_density_fwd_ex(enc_out) kept for these very samples and parameters
+int tn_prop_density_bwd_ex(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, const float* d_density, int64_t N,
+                           int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins, float* d_directions, const float* saved_enc,
+                           tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(net && origins && directions && e_bins && d_density && workspace, "tn_prop_density_bwd: null pointer");
   TN_REQUIRE(net->grid.table && net->grid.table_grad && net->w0 && net->b0 && net->w1 && net->b1 && net->gw0 && net->gb0 && net->gw1 && net->gb1,
@@ -286,7 +310,10 @@ extern "C" int tn_prop_density_bwd(const TnPropNet* net, const float* origins, c
   uint32_t* zp;
   int zw;
   tn_grid_scatter_counters(net->grid, P, scratch, &zp, &zw);
-  hipLaunchKernelGGL(k_prop_bwd_mlp, dim3(grid), dim3(threads), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw);
+  if (saved_enc != nullptr)
+    hipLaunchKernelGGL(k_prop_bwd_mlp<true>, dim3(grid), dim3(threads), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw, saved_enc);
+  else
+    hipLaunchKernelGGL(k_prop_bwd_mlp<false>, dim3(grid), dim3(threads), 0, st, k, origins, directions, e_bins, d_density, N, S, ws_denc, zp, zw, saved_enc);
   TN_CHECK_LAUNCH("tn_prop_density_bwd");
   return tn_grid_scatter_launch(net->grid, origins, directions, e_bins, ws_denc, TN_LD_LEVEL_MAJOR, N, S, d_origins, d_directions, scratch, st, nullptr,
                                 zw > 0);

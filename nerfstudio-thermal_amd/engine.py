@@ -57,6 +57,7 @@ class Branch:
     expected_depth: Tensor
     prop_grad: bool
     fwd_buf: Optional[Tensor] = None  # the one buffer of tn_render_rays_train (fused training forward): what tn_render_rays_train_bwd reads
+    prop_enc_saved: bool = False      # ... and it holds the proposal levels' encodings (forward ran with save_prop_enc)
 
 
 def exp_decay_lr(step: int, lr_init: float, lr_final: float, max_steps: int) -> float:
@@ -161,12 +162,12 @@ class RenderEngine:
             # launches itself and every result is a view of one allocation -- the host side of a step is what bounds small batches and the
             # drop-in path
             r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag,
-                                      wait_event=wait_event, zero_fill=zero_fill)
+                                      wait_event=wait_event, zero_fill=zero_fill, save_prop_enc=bool(prop_grad))
             levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=lv["median"])
                       for S, lv in zip(self.counts, r["levels"])]
             return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
                           rgb_samples=r["rgb_samples"], comp=r["rgb"], accumulation=r["accumulation"], depth=r["depth"],
-                          expected_depth=r["expected_depth"], prop_grad=prop_grad, fwd_buf=r["buf"])
+                          expected_depth=r["expected_depth"], prop_grad=prop_grad, fwd_buf=r["buf"], prop_enc_saved=r["prop_enc_saved"])
         first = None
         if training and pose is not None:
             if _FUSE:  # pose correction and the level-0 bins are independent: one launch
@@ -419,7 +420,7 @@ class RenderEngine:
                 # by the library in the same order per stream
                 ops.render_rays_train_bwd(props, fld, br.fwd_buf, br.origins, br.directions, cam, self.counts, dc,
                                           [dws[0] if br.prop_grad else None, dws[1] if br.prop_grad else None, dws[2]], d_dens_extra[sfx], d_o, d_d,
-                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx))
+                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx), prop_enc_saved=br.prop_enc_saved)
                 br._d_o, br._d_d = d_o, d_d
                 continue
             if _FUSE:

@@ -185,7 +185,7 @@ class _RenderFn(torch.autograd.Function):
                                           (g_comp.contiguous() if g_comp is not None else z(br.comp)),
                                           [g_w[0][..., 0].contiguous() if pg else None, g_w[1][..., 0].contiguous() if pg else None, dw2],
                                           g_dens[..., 0].contiguous() if g_dens is not None else None, d_o, d_d,
-                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx))
+                                          tag="main", side_tags=("side0" + sfx, "side1" + sfx), prop_enc_saved=br.prop_enc_saved)
                 d_od[sfx] = (d_o, d_d)
                 continue
             d_rgb, d_dens = ops.render_bwd(lv[2].e_bins, lv[2].density, br.rgb_samples, lv[2].weights,

@@ -698,11 +698,13 @@ _TRAIN_LAYOUTS: dict = {}
 
 def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Optional[Tensor], frozen: Optional[Tensor], origins: Tensor,
                       directions: Tensor, cam: Tensor, nears: Tensor, fars: Tensor, counts: Sequence[int], anneal: float,
-                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main", wait_event=None, zero_fill: Optional[Tensor] = None):
+                      jitters: Optional[Sequence[Optional[Tensor]]] = None, tag: str = "main", wait_event=None, zero_fill: Optional[Tensor] = None,
+                      save_prop_enc: bool = False):
     """The training forward of one branch in ONE library call (tn_render_rays_train): pose correction, proposal sampling with jitter, field
     (activations kept in the field's workspace `tag`), weights, renderers.  Every result is a view of one allocation.
     wait_event: a torch.cuda.Event the stream waits for right before the field's first parameter read (the previous step's Adam, see engine).
     zero_fill: a float tensor (whole multiples of 4 elements, 16-byte aligned) the call clears inside the field's first launch.
+    save_prop_enc: the proposal networks take a gradient this iteration: their encodings are kept in the buffer for render_rays_train_bwd.
     -> dict(origins, directions [N,3]; levels: 3 x dict(s_bins, e_bins, density, weights, median); rgb_samples [N,S2,C]; rgb [N,C];
     accumulation, depth, expected_depth [N,1])."""
     N = origins.shape[0]
@@ -716,7 +718,7 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
         arr = (C.c_int64 * _lib.TN_RENDER_TRAIN_OFFSETS)()
         check(lib.tn_render_rays_train_layout(N, S0, S1, S2, Cc, arr, _lib.TN_RENDER_TRAIN_OFFSETS), "tn_render_rays_train_layout")
         off = _TRAIN_LAYOUTS[key] = [int(v) for v in arr]
-    buf = torch.empty(off[22], device=dev)
+    buf = torch.empty(off[_lib.TN_RENDER_TRAIN_OFFSETS - 1], device=dev)
     ws = fld.workspace(N * S2, True, tag)
     jit = list(jitters) if jitters is not None else [None, None, None]
     Cn = pose.shape[0] if pose is not None else 0
@@ -728,7 +730,8 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
                                    _f32(_lin_table("spaced", S0, dev), "lin"), _f32(_lin_table("pdf", S1, dev), "u1"), _f32(_lin_table("pdf", S2, dev), "u2"),
                                    C.c_void_p(ws.data_ptr()), _nbytes(ws), C.c_void_p(buf.data_ptr()),
                                    C.c_void_p(wait_event.cuda_event) if wait_event is not None else None,
-                                   C.c_void_p(zero_fill.data_ptr()) if zero_fill is not None else None, _nbytes(zero_fill), _stream()), "tn_render_rays_train")
+                                   C.c_void_p(zero_fill.data_ptr()) if zero_fill is not None else None, _nbytes(zero_fill), 1 if save_prop_enc else 0,
+                                   _stream()), "tn_render_rays_train")
 
     so = buf.storage_offset()
 
@@ -740,7 +743,7 @@ def render_rays_train(props: Sequence[PropNetParams], fld: FieldParams, pose: Op
         b = 2 + 5 * i
         levels.append({"s_bins": v(b, N, S + 1), "e_bins": v(b + 1, N, S + 1), "density": v(b + 2, N, S), "weights": v(b + 3, N, S), "median": v(b + 4, N, 1)})
     levels.append({"s_bins": v(12, N, S2 + 1), "e_bins": v(13, N, S2 + 1), "density": v(14, N, S2), "weights": v(15, N, S2), "median": v(19, N, 1)})
-    return {"buf": buf, "origins": v(0, N, 3) if pose is not None else origins, "directions": v(1, N, 3) if pose is not None else directions, "levels": levels,
+    return {"buf": buf, "prop_enc_saved": bool(save_prop_enc), "origins": v(0, N, 3) if pose is not None else origins, "directions": v(1, N, 3) if pose is not None else directions, "levels": levels,
             "rgb_samples": v(16, N, S2, Cc), "rgb": v(17, N, Cc), "accumulation": v(18, N, 1), "depth": v(19, N, 1), "expected_depth": v(20, N, 1)}
 
 
@@ -828,7 +831,7 @@ class TrainStepCall:
         st.nears, st.fars = _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N)
         st.anneal, st.prop_grad = float(anneal), 1 if prop_grad else 0
         st.jitter0, st.jitter1, st.jitter2 = (_ray_scalar(j, "jitter", N) for j in jitters)
-        buf = torch.empty(self.off[22], device=dev)
+        buf = torch.empty(self.off[_lib.TN_RENDER_TRAIN_OFFSETS - 1], device=dev)
         st.fwd_out = C.c_void_p(buf.data_ptr())
         st.acc, st.acc_bytes = C.c_void_p(acc_flat.data_ptr()), _nbytes(acc_flat)
         st.losses16, st.loss_lines = _f32(acc["L"], "losses16", (16,)), _f32(acc["Lp"], "loss_lines", (LOSS_LINES, 16))
@@ -863,7 +866,8 @@ _BWD_TMP: dict = {}
 
 def render_rays_train_bwd(props: Sequence[PropNetParams], fld: FieldParams, fwd_buf: Tensor, origins: Tensor, directions: Tensor, cam: Tensor,
                           counts: Sequence[int], d_comp: Tensor, d_weights: Sequence[Optional[Tensor]], d_density_extra: Optional[Tensor],
-                          d_origins: Optional[Tensor], d_directions: Optional[Tensor], tag: str = "main", side_tags=("side0", "side1")) -> None:
+                          d_origins: Optional[Tensor], d_directions: Optional[Tensor], tag: str = "main", side_tags=("side0", "side1"),
+                          prop_enc_saved: bool = False) -> None:
     """The training backward of one branch in ONE library call (tn_render_rays_train_bwd): renderer backward, field backward (+ d position, table
     scatter) and -- when d_weights[0] / d_weights[1] are given -- both proposal networks' backward on the library's companion streams.
     fwd_buf: the buffer ops.render_rays_train returned ("buf"); origins / directions: its pose-corrected rays; d_weights = [level0, level1, fine]."""
@@ -891,7 +895,7 @@ def render_rays_train_bwd(props: Sequence[PropNetParams], fld: FieldParams, fwd_
                                        C.c_void_p(ws.data_ptr()), _nbytes(ws), C.c_void_p(w0.data_ptr()) if prop_grad else None, _nbytes(w0) if prop_grad else 0,
                                        C.c_void_p(w1.data_ptr()) if prop_grad else None, _nbytes(w1) if prop_grad else 0,
                                        C.c_void_p(tmp.data_ptr()), _f32(d_origins, "d_origins", (N, 3), True), _f32(d_directions, "d_directions", (N, 3), True),
-                                       _stream()), "tn_render_rays_train_bwd")
+                                       1 if (prop_enc_saved and prop_grad) else 0, _stream()), "tn_render_rays_train_bwd")
 
 
 _RENDER_SCRATCH: dict = {}
