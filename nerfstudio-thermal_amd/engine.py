@@ -162,7 +162,8 @@ class RenderEngine:
             # launches itself and every result is a view of one allocation -- the host side of a step is what bounds small batches and the
             # drop-in path
             r = ops.render_rays_train(props, fld, pose, frozen, origins, directions, cam, nears, fars, self.counts, anneal, jitters, tag=tag,
-                                      wait_event=wait_event, zero_fill=zero_fill, save_prop_enc=bool(prop_grad))
+                                      wait_event=wait_event, zero_fill=zero_fill,
+                                      save_prop_enc=bool(prop_grad) and self.__dict__.get("_bwd_reads_prop_enc", True))
             levels = [Level(S=S, s_bins=lv["s_bins"], e_bins=lv["e_bins"], density=lv["density"], weights=lv["weights"], median=lv["median"])
                       for S, lv in zip(self.counts, r["levels"])]
             return Branch(origins=r["origins"], directions=r["directions"], origins_in=o_in, directions_in=d_in, levels=levels,
@@ -846,7 +847,13 @@ class RenderEngine:
             losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler)
             self.step_cb(step)
             return losses
-        out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal, prealloc_accumulators=True)
+        # (the overlapped data-parallel schedule runs the proposal networks' backward through the per-network entry points, which gather again:
+        # the forward then need not keep their encodings)
+        self._bwd_reads_prop_enc = not (grad_hook is not None and getattr(grad_hook, "pipelined", False) and not self.separate) and _ONE_CALL_BWD
+        try:
+            out, branches = self.get_outputs(origins, directions, cam, True, jitters, jitters_thermal, prealloc_accumulators=True)
+        finally:
+            self._bwd_reads_prop_enc = True
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
             # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)
             grad_hook.begin(self.arena)
