@@ -115,7 +115,8 @@ int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, con
               float* pixel_area, float* directions_norm, tn_stream_t stream);
 /* N2 + a1 in ONE launch (VanillaDataManager.next_train, data/datamanagers/base_datamanager.py:538-547: pixel sampler -> ground truth ->
  * RayGenerator): arguments of tn_sample_pixels followed by those of tn_raygen without ray_indices (the sampled pixel is handed over in
- * registers; ray_indices is still written).  Same results as the two calls. */
+ * registers; ray_indices is still written).  Same results as the two calls. 
+ * pixel_area may be NULL (a trainer whose model does not read it: the two extra undistortions per ray that only serve it are skipped). */
 int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                    const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
                    int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,

@@ -226,8 +226,10 @@ __device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64
   const float* R = g.c2w + cam * 12;
   float dir[3][3];
   float nrm0 = 0.0f;
+  const int nq = g.pixel_area ? 3 : 1;  // (the +1-pixel neighbours only serve pixel_area: two of the three Newton undistortions, the kernel's serial chain)
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
+    if (q >= nq) break;
     float a = u[q], b = v[q];
     if (g.any_distortion) undistort(a, b, g.distortion + cam * 6, a, b);
     b = -b;  // OpenCV -> OpenGL
@@ -241,15 +243,17 @@ __device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64
     dir[q][0] = w0 / n; dir[q][1] = w1 / n; dir[q][2] = w2 / n;
     if (q == 0) nrm0 = n;
   }
-  float ddx = 0.0f, ddy = 0.0f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float a = dir[0][c] - dir[1][c], b = dir[0][c] - dir[2][c];
-    ddx += a * a; ddy += b * b;
-  }
   g.origins[i * 3 + 0] = R[3]; g.origins[i * 3 + 1] = R[7]; g.origins[i * 3 + 2] = R[11];
   g.directions[i * 3 + 0] = dir[0][0]; g.directions[i * 3 + 1] = dir[0][1]; g.directions[i * 3 + 2] = dir[0][2];
-  g.pixel_area[i] = sqrtf(ddx) * sqrtf(ddy);
+  if (g.pixel_area) {
+    float ddx = 0.0f, ddy = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = dir[0][c] - dir[1][c], b = dir[0][c] - dir[2][c];
+      ddx += a * a; ddy += b * b;
+    }
+    g.pixel_area[i] = sqrtf(ddx) * sqrtf(ddy);
+  }
   if (g.directions_norm) g.directions_norm[i] = nrm0;
 }
 __global__ void k_raygen(const int64_t* __restrict__ ray_indices, RaygenArgs g, int64_t N) {
@@ -288,7 +292,7 @@ extern "C" int tn_sample_rays(const float* images, const int64_t* image_offsets,
   int rc = sample_pixels_args("tn_sample_rays", images, image_offsets, heights, widths, is_thermal, image_idx, num_images, u, num_rays, patch_size,
                               ray_indices, image, is_thermal_out, camera_indices, a);
   if (rc) return rc;
-  TN_REQUIRE(c2w && fx && fy && cx && cy && origins && directions && pixel_area && num_cameras >= 1, "tn_sample_rays: bad camera arguments");
+  TN_REQUIRE(c2w && fx && fy && cx && cy && origins && directions && num_cameras >= 1, "tn_sample_rays: bad camera arguments");  // (pixel_area may be NULL)
   RaygenArgs g{c2w, fx, fy, cx, cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, origins, directions, pixel_area, directions_norm};
   hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), a, g);
   TN_CHECK_LAUNCH("tn_sample_rays");

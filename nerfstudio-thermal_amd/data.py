@@ -26,7 +26,8 @@ class DeviceDataManager:
     def _make(self) -> Tuple[Tensor, ...]:
         n = self.num_rays
         u = self._rand.take((n // (self.patch * self.patch), 3))  # what PatchPixelSampler draws with torch.rand (drawn 32 steps at a time)
-        o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch)  # pixel sampler + GT gather + raygen: one launch
+        # pixel sampler + GT gather + raygen: one launch (the bundle's pixel_area is not part of what next_train hands on: not computed)
+        o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch, want_pixel_area=False)
         return o, d, cam, img, is_th
 
     def _launch_prefetch(self) -> None:

@@ -280,9 +280,10 @@ def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int =
     return (idx, img, is_th, cam) if want_camera_indices else (idx, img, is_th)
 
 
-def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2):
+def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2, want_pixel_area: bool = True):
     """sample_pixels + raygen in one launch (tn_sample_rays) -> origins [N,3], directions [N,3], camera_indices [N] int64, image [N,3],
-    is_thermal [N], ray_indices [N,3].  cameras: c2w [C,3,4], fx, fy, cx, cy [C], optional distortion [C,6]."""
+    is_thermal [N], ray_indices [N,3].  cameras: c2w [C,3,4], fx, fy, cx, cy [C], optional distortion [C,6].
+    want_pixel_area=False: the bundle's pixel_area (which thermal-nerfacto never reads) is not computed -- two of the three undistortions per ray."""
     n_img = cache.offsets.shape[0]
     dev = cache.buffer.device
     if u.device != dev or u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (num_rays // (patch_size * patch_size), 3):
@@ -298,7 +299,8 @@ def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patc
                                      n_img, p(u), num_rays, patch_size, p(idx), p(img), p(is_th), p(cam),
                                      _f32(c2w, "c2w", (Cn, 3, 4)), _f32(cameras["fx"], "fx", (Cn,)), _f32(cameras["fy"], "fy", (Cn,)),
                                      _f32(cameras["cx"], "cx", (Cn,)), _f32(cameras["cy"], "cy", (Cn,)),
-                                     _f32(cameras.get("distortion"), "distortion", (Cn, 6), optional=True), Cn, p(o), p(d), p(area), p(nrm), _stream()),
+                                     _f32(cameras.get("distortion"), "distortion", (Cn, 6), optional=True), Cn, p(o), p(d), p(area) if want_pixel_area else None,
+                                     p(nrm), _stream()),
           "tn_sample_rays")
     return o, d, cam, img, is_th, idx
 
