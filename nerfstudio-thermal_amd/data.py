@@ -26,8 +26,9 @@ class DeviceDataManager:
     def _make(self) -> Tuple[Tensor, ...]:
         n = self.num_rays
         u = self._rand.take((n // (self.patch * self.patch), 3))  # what PatchPixelSampler draws with torch.rand (drawn 32 steps at a time)
-        # pixel sampler + GT gather + raygen: one launch (the bundle's pixel_area is not part of what next_train hands on: not computed)
-        o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch, want_pixel_area=False)
+        # pixel sampler + GT gather + raygen: one launch.  (pixel_area is computed as the reference's RayGenerator computes it every iteration,
+        # although thermal-nerfacto never reads it; ops.sample_rays(want_pixel_area=False) would skip two of the three undistortions per ray.)
+        o, d, cam, img, is_th, _ = ops.sample_rays(self.cache, n, u, self.cam, self.patch)
         return o, d, cam, img, is_th
 
     def _launch_prefetch(self) -> None:
