@@ -202,8 +202,9 @@ int tn_field_fwd(const TnField* field, const float* origins, const float* direct
                  float* density_pre, tn_stream_t stream);
 /* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated).
  * d_rgb = NULL: density-only backward of tn_field_density_fwd(training != 0) (see there).
- * The appearance embedding's gradient is formed from per-camera sums kept in the workspace (hw0[:, 31:63]^T times head layer 0's bias
- * gradient restricted to the camera): num_images <= TN_FIELD_MAX_IMAGES, refused with TN_EINVAL beyond.  The forward (training != 0) clears
+ * The appearance embedding's gradients (the embedding rows and the embedding columns of the head's first weight matrix) are formed from
+ * per-camera sums kept in the workspace (head layer 0's bias gradient restricted to the camera; the training forward likewise adds a
+ * per-camera vector instead of multiplying the embedding per sample): num_images <= TN_FIELD_MAX_IMAGES, refused with TN_EINVAL beyond.  The forward (training != 0) clears
  * those sums and the backward leaves them cleared: the workspace may come from an uninitialised allocation. */
 #define TN_FIELD_MAX_IMAGES 4096
 int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
@@ -212,8 +213,9 @@ int tn_field_bwd(const TnField* field, const float* origins, const float* direct
 /* The same backward in phases, for data-parallel training: the table gradient of a level range is final as soon as its scatter has run,
  * so the caller can start that range's all-reduce (DDP's bucketed reducer, pipelines/base_pipeline.py:281-283) while the next range is
  * scattered.  phases is a bit set; tn_field_bwd == all three with levels [0, num_levels):
- *   TN_BWD_MLP      MLP backward + weight/bias/embedding gradients (two launches: the fused chain, then one small block per camera for the
- *                   embedding rows) and, when d_origins is given, d position from the forward's saved
+ *   TN_BWD_MLP      MLP backward + weight/bias/embedding gradients (the fused chain; the embedding's two gradients are finished from its
+ *                   per-camera sums at the head of the d-position launch, or in a small launch of their own without one) and, when
+ *                   d_origins is given, d position from the forward's saved
  *                   d enc / d offset (k_field_dpos); with TN_BWD_FORK_DPOS that second launch goes to a library-owned companion stream
  *                   beside the scatter -- worth it only when other streams are busy anyway (a second active queue costs more than it hides)
  *   TN_BWD_SCATTER  table gradient of levels [level_begin, level_end); needs TN_BWD_MLP done
