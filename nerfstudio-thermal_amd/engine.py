@@ -248,6 +248,9 @@ class RenderEngine:
             if (self.pose_thermal if sfx else self.pose) is not None:
                 zkeys.append(("d_o", sfx)); zshapes.append((N, 3))
                 zkeys.append(("d_d", sfx)); zshapes.append((N, 3))
+        if self.separate and self.cfg.density_loss_mult > 0:  # the density loss's four gradient buffers (tn_l1_loss accumulates into them)
+            for k in ("g_d2", "g_dt", "g_d", "g_d2t"):
+                zkeys.append((k, "")); zshapes.append((N, self.counts[2]))
         return zkeys, zshapes
 
     @staticmethod
@@ -397,8 +400,7 @@ class RenderEngine:
             a, bb = c.density_loss_mult, c.rgb_density_loss_mult * c.density_loss_mult
             d2, d2t = out["density2"].squeeze(-1), out["density2_thermal"].squeeze(-1)
             dens, dens_t = b.levels[-1].density, bt.levels[-1].density
-            g_d2, g_dt = torch.zeros_like(d2), torch.zeros_like(dens_t)
-            g_d, g_d2t = torch.zeros_like(dens), torch.zeros_like(d2t)
+            g_d2, g_dt, g_d, g_d2t = Z[("g_d2", "")], Z[("g_dt", "")], Z[("g_d", "")], Z[("g_d2t", "")]  # (zero, from the step's one allocation)
             # a*|d2.detach - dens_t| + b*|d2 - dens_t.detach|  and  a*|dens.detach - d2t| + b*|dens - d2t.detach|   (:336-344)
             ops.l1_loss(d2, dens_t, bb, a, L[10:11], g_d2, g_dt)
             ops.l1_loss(dens, d2t, bb, a, L[10:11], g_d, g_d2t)
