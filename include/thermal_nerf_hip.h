@@ -305,8 +305,8 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
  * Everything later stages need goes into ONE buffer `out` (256-byte aligned); tn_render_rays_train_layout fills offsets[] (floats) with the
  * position of: 0 origins 1 directions (pose-corrected; unused when pose_adjustment is NULL) | 2 s_bins0 3 e_bins0 4 density0 5 weights0
  * 6 median0 | 7..11 the same for level 1 | 12 s_bins2 13 e_bins2 14 density2 15 weights2 | 16 rgb_samples [N,S2,C] 17 comp [N,C]
- * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22, 23 the proposal levels' encodings [N*S0][10], [N*S1][10] (written
- * only with save_prop_enc) | 24 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
+ * 18 accumulation 19 depth_median 20 depth_expected [N] | 21 scratch | 22, 23 the proposal levels' encodings, N*S0*10 and N*S1*10 floats
+ * (level-major [5][N*S_k] float2; written only with save_prop_enc) | 24 = total floats; num_offsets >= TN_RENDER_TRAIN_OFFSETS.
  * save_prop_enc != 0: the proposal networks take a gradient this iteration (ray_samplers.py:591): their encodings are kept in `out`, and
  * tn_render_rays_train_bwd(prop_enc_saved != 0) reads them back instead of repeating the 40 table reads per sample -- the same values.
  * wait_event_before_field: NULL, or a hipEvent_t that `stream` waits for right before the field's first read of its parameters -- a trainer

@@ -30,7 +30,7 @@ __device__ __forceinline__ void prop_stage_weights(const PropK& net, float* s_w)
 }
 
 // SAVE_ENC (training iterations in which the proposal networks take a gradient): the 10 encoding features of every sample are kept
-// ([P][10] floats, 40 B per lane: whole cache lines per wave) so that k_prop_bwd_mlp does not repeat the 40 gathers per sample.
+// (level-major [5][P] float2) so that k_prop_bwd_mlp does not repeat the 40 gathers per sample.
 template <bool SAVE_ENC>
 __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
                                                      const float* __restrict__ e_bins, int64_t N, int S, float* __restrict__ density,
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
       float2 v = tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
       enc[2 * l] = v.x;
       enc[2 * l + 1] = v.y;
-      if (SAVE_ENC) *reinterpret_cast<float2*>(enc_out + i * PF + 2 * l) = v;
+      if (SAVE_ENC) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;  // level-major [PL][P] float2: 512 contiguous bytes per wave and level
     }
     float out = s_w[PH * PROP_WROW];
 #pragma unroll 4
@@ -79,7 +79,7 @@ extern "C" int tn_prop_density_fwd(const TnPropNet* net, const float* origins, c
                                    int32_t S, float* density, tn_stream_t stream) {
   return tn_prop_density_fwd_ex(net, origins, directions, e_bins, N, S, density, nullptr, stream);
 }
-// enc_out: NULL, or [N*S][10] floats that receive the samples' encodings (for tn_prop_density_bwd_ex; csrc/tn_pipeline.hip)
+// enc_out: NULL, or N*S*10 floats (level-major [5][N*S] float2) that receive the samples' encodings (for tn_prop_density_bwd_ex; csrc/tn_pipeline.hip)
 int tn_prop_density_fwd_ex(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                            float* density, float* enc_out, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
@@ -145,7 +145,7 @@ __device__ __forceinline__ float prop_row_sum(float x) {  // sum over the 16 lan
 // One block of 16 waves per CU (4 per SIMD): the kernel ends with one atomic per weight and block, and atomics on one 64-B line execute one after
 // the other (~25 ns each).  With 1024 blocks of 4 waves that burst was 57 of the kernel's 105 us.
 #define PB_THREADS 1024
-// HAVE_ENC: the forward of this iteration kept the samples' encodings (k_prop_fwd<true>): they are read back (40 B per lane) instead of
+// HAVE_ENC: the forward of this iteration kept the samples' encodings (k_prop_fwd<true>): they are read back (five coalesced float2 per lane) instead of
 // gathered again (40 table reads per sample: ~2/5 of this kernel) -- the same values, bit for bit.
 template <bool HAVE_ENC>
 __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const float* __restrict__ origins, const float* __restrict__ directions,
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
       float enc[PF];
 #pragma unroll
       for (int l = 0; l < PL; ++l) {
-        const float2 v = HAVE_ENC ? *reinterpret_cast<const float2*>(saved_enc + ic * PF + 2 * l)
+        const float2 v = HAVE_ENC ? *reinterpret_cast<const float2*>(saved_enc + ((int64_t)l * P + ic) * 2)
                                   : tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
         enc[2 * l] = v.x;
         enc[2 * l + 1] = v.y;
