@@ -220,10 +220,12 @@ def kernel_roofline(eng, cam_t, idx):
     for name, net, L in grids:
         # level-major [L][P] float2, as the backward kernels of all three grids hand their d enc over
         g_enc = (torch.randn((N * L.S, net.num_levels, 2), device=o.device) * 1e-3).permute(1, 0, 2).contiguous()
-        # as the step calls it: the proposal grids' scatter also yields d position; the main field's does not (k_field_dpos does, beside it)
+        # as the step calls it: the proposal grids' scatter also yields d position; the main field's does not (k_field_dpos does, beside it);
+        # shared mode: the step's optimiser launch leaves the gradients zero and every table sees one scatter per iteration, so the fold stores
+        # instead of adding (TnGrid.table_grad_is_zero) -- timed that way here
         dpos = (d_o, d_d) if net.num_levels == 5 else (None, None)
         ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
-                                              L.e_bins, g_enc, *dpos))
+                                              L.e_bins, g_enc, *dpos, grad_is_zero=not eng.separate))
         rows.append((f"scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
     eng.arena.zero_grad()
     return rows

@@ -34,6 +34,7 @@ class TnGrid(C.Structure):
         ("log2_hashmap_size", _i32),
         ("res", _f * TN_MAX_LEVELS),
         ("nonfinite_flag", _p),
+        ("table_grad_is_zero", _i32),
     ]
 
 

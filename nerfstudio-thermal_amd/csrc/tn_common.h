@@ -50,6 +50,7 @@ struct GridK {
   uint32_t tsize;   // 2^log2T
   float res[TN_MAX_LEVELS];
   float* nonfinite;  // TnGrid::nonfinite_flag
+  int grad_zero;     // TnGrid::table_grad_is_zero
 };
 static inline GridK make_gridk(const TnGrid& g) {
   GridK k;
@@ -60,6 +61,7 @@ static inline GridK make_gridk(const TnGrid& g) {
   k.mask = k.tsize - 1u;
   for (int i = 0; i < TN_MAX_LEVELS; ++i) k.res[i] = g.res[i];
   k.nonfinite = g.nonfinite_flag;
+  k.grad_zero = g.table_grad_is_zero;
   return k;
 }
 

@@ -589,7 +589,11 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
   // (4 chunks per bucket), which then ran twice as long as the other six.
   const uint32_t ch = (blk - bk.blk0[l]) / bk.nslices, sl = (blk - bk.blk0[l]) % bk.nslices;
   (void)chunks_per_bucket;
-  const uint32_t count = min(bk.count[(size_t)(l * bk.nslices + sl) * bk.cstride], bk.cap);
+  const uint32_t raw_count = bk.count[(size_t)(l * bk.nslices + sl) * bk.cstride];
+  const uint32_t count = min(raw_count, bk.cap);
+  // table_grad_is_zero holds for this bucket's slots only if nothing has been added to them since the promise was given: a bucket that overflowed
+  // sent its surplus records straight into table_grad (bin pass, float atomics) -- those slots must be added to, not stored
+  const bool store = g.grad_zero && raw_count <= bk.cap;
   const uint32_t begin = ch * chunk;
   if (begin >= count) return;  // whole block leaves together
   if (bk.trace && threadIdx.x == 0) bk.trace[16 * blk] = wall_clock64();
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
       if (t < slots) {
         v[u] = make_float2((float)ax[t], (float)ay[t]);
         nz[u] = v[u].x != 0.0f || v[u].y != 0.0f;  // untouched slots keep an exactly-zero gradient
-        if (nz[u] && !split) cv[u] = dst[t];
+        if (nz[u] && !split) cv[u] = store ? make_float2(0.f, 0.f) : dst[t];  // (the caller vouches for zeros: nothing to read back)
       }
     }
 #pragma unroll

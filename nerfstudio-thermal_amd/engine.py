@@ -340,9 +340,10 @@ class RenderEngine:
 
     # ---------------------------------------------------------------- losses + backward (no autograd tape)
     def loss_and_backward(self, out: Dict[str, object], branches: Dict[str, Branch], cam: Tensor, image: Tensor, is_thermal: Tensor,
-                          dp=None) -> Dict[str, Tensor]:
+                          dp=None, _grads_are_zero: bool = False) -> Dict[str, Tensor]:
         """get_metrics_dict['distortion'] + get_loss_dict (models/thermal_nerfacto.py:253-388) and the gradient of their sum with respect to
-        every parameter, accumulated into the arena's gradient buffer."""
+        every parameter, accumulated into the arena's gradient buffer.  (_grads_are_zero: train_step's promise, see _set_grad_zero.)"""
+        self._set_grad_zero(_grads_are_zero)
         c = self.cfg
         N = image.shape[0]
         dev = self.device
@@ -638,6 +639,20 @@ class RenderEngine:
                 if o is not None:
                     o.__dict__["nonfinite_flag"] = flag(g)
 
+    def _set_grad_zero(self, flag: bool) -> None:
+        """TnGrid.table_grad_is_zero on every grid of the model: the promise that a table's gradient holds zeros when its scatter starts and is
+        scattered into once (the fold then stores instead of adding).  Only train_step can give it -- it owns the whole iteration: the arena's
+        gradients are zero when its backward starts, and in shared mode every table sees one scatter.  Everything else (loss_and_backward called
+        directly, the autograd nodes of the drop-in path: several backward passes may share one arena) withdraws it."""
+        flag = bool(flag) and not self.separate
+        if self.__dict__.get("_grad_zero_flag", False) == flag:
+            return
+        self._grad_zero_flag = flag
+        for o in list(self.props) + [self.field] + (list(self.props_thermal) if self.separate else []) + (
+                [self.field_thermal] if self.field_thermal is not None else []):
+            if o is not None:
+                o.__dict__["grad_is_zero"] = flag
+
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,
                        grad_scaler=None, skipped_have_no_grads: bool = False) -> None:
@@ -818,6 +833,7 @@ class RenderEngine:
             lo, hi = a.group_range[g]
             ranges.append((lo, hi, self.group_steps[g], lr0, lr_final, max_steps, gidx[g]))
         a.grads_clean = False
+        self._set_grad_zero(True)  # (train_step made sure the arena's gradients are zero; shared mode: one scatter per table)
         call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count - 1)
         a.grads_clean = True  # the Adam launch consumed the gradients of every group that received any
         self.last_updated = bool(updated)
@@ -859,7 +875,7 @@ class RenderEngine:
         if grad_hook is not None and getattr(grad_hook, "pipelined", False):
             # data-parallel gradient all-reduce overlapped with the backward pass (parallel.OverlappedGradReducer)
             grad_hook.begin(self.arena)
-            losses = self.loss_and_backward(out, branches, cam, image, is_thermal, dp=grad_hook)
+            losses = self.loss_and_backward(out, branches, cam, image, is_thermal, dp=grad_hook, _grads_are_zero=True)
             # proposal networks that got no gradient this step are not stepped either: nothing to exchange for them
             skip = () if branches[""].prop_grad else ("proposal_networks",)
             idle = [self.arena.group_range[g] for g in skip]
@@ -875,7 +891,7 @@ class RenderEngine:
                 grad_hook.finish(skip=idle)
                 self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)
         else:
-            losses = self.loss_and_backward(out, branches, cam, image, is_thermal)
+            losses = self.loss_and_backward(out, branches, cam, image, is_thermal, _grads_are_zero=True)
             if grad_hook is not None:
                 grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
             skip = () if branches[""].prop_grad else ("proposal_networks",)

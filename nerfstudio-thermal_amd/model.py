@@ -141,6 +141,7 @@ class _RenderFn(torch.autograd.Function):
         branches, cam = ctx.branches, ctx.cam
         arena = eng.arena
         arena.grads_clean = False  # this node (and autograd, through the aliased .grad views) writes into the arena's gradient buffer
+        eng._set_grad_zero(False)  # (several backward passes may add into one arena: the scatters must add, not store)
         dev = eng.device
         it = iter(grads)
         N = cam.shape[0]

@@ -74,10 +74,12 @@ def _i64(t: Tensor, name: str, shape: Tuple[int, ...]):
 
 
 def _grid_struct(table: Tensor, grad: Optional[Tensor], num_levels: int, log2_hashmap_size: int, res: Sequence[float],
-                 nonfinite_flag: Optional[Tensor] = None) -> TnGrid:
-    """nonfinite_flag: 1-element float device tensor the table-gradient scatter raises on an inf / NaN entry (TnGrid.nonfinite_flag), or None."""
+                 nonfinite_flag: Optional[Tensor] = None, grad_is_zero: bool = False) -> TnGrid:
+    """nonfinite_flag: 1-element float device tensor the table-gradient scatter raises on an inf / NaN entry (TnGrid.nonfinite_flag), or None.
+    grad_is_zero: the caller's promise that `grad` holds zeros when a scatter starts (TnGrid.table_grad_is_zero: the fold stores instead of adding)."""
     T = 2**log2_hashmap_size
     g = TnGrid()
+    g.table_grad_is_zero = 1 if (grad_is_zero and grad is not None) else 0
     g.nonfinite_flag = _f32(nonfinite_flag, "nonfinite_flag", (1,), optional=True) if (nonfinite_flag is not None and grad is not None) else None
     g.table = _f32(table, "hash_table", (num_levels * T, 2))
     g.table_grad = _f32(grad, "hash_table.grad", (num_levels * T, 2), optional=True)
@@ -117,7 +119,8 @@ class PropNetParams:
         # (key: the table's addresses stand for all of them -- every tensor is a view of the same arena; assigning a field drops the cached
         # struct, see __setattr__ -- 25 data_ptr() calls per struct and step were ~10 us each on the path to the two library calls)
         gt = g.get("table")
-        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0)
+        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0,
+               bool(self.__dict__.get("grad_is_zero", False)))
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -127,7 +130,8 @@ class PropNetParams:
 
     def _build_cstruct(self, g) -> TnPropNet:
         s = TnPropNet()
-        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"))
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"),
+                              bool(self.__dict__.get("grad_is_zero", False)))
         H, F = 16, self.num_levels * 2
         s.w0, s.b0 = _f32(self.w0, "w0", (H, F)), _f32(self.b0, "b0", (H,))
         s.w1, s.b1 = _f32(self.w1, "w1", (1, H)), _f32(self.b1, "b1", (1,))
@@ -179,7 +183,8 @@ class FieldParams:
             raise ValueError("gradient buffers required")
         nf = self.__dict__.get("nonfinite_flag")
         gt = g.get("table")  # (as PropNetParams.cstruct: the table's addresses stand for the arena's; __setattr__ drops the cache)
-        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0)
+        key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0,
+               bool(self.__dict__.get("grad_is_zero", False)))
         hit = self.__dict__.get("_cs")
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -189,7 +194,8 @@ class FieldParams:
 
     def _build_cstruct(self, g) -> TnField:
         s = TnField()
-        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"))
+        s.grid = _grid_struct(self.table, g.get("table"), self.num_levels, self.log2_hashmap_size, self.res, self.__dict__.get("nonfinite_flag"),
+                              bool(self.__dict__.get("grad_is_zero", False)))
         for k, shp in self.shapes().items():
             setattr(s, k, _f32(getattr(self, k), k, shp))
             setattr(s, "g" + k, _f32(g.get(k), "g" + k, shp, optional=True))
@@ -595,9 +601,11 @@ _SCATTER_WS: dict = {}
 
 
 def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashmap_size: int, res, origins: Tensor, directions: Tensor, e_bins: Tensor,
-                 g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, use_workspace: bool = True) -> None:
+                 g_enc: Tensor, d_origins: Optional[Tensor] = None, d_directions: Optional[Tensor] = None, use_workspace: bool = True,
+                 grad_is_zero: bool = False) -> None:
     """Backward of the hash encoding wrt the table (+ positions): trilinear scatter-add of g_enc [N*S, ld] -- or, level-major, [num_levels, N*S, 2]
-    -- into table_grad.  use_workspace=False adds every level straight into the hashed gradient (no dense replicas for the coarse levels)."""
+    -- into table_grad.  use_workspace=False adds every level straight into the hashed gradient (no dense replicas for the coarse levels).
+    grad_is_zero: the promise of TnGrid.table_grad_is_zero (table_grad holds zeros now: the fold stores instead of adding)."""
     N, S = e_bins.shape[0], e_bins.shape[1] - 1
     level_major = g_enc.dim() == 3
     if level_major and tuple(g_enc.shape) != (num_levels, N * S, 2):
@@ -610,7 +618,7 @@ def hash_scatter(table: Tensor, table_grad: Tensor, num_levels: int, log2_hashma
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=origins.device)
             _SCATTER_WS[str(origins.device)] = ws
-    g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res)
+    g = _grid_struct(table, table_grad, num_levels, log2_hashmap_size, res, grad_is_zero=grad_is_zero)
     check(_lib.load().tn_hash_scatter(C.byref(g), _f32(origins, "origins", (N, 3)), _f32(directions, "directions", (N, 3)), _f32(e_bins, "e_bins", (N, S + 1)),
                                       _f32(g_enc, "g_enc", None if level_major else (N * S, ld)), ld, N, S, _f32(d_origins, "d_origins", (N, 3), True),
                                       _f32(d_directions, "d_directions", (N, 3), True), C.c_void_p(ws.data_ptr()) if ws is not None else None, _nbytes(ws),

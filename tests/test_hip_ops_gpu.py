@@ -991,3 +991,25 @@ def test_field_fwd_bwd_many_cameras():
             assert md(got, ref) <= 3e-4 * scale, (rep, short, md(got, ref), scale)
     gemb = arena.grad_view(k["emb"])
     assert float(gemb[I - 40:].abs().max()) == 0.0  # cameras without a ray keep an exactly-zero embedding gradient
+
+
+def test_hash_scatter_store_variant_equals_the_adding_one():
+    """TnGrid.table_grad_is_zero: with the promise kept (zeros in table_grad) the storing fold gives what the adding one gives -- same non-zero
+    pattern, same values up to the order of the fold's double-precision atomics -- at the production shape of the main grid."""
+    L, log2T = 16, 19
+    N, S = 4096, 48
+    res = ops.level_resolutions(L, 16, 2048)
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    table = torch.from_numpy(synth.uniform("hst", (L * 2**log2T, 2), seed=SEED)).to(DEV)
+    g_enc = g(torch.from_numpy(synth.uniform("hsg", (L, N * S, 2), seed=SEED)) * 1e-3)
+    out = []
+    for zero in (False, True):
+        tg = torch.zeros((L * 2**log2T, 2), device=DEV)
+        ops.hash_scatter(table, tg, L, log2T, res, g(r["origins"]), g(r["directions"]), g(e), g_enc, None, None, grad_is_zero=zero)
+        out.append(tg)
+    a, b = out
+    assert torch.equal(a == 0, b == 0)
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 1e-5 * scale  # (float atomics of the overflow / replica paths, order of the fold's double atomics)
