@@ -29,8 +29,9 @@ for net, L in ((eng.props[0], lv[0]), (eng.props[1], lv[1]), (eng.field, lv[2]))
     # the proposal grids' scatter computes d position itself; the main field's does not (k_field_dpos does, from the saved d enc / d offset)
     with_dpos = net.num_levels == 5
     for _ in range(R):
+        # (as the shared-mode step runs it: the gradients are zero when the scatter starts, the fold stores -- TnGrid.table_grad_is_zero)
         ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions, L.e_bins, g_enc,
-                         d_o if with_dpos else None, d_d if with_dpos else None)
+                         d_o if with_dpos else None, d_d if with_dpos else None, grad_is_zero=True)
     torch.cuda.synchronize()
 gd = torch.rand_like(lv[2].density) * 1e-2; gc = torch.rand_like(b.rgb_samples)
 ph = ops._lib
