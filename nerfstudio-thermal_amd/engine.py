@@ -863,6 +863,7 @@ class RenderEngine:
                 and not self.overlap_adam and getattr(self, "scatter_events", None) is None
                 and self.field.num_channels == 4 and "camera_opt" in self.arena.optimised_groups):
             losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler)
+            self._set_grad_zero(False)  # the promise holds for this iteration's scatters only (anybody may call the ops on these grids next)
             self.step_cb(step)
             return losses
         # (the overlapped data-parallel schedule runs the proposal networks' backward through the per-network entry points, which gather again:
@@ -896,5 +897,6 @@ class RenderEngine:
                 grad_hook(self.arena)  # data-parallel gradient all-reduce, after the backward pass
             skip = () if branches[""].prop_grad else ("proposal_networks",)
             self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)
+        self._set_grad_zero(False)  # the promise holds for this iteration's scatters only
         self.step_cb(step)
         return losses

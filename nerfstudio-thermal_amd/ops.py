@@ -121,11 +121,14 @@ class PropNetParams:
         gt = g.get("table")
         key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0,
                bool(self.__dict__.get("grad_is_zero", False)))
-        hit = self.__dict__.get("_cs")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        s = self._build_cstruct(g)
-        self.__dict__["_cs"] = (key, s)
+        cache = self.__dict__.get("_cs")
+        if cache is None:
+            cache = self.__dict__["_cs"] = {}
+        s = cache.get(key)
+        if s is None:
+            if len(cache) >= 8:  # (addresses moved, flags toggled: a handful of variants at most)
+                cache.clear()
+            s = cache[key] = self._build_cstruct(g)
         return s
 
     def _build_cstruct(self, g) -> TnPropNet:
@@ -185,11 +188,14 @@ class FieldParams:
         gt = g.get("table")  # (as PropNetParams.cstruct: the table's addresses stand for the arena's; __setattr__ drops the cache)
         key = (self.table.data_ptr(), gt.data_ptr() if gt is not None else 0, len(g), nf.data_ptr() if nf is not None else 0,
                bool(self.__dict__.get("grad_is_zero", False)))
-        hit = self.__dict__.get("_cs")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        s = self._build_cstruct(g)
-        self.__dict__["_cs"] = (key, s)
+        cache = self.__dict__.get("_cs")
+        if cache is None:
+            cache = self.__dict__["_cs"] = {}
+        s = cache.get(key)
+        if s is None:
+            if len(cache) >= 8:
+                cache.clear()
+            s = cache[key] = self._build_cstruct(g)
         return s
 
     def _build_cstruct(self, g) -> TnField:
