@@ -134,7 +134,8 @@ class OverlappedGradReducer:
             # AVG only where it divides by something: RCCL runs AVG as "multiply, then sum" -- with ONE rank a copy kernel over the whole slice
             # (oneRankReduce<FuncPreMulSum>: 116 us of kernel time per step for the 100 MB of gradients, beside the folds), whereas an in-place
             # SUM over one rank launches nothing.  The mean over one rank is the identity either way.
-            self._avg = dist.get_backend(self.group) == "nccl" and self.world > 1
+            # (TN_DP_ONE_RANK_AVG=1 keeps AVG there: the A/B switch of that measurement.)
+            self._avg = dist.get_backend(self.group) == "nccl" and (self.world > 1 or os.environ.get("TN_DP_ONE_RANK_AVG", "0") == "1")
         return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
 
     def begin(self, arena) -> None:
