@@ -184,3 +184,18 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
             m = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip())
             decl.add(m.group(1))
     assert decl == set(names), (decl ^ set(names))
+
+
+def test_train_step_argument_block_is_validated_before_any_launch(lib):
+    """tn_train_step refuses a missing or half-filled argument block on the host (no device needed) and accepts an empty batch."""
+    import ctypes as C
+
+    from nerfstudio_thermal_amd import _lib as L
+
+    assert lib.tn_train_step(None, None) == -22
+    assert b"null argument block" in lib.tn_last_error()
+    a = L.TnTrainStep()  # all zero: N == 0, an empty batch touches nothing
+    assert lib.tn_train_step(C.byref(a), None) == 0
+    a.N = 4096
+    assert lib.tn_train_step(C.byref(a), None) == -22
+    assert b"null pointer" in lib.tn_last_error()
