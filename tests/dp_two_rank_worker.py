@@ -1,0 +1,126 @@
+"""One rank of tests/test_dp_two_ranks_gpu.py: the data-parallel train step (engine.train_step + parallel.OverlappedGradReducer, world size 2) on
+REAL kernels.  A GPU box has one GPU, so both ranks drive cuda:0 and the collectives go through gloo (RCCL refuses two ranks on one device);
+everything around the collective -- the phased backward, the level ranges, the second communicator for the proposal networks, the order of the
+exchanges, the sum / scale, Adam on the exchanged gradients -- is the code a multi-GPU run executes.
+
+    python tests/dp_two_rank_worker.py <rank> <world> <port> <golden_dir> <out.json>
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    rank, world, port, golden_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    from test_model_gpu import build, dev_inputs
+
+    from nerfstudio_thermal_amd.parallel import OverlappedGradReducer, broadcast_params
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    mode = os.environ.get("TN_TEST_DENSITY_MODE", "shared")
+    ocfg, cfg, arena, eng = build(mode)
+    gi, o, d, cam = dev_inputs(golden_dir)
+    img, is_th = gi["image"].to("cuda"), gi["is_thermal"].to("cuda")
+    jit = [j.to("cuda").reshape(-1).contiguous() for j in gi["jitters"]]
+    jit_t = [j.to("cuda").reshape(-1).contiguous() for j in gi["jitters_thermal"]]
+
+    def batch(r):
+        # rank r's rays: the golden batch rolled by 16 r rays (whole 2x2 patches), ground truth rolled with them
+        return tuple(torch.roll(t, 16 * r, 0).contiguous() for t in (o, d, cam, img, is_th))
+
+    broadcast_params(arena)
+    # what the exchange must deliver: the mean of the ranks' gradients -- every rank's batch through the PLAIN backward here, same parameters, same jitters
+    ref = []
+    eng.set_anneal_for_step(0)  # (what train_step does first: the proposal weights' anneal exponent of iteration 0)
+    for r in range(world):
+        bo, bd, bc, bi, bt = batch(r)
+        arena.zero_grad()
+        outp, br = eng.get_outputs(bo, bd, bc, True, jit, jit_t)
+        eng.loss_and_backward(outp, br, bc, bi, bt)
+        torch.cuda.synchronize()
+        ref.append(arena.grads.clone())
+    arena.zero_grad()
+    expected = sum(ref) / world
+    noise_scale = float(expected.abs().max())
+
+    class Capture(OverlappedGradReducer):
+        captured = None
+
+        def finish(self, skip=None):
+            super().finish(skip)
+            if self.captured is None:
+                torch.cuda.synchronize()
+                self.captured = self._arena.grads.clone()
+
+    hook = Capture(world, level_chunks=(6, 6, 4))
+    bo, bd, bc, bi, bt = batch(rank)
+    losses = None
+    for step in range(3):
+        losses = eng.train_step(bo, bd, bc, bi, bt, step, jitters=jit, jitters_thermal=jit_t, grad_hook=hook)
+    torch.cuda.synchronize()
+    got = hook.captured
+    # parameters after three steps: every rank must hold rank 0's, bit for bit
+    mine = arena.params.detach().cpu()
+    theirs = mine.clone()
+    dist.broadcast(theirs, src=0)
+    per_group = {}
+    for g in arena.optimised_groups:
+        lo, hi = arena.group_range[g]
+        sl = slice(lo, hi)
+        per_group[g] = {"mean": float((got[sl] - expected[sl]).abs().max()), "sum": float((got[sl] - world * expected[sl]).abs().max()),
+                        "own": float((got[sl] - ref[rank][sl]).abs().max()), "scale": float(expected[sl].abs().max())}
+    res = {
+        "rank": rank,
+        "per_group": per_group,
+        "grad_err": float((got - expected).abs().max()),
+        "grad_scale": noise_scale,
+        "own_vs_mean": float((ref[rank] - expected).abs().max()),  # the ranks' gradients DO differ: the exchange is not vacuous
+        "zero_mismatch": int(((got == 0) != (expected == 0)).sum()),
+        "params_equal_rank0": bool(torch.equal(mine, theirs)),
+        "params_finite": bool(torch.isfinite(mine).all()),
+        "losses": {k: float(v) for k, v in losses.items()},
+    }
+    if os.environ.get("TN_TEST_REDUCER", "overlapped") == "sharded":
+        # the sharded-optimiser schedule (reduce-scatter -> Adam on the owned 1/world piece -> all-gather of the parameters; gloo: all-reduce +
+        # all-gather) from the same start: bit-identical parameters on every rank, and the all-reduce schedule's parameters up to the noise of
+        # two runs (Adam with eps 1e-15 turns last-bit gradient differences into lr-sized steps on near-zero entries: compared in the L2 sense)
+        from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+        ocfg2, cfg2, arena2, eng2 = build(mode)
+        init = arena2.params.detach().clone()
+        broadcast_params(arena2)
+        class Counting(ShardedGradReducer):
+            slices = 0
+
+            def gather_params(self):
+                self.slices += len(self._gather)  # slices that were reduce-scattered, updated by their owner and gathered back
+                super().gather_params()
+
+        sh = Counting(world, rank, min_shard=1 << 10, level_chunks=(6, 6, 4))
+        for step in range(3):
+            eng2.train_step(bo, bd, bc, bi, bt, step, jitters=jit, jitters_thermal=jit_t, grad_hook=sh)
+        torch.cuda.synchronize()
+        mine2 = arena2.params.detach().cpu()
+        theirs2 = mine2.clone()
+        dist.broadcast(theirs2, src=0)
+        res["sharded"] = {"params_equal_rank0": bool(torch.equal(mine2, theirs2)), "params_finite": bool(torch.isfinite(mine2).all()),
+                          "dist_to_allreduce": float((arena2.params - arena.params).double().norm()),
+                          "moved": float((arena.params - init).double().norm()),
+                          "sharded_slices": sh.slices}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
