@@ -18,8 +18,48 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def main_ddp(rank, world, port, golden_dir, out_path):
+    """The reference's own multi-GPU path on the drop-in classes: DistributedDataParallel(model, find_unused_parameters=True)
+    (pipelines/base_pipeline.py:281-283) around the Trainer's iteration (engine/trainer.py:455-499), two ranks with different batches."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from nerfstudio_thermal_amd.rays import RayBundle
+    from test_trainer_sequence_gpu import _reference_train_iteration, _setup
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    mode = os.environ.get("TN_TEST_DENSITY_MODE", "shared")
+    model, opt, rb, batch, _ = _setup(golden_dir, mode)
+    init = model.arena.params.detach().clone()
+    sh = 16 * rank  # this rank's rays: the golden batch rolled by whole 2x2 patches, ground truth rolled with them
+    rb = RayBundle(origins=torch.roll(rb.origins, sh, 0).contiguous(), directions=torch.roll(rb.directions, sh, 0).contiguous(),
+                   pixel_area=torch.roll(rb.pixel_area, sh, 0).contiguous(), camera_indices=torch.roll(rb.camera_indices, sh, 0).contiguous())
+    batch = {k: torch.roll(v, sh, 0).contiguous() for k, v in batch.items()}
+    ddp = DDP(model, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)  # (broadcasts rank 0's parameters and buffers)
+    scaler = torch.amp.GradScaler("cuda")
+    seen_idle = False
+    for step in range(13):  # (the first iteration without a proposal update is the 11th)
+        torch.manual_seed(100 + step)  # the ranks draw the same jitter: their gradients differ through the batches alone
+        model.engine.__dict__.pop("_rand", None)
+        losses, _ = _reference_train_iteration(model, opt, scaler, rb, batch, step, True, call=ddp)
+        seen_idle = seen_idle or not model.engine.last_updated
+    torch.cuda.synchronize()
+    mine = model.arena.params.detach().cpu()
+    theirs = mine.clone()
+    dist.broadcast(theirs, src=0)
+    res = {"rank": rank, "params_equal_rank0": bool(torch.equal(mine, theirs)), "params_finite": bool(torch.isfinite(mine).all()),
+           "moved": float((model.arena.params - init).double().norm()), "seen_idle": bool(seen_idle), "scale": float(scaler.get_scale()),
+           "losses": {k: float(v) for k, v in losses.items()}}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port, golden_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    if os.environ.get("TN_TEST_REDUCER", "overlapped") == "ddp":
+        return main_ddp(rank, world, port, golden_dir, out_path)
     from test_model_gpu import build, dev_inputs
 
     from nerfstudio_thermal_amd.parallel import OverlappedGradReducer, broadcast_params

@@ -15,13 +15,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("mode,reducer", [("shared", "overlapped"), ("separate", "overlapped"), ("shared", "sharded")])
-def test_two_ranks_exchange_the_mean_and_stay_identical(golden_dir, tmp_path, mode, reducer):
+def _run_ranks(golden_dir, tmp_path, mode, reducer, world=2):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    world = 2
     env = dict(os.environ, TN_TEST_DENSITY_MODE=mode, TN_TEST_REDUCER=reducer, MASTER_ADDR="127.0.0.1", GLOO_SOCKET_IFNAME="lo")
     outs = [str(tmp_path / f"rank{r}.json") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_two_rank_worker.py"), str(r), str(world), str(port), golden_dir, outs[r]],
@@ -36,7 +34,12 @@ def test_two_ranks_exchange_the_mean_and_stay_identical(golden_dir, tmp_path, mo
                 p.kill()
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
-    res = [json.load(open(o)) for o in outs]
+    return [json.load(open(o)) for o in outs]
+
+
+@pytest.mark.parametrize("mode,reducer", [("shared", "overlapped"), ("separate", "overlapped"), ("shared", "sharded")])
+def test_two_ranks_exchange_the_mean_and_stay_identical(golden_dir, tmp_path, mode, reducer):
+    res = _run_ranks(golden_dir, tmp_path, mode, reducer)
     for r in res:
         scale = r["grad_scale"]
         assert r["own_vs_mean"] > 1e-3 * scale, r  # the two batches give different gradients
@@ -51,3 +54,15 @@ def test_two_ranks_exchange_the_mean_and_stay_identical(golden_dir, tmp_path, mo
             assert sh["sharded_slices"] >= 3, sh  # the table's level ranges at least, in every one of the three steps
     for k in res[0]["losses"]:  # each rank reports the loss of ITS batch: different batches, same order of magnitude, all finite
         assert all(abs(r["losses"][k]) < 1e6 for r in res)
+
+
+@pytest.mark.parametrize("mode", ["shared", "separate"])
+def test_two_ranks_under_distributed_data_parallel(golden_dir, tmp_path, mode):
+    """The reference's own wrap (pipelines/base_pipeline.py:281-283) of the drop-in model, two ranks with different batches through the Trainer's
+    GradScaler iteration: arena-view parameters, None gradients on idle parameters (proposal networks on iterations without an update, the thermal
+    twins in shared mode) -- the ranks must end on bit-identical parameters, and must have moved."""
+    res = _run_ranks(golden_dir, tmp_path, mode, "ddp")
+    for r in res:
+        assert r["params_equal_rank0"] and r["params_finite"], r
+        assert r["moved"] > 0 and r["seen_idle"], r
+    assert res[0]["scale"] == res[1]["scale"]
