@@ -150,6 +150,49 @@ def one_step_api(model, optimizers, cam_t, cache, num_rays, step, grad_scaler=No
     return losses
 
 
+class _TrainerShim:
+    """What nerfstudio's Trainer holds, as far as trainer.FusedTrainerMixin reads it (engine/trainer.py:85-140): nerfstudio itself is not
+    importable on the GPU box.  `step()` is the body of the Trainer's loop: callbacks, train_iteration, callbacks (engine/trainer.py:258-276)."""
+
+    def __init__(self, model, optimizers, datamanager_next):
+        import types
+
+        self.pipeline = types.SimpleNamespace(model=model, datamanager=types.SimpleNamespace(next_train=datamanager_next))
+        self.optimizers = optimizers
+        self.mixed_precision = True
+        self.grad_scaler = torch.amp.GradScaler("cuda")
+        self.gradient_accumulation_steps = {g: 1 for g in optimizers.optimizers}
+        self.config = types.SimpleNamespace(log_gradients=False)
+        self.callbacks = model.get_training_callbacks()
+
+    def train_iteration(self, step):
+        raise RuntimeError("the fused trainer fell through to the reference iteration")
+
+    def step(self, step):
+        from nerfstudio_thermal_amd.model import TrainingCallbackLocation as Loc
+
+        for cb in self.callbacks:
+            cb.run_callback_at_location(step, Loc.BEFORE_TRAIN_ITERATION)
+        out = self.train_iteration(step)
+        for cb in self.callbacks:
+            cb.run_callback_at_location(step, Loc.AFTER_TRAIN_ITERATION)
+        return out
+
+
+def make_fused_trainer(model, cam_t, cache, rays):
+    """The reference Trainer's loop body on trainer.FusedTrainerMixin (what `ns-train thermal-nerfacto-hip` runs: plugin.py)."""
+    from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
+    from nerfstudio_thermal_amd.rays import RayBundle
+    from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
+
+    def next_train(step):
+        o, d, cam, img, is_th = _datamanager(model, cam_t, cache, rays).next_train(step)
+        return RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None]), {"image": img, "is_thermal": is_th}
+
+    cls = type("HipTrainer", (FusedTrainerMixin, _TrainerShim), {})
+    return cls(model, Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam), next_train)
+
+
 def time_ms(fn, iters=10, warmup=2):
     for _ in range(warmup):
         fn()
@@ -399,7 +442,12 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
     api = path == "model-api"
     cam_t, idx, _, _ = make_batch(device, rays, seed=42)
     cache = make_image_cache(device)
-    if api:
+    if path == "fused-trainer":
+        cfg, arena, model = build_model(device, mode=mode, nerf_samples=nerf_samples)
+        eng = model.engine
+        trainer = make_fused_trainer(model, cam_t, cache, rays)
+        run = trainer.step
+    elif api:
         from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
 
         cfg, arena, model = build_model(device, mode=mode, nerf_samples=nerf_samples)
@@ -447,8 +495,10 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
                                              "note": "torch.autograd.set_multithreading_enabled(False) (nerfstudio_thermal_amd.configure_host, opt-in); "
                                                      "ms_per_step above is with torch's defaults"}}
     name, ms, nbytes = next(r for r in kernel_roofline(eng, cam_t, idx) if r[0] == DOMINANT)
-    return {**opt_in, "workload": f"density_mode={mode}, {rays} rays, {nerf_samples} field samples, path {path}" + (" (autocast + torch.amp.GradScaler + HipFusedAdam: "
-            "the reference Trainer's sequence, engine/trainer.py:455-499)" if api else " (device-side GradScaler)"),
+    how = {"model-api": " (autocast + torch.amp.GradScaler + HipFusedAdam: the reference Trainer's sequence, engine/trainer.py:455-499)",
+           "fused-trainer": " (the reference Trainer's loop body -- callbacks, train_iteration, callbacks -- with train_iteration on the fused step: "
+                            "trainer.FusedTrainerMixin, what the method plugin's TrainerConfig._target runs)"}.get(path, " (device-side GradScaler)")
+    return {**opt_in, "workload": f"density_mode={mode}, {rays} rays, {nerf_samples} field samples, path {path}" + how,
             "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rays_per_s": rays * steps / dt, "proposal_update_fraction": upd / steps,
             "dominant_kernel": name, "dominant_kernel_ms": ms, "dominant_kernel_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
@@ -795,7 +845,8 @@ def main():
             result["extra"] = {}
             for key, kw in (("separate_8192", dict(mode="separate", rays=8192, nerf_samples=48, path="fused", steps=12, warmup=4)),
                             ("nerf_samples_96", dict(mode="shared", rays=4096, nerf_samples=96, path="fused", steps=20, warmup=6)),
-                            ("model_api_amp", dict(mode="shared", rays=4096, nerf_samples=48, path="model-api", steps=20, warmup=6))):
+                            ("model_api_amp", dict(mode="shared", rays=4096, nerf_samples=48, path="model-api", steps=20, warmup=6)),
+                            ("fused_trainer", dict(mode="shared", rays=4096, nerf_samples=48, path="fused-trainer", steps=20, warmup=6))):
                 try:
                     result["extra"][key] = extra_leg(device, **kw)
                 except Exception as e:  # noqa: BLE001

@@ -580,6 +580,7 @@ class RenderEngine:
         if not finished:
             ops.losses_finish(Lp, L)
         self._kernel_flags_done = bool(handled) and handled == {g for g in self.arena.optimised_groups if g.startswith("camera_opt")}
+        self._last_losses16, self._last_num_rays = L, int(image.shape[0])  # (train_metrics)
         losses = {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
                   "distortion_loss": L[9]}
         if self.separate and c.density_loss_mult > 0:
@@ -840,13 +841,53 @@ class RenderEngine:
         if updated:
             self.steps_since_update = 0
         L = acc["L"]
+        self._last_losses16, self._last_num_rays = L, int(N)  # (train_metrics)
         return {"rgb_loss": L[0], "thermal_loss": L[1], "tv_pixel_loss": L[2], "cross_channel_loss": L[3], "interlevel_loss": L[8],
                 "distortion_loss": L[9], "camera_opt_regularizer": L[11]}
 
+    def _metric_poses(self):
+        return [p for p in ((self.pose, self.pose_thermal) if self.separate else (self.pose,)) if p is not None]
+
+    def pose_metrics(self) -> Dict[str, Tensor]:
+        """camera_opt_translation / camera_opt_rotation (cameras/camera_optimizers.py:197-202) of the CURRENT pose corrections, one small launch.
+        The reference's metrics_dict holds them as they are when the forward runs -- before the iteration's optimiser step: take them before
+        train_step and hand them to train_metrics."""
+        poses = self._metric_poses()
+        out: Dict[str, Tensor] = {}
+        if poses:
+            dummy = self.__dict__.get("_metric_ones")
+            if dummy is None:
+                dummy = self._metric_ones = torch.ones(16, device=poses[0].device)
+            m = torch.empty(8, device=poses[0].device)
+            ops.train_metrics(dummy, 4, 1.0, poses, m)
+            for k, sfx in enumerate(("", "_thermal")[:len(poses)]):
+                out[f"camera_opt_translation{sfx}"], out[f"camera_opt_rotation{sfx}"] = m[2 + 2 * k], m[3 + 2 * k]
+        return out
+
+    def train_metrics(self, pose_metrics: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+        """metrics_dict of the iteration train_step just enqueued (models/thermal_nerfacto.py:253-282): the PSNR per spectrum from the pixel-loss
+        sums and the distortion metric -- one small launch (tn_train_metrics) behind the step, no host synchronisation -- plus `pose_metrics`
+        (see there).  Call before the next train_step (the loss vector is the step's accumulator)."""
+        L = self.__dict__.get("_last_losses16")
+        if L is None:
+            raise RuntimeError("train_metrics: no train_step has run")
+        c = self.cfg
+        m = torch.empty(8, device=L.device)
+        ops.train_metrics(L, self._last_num_rays, c.thermal_loss_mult, [], m)
+        out = {"psnr_rgb": m[0], "psnr_thermal": m[1]}
+        nsfx = 2 if self.separate else 1
+        if c.distortion_loss_mult > 0:
+            out["distortion"] = L[9] / (c.distortion_loss_mult * nsfx)
+        out.update(pose_metrics or {})
+        return out
+
     def train_step(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, step: int,
-                   jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True, grad_scaler=None) -> Dict[str, Tensor]:
+                   jitters=None, jitters_thermal=None, grad_hook=None, scheduled: bool = True, grad_scaler=None,
+                   step_callback: bool = True) -> Dict[str, Tensor]:
         """Trainer.train_iteration (engine/trainer.py:455-499) for this model: callbacks, forward, losses, backward, (all-reduce), Adam.
-        grad_scaler: optim.DeviceGradScaler or None (see optimizer_step)."""
+        grad_scaler: optim.DeviceGradScaler or None (see optimizer_step).
+        step_callback=False: the caller runs the model's AFTER_TRAIN_ITERATION callback itself (the reference Trainer's loop does,
+        engine/trainer.py:258-276: trainer.FusedTrainerMixin) -- the sampler's update counter must advance once per iteration."""
         self.set_anneal_for_step(step)
         if grad_scaler is not None:
             grad_scaler.begin_step()
@@ -864,7 +905,8 @@ class RenderEngine:
                 and self.field.num_channels == 4 and "camera_opt" in self.arena.optimised_groups):
             losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler)
             self._set_grad_zero(False)  # the promise holds for this iteration's scatters only (anybody may call the ops on these grids next)
-            self.step_cb(step)
+            if step_callback:
+                self.step_cb(step)
             return losses
         # (the overlapped data-parallel schedule runs the proposal networks' backward through the per-network entry points, which gather again:
         # the forward then need not keep their encodings)
@@ -898,5 +940,6 @@ class RenderEngine:
             skip = () if branches[""].prop_grad else ("proposal_networks",)
             self.optimizer_step(scheduled=scheduled, skip_groups=skip, grad_scaler=grad_scaler, skipped_have_no_grads=True)
         self._set_grad_zero(False)  # the promise holds for this iteration's scatters only
-        self.step_cb(step)
+        if step_callback:
+            self.step_cb(step)
         return losses

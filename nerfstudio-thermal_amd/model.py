@@ -591,13 +591,14 @@ class ThermalNerfactoModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ fused fast path
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor], step: int, grad_hook=None, jitters=None, jitters_thermal=None,
-                        grad_scaler=None):
+                        grad_scaler=None, step_callback: bool = True):
         """Trainer.train_iteration for this model without an autograd tape: callbacks + forward + losses + backward (+ all-reduce) + Adam.
         grad_scaler: optim.DeviceGradScaler -- the reference Trainer's GradScaler semantics (skip on inf / NaN, scale growth / backoff, LR-schedule
         lag; engine/trainer.py:470-495) decided on the device -- or None."""
         cam = ray_bundle.camera_indices.reshape(-1).contiguous()
         return self.engine.train_step(ray_bundle.origins.contiguous(), ray_bundle.directions.contiguous(), cam, batch["image"].to(self.device)[..., :3].contiguous(),
-                                      batch["is_thermal"].to(self.device).float().contiguous(), step, jitters, jitters_thermal, grad_hook, grad_scaler=grad_scaler)
+                                      batch["is_thermal"].to(self.device).float().contiguous(), step, jitters, jitters_thermal, grad_hook, grad_scaler=grad_scaler,
+                                      step_callback=step_callback)
 
     # ------------------------------------------------------------------------------------------------ eval
     @torch.no_grad()

@@ -5,6 +5,7 @@ When nerfstudio itself is importable the full TrainerConfig of method_configs["t
 rebuilt with this package's model config; otherwise a plain description object carrying the same optimiser table is exposed."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Any, Dict
 
@@ -45,6 +46,14 @@ def _build():
     base = copy.deepcopy(method_configs["thermal-nerfacto"])
     base.method_name = "thermal-nerfacto-hip"
     base.pipeline.model = model_config()
+    if os.environ.get("TN_FUSED_TRAINER", "1") != "0":
+        # TrainerConfig._target (engine/trainer.py:56): the reference Trainer with its train_iteration on the fused step (trainer.py); loop,
+        # callbacks, logging, evaluation, checkpoints and viewer stay the reference's.  TN_FUSED_TRAINER=0: the unmodified Trainer.
+        from nerfstudio.engine.trainer import Trainer
+
+        from .trainer import FusedTrainerMixin
+
+        base._target = type("HipTrainer", (FusedTrainerMixin, Trainer), {"__doc__": FusedTrainerMixin.__doc__})
     return MethodSpecification(config=base, description=MethodDescription().description)
 
 

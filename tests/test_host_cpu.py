@@ -165,6 +165,13 @@ def test_method_plugin_builds_a_method_specification_inside_nerfstudio(monkeypat
             "nerfstudio.configs.method_configs": types.ModuleType("nerfstudio.configs.method_configs")}
     mods["nerfstudio.plugins.types"].MethodSpecification = MethodSpecification
     mods["nerfstudio.configs.method_configs"].method_configs = table
+
+    class Trainer:  # engine/trainer.py: TrainerConfig._target
+        pass
+
+    mods["nerfstudio.engine"] = types.ModuleType("nerfstudio.engine")
+    mods["nerfstudio.engine.trainer"] = types.ModuleType("nerfstudio.engine.trainer")
+    mods["nerfstudio.engine.trainer"].Trainer = Trainer
     for k, v in mods.items():
         monkeypatch.setitem(sys.modules, k, v)
     spec = plugin._build()
@@ -173,6 +180,15 @@ def test_method_plugin_builds_a_method_specification_inside_nerfstudio(monkeypat
     assert spec.config.pipeline.datamanager == "dm" and spec.config.max_num_iterations == 30000
     assert table["thermal-nerfacto"].method_name == "thermal-nerfacto" and isinstance(table["thermal-nerfacto"].pipeline.model, str)  # a copy
     spec.config.pipeline.model.validate_for_hip()
+    # the Trainer the method runs under: the reference's, with its iteration on the fused step (TN_FUSED_TRAINER=0: the reference's, untouched)
+    from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
+
+    assert issubclass(spec.config._target, FusedTrainerMixin) and issubclass(spec.config._target, Trainer)
+    assert spec.config._target.__mro__.index(FusedTrainerMixin) < spec.config._target.__mro__.index(Trainer)
+    assert not hasattr(table["thermal-nerfacto"], "_target")
+    monkeypatch.setenv("TN_FUSED_TRAINER", "0")
+    assert not hasattr(plugin._build().config, "_target")
+    monkeypatch.delenv("TN_FUSED_TRAINER")
     # a nerfstudio without the method: loud
     del table["thermal-nerfacto"]
     with pytest.raises(KeyError):
