@@ -56,10 +56,47 @@ def main_ddp(rank, world, port, golden_dir, out_path):
     dist.destroy_process_group()
 
 
+def main_fused_trainer(rank, world, port, golden_dir, out_path):
+    """trainer.FusedTrainerMixin with two ranks: the Trainer's iteration on the fused step, the gradient exchange issued by the mixin
+    (parallel.OverlappedGradReducer over the default process group) instead of DistributedDataParallel's autograd hooks."""
+    from nerfstudio_thermal_amd.parallel import broadcast_params
+    from nerfstudio_thermal_amd.rays import RayBundle
+    from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
+    from test_fused_trainer_gpu import RefTrainer
+    from test_trainer_sequence_gpu import _setup
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    mode = os.environ.get("TN_TEST_DENSITY_MODE", "shared")
+    model, opt, rb, batch, _ = _setup(golden_dir, mode)
+    init = model.arena.params.detach().clone()
+    broadcast_params(model.arena)  # (what the DistributedDataParallel wrap of the pipeline does at construction)
+    sh = 16 * rank
+    rb = RayBundle(origins=torch.roll(rb.origins, sh, 0).contiguous(), directions=torch.roll(rb.directions, sh, 0).contiguous(),
+                   pixel_area=torch.roll(rb.pixel_area, sh, 0).contiguous(), camera_indices=torch.roll(rb.camera_indices, sh, 0).contiguous())
+    batch = {k: torch.roll(v, sh, 0).contiguous() for k, v in batch.items()}
+    trainer = type("HipTrainer", (FusedTrainerMixin, RefTrainer), {})(model, opt, rb, batch)
+    loss, loss_dict, metrics = trainer.loop(range(13))
+    torch.cuda.synchronize()
+    mine = model.arena.params.detach().cpu()
+    theirs = mine.clone()
+    dist.broadcast(theirs, src=0)
+    res = {"rank": rank, "params_equal_rank0": bool(torch.equal(mine, theirs)), "params_finite": bool(torch.isfinite(mine).all()),
+           "moved": float((model.arena.params - init).double().norm()), "seen_idle": True, "scale": 65536.0,
+           "reference_iterations": trainer.ref_iterations, "exchanges": type(trainer.__dict__.get("_tn_grad_hook")).__name__,
+           "losses": {k: float(v) for k, v in loss_dict.items()}}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port, golden_dir, out_path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     if os.environ.get("TN_TEST_REDUCER", "overlapped") == "ddp":
         return main_ddp(rank, world, port, golden_dir, out_path)
+    if os.environ.get("TN_TEST_REDUCER", "overlapped") == "fused_trainer":
+        return main_fused_trainer(rank, world, port, golden_dir, out_path)
     from test_model_gpu import build, dev_inputs
 
     from nerfstudio_thermal_amd.parallel import OverlappedGradReducer, broadcast_params

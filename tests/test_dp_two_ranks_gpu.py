@@ -66,3 +66,12 @@ def test_two_ranks_under_distributed_data_parallel(golden_dir, tmp_path, mode):
         assert r["params_equal_rank0"] and r["params_finite"], r
         assert r["moved"] > 0 and r["seen_idle"], r
     assert res[0]["scale"] == res[1]["scale"]
+
+
+def test_two_ranks_under_the_fused_trainer(golden_dir, tmp_path):
+    """trainer.FusedTrainerMixin on two ranks: no iteration falls through to the reference sequence, the mixin's own exchange keeps the ranks'
+    parameters bit-identical over 13 iterations (with and without a proposal update)."""
+    res = _run_ranks(golden_dir, tmp_path, "shared", "fused_trainer")
+    for r in res:
+        assert r["params_equal_rank0"] and r["params_finite"] and r["moved"] > 0, r
+        assert r["reference_iterations"] == 0 and r["exchanges"] == "OverlappedGradReducer", r
