@@ -23,6 +23,7 @@ namespace {
 struct Companion {
   hipStream_t side = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  bool forked = false;  // work has been forked to `side` since the last join: a join without it has nothing to wait for
 };
 std::mutex g_comp_mu;
 // key: (device, caller stream, companion index).  Index 0: the field backward's d-position kernel; 1, 2: the proposal networks' backward in
@@ -56,6 +57,7 @@ hipStream_t tn_fork_n(hipStream_t user, int idx) {
   Companion* c = companion_of(user, idx);
   if (c == nullptr) return nullptr;
   if (hipEventRecord(c->fork_ev, user) != hipSuccess || hipStreamWaitEvent(c->side, c->fork_ev, 0) != hipSuccess) return nullptr;
+  c->forked = true;
   return c->side;
 }
 hipStream_t tn_fork(hipStream_t user) { return tn_fork_n(user, 0); }
@@ -66,7 +68,8 @@ void tn_join_n(hipStream_t user, int idx) {
   {
     std::lock_guard<std::mutex> lk(g_comp_mu);
     auto it = g_comp.find(CompKey{dev, user, idx});
-    if (it == g_comp.end()) return;
+    if (it == g_comp.end() || !it->second.forked) return;  // (an event record + wait on an idle companion is not free: two queue round trips)
+    it->second.forked = false;
     c = it->second;
   }
   (void)hipEventRecord(c.join_ev, c.side);
@@ -75,7 +78,8 @@ void tn_join_n(hipStream_t user, int idx) {
 void tn_join_all(hipStream_t user) { tn_join_n(user, 0); }
 void tn_join(hipStream_t user, hipStream_t companion) {
   Companion* c = companion_of(user, 0);
-  if (c == nullptr || companion != c->side) return;
+  if (c == nullptr || companion != c->side || !c->forked) return;
+  c->forked = false;
   (void)hipEventRecord(c->join_ev, c->side);
   (void)hipStreamWaitEvent(user, c->join_ev, 0);
 }
