@@ -867,6 +867,11 @@ def main():
                 result["cpu_baseline"]["other_thread_counts"] = {"8": {"value": v8, "s_per_step": t8, "steps": 2},
                                                                  "1": {"value": v1, "s_per_step": t1, "steps": 1, "rays": rays // 4}}
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        if (world > 1 or args.force_dp) and not api and args.mode == "shared" and rays == RAYS_PER_GPU and result["ms_per_step"] > 1.5:
+            # (diagnostic on stderr only: DESIGN.md section 8.0 -- with an unlucky placement of the streams on the runtime's hardware queues every step
+            # idles ~0.9 ms; measured on one rank with GPU_MAX_HW_QUEUES=4, while 2 / 3 / 8 run at 0.89-1.01 ms)
+            print(f"bench.py: {result['ms_per_step']:.2f} ms per step is ~1 ms above what this schedule takes on one rank (0.9 ms): if rocprofv3 shows the GPU idle "
+                  "between two kernels of the main stream, try another GPU_MAX_HW_QUEUES (the package sets 8 unless the environment has a value)", file=sys.stderr)
         print(json.dumps(result))
     barrier()
     if torch.distributed.is_initialized():
