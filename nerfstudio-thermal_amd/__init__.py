@@ -12,6 +12,9 @@ import os as _os
 # GEMMs, two RCCL communicators, copies).  The ROCm runtime multiplexes a process's streams onto 4 hardware queues by default; a stream
 # that shares a queue with another one serialises behind it -- e.g. an all-reduce waiting for the proposal backward blocks the main
 # stream's kernels queued after it (bench.py --force-dp: 2.75 ms/step with 4 queues, 1.42 ms with 8; the single-GPU step does not care).
+# Round 4 sweep of the one-rank data-parallel step (profiles/r04_experiments.md): 8 -> 0.887 ms, 6 / 12 / 16 / 24 -> ~1.02, 4 / 5 / 7 -> 1.8-2.1 (the GPU idles
+# ~0.9 ms per step), 2 / 3 -> 0.94-1.01; the single-GPU step is the same with 3, 4 and 8.  The runtime deals streams onto the queues in creation order, so
+# the best count belongs to THIS set of streams: with another one (more communicators, another torch version) re-measure.
 # Must be in the environment before the first HIP call of the process; an explicit setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
