@@ -180,17 +180,19 @@ class _TrainerShim:
 
 
 def make_fused_trainer(model, cam_t, cache, rays):
-    """The reference Trainer's loop body on trainer.FusedTrainerMixin (what `ns-train thermal-nerfacto-hip` runs: plugin.py)."""
+    """The reference Trainer's loop body on trainer.FusedTrainerMixin with the DataManager adapter (what `ns-train thermal-nerfacto-hip` runs:
+    plugin.py installs HipTrainer + the device datamanager): `pipeline.datamanager.next_train(step)` is datamanager.TrainRaySource.next -- one
+    launch -> the reference's (RayBundle, batch) pair with every field (pixel_area, directions_norm, indices)."""
+    from nerfstudio_thermal_amd import synth
+    from nerfstudio_thermal_amd.datamanager import TrainRaySource
     from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
-    from nerfstudio_thermal_amd.rays import RayBundle
     from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
 
-    def next_train(step):
-        o, d, cam, img, is_th = _datamanager(model, cam_t, cache, rays).next_train(step)
-        return RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None]), {"image": img, "is_thermal": is_th}
-
+    cams = synth.synth_cameras()
+    src = TrainRaySource([torch.from_numpy(im) for im in synth.synth_images(cams)], cams["is_thermal"].astype(np.float32), cam_t, rays, 2, model.device,
+                         shuffle=False)
     cls = type("HipTrainer", (FusedTrainerMixin, _TrainerShim), {})
-    return cls(model, Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam), next_train)
+    return cls(model, Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam), src.next)
 
 
 def time_ms(fn, iters=10, warmup=2):

@@ -248,6 +248,25 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   TN_REQUIRE(a->num_ranges == 0 || (a->params && a->grads && a->exp_avg && a->exp_avg_sq), "tn_train_step: null arena pointer");
   const int C = a->field->num_channels;
   TN_REQUIRE(C == 4, "tn_train_step: the shared-density model renders RGB + thermal from one field (4 channels), got %d", C);
+  // Everything a LATER stage would refuse is refused HERE, before the first launch: sizes of the three workspaces, sample counts, alignment of the
+  // forward's buffer and of the accumulator block -- so an error return means nothing was enqueued (the caller's step counters then still match the
+  // device's; the inner entry points keep their own checks).
+  TN_REQUIRE(a->N > 0 && a->S0 >= 1 && a->S1 >= 1 && a->S2 >= 1 && a->S0 <= TN_MAX_SAMPLES && a->S1 <= TN_MAX_SAMPLES && a->S2 <= TN_MAX_SAMPLES,
+             "tn_train_step: bad N=%lld S=(%d, %d, %d)", (long long)a->N, a->S0, a->S1, a->S2);
+  TN_REQUIRE(((uintptr_t)a->fwd_out % 256) == 0, "tn_train_step: the forward's buffer must be 256-byte aligned");
+  TN_REQUIRE(((uintptr_t)a->acc % 16) == 0 && a->acc_bytes >= 0 && a->acc_bytes % 16 == 0, "tn_train_step: the accumulator block must be 16-byte aligned and sized");
+  TN_REQUIRE(a->lin_spaced0 && a->lin_pdf1 && a->lin_pdf2 && a->field_workspace, "tn_train_step: null sampler table / field workspace");
+  {
+    const int64_t need_f = tn_field_workspace_bytes(a->N * (int64_t)a->S2, 1);
+    TN_REQUIRE(a->field_workspace_bytes >= need_f, "tn_train_step: field workspace of %lld bytes, tn_field_workspace_bytes(%lld, 1) = %lld",
+               (long long)a->field_workspace_bytes, (long long)(a->N * (int64_t)a->S2), (long long)need_f);
+    if (a->prop_grad) {
+      const int64_t need0 = tn_prop_workspace_bytes(a->N * (int64_t)a->S0), need1 = tn_prop_workspace_bytes(a->N * (int64_t)a->S1);
+      TN_REQUIRE(a->prop_workspace_bytes0 >= need0 && a->prop_workspace_bytes1 >= need1,
+                 "tn_train_step: proposal workspaces of %lld / %lld bytes, tn_prop_workspace_bytes = %lld / %lld", (long long)a->prop_workspace_bytes0,
+                 (long long)a->prop_workspace_bytes1, (long long)need0, (long long)need1);
+    }
+  }
   int64_t off[TRO_COUNT];
   train_layout(a->N, a->S0, a->S1, a->S2, C, off);
   int rc;

@@ -23,6 +23,13 @@ class DeviceDataManager:
         self._pending: Optional[Tuple[Tuple[Tensor, ...], torch.cuda.Event]] = None
         self._rand = ops.UniformPool(self.device)
 
+    def next_train_full(self, step: int = 0) -> Tuple[Tensor, ...]:
+        """-> origins, directions, camera_indices, image, is_thermal, ray_indices [N,3] int64 (camera,row,col), pixel_area [N,1], directions_norm [N,1]:
+        every field of the reference's (RayBundle, batch) pair (datamanager.TrainRaySource builds the pair).  Same launch as next_train."""
+        n = self.num_rays
+        u = self._rand.take((n // (self.patch * self.patch), 3))
+        return ops.sample_rays(self.cache, n, u, self.cam, self.patch, with_bundle_extras=True)
+
     def _make(self) -> Tuple[Tensor, ...]:
         n = self.num_rays
         u = self._rand.take((n // (self.patch * self.patch), 3))  # what PatchPixelSampler draws with torch.rand (drawn 32 steps at a time)

@@ -821,21 +821,28 @@ class RenderEngine:
         keys, shapes = self._accumulator_spec(N, {"": bool(updated), "_thermal": False})
         views, flat = self._zeros_many(shapes, fill=False)  # cleared inside the field's first launch
         acc = {k[0]: v for k, v in zip(keys, views)}
-        # optimiser bookkeeping of optimizer_step: Adam step counts per group, LR schedule position (evaluated on the device at count - lag)
-        self.adam_step_count += 1
+        # optimiser bookkeeping of optimizer_step: Adam step counts per group, LR schedule position (evaluated on the device at count - lag).
+        # Worked out on copies and COMMITTED only after the library accepted the call: tn_train_step validates every stage's arguments and
+        # workspace sizes before its first launch, so a refused call (TN_EINVAL) has enqueued nothing and must leave the host counters where the
+        # device's are.
         if not hasattr(self, "group_steps"):
             self.group_steps = {}
+        group_steps = dict(self.group_steps)
         ranges = []
         for g in a.optimised_groups:
             if g == "proposal_networks" and not updated:
                 continue  # ran under no_grad this iteration (ray_samplers.py:605-610): not stepped, keeps its step count
-            self.group_steps[g] = self.group_steps.get(g, 0) + 1
+            group_steps[g] = group_steps.get(g, 0) + 1
             lr0, lr_final, max_steps = OPTIMIZERS[g]
             lo, hi = a.group_range[g]
-            ranges.append((lo, hi, self.group_steps[g], lr0, lr_final, max_steps, gidx[g]))
-        a.grads_clean = False
+            ranges.append((lo, hi, group_steps[g], lr0, lr_final, max_steps, gidx[g]))
         self._set_grad_zero(True)  # (train_step made sure the arena's gradients are zero; shared mode: one scatter per table)
-        call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count - 1)
+        try:
+            call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count)
+        finally:
+            self._set_grad_zero(False)  # the promise holds for this call's scatters only -- also when the call was refused
+        self.adam_step_count += 1
+        self.group_steps = group_steps
         a.grads_clean = True  # the Adam launch consumed the gradients of every group that received any
         self.last_updated = bool(updated)
         if updated:

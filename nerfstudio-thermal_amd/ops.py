@@ -292,9 +292,10 @@ def sample_pixels(cache: ImageCache, num_rays: int, u: Tensor, patch_size: int =
     return (idx, img, is_th, cam) if want_camera_indices else (idx, img, is_th)
 
 
-def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2, want_pixel_area: bool = True):
+def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2, want_pixel_area: bool = True, with_bundle_extras: bool = False):
     """sample_pixels + raygen in one launch (tn_sample_rays) -> origins [N,3], directions [N,3], camera_indices [N] int64, image [N,3],
-    is_thermal [N], ray_indices [N,3].  cameras: c2w [C,3,4], fx, fy, cx, cy [C], optional distortion [C,6].
+    is_thermal [N], ray_indices [N,3] (+ pixel_area [N,1], directions_norm [N,1] with with_bundle_extras=True: the rest of the reference's
+    RayBundle, cameras/cameras.py:904-928).  cameras: c2w [C,3,4], fx, fy, cx, cy [C], optional distortion [C,6].
     want_pixel_area=False: the bundle's pixel_area (which thermal-nerfacto never reads) is not computed -- two of the three undistortions per ray."""
     n_img = cache.offsets.shape[0]
     dev = cache.buffer.device
@@ -314,6 +315,8 @@ def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patc
                                      _f32(cameras.get("distortion"), "distortion", (Cn, 6), optional=True), Cn, p(o), p(d), p(area) if want_pixel_area else None,
                                      p(nrm), _stream()),
           "tn_sample_rays")
+    if with_bundle_extras:
+        return o, d, cam, img, is_th, idx, area, nrm
     return o, d, cam, img, is_th, idx
 
 
@@ -862,6 +865,10 @@ class TrainStepCall:
             st.offsets[k], st.counts[k], st.steps[k] = int(lo), int(hi - lo), int(step)
             st.lrs[k], st.lr_finals[k], st.sched_max_steps[k], st.flag_index[k] = float(lr0), float(lr1), int(ms), int(fl)
         st.sched_step = int(sched_step)
+        # GradScaler's growth / backoff settings are read from the scaler EVERY call: DeviceGradScaler.load_state_dict() on the same object (a resumed
+        # run) changes them, and the five-call path reads fused_update_args() per step too -- the two paths must keep agreeing after a resume.
+        _, _, _, gf, bf, gi = self.scaler.fused_update_args()
+        st.growth_factor, st.backoff_factor, st.growth_interval = float(gf), float(bf), int(gi)
         self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters)  # alive until the next call replaces them
         check(_lib.load().tn_train_step(C.byref(st), _stream()), "tn_train_step")
         return buf

@@ -398,7 +398,14 @@ class Optimizers:
             index = self._opt_index = {n: i for i, n in enumerate(self.optimizers)}
         device = next(iter(live[0][1]._where.values()))[0].params.device
         found, views, skipped = self._amp_state(device)
-        found.zero_()
+        # only the entries of the optimisers stepped by THIS call are cleared: the views handed to GradScaler alias this buffer, and a second call in
+        # the same iteration (two disjoint group lists before grad_scaler.update()) must not wipe the flags the first one raised
+        mine_idx = [index[n] for n, _ in live]
+        if len(mine_idx) == len(self.optimizers):
+            found.zero_()
+        else:
+            found[mine_idx[0]:mine_idx[-1] + 1].zero_() if mine_idx == list(range(mine_idx[0], mine_idx[-1] + 1)) else found.index_fill_(
+                0, torch.as_tensor(mine_idx, device=device), 0.0)
         work = []  # (flag, arena, lo, hi, step, lr, (beta1, beta2, eps))
         for n, o in live:
             gi = index[n]

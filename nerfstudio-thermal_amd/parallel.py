@@ -287,18 +287,16 @@ class ShardedGradReducer(OverlappedGradReducer):
     def finish_iter(self, skip: Optional[List[Tuple[int, int]]] = None):
         """As OverlappedGradReducer.finish_iter, but a reduce-scattered slice yields only the piece this rank owns (and is remembered for
         gather_params)."""
-        sharded = dict(self._sharded)
-        ranges_before = list(self._ranges)
-        own = {}
-        for k, (lo, hi) in sharded.items():
-            own[(lo, hi)] = self._own(lo, hi)
+        # Ownership is resolved PER PIECE, as it is yielded: the parent's generator issues the leftover ranges through self.reduce_range before
+        # its first yield, and that may shard them too (separate mode: a whole idle-free proposal group as one leftover of >= min_shard floats).
+        # A snapshot of self._sharded taken before the loop would miss those: the full range would get Adam on gradients of which only the
+        # owned piece holds the mean, and the parameters would never be gathered.
         for piece in super().finish_iter(skip):
-            if piece in own:
+            if piece in self._sharded.values():
                 self._gather.append(piece)
-                yield own[piece]
+                yield self._own(*piece)
             else:
                 yield piece
-        del ranges_before
 
     def gather_params(self) -> None:
         """All-gather of the parameters of every sharded slice (each rank contributes the piece its Adam launch just updated); the current

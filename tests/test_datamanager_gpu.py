@@ -1,0 +1,107 @@
+"""The DataManager adapter (nerfstudio_thermal_amd/datamanager.py) on the GPU: `next_train(step) -> (RayBundle, batch)` with the reference's
+batch keys, every value consistent with the scene on disk (data/datamanagers/base_datamanager.py:538-547, data/pixel_samplers.py:296-337,389-441,
+model_components/ray_generators.py:40-55)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(tmp_path_factory):
+    import nerfstudio_thermal_amd  # noqa: F401
+    from nerfstudio_thermal_amd import synth
+    from nerfstudio_thermal_amd.dataparser import write_rgbt_dataset
+
+    cams = synth.synth_cameras()
+    images = synth.synth_images(cams)
+    d = str(tmp_path_factory.mktemp("dm") / "scene")
+    write_rgbt_dataset(d, cams, images)
+    return d
+
+
+def test_next_train_is_the_references_pair(scene):
+    from nerfstudio_thermal_amd import ops
+    from nerfstudio_thermal_amd.datamanager import HipDataManager, HipDataManagerConfig
+    from nerfstudio_thermal_amd.dataparser import ThermalNerfDataParserConfig
+    from nerfstudio_thermal_amd.rays import RayBundle
+
+    cfg = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=1026, eval_num_rays_per_batch=64)
+    dm = cfg.setup(device="cuda:0", test_mode="val")
+    assert isinstance(dm, HipDataManager) and dm.get_param_groups() == {} and dm.get_training_callbacks(None) == []
+    n_img = len(dm.train_dataset)
+    assert dm.get_train_rays_per_batch() == 1024  # PatchPixelSampler.set_num_rays_per_batch: a multiple of patch_size^2
+    images = [dm.train_dataset.get_image_float32(i) for i in range(n_img)]
+    is_th = dm.train_dataset.metadata["is_thermal"]
+    cams = dm._train_src.cameras
+    for step in range(3):
+        rb, batch = dm.next_train(step)
+        assert isinstance(rb, RayBundle) and set(batch) == {"image", "indices", "is_thermal"}
+        idx = batch["indices"].cpu()
+        assert idx.dtype == torch.int64 and tuple(idx.shape) == (1024, 3)
+        assert tuple(rb.origins.shape) == (1024, 3) and tuple(rb.camera_indices.shape) == (1024, 1) and tuple(rb.pixel_area.shape) == (1024, 1)
+        assert torch.equal(rb.camera_indices[:, 0].cpu(), idx[:, 0])
+        # num_rays // num_images rays per image, image after image in batch order, the last image takes the remainder (pixel_samplers.py:296-312)
+        per = (1024 // n_img // 4) * 4
+        order = dm._train_src.batch_order
+        expect_cam = sum(([c] * per for c in order[:-1]), []) + [order[-1]] * (1024 - per * (n_img - 1))
+        assert idx[:, 0].tolist() == expect_cam
+        # 2x2 patches: 4 consecutive rays = (y,x), (y,x+1), (y+1,x), (y+1,x+1)
+        p = idx.view(-1, 4, 3)
+        assert torch.equal(p[:, 1, 2], p[:, 0, 2] + 1) and torch.equal(p[:, 2, 1], p[:, 0, 1] + 1) and torch.equal(p[:, 3, 1:], p[:, 0, 1:] + 1)
+        # ground truth and is_thermal are those of the indexed pixels / images
+        gt = torch.stack([images[c][y, x] for c, y, x in idx.tolist()])
+        assert torch.equal(batch["image"].cpu(), gt)
+        assert batch["is_thermal"].cpu().tolist() == [float(is_th[c]) for c in idx[:, 0].tolist()]
+        # the bundle is RayGenerator(indices) on the split's cameras
+        o, d, area, nrm = ops.raygen(batch["indices"], cams["c2w"], cams["fx"], cams["fy"], cams["cx"], cams["cy"], cams["distortion"])
+        assert torch.equal(rb.origins, o) and torch.equal(rb.directions, d) and torch.equal(rb.pixel_area, area)
+        assert torch.equal(rb.metadata["directions_norm"], nrm)
+    assert dm.train_count == 3
+    # fresh pixels every step
+    a, b = dm.next_train(3)[1]["indices"], dm.next_train(4)[1]["indices"]
+    assert not torch.equal(a, b)
+    # eval side: one image at a time, round robin; every image once through the fixed-indices view
+    cam, eb = dm.next_eval_image(0)
+    assert eb["image"].shape[:2] == (cam.height, cam.width) and eb["image"].device.type == "cuda"
+    assert len(dm.fixed_indices_eval_dataloader) == len(dm.eval_dataset)
+    assert dm.get_datapath().name == "scene"
+
+
+def test_adapter_feeds_the_fused_trainer(scene):
+    """trainer.fused_train_iteration reads pipeline.datamanager.next_train(step) -> the adapter's pair goes straight into the fused step."""
+    import types
+
+    from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+    from nerfstudio_thermal_amd.datamanager import HipDataManagerConfig
+    from nerfstudio_thermal_amd.dataparser import ThermalNerfDataParserConfig
+    from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
+    from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
+
+    dm = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=256).setup(device="cuda:0")
+    cfg = ThermalNerfactoModelConfig(density_mode="shared", log2_hashmap_size=12)
+    for a in cfg.proposal_net_args_list:
+        a["log2_hashmap_size"] = 10
+    model = cfg.setup(scene_box=dm.train_dataset.scene_box, num_train_data=len(dm.train_dataset), metadata=dm.train_dataset.metadata, device="cuda:0")
+    model.train()
+
+    class _Base:
+        def train_iteration(self, step):
+            raise AssertionError("fell through to the reference iteration")
+
+    class _T(FusedTrainerMixin, _Base):
+        pass
+
+    t = _T()
+    t.pipeline = types.SimpleNamespace(model=model, datamanager=dm)
+    t.optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam)
+    t.mixed_precision, t.grad_scaler = True, torch.amp.GradScaler("cuda")
+    t.gradient_accumulation_steps = {}
+    t.config = types.SimpleNamespace(log_gradients=False)
+    before = model.arena.params.clone()
+    for step in range(3):
+        loss, loss_dict, metrics = t.train_iteration(step)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and set(loss_dict) >= {"rgb_loss", "thermal_loss", "interlevel_loss", "distortion_loss"}
+    assert dm.train_count == 3 and not torch.equal(before, model.arena.params)

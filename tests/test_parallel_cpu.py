@@ -202,18 +202,21 @@ def _sharded_worker(rank, world, port, q):
         return pieces, arena.params.clone()
 
     pieces_a, params_a = run(OverlappedGradReducer(world, side_group=None))
-    pieces_b, params_b = run(ShardedGradReducer(world, rank, min_shard=1024, side_group=None))
+    hook_b = ShardedGradReducer(world, rank, min_shard=1024, side_group=None)
+    pieces_b, params_b = run(hook_b)
     lo, hi = arena.live_range
     mean_g = base_g * (sum(range(1, world + 1)) / world)
     expect = base_p.clone()
     expect[lo:hi] -= 0.1 * mean_g[lo:hi]
     ok_ref = bool(torch.allclose(params_a[lo:hi], expect[lo:hi], rtol=1e-6, atol=1e-7))
     ok_same = bool(torch.equal(params_a, params_b))
-    # this rank ran its update on 1/world of the table only, on the whole of everything else
+    # this rank ran its update on 1/world of every sharded slice (the two table ranges, and whichever leftover finish_iter found shardable:
+    # here the proposal networks' group), on the whole of everything else
     n_a = sum(b - a for a, b in pieces_a)
     n_b = sum(b - a for a, b in pieces_b)
     own = [(a, b) for a, b in pieces_b if t0 <= a and b <= t0 + tn]
-    ok_own = sum(b - a for a, b in own) == tn // world and n_b == n_a - tn + tn // world
+    n_sharded = sum(b - a for a, b in hook_b._sharded.values())
+    ok_own = sum(b - a for a, b in own) == tn // world and n_sharded >= tn and n_b == n_a - n_sharded + n_sharded // world
     q.put((rank, ok_ref, ok_same, ok_own, params_b[t0:t0 + tn].double().sum().item()))
     dist.barrier()
     dist.destroy_process_group()
@@ -233,6 +236,72 @@ def test_two_rank_sharded_optimizer_equals_allreduce_path():
     for rank, ok_ref, ok_same, ok_own, _ in res:
         assert ok_ref and ok_same and ok_own, res
     assert res[0][4] == res[1][4]  # the gathered table is bit-identical on both ranks
+
+
+def _sharded_leftover_worker(rank, world, port, q):
+    """A slice that only finish_iter's LEFTOVER pass issues can be sharded too (separate mode: a whole proposal group as one leftover).  gloo has
+    no reduce-scatter and all-reduces the slice, which hides a missed ownership; so the collective is followed by what reduce-scatter would leave
+    behind: NaN in every piece this rank does not own.  The owned piece alone may reach the update, and the parameters must be gathered."""
+    from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+    class _PoisoningReducer(ShardedGradReducer):
+        def reduce_range(self, lo, hi, side=False):
+            n = len(self._sharded)
+            super().reduce_range(lo, hi, side)
+            if len(self._sharded) > n:
+                self._works[-1].wait()
+                a, b = self._own(lo, hi)
+                self._arena.grads[lo:a] = float("nan")
+                self._arena.grads[b:hi] = float("nan")
+
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base_p = torch.from_numpy(synth.uniform("p", (arena.total,), seed=5))
+    base_g = torch.from_numpy(synth.uniform("g", (arena.total,), seed=3))
+    t0, tshape = arena.layout["field.mlp_base.model.0.hash_table"]
+    tn = int(np.prod(tshape))
+    q4 = tn // 4
+    lo, hi = arena.live_range
+
+    def run(hook):
+        arena.params.copy_(base_p)
+        arena.grads.copy_(base_g * (rank + 1))
+        hook.begin(arena)
+        hook.reduce_range(lo, t0 + q4)            # everything but the middle half of the table is exchanged explicitly ...
+        hook.reduce_range(t0 + 3 * q4, hi)
+        pieces = list(hook.finish_iter())         # ... so (t0 + q4, t0 + 3 q4) is ONE leftover inside one optimiser group: shardable
+        for a, b in pieces:
+            arena.params[a:b] -= 0.1 * arena.grads[a:b]
+        if getattr(hook, "sharded", False):
+            hook.gather_params()
+        return pieces, arena.params.clone()
+
+    _, params_a = run(OverlappedGradReducer(world, side_group=None))
+    hook = _PoisoningReducer(world, rank, min_shard=1024, side_group=None)
+    pieces_b, params_b = run(hook)
+    mid = (t0 + q4, t0 + 3 * q4)
+    was_sharded = mid in hook._sharded.values()
+    own = hook._own(*mid)
+    q.put((rank, was_sharded, own in pieces_b and mid not in pieces_b, bool(torch.isfinite(params_b).all()), bool(torch.equal(params_a, params_b))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_leftover_range_is_owned_and_gathered():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_leftover_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, was_sharded, own_only, finite, same in res:
+        assert was_sharded, "the leftover was meant to be shardable (the test's premise)"
+        assert own_only and finite and same, res
 
 
 def _bf16_worker(rank, world, port, q):

@@ -153,6 +153,40 @@ def test_scaler_sequence_hip_vs_torch_adam_and_skip_on_inf(golden_dir, mode):
         assert kA == kB == ([5] if name.startswith("proposal_networks") else [4]), (name, kA, kB)
 
 
+def test_two_scaler_steps_in_one_iteration_keep_each_others_found_inf(golden_dir):
+    """optimizer_scaler_step_some called TWICE before grad_scaler.update() (two disjoint group lists): the flags the first call raised must
+    still be there when update() collects them -- the per-optimiser found_inf views alias one buffer, and the second call clears only the
+    entries of the optimisers it steps."""
+    import functools
+
+    from nerfstudio_thermal_amd.model import TrainingCallbackLocation as Loc
+    from nerfstudio_thermal_amd.optim import HipFusedAdam
+
+    m, o, rb, batch, jit = _setup(golden_dir, "shared", HipFusedAdam)
+    s = torch.amp.GradScaler("cuda")
+    _reference_train_iteration(m, o, s, rb, batch, 0, True, jit)  # a clean iteration first (optimiser state exists)
+    bad = dict(batch)
+    bad["image"] = torch.full_like(batch["image"], float("inf"))  # reaches fields + camera_opt, not the proposal networks
+    for cb in m.get_training_callbacks():
+        cb.run_callback_at_location(1, Loc.BEFORE_TRAIN_ITERATION)
+    o.zero_grad_some(list(o.optimizers.keys()))
+    with torch.autocast(device_type="cuda"):
+        out = m.get_outputs(m.collider(rb[...]), *jit)
+        loss = functools.reduce(torch.add, m.get_loss_dict(out, bad, m.get_metrics_dict(out, bad)).values())
+    s.scale(loss).backward()
+    first = [g for g in o.optimizers if not g.startswith("proposal_networks")]
+    second = [g for g in o.optimizers if g.startswith("proposal_networks")]
+    before = _snapshot(m)
+    o.optimizer_scaler_step_some(s, first)   # raises found_inf for fields / camera_opt
+    o.optimizer_scaler_step_some(s, second)  # finite gradients: must not wipe the flags above
+    s.update()
+    assert s.get_scale() == 32768.0, "the non-finite gradients of the first call were forgotten"
+    after = _snapshot(m)
+    for g, sl in _group_slices(m).items():
+        same = all(bool(torch.equal(b[sl], a[sl])) for b, a in zip(before, after))
+        assert same != g.startswith("proposal_networks"), g
+
+
 def test_max_norm_clipping_matches_torch(golden_dir):
     """engine/optimizers.py:160-173 with OptimizerConfig.max_norm set: unscale_, clip_grad_norm_, then the step; HipFusedAdam against torch.optim.Adam."""
     from nerfstudio_thermal_amd.optim import HipFusedAdam
