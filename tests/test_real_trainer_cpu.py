@@ -105,6 +105,21 @@ def test_plugin_builds_a_method_specification(ns):
         assert getattr(c.pipeline.model, flag) == getattr(ref.pipeline.model, flag), flag
 
 
+def test_a_method_table_without_the_method_is_an_error_not_a_fallback(ns, monkeypatch):
+    import nerfstudio.configs.method_configs as mc
+
+    table = dict(ns["method_configs"])
+    del table["thermal-nerfacto"]
+    monkeypatch.setattr(mc, "method_configs", table)
+    with pytest.raises(KeyError):
+        ns["plugin"]._build()
+    # and _build() copies: the reference's entry is never mutated
+    monkeypatch.setattr(mc, "method_configs", ns["method_configs"])
+    ref = ns["method_configs"]["thermal-nerfacto"]
+    spec = ns["plugin"]._build()
+    assert spec.config is not ref and spec.config.pipeline is not ref.pipeline and type(ref.pipeline.model).__module__.startswith("nerfstudio.models")
+
+
 def test_switches_and_the_in_tree_name(ns, monkeypatch):
     plugin = ns["plugin"]
     monkeypatch.setenv("TN_FUSED_TRAINER", "0")
