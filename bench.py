@@ -21,7 +21,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: see nerfstudio-thermal_amd/__init__.py
+# (no GPU_MAX_HW_QUEUES here: the schedules fit the runtime's default four hardware queues -- nerfstudio-thermal_amd/__init__.py; the
+# environment's own setting, if any, is reported in the JSON as `hw_queues_env`)
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
@@ -208,8 +209,10 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# bench row -> kernels of profiles/r04_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only
-DOMINANT = "scatter(main grid)"  # the launch pair with the largest share of the step (every step; the proposal grids' only on update steps)
+# bench row -> kernels of profiles/r04_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only.
+# The DOMINANT row (the top-level `roofline` object) is derived from the measured stand-alone times x launches per step (rows of kernel_roofline:
+# proposal-grid rows count only on update steps), not named here.
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X (256 CUs x 4 x 64 FLOP/cycle/SIMD... MI355X_MICROARCH.md); scripts/microbench/mfma_rate.hip sustains 155
 # kernel name + points of the launch; the key in the PMC file also carries the grid's y extent (level groups: "k_grid_bin<false> 196608x4"),
 # which changes with the block size of the bin pass -- matched by prefix
 PMC_KEYS = {
@@ -272,8 +275,24 @@ def kernel_roofline(eng, cam_t, idx):
         ms = time_ms(lambda: ops.hash_scatter(net.table, net.grads["table"], net.num_levels, net.log2_hashmap_size, net.res, b.origins, b.directions,
                                               L.e_bins, g_enc, *dpos, grad_is_zero=not eng.separate))
         rows.append((f"scatter({name})", ms, 2 * N * L.S * net.num_levels * 8 * 8))
+    # ---- the MFMA-bound launches of the main field, stand-alone: forward (prep + XCD-affine gather + chain) and the backward's MLP phase
+    # (k_field_bwd_fused: chain + every weight gradient).  FLOPs are ALGORITHMIC: per sample the base MLP 2 (32 64 + 64 16) = 6 144
+    # and the head 2 (63 64 + 64 64 + 64 4) = 16 768 forward; the backward (d input + d weight of every layer) = twice that.
+    S2 = lv[2].S
+    P2 = N * S2
+    fwd_flop = P2 * (6144 + 16768)
+    ms_f = time_ms(lambda: ops.field_fwd(eng.field, b.origins, b.directions, cam, lv[2].e_bins, training=True))
+    gd, gc = torch.rand_like(lv[2].density), torch.rand_like(b.rgb_samples)
+    ms_b = time_ms(lambda: ops.field_bwd_phase(eng.field, b.origins, b.directions, cam, lv[2].e_bins, gd, gc, None, None, ops._lib.TN_BWD_MLP | ops._lib.TN_BWD_JOIN))
+    mfma = [("tn_field_fwd (k_field_prep + k_field_encode_xcd + k_field_mlp_fwd)", ms_f, fwd_flop, 160 * 4096),
+            ("k_field_bwd_fused (MLP phase of tn_field_bwd)", ms_b, 2 * fwd_flop, 344 * 4096)]
     eng.arena.zero_grad()
-    return rows
+    tiles = (P2 + 31) // 32
+    return rows, [{"kernel": n, "ms": m, "flop_per_launch": fl, "achieved_tflops": fl / (m * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                   "frac": fl / (m * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "issued_mfma_flop_per_launch": tiles * per_tile,
+                   "note": "flop_per_launch = algorithmic (SURVEY.md 8d); issued = MFMA instructions x their FLOPs (the embedding's share was removed by algebra); "
+                           "the forward launch group also holds the HBM/L2-bound gather (about half of its time)"}
+                  for n, m, fl, per_tile in mfma]
 
 
 def step_algorithmic_bytes(arena, mode, rays, update_frac, nerf_samples=48):
@@ -429,11 +448,42 @@ def parity_vs_reference(eng, device):
 
     rgb, th, den = cmp("rgb"), cmp("rgb_thermal"), cmp("density")
     derr = (out["density"].detach().cpu().double() - torch.from_numpy(g["eval/density"]).double()).abs()
-    return {"against": "tests/golden/model_shared_default256.npz = outputs of the reference itself (torch path), 256 rays, 16x2^19 + 2x(5x2^17) tables, eval render",
-            "psnr_rgb_db": rgb["psnr_db"], "psnr_thermal_db": th["psnr_db"], "max_abs_rgb": rgb["max_abs"], "max_abs_thermal": th["max_abs"],
-            "max_abs_density": den["max_abs"], "density_frac_above_1e-4": float((derr > 1e-4).double().mean()),
-            "tolerances": {"rgb_thermal_abs": 1e-3, "density_abs": 1e-4, "note": "density after the WHOLE sampling chain is conditioned by the "
-                           "reference's own 1-ulp response (1.2e-4, tests/test_conditioning_cpu.py); strict 1e-4 holds on identical samples (tests/test_model_gpu.py)"}}
+    res = {"against": "tests/golden/model_shared_default256.npz = outputs of the reference itself (torch path), 256 rays, 16x2^19 + 2x(5x2^17) tables, eval render",
+           "psnr_rgb_db": rgb["psnr_db"], "psnr_thermal_db": th["psnr_db"], "max_abs_rgb": rgb["max_abs"], "max_abs_thermal": th["max_abs"],
+           "max_abs_density": den["max_abs"], "density_frac_above_1e-4": float((derr > 1e-4).double().mean()),
+           "tolerances": {"rgb_thermal_abs": 1e-3, "density_abs": 1e-4, "note": "density after the WHOLE sampling chain is conditioned by the "
+                          "reference's own 1-ulp response (1.3e-4, tests/test_conditioning_cpu.py); strict 1e-4 holds on identical samples (tests/test_model_gpu.py)"}}
+    # ---- conditioning of the chain, tracked per round: the error as a multiple of the reference arithmetic's own response to ONE ulp of its field
+    # sample bins (tests/golden/conditioning.json: data written by oracle/make_conditioning.py; the test bound is K_CHAIN = 6), its share above 1e-4
+    # against the reference's share under +-4 ulps, and how many of the HIP sampler's resampled bins sit more than 64 ulps from the reference's
+    # (train forward with the golden's jitter: a bin that fell into the neighbouring CDF interval)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "conditioning.json")) as f:
+            cond = json.load(f)["shared/default256"]
+        res["density_err_over_1ulp_response"] = den["max_abs"] / cond["ulp1_max"]
+        res["density_share_above_1e-4_over_reference_share_at_4ulp"] = res["density_frac_above_1e-4"] / cond["ulp4_frac_above_1e-4"]
+        res["conditioning"] = {"reference_1ulp_max": cond["ulp1_max"], "reference_4ulp_share_above_1e-4": cond["ulp4_frac_above_1e-4"], "test_bound_K_CHAIN": 6.0}
+        from nerfstudio_thermal_amd import synth
+
+        n = int(g["num_rays"])
+        jit = [torch.from_numpy(j).to(device).reshape(-1).contiguous() for j in synth.synth_jitters(n)]
+        saved = eng.anneal
+        eng.set_anneal_for_step(500)
+        assert abs(eng.anneal - float(g["train/anneal"])) < 1e-12
+        _, br = eng.get_outputs(o, d, cam, True, jit, None)
+        eng.anneal = saved
+        shares = {}
+        for i, lv in enumerate(br[""].levels):
+            a = lv.e_bins.detach().cpu().contiguous().view(torch.int32).to(torch.int64)
+            b = torch.from_numpy(np.ascontiguousarray(g[f"train/ebins_{i}"])).view(torch.int32).to(torch.int64)
+            dist = (a - b).abs()  # positive floats: the int32 views are monotone in the value
+            shares[f"level{i}"] = {"identical": float((dist == 0).double().mean()), "within_4ulp": float((dist <= 4).double().mean()),
+                                   "beyond_64ulp": float((dist > 64).double().mean())}
+        res["sampler_bins_vs_reference_ulp"] = shares
+        res["bins_beyond_64ulp_share"] = shares["level2"]["beyond_64ulp"]
+    except Exception as e:  # noqa: BLE001  (diagnostics never cost the parity block)
+        res["conditioning_error"] = repr(e)
+    return res
 
 
 def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
@@ -587,6 +637,10 @@ def main():
     ap.add_argument("--dp-bf16", action="store_true", help="N>1: the big gradient slices travel as bfloat16 (half the bytes per xGMI link; changes numerics)")
     ap.add_argument("--force-dp", action="store_true", help="diagnostic: run the N>1 schedule (phased backward + overlapped RCCL all-reduce) on a "
                     "1-rank process group, to see what the schedule itself costs")
+    ap.add_argument("--force-dp-sum", action="store_true", help="--force-dp: let the one-rank group exchange with SUM (RCCL launches nothing in place) instead of "
+                    "AVG (a real RCCL kernel beside the folds, what N > 1 runs): the schedule's own cost without any collective kernel")
+    ap.add_argument("--no-dp-guard", action="store_true", help="N>1 / --force-dp: skip parallel.ScheduleGuard (a few plain and a few overlapped steps are timed before "
+                    "the warm-up, and a few of the simple schedule; the faster of the two real schedules runs -- switched in process)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launcher test: spawn / join the ranks, all-reduce once, print the rank count, exit")
     ap.add_argument("--long-steps", type=int, default=200, help="extra steps after the timed region for the BASELINE.md 3.4 figure (median of >= 200 "
                     "per-step times, reported as extra keys; `value` always follows --steps).  0 disables")
@@ -654,12 +708,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if not args.force_dp_sum:
+            # AVG on the one-rank group: RCCL then runs a real kernel over every exchanged slice, beside the folds -- as N > 1 does.  (With SUM a
+            # one-rank group launches nothing: --force-dp-sum measures the schedule without any collective kernel.)
+            os.environ["TN_DP_ONE_RANK_AVG"] = "1"
         torch.distributed.init_process_group("nccl", rank=0, world_size=1)
         hook = make_hook(1)
         if args.dp_adam_per_range:
             hook.adam_per_range = True
         if args.dp_chunks == 0:
-            hook.world = 2  # GradAllReducer returns early at world 1: make it issue the collective (the 1/2 scale does not matter here)
+            hook.force = True  # GradAllReducer returns early at world 1: make it issue the collective
 
     def barrier():
         if world > 1:
@@ -686,6 +744,44 @@ def main():
         if api:
             return one_step_api(model, optimizers, cam_t, cache, rays, step, scaler, call=ddp)
         return one_step(eng, cam_t, cache, rays, step, hook, scaler)
+
+    # ---- parallel.ScheduleGuard: the overlapped data-parallel schedule against the plain step, measured here, before the warm-up.  A stall of the
+    # overlapped schedule switches the run to the simple one IN PROCESS; the JSON says which schedule ran and why.
+    dp_info = None
+    if hook is not None and not api:
+        dp_info = {"schedule": "overlapped" if getattr(hook, "pipelined", False) else "simple", "guard": None,
+                   "streams": "main + one side stream (both proposal networks) + RCCL's; d position in line; one communicator, proposal exchange issued last",
+                   "one_rank_reduce_op": (None if world > 1 else ("SUM" if args.force_dp_sum else "AVG"))}
+        if getattr(hook, "pipelined", False) and not args.no_dp_guard and not args.dp_shard_optimizer and args.mode == "shared":
+            from nerfstudio_thermal_amd.parallel import ScheduleGuard
+
+            guard = ScheduleGuard(world)
+
+            def timed(h, n=6, skip=2):
+                nonlocal gstep
+                ts = []
+                for _ in range(n):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    one_step(eng, cam_t, cache, rays, gstep, h, scaler)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                    gstep += 1
+                return float(np.median(ts[skip:]))
+
+            gstep = 0
+            simple_hook = GradAllReducer(world, force=(world == 1))
+            plain_ms = timed(None)        # un-exchanged steps: every rank drifts on its own rays ...
+            over_ms = timed(hook)
+            simple_ms = timed(simple_hook)
+            dec = guard.decide(plain_ms, over_ms, simple_ms)
+            guard.resync(arena)           # ... and is brought back to rank 0's parameters and Adam moments here
+            dp_info["guard"] = dec
+            if dec["schedule"] == "simple":
+                hook = simple_hook
+                dp_info["schedule"] = "simple (picked by the guard: overlapped step %.2f ms, simple step %.2f ms, plain step %.2f ms)" % (
+                    dec["overlapped_ms"], dec["simple_ms"], dec["plain_ms"])
+                print("bench.py: " + dp_info["schedule"], file=sys.stderr)
 
     # The "render PSNR vs ref" half of the metric, on the untouched synthetic weights the reference golden was rendered with (before any training
     # step changes them, outside every timed region)
@@ -782,11 +878,15 @@ def main():
                 in_step = {"mean_ms": float(np.mean([t for t, _ in tms])),
                            "mean_ms_update_steps": float(np.mean([t for t, u in tms if u])) if any(u for _, u in tms) else None,
                            "mean_ms_other_steps": float(np.mean([t for t, u in tms if not u])) if any(not u for _, u in tms) else None}
-        rows = kernel_roofline(eng, cam_t, idx)
+        rows, mfma_rows = kernel_roofline(eng, cam_t, idx)
         if args.ops:
             for name, ms, nbytes in rows:
                 print(f"{name:60s} {ms*1e3:9.1f} us  {nbytes/ms/1e6:8.1f} GB/s algorithmic", file=sys.stderr)
-        name, ms, nbytes = next(r for r in rows if r[0] == DOMINANT)
+        # the dominant HBM-bound launch (pair) = largest measured share of a step: stand-alone time x launches per step (the proposal grids'
+        # scatters run on update steps only).  The MFMA-bound kernel has its own object (`roofline.mfma`).
+        upd_share = updates / max(args.steps, 1)
+        shares = {r[0]: r[1] * (upd_share if "prop" in r[0] and r[0].startswith("scatter") else 1.0) for r in rows}
+        name, ms, nbytes = max(rows, key=lambda r: shares[r[0]])
         achieved = nbytes / (ms * 1e-3) / 1e9
         pmc, why = load_pmc() if (rays == 4096 and args.mode == "shared") else (None, "PMC passes cover the 4096-ray shared workload only")
         traffic = None
@@ -805,7 +905,10 @@ def main():
                     "frac_in_step": None if in_step is None else nbytes / (in_step["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "note": "the main grid's scatter entry point = k_grid_bin + k_grid_fold as the field backward calls it (d position comes from "
                             "k_field_dpos); the bin pass is bound by instruction issue, the fold streams its records into double-precision LDS atomics",
-                    "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9} for n, m, bts in rows},
+                    "dominant_by": {"rule": "stand-alone ms x launches per step at this run's proposal-update fraction", "ms_per_step": shares},
+                    "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9, "frac": bts / (m * 1e-3) / 1e9 / HBM_PEAK_GBS} for n, m, bts in rows},
+                    # the MFMA-bound launches (fp32 MFMA: v_mfma_f32_32x32x2_f32 / 16x16x4_f32): achieved TFLOP/s against the dense fp32 peak
+                    "mfma": mfma_rows[1], "mfma_all": mfma_rows,
                     # SURVEY 8d's whole-step figure: (N x bytes_ray + bytes_step) / t_step against the HBM peak
                     "step": {"algorithmic_bytes": step_bytes, "achieved": step_gbs, "frac": step_gbs / HBM_PEAK_GBS, "proposal_update_fraction": upd}}
         if traffic is None:
@@ -836,6 +939,8 @@ def main():
                        "final_loss": final_loss},
             "rccl_ranks": rccl_ranks,
             "per_rank_ms_per_step": per_rank_ms,
+            "dp": dp_info,
+            "hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"),
             "long_run": long_run,
             "roofline": roofline,
         }
@@ -869,11 +974,6 @@ def main():
                 result["cpu_baseline"]["other_thread_counts"] = {"8": {"value": v8, "s_per_step": t8, "steps": 2},
                                                                  "1": {"value": v1, "s_per_step": t1, "steps": 1, "rays": rays // 4}}
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-        if (world > 1 or args.force_dp) and not api and args.mode == "shared" and rays == RAYS_PER_GPU and result["ms_per_step"] > 1.5:
-            # (diagnostic on stderr only: DESIGN.md section 8.0 -- with an unlucky placement of the streams on the runtime's hardware queues every step
-            # idles ~0.9 ms; measured on one rank with GPU_MAX_HW_QUEUES=4, while 2 / 3 / 8 run at 0.89-1.01 ms)
-            print(f"bench.py: {result['ms_per_step']:.2f} ms per step is ~1 ms above what this schedule takes on one rank (0.9 ms): if rocprofv3 shows the GPU idle "
-                  "between two kernels of the main stream, try another GPU_MAX_HW_QUEUES (the package sets 8 unless the environment has a value)", file=sys.stderr)
         print(json.dumps(result))
     barrier()
     if torch.distributed.is_initialized():

@@ -6,17 +6,14 @@ There is no CPU fallback: every op raises if the HIP library is missing.
 """
 __version__ = "0.1.0"
 
-import os as _os
-
-# The data-parallel step keeps six HIP streams busy (main, proposal side stream, the library's companion stream for the weight-gradient
-# GEMMs, two RCCL communicators, copies).  The ROCm runtime multiplexes a process's streams onto 4 hardware queues by default; a stream
-# that shares a queue with another one serialises behind it -- e.g. an all-reduce waiting for the proposal backward blocks the main
-# stream's kernels queued after it (bench.py --force-dp: 2.75 ms/step with 4 queues, 1.42 ms with 8; the single-GPU step does not care).
-# Round 4 sweep of the one-rank data-parallel step (profiles/r04_experiments.md): 8 -> 0.887 ms, 6 / 12 / 16 / 24 -> ~1.02, 4 / 5 / 7 -> 1.8-2.1 (the GPU idles
-# ~0.9 ms per step), 2 / 3 -> 0.94-1.01; the single-GPU step is the same with 3, 4 and 8.  The runtime deals streams onto the queues in creation order, so
-# the best count belongs to THIS set of streams: with another one (more communicators, another torch version) re-measure.
-# Must be in the environment before the first HIP call of the process; an explicit setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Hardware queues.  The ROCm runtime multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that
+# share a queue serialise behind each other.  The package does NOT touch the environment (round 4 wrote GPU_MAX_HW_QUEUES=8 into it at import:
+# process-global, silently ignored once HIP is initialised, and the optimum of one particular set of streams).  Instead the schedules fit the
+# default: the single-GPU step uses four streams on proposal-update iterations (main, two proposal side streams, the d-position companion) and
+# one otherwise; the data-parallel step uses three (main, ONE side stream for both proposal networks, RCCL's) -- profiles/r05_dp_hwq_sweep.json
+# holds bench.py --force-dp for GPU_MAX_HW_QUEUES in {unset, 4, 5, 7, 8, 16}.  If a deployment adds streams of its own (more communicators, a
+# prefetcher), GPU_MAX_HW_QUEUES=8 in the job's environment is the first thing to try, and parallel.ScheduleGuard falls back to the
+# simple schedule in process when the overlapped one measures slower than it should.
 
 
 def configure_host(single_thread_backward: bool = True) -> None:

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
   //       j < lim (delta = bucket * cap + reserved base - staging offset; lim = staging offset + room left in the bucket), else the bucket is full
   __shared__ uint32_t s_cnt[BIN_MAX_COUNTERS], s_loff[BIN_MAX_COUNTERS];
   __shared__ uint2 s_dl[BIN_MAX_COUNTERS];
-  __shared__ uint32_t s_tot[TN_MAX_LEVELS];
+  __shared__ uint32_t s_tot[TN_MAX_LEVELS], s_lb[TN_MAX_LEVELS];
   __shared__ uint32_t s_idx[BIN_THREADS * 8];
   __shared__ float2 s_val[BIN_THREADS * 8];
   const int lane = tn_lane();
@@ -424,87 +424,102 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
     if (lane == 0) s_tot[li] = run;
   }
   __syncthreads();
-  // ---- phase B: values, ranks, staging in bucket order, coalesced copy-out
+  // ---- phase B: values, ranks, staging in bucket order, coalesced copy-out -- in ROUNDS of consecutive levels of the block.  Phase A knows how
+  // many records every level stages (s_tot), so as many levels as fit the staging area share one round = one pair of block barriers: on the
+  // levels where same-cell runs are merged a block stages a few hundred records, not 4096 (the proposal grids: all five levels in one round),
+  // and the pass spent more than half of its wave-cycles parked at those barriers (profiles/r04_pmc.json).  A staged record carries its level
+  // (bits 24+ of s_idx; slots have at most 20 bits on this path) and s_lb holds the level's first staging position of the round.
   float dpx = 0.f, dpy = 0.f, dpz = 0.f;
   const uint32_t smask = (1u << bk.slice_log2) - 1u;
+  int li0 = 0;
 #pragma unroll 1
-  for (int li = 0; li < nlev; ++li) {
-    const int l = blockIdx.y + li * level_groups;
-    const float res = g.res[l];
-    const bool merge = (bk.merge_mask >> l) & 1u;
-    BinLevel b;
-    if (!WANT_DPOS && li == 0) b = bfirst;
-    else bin_level(c, res, g.mask, merge, live, lane, b);
-    // row-major [P][ld], or level-major [L][P] float2 (TN_LD_LEVEL_MAJOR: the 64 lanes of a wave then read four runs of 16 consecutive float2
-    // instead of 64 pieces of 8 bytes 128 B apart -- 114 MB fetched for the main grid's 25 MB of d enc)
-    float2 gv = make_float2(0.f, 0.f);
-    if (li < GVP) {
+  while (li0 < nlev) {
+    uint32_t round_total = s_tot[li0];
+    int li1 = li0 + 1;
+    while (li1 < nlev && round_total + s_tot[li1] <= (uint32_t)(BIN_THREADS * 8)) round_total += s_tot[li1++];
+    uint32_t lbase = 0;
+#pragma unroll 1
+    for (int li = li0; li < li1; ++li) {
+      const int l = blockIdx.y + li * level_groups;
+      const float res = g.res[l];
+      const bool merge = (bk.merge_mask >> l) & 1u;
+      BinLevel b;
+      if (!WANT_DPOS && li == 0) b = bfirst;
+      else bin_level(c, res, g.mask, merge, live, lane, b);
+      // row-major [P][ld], or level-major [L][P] float2 (TN_LD_LEVEL_MAJOR: the 64 lanes of a wave then read four runs of 16 consecutive float2
+      // instead of 64 pieces of 8 bytes 128 B apart -- 114 MB fetched for the main grid's 25 MB of d enc)
+      float2 gv = make_float2(0.f, 0.f);
+      if (li < GVP) {
 #pragma unroll
-      for (int q = 0; q < GVP; ++q)
-        if (q == li) gv = gvp[q];
-    } else if (live) {
-      gv = *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p);
-    }
-    if (WANT_DPOS) {
-      // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
-      const float2* tb = g.table + (size_t)l * g.tsize;
-      float sk[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float2 t = tb[b.idx[k]];
-        sk[k] = gv.x * t.x + gv.y * t.y;
+        for (int q = 0; q < GVP; ++q)
+          if (q == li) gv = gvp[q];
+      } else if (live) {
+        gv = *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p);
       }
-      float ax = 0.f, ay = 0.f, az = 0.f;
+      if (WANT_DPOS) {
+        // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
+        const float2* tb = g.table + (size_t)l * g.tsize;
+        float sk[8];
 #pragma unroll
-      for (int v = 0; v < 2; ++v)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          ax += b.wy[u] * b.wz[v] * (sk[1 + 2 * u + 4 * v] - sk[0 + 2 * u + 4 * v]);
-          ay += b.wx[u] * b.wz[v] * (sk[u + 2 + 4 * v] - sk[u + 0 + 4 * v]);
-          az += b.wx[u] * b.wy[v] * (sk[u + 2 * v + 4] - sk[u + 2 * v + 0]);
+        for (int k = 0; k < 8; ++k) {
+          const float2 t = tb[b.idx[k]];
+          sk[k] = gv.x * t.x + gv.y * t.y;
         }
-      dpx += ax * res;
-      dpy += ay * res;
-      dpz += az * res;
-    }
-    float vx[8], vy[8];
+        float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float w = b.wx[k & 1] * b.wy[(k >> 1) & 1] * b.wz[k >> 2];
-      vx[k] = w * gv.x;
-      vy[k] = w * gv.y;
-    }
-    if (merge && b.maxlen > 1) bin_run_sums(vx, vy, lane, b);  // the run's last lane ends up with the run's sums
-    if (b.emit) {
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            ax += b.wy[u] * b.wz[v] * (sk[1 + 2 * u + 4 * v] - sk[0 + 2 * u + 4 * v]);
+            ay += b.wx[u] * b.wz[v] * (sk[u + 2 + 4 * v] - sk[u + 0 + 4 * v]);
+            az += b.wx[u] * b.wy[v] * (sk[u + 2 * v + 4] - sk[u + 2 * v + 0]);
+          }
+        dpx += ax * res;
+        dpy += ay * res;
+        dpz += az * res;
+      }
+      float vx[8], vy[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const uint32_t pos = atomicAdd(&s_cnt[li * ns + (b.idx[k] >> bk.slice_log2)], 1u);
-        s_idx[pos] = b.idx[k];
-        s_val[pos] = make_float2(vx[k], vy[k]);
+        const float w = b.wx[k & 1] * b.wy[(k >> 1) & 1] * b.wz[k >> 2];
+        vx[k] = w * gv.x;
+        vy[k] = w * gv.y;
       }
-    }
-    if (li == 0 && my_li < nlev) {  // the reservations of this wave's level have had the whole first level's staging to come back
+      if (merge && b.maxlen > 1) bin_run_sums(vx, vy, lane, b);  // the run's last lane ends up with the run's sums
+      if (tid == 0) s_lb[li] = lbase;
+      if (b.emit) {
+        const uint32_t tag = (uint32_t)li << 24;
 #pragma unroll
-      for (int u = 0; u < GB; ++u) {
-        const int sl = u * 64 + lane;
-        if (u * 64 < ns && sl < ns) {
-          const uint32_t loff = s_loff[my_li * ns + sl], r = gb[u];
-          s_dl[my_li * ns + sl] = make_uint2((uint32_t)sl * bk.cap + r - loff, loff + (r < bk.cap ? bk.cap - r : 0u));
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t pos = atomicAdd(&s_cnt[li * ns + (b.idx[k] >> bk.slice_log2)], 1u) + lbase;
+          s_idx[pos] = b.idx[k] | tag;
+          s_val[pos] = make_float2(vx[k], vy[k]);
+        }
+      }
+      lbase += s_tot[li];
+      if (li == 0 && my_li < nlev) {  // the reservations of this wave's level have had the whole first level's staging to come back
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const int sl = u * 64 + lane;
+          if (u * 64 < ns && sl < ns) {
+            const uint32_t loff = s_loff[my_li * ns + sl], r = gb[u];
+            s_dl[my_li * ns + sl] = make_uint2((uint32_t)sl * bk.cap + r - loff, loff + (r < bk.cap ? bk.cap - r : 0u));
+          }
         }
       }
     }
     __syncthreads();
-    const uint32_t total = s_tot[li];
-    uint16_t* __restrict__ idx_l = bk.idx + (size_t)l * bk.level_stride;  // (wave-uniform bases + 32-bit record offsets: nslices * cap < 2^32)
-    float2* __restrict__ val_l = bk.val + (size_t)l * bk.level_stride;
-    for (uint32_t j = tid; j < total; j += BIN_THREADS) {
-      const uint32_t id = s_idx[j];
-      const float2 v = s_val[j];
-      const uint2 dl = s_dl[li * ns + (id >> bk.slice_log2)];
+    for (uint32_t J = tid; J < round_total; J += BIN_THREADS) {
+      const uint32_t tagged = s_idx[J];
+      const float2 v = s_val[J];
+      const uint32_t lr = tagged >> 24, id = tagged & 0xffffffu;
+      const uint32_t l = blockIdx.y + lr * (uint32_t)level_groups;
+      const uint32_t j = J - s_lb[lr];  // position among the level's staged records
+      const uint2 dl = s_dl[lr * ns + (id >> bk.slice_log2)];
       if (j < dl.y) {
-        const uint32_t at = j + dl.x;
-        idx_l[at] = (uint16_t)(id & smask);
-        val_l[at] = v;
+        const size_t at = (size_t)l * bk.level_stride + (j + dl.x);  // nslices * cap < 2^32 per level
+        bk.idx[at] = (uint16_t)(id & smask);
+        bk.val[at] = v;
       } else {  // bucket full: add straight into the gradient
         float* dst = reinterpret_cast<float*>(g.grad + (size_t)l * g.tsize + id);
         if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
@@ -512,7 +527,8 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
         if (g.nonfinite != nullptr && ((v.x - v.x) + (v.y - v.y)) != 0.0f) *g.nonfinite = 1.0f;
       }
     }
-    __syncthreads();  // the staging area is reused by the next level
+    __syncthreads();  // the staging area is reused by the next round
+    li0 = li1;
   }
   if (WANT_DPOS) {
     float wxg, wyg, wzg;

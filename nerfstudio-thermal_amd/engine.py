@@ -435,14 +435,16 @@ class RenderEngine:
             if d_dens_extra[sfx] is not None:
                 d_dens += d_dens_extra[sfx]
             # The proposal networks' backward (own tables, MLPs and scatter; d origins / d directions are accumulated atomically) is
-            # independent of the main field's and runs on ONE side stream: with the library's companion streams (tn_fork) that makes four
-            # streams, the number of hardware queues ROCm multiplexes streams onto by default -- a fifth stream shares a queue with another
-            # and serialises behind it (measured: one side stream per proposal level made the step 1.7x slower).
+            # independent of the main field's and runs on side streams.
+            #   plain step: level 0 on one side stream, level 1 on a second one (both beside the field's backward, which also forks d position
+            #   to the library's companion stream) -- measured 1.249 -> 1.216 ms per step against one shared side stream.
+            #   data-parallel schedule: BOTH levels, one after the other, on ONE side stream, and nothing else forks (d position runs in line).
+            #   The step then keeps three streams busy -- main, this one, RCCL's -- so that with the runtime's DEFAULT four hardware queues every
+            #   busy stream has a queue of its own.  Round 4's schedule (side stream + companion stream + level 1 behind the table ranges + two
+            #   communicators) ran at 0.89 ms with GPU_MAX_HW_QUEUES=8 and stalled at 1.8-2.1 ms with 4 / 5 / 7: which streams shared a queue
+            #   decided a factor of two (profiles/r04_experiments.md; sweep of this schedule: profiles/r05_dp_hwq_sweep.json).
             side = None
-            # The level-0 network (256 samples per ray: 2/3 of the proposal work) goes to the first side stream.  Both levels on ONE side
-            # stream left the main stream idle for the last ~250 us of every proposal-update step (rocprofv3 timeline of the step); the
-            # level-1 network gets a side stream of its own below (data-parallel schedule: behind the table ranges on the main stream).
-            on_side = (0,)
+            on_side = (0, 1) if pipelined else (0,)
             if br.prop_grad:
                 side = self._side_stream()
                 main = torch.cuda.current_stream()
@@ -451,17 +453,11 @@ class RenderEngine:
                     for i in on_side:
                         dd = ops.weights_bwd(lv[i].e_bins, lv[i].density, lv[i].weights, dws[i])
                         ops.prop_density_bwd(props[i], br.origins, br.directions, lv[i].e_bins, dd, d_o, d_d, tag=f"side{i}")
-                        if pipelined:  # this network's gradients are final: exchange them while the next one / the main field is still at work
-                            glo, ghi = self.arena.group_range["proposal_networks"]
-                            first = [self.arena.layout[f"proposal_networks.{k}.mlp_base.0.hash_table"][0] for k in range(2)]
-                            dp.reduce_range(first[i] if i else glo, first[i + 1] if i + 1 < 2 else ghi, side=True)
             if pipelined:
                 # main table in level ranges: each range's all-reduce runs beside the scatter of the next one
                 ph = ops._lib
-                # (d position beside the scatter only when the proposal networks' backward keeps other queues busy anyway: alone it stretches
-                # the bin pass by more than it hides, as in the plain step)
-                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d,
-                                    ph.TN_BWD_MLP | (ph.TN_BWD_FORK_DPOS if br.prop_grad else 0))
+                # (d position in line: one stream less -- see above)
+                ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_MLP)
                 if _FUSE and pose is not None and not br.prop_grad:
                     # Nothing else adds to d origins / d directions on a step without a proposal update: the pose gradient (+ the loss sums and
                     # the camera regulariser) can be finished NOW, and with it everything behind the table in the arena is final -- MLP
@@ -497,11 +493,6 @@ class RenderEngine:
                                         ph.TN_BWD_SCATTER_FOLD if two_step else ph.TN_BWD_SCATTER, lb, le)
                     dp.reduce_range(t0 + lb * T2, t0 + le * T2)
                 ops.field_bwd_phase(fld, br.origins, br.directions, cam, lv[2].e_bins, d_dens, d_rgb, d_o, d_d, ph.TN_BWD_JOIN)
-                if br.prop_grad:  # the level-1 proposal network, behind the table ranges on the main stream and the main communicator
-                    dd = ops.weights_bwd(lv[1].e_bins, lv[1].density, lv[1].weights, dws[1])
-                    ops.prop_density_bwd(props[1], br.origins, br.directions, lv[1].e_bins, dd, d_o, d_d, tag="main1")
-                    glo, ghi = self.arena.group_range["proposal_networks"]
-                    dp.reduce_range(self.arena.layout["proposal_networks.1.mlp_base.0.hash_table"][0], ghi)
             else:
                 # the level-1 network on a second side stream (the package asks the runtime for 8 hardware queues, see __init__.py; with
                 # the default 4 a fifth busy stream shares a queue and serialises).  Measured: 1.249 -> 1.216 ms per step.
@@ -531,6 +522,11 @@ class RenderEngine:
                     torch.cuda.current_stream().wait_stream(side1)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
+                if pipelined:
+                    # both proposal networks' gradients are final: ONE collective for the group, on the same communicator as the table ranges and
+                    # issued behind them (a communicator runs its collectives in issue order: ahead of the table ranges it would hold them up until
+                    # the whole proposal backward is through, which is why round 4 needed a second communicator)
+                    dp.reduce_range(*self.arena.group_range["proposal_networks"])
             br._d_o, br._d_d = d_o, d_d  # cross-evaluation gradients are added below before the pose backward
         if self.separate and c.density_loss_mult > 0:
             # density2 = field at the thermal branch's samples/rays; density2_thermal = field_thermal at the rgb branch's

@@ -43,15 +43,18 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
 
 
 class GradAllReducer:
-    """Mean all-reduce of the arena's live gradient range.  Use as `grad_hook` of RenderEngine.train_step."""
+    """Mean all-reduce of the arena's live gradient range AFTER the backward pass: the simple schedule (no side streams beyond the plain step's,
+    no collective beside a kernel).  Use as `grad_hook` of RenderEngine.train_step.  force=True issues the collective on a one-rank group too
+    (bench.py --force-dp --dp-chunks 0: the measurement wants RCCL's launch in the step)."""
 
-    def __init__(self, world_size: int, chunks: int = 1, group=None):
+    def __init__(self, world_size: int, chunks: int = 1, group=None, force: bool = False):
         self.world = world_size
         self.chunks = max(1, chunks)
         self.group = group
+        self.force = force
 
     def __call__(self, arena) -> None:
-        if self.world <= 1:
+        if self.world <= 1 and not (self.force and dist.is_initialized()):
             return
         lo, hi = arena.live_range
         flat = arena.grads[lo:hi]
@@ -62,7 +65,56 @@ class GradAllReducer:
             works.append(dist.all_reduce(flat[s : s + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
-        flat.mul_(1.0 / self.world)
+        if self.world > 1:
+            flat.mul_(1.0 / self.world)
+
+
+class ScheduleGuard:
+    """Picks the data-parallel schedule from MEASURED step times, in process, before the run proper.
+
+    The overlapped schedule (OverlappedGradReducer: table level ranges exchanged beside the folds, the proposal networks on a side stream) keeps
+    three streams busy.  On this runtime, kernels of two busy hardware queues slow each other down by far more than the work they share, and
+    which streams share a queue is decided by GPU_MAX_HW_QUEUES and stream creation order (profiles/r05_dp_hwq_sweep.json:
+    the one-rank overlapped step runs at 0.94 ms with the default 4 queues and at 1.25-1.5 ms with 5-16).  The schedule was cut down to three
+    streams so that the default suffices, and this guard is the belt to those braces: the caller times a few steps WITHOUT any exchange (the
+    plain step), a few with the overlapped schedule and a few with the simple one (GradAllReducer: one all-reduce after the backward, no stream
+    beyond the plain step's), and the faster of the two real schedules runs.  Never re-execs, never touches the environment.
+
+    All ranks must take the same branch (the collectives of the two schedules differ): the times are MAX-reduced over the group first.
+    The plain steps apply UN-exchanged gradients: afterwards `resync(arena)` makes rank 0's parameters and Adam moments everybody's."""
+
+    def __init__(self, world_size: int, ratio: float = 1.5, group=None):
+        self.world, self.ratio, self.group = world_size, float(ratio), group
+        self.decision: Optional[dict] = None
+
+    def decide(self, plain_ms: float, overlapped_ms: float, simple_ms: Optional[float] = None) -> dict:
+        """Times in ms per step, measured by the caller on THIS rank; every rank gets the same answer (MAX over the group first).
+        Without `simple_ms`: the overlapped schedule is dropped when it costs more than ratio x the plain step (the stall signature).
+        With `simple_ms` (the simple schedule timed too -- what bench.py does): the FASTER of the two real schedules runs; the overlapped one is
+        kept unless the simple one beats it by more than 5 % (on N > 1 an overlapped step may legitimately exceed ratio x plain -- the exchange of
+        78 MB over one xGMI link takes longer than the whole backward -- and still be the better schedule)."""
+        t = torch.tensor([float(plain_ms), float(overlapped_ms), float("nan") if simple_ms is None else float(simple_ms)], dtype=torch.float64)
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            nan = torch.isnan(t)
+            t = torch.where(nan, torch.full_like(t, float("inf")), t).to(dev)  # (MAX over ranks must not lose a NaN)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            t = t.cpu()
+            t = torch.where(torch.isinf(t), torch.full_like(t, float("nan")), t)
+        plain, over, simple = float(t[0]), float(t[1]), float(t[2])
+        stalled = not (over <= self.ratio * plain)  # (a NaN time counts as a stall)
+        if simple_ms is None or simple != simple:
+            pick = "simple" if stalled else "overlapped"
+        else:
+            pick = "overlapped" if (over == over and over <= simple / 0.95) else "simple"
+        self.decision = {"schedule": pick, "plain_ms": plain, "overlapped_ms": over, "simple_ms": None if simple != simple else simple,
+                         "ratio": over / plain if plain > 0 else float("inf"), "threshold": self.ratio, "stalled": stalled}
+        return self.decision
+
+    def resync(self, arena, src: int = 0) -> None:
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for t in (arena.params, arena.exp_avg, arena.exp_avg_sq):
+                dist.broadcast(t, src=src, group=self.group)
 
 
 class OverlappedGradReducer:

@@ -32,11 +32,24 @@ def main():
         print(f"{name:<78} calls={calls:5d} avg_us={avg:9.1f} tot_ms={tot:8.2f} {pct:5.1f}%")
     if "--tail" in sys.argv:
         n = int(sys.argv[sys.argv.index("--tail") + 1])
-        print(f"\nstand-alone launches (last {n} of each):")
-        for r in rows[:12]:
+        # Only the kernels bench.py launches ALONE after the steps (kernel_roofline: the proposal forward, the three table scatters, the main field's
+        # forward launch group and its backward MLP phase) have a stand-alone tail; for every other kernel the last launches are in-step launches
+        # (round 4 printed those under the same heading: profiles/r04_bench_n1_kernel_stats_tail.txt lists k_prop_bwd_mlp at 191.7 us there).
+        alone = ("k_prop_fwd", "k_grid_bin", "k_grid_fold", "k_field_prep", "k_field_encode_xcd", "k_field_mlp_fwd", "k_field_bwd_fused", "k_field_pack",
+                 "k_field_emb_finish")
+        is_alone = lambda name: any(a in name for a in alone)  # noqa: E731
+
+        def tail(r):
             q = f"select end-start from kernels where name=? {'and ' + gx + '=?' if split and gx else ''} order by start desc limit {n}"
             d = [x[0] for x in con.execute(q, (r[0], r[1]) if split and gx else (r[0],))]
-            print(f"{r[0][:60]:<62}{(' [grid %d]' % r[1]) if split and gx else '':<16} tail_avg_us={sum(d) / len(d) / 1e3:9.1f}")
+            return f"{r[0][:60]:<62}{(' [grid %d]' % r[1]) if split and gx else '':<16} tail_avg_us={sum(d) / len(d) / 1e3:9.1f}"
+
+        print(f"\nSTAND-ALONE launches (last {n} of each; kernels bench.py launches alone after the steps -- reproduces roofline.avg_launch_ms / roofline.mfma):")
+        for r in [r for r in rows if is_alone(r[0])][:14]:
+            print(tail(r))
+        print(f"\nIN-STEP launches (last {n} of each; kernels that only ever run inside a training step, beside whatever the step runs on other streams -- NOT stand-alone):")
+        for r in [r for r in rows if not is_alone(r[0])][:12]:
+            print(tail(r))
     if len(args) > 1:
         with open(args[1], "w", newline="") as f:
             w = csv.writer(f)

@@ -22,3 +22,19 @@ def test_default_size_sensitivity_is_reported(golden_dir):
     """Same measurement at the shipped table sizes (16 x 2^19, 5 x 2^17), 64 rays: the bound the default-size chained tests derive theirs from."""
     s = oracle_density_sensitivity(golden_dir, "shared", "default")[""]
     assert 1e-6 < s["max"] < 5e-3, s
+
+
+def test_conditioning_fixture_is_what_the_oracle_measures(golden_dir):
+    """tests/golden/conditioning.json (oracle/make_conditioning.py) -- the file bench.py reads for `parity.density_err_over_1ulp_response` --
+    against a fresh measurement on the default-size, 64-ray set."""
+    import json
+    import os
+
+    with open(os.path.join(golden_dir, "conditioning.json")) as f:
+        fx = json.load(f)
+    assert set(fx) == {"shared/tiny", "shared/default", "shared/default256"}
+    s1 = oracle_density_sensitivity(golden_dir, "shared", "default", ulps=1)[""]
+    assert fx["shared/default"]["ulp1_max"] == pytest.approx(s1["max"], rel=1e-3)
+    assert fx["shared/default"]["ulp1_frac_above_1e-4"] == pytest.approx(s1["frac"], abs=1e-4)
+    for v in fx.values():
+        assert 1e-4 < v["ulp1_max"] < v["ulp4_max"] < 1e-3 and v["ulp1_frac_above_1e-4"] < v["ulp4_frac_above_1e-4"] < 0.05

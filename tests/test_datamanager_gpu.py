@@ -27,7 +27,7 @@ def test_next_train_is_the_references_pair(scene):
     from nerfstudio_thermal_amd.dataparser import ThermalNerfDataParserConfig
     from nerfstudio_thermal_amd.rays import RayBundle
 
-    cfg = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=1026, eval_num_rays_per_batch=64)
+    cfg = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.75), train_num_rays_per_batch=1026, eval_num_rays_per_batch=64)
     dm = cfg.setup(device="cuda:0", test_mode="val")
     assert isinstance(dm, HipDataManager) and dm.get_param_groups() == {} and dm.get_training_callbacks(None) == []
     n_img = len(dm.train_dataset)

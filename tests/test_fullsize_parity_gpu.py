@@ -280,3 +280,105 @@ def test_separate_mode_field_bwd_with_cross_terms_8192(prefix, C):
         err = (got.detach().cpu() - ref).abs().amax(dim=1) / float(ref.abs().max())
         assert int((err > 3e-4).sum()) <= 32, int((err > 3e-4).sum())
         assert float(err.max()) <= 0.1, float(err.max())
+
+
+def test_separate_mode_train_step_8192():
+    """BASELINE configs[2] as a WHOLE step at its size: density_mode=separate + density loss, 8192 rays, default tables.  The HIP engine runs the
+    training forward (both samplers, both fields, the two cross-evaluated densities) and loss_and_backward; the oracle is handed the engine's OWN
+    sample bins of every level and branch (identical samples: the chain's conditioning stays out of the comparison) and
+    evaluates everything behind them -- proposal densities -> weights, fields, compositing for both spectra, density2 / density2_thermal, every
+    entry of get_loss_dict incl. the density loss with its detach asymmetry (models/thermal_nerfacto.py:284-388,403-489).  Checked: both branches'
+    composited outputs and accumulations (1e-3 north_star, measured ~1e-5), the four densities (1e-4 relative to the density scale), the proposal
+    and field weights, every loss key, and the gradients that see the cross-term wiring end to end: both fields' MLPs + embeddings, all four
+    proposal MLPs, both pose corrections (oracle autograd on the same bins)."""
+    from nerfstudio_thermal_amd.engine import RenderEngine
+
+    n = 8192
+    ocfg = orc.OracleConfig(density_mode="separate")
+    params = {k: torch.from_numpy(v) for k, v in synth.synth_params(orc.param_shapes(ocfg), seed=SEED).items()}
+    cfg = ThermalNerfactoModelConfig(density_mode="separate")
+    arena = ParamArena(cfg, ocfg.num_images, DEV)
+    arena.load(params)
+    eng = RenderEngine(cfg, arena, ocfg.num_images, list(ocfg.is_thermal_cam))
+    cams = synth.synth_cameras()
+    idx = synth.synth_ray_indices(cams, n, seed=42)
+    o0, d0, cam = patch_rays(n)
+    img, is_th = (torch.from_numpy(a) for a in synth.synth_gt(idx, cams, seed=42))
+    jit = [torch.from_numpy(j).reshape(-1) for j in synth.synth_jitters(n)]
+    jit_t = [torch.from_numpy(j).reshape(-1) for j in synth.synth_jitters(n, tag="_thermal")]
+    eng.set_anneal_for_step(500)
+    arena.zero_grad()
+    out, branches = eng.get_outputs(g(o0), g(d0), g(cam), True, [g(j) for j in jit], [g(j) for j in jit_t])
+    losses = eng.loss_and_backward(out, branches, g(cam), g(img), g(is_th))
+    torch.cuda.synchronize()
+
+    # ---- the oracle on the engine's bins
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    isth_cam = torch.tensor(ocfg.is_thermal_cam, dtype=torch.bool)
+    oo = {}
+    rays = {}
+    for sfx, fprefix, pprefix, pose_key, frozen in (("", "field", "proposal_networks", "camera_optimizer.pose_adjustment", isth_cam),
+                                                      ("_thermal", "field_thermal", "proposal_networks_thermal", "camera_optimizer_thermal.pose_adjustment", ~isth_cam)):
+        o, d = orc.apply_pose_adjustment(p[pose_key], frozen, cam, o0, d0)
+        rays[sfx] = (o, d)
+        lv = branches[sfx].levels
+        smp = [orc.Samples(s_bins=l.s_bins.detach().cpu(), e_bins=l.e_bins.detach().cpu()) for l in lv]
+        wl = []
+        for i in range(2):
+            wl.append(orc.get_weights(smp[i].deltas, orc.prop_density(p, pprefix, i, ocfg, smp[i].positions(o, d))))
+        dens, geo, _, _ = orc.field_density(p, fprefix, ocfg, smp[2].positions(o, d))
+        rgb = orc.field_color(p, fprefix, ocfg, d, geo, cam, True)
+        w = orc.get_weights(smp[2].deltas, dens)
+        wl.append(w)
+        oo[f"rgb{sfx}"] = orc.composite_rgb(rgb, w, True)
+        oo[f"accumulation{sfx}"] = orc.accumulation(w)
+        oo[f"density{sfx}"] = dens
+        oo[f"weights_list{sfx}"], oo[f"samples_list{sfx}"] = wl, smp
+    oo["density2"] = orc.field_density(p, "field", ocfg, oo["samples_list_thermal"][2].positions(*rays["_thermal"]))[0]
+    oo["density2_thermal"] = orc.field_density(p, "field_thermal", ocfg, oo["samples_list"][2].positions(*rays[""]))[0]
+    ref_losses = orc.loss_dict(p, ocfg, oo, img, is_th, training=True)
+    sum(ref_losses.values()).backward()
+
+    # ---- forward: composites (north_star 1e-3 abs), densities (1e-4 of the scale), weights
+    for sfx in ("", "_thermal"):
+        assert md(out[f"rgb{sfx}"], oo[f"rgb{sfx}"]) <= 1e-3, (sfx, md(out[f"rgb{sfx}"], oo[f"rgb{sfx}"]))
+        assert md(out[f"rgb{sfx}"], oo[f"rgb{sfx}"]) <= 5e-5, ("measured ~1e-5 on identical samples", sfx, md(out[f"rgb{sfx}"], oo[f"rgb{sfx}"]))
+        assert md(out[f"accumulation{sfx}"], oo[f"accumulation{sfx}"]) <= 1e-4
+        for key in (f"density{sfx}", "density2" + sfx):
+            ref = oo[key].detach()
+            assert md(out[key].reshape(ref.shape), ref) <= 1e-4 * max(1.0, float(ref.abs().max())), (key, md(out[key].reshape(ref.shape), ref), float(ref.abs().max()))
+        for i, l in enumerate(branches[sfx].levels):
+            ref = oo[f"weights_list{sfx}"][i][..., 0].detach()
+            assert md(l.weights, ref) <= 2e-5, (sfx, i, md(l.weights, ref))
+    # ---- every loss key
+    assert sorted(losses) == sorted(ref_losses)
+    for k, v in ref_losses.items():
+        a, b = float(losses[k]), float(v)
+        assert abs(a - b) <= 2e-4 * abs(b) + 1e-9, (k, a, b)
+    assert float(ref_losses["density_loss"]) > 0
+    # ---- gradients through the whole wiring (sums over all 8192 x S samples: a handful of ReLU units within rounding of zero move an entry by
+    # up to one sample's contribution, as in test_field_bwd_production_shape)
+    checked = 0
+    for name in arena.names():
+        if name.endswith("hash_table"):
+            continue
+        ref = p[name].grad
+        got = arena.grad_view(name)
+        if ref is None:
+            assert float(got.abs().max()) == 0.0, name
+            continue
+        scale = float(ref.abs().max())
+        tol = 2e-2 if "pose_adjustment" in name else 5e-3
+        assert md(got, ref) <= tol * scale, (name, md(got, ref), scale)
+        checked += 1
+    assert checked >= 2 * 11 + 4 * 4 + 2
+    # ---- and the tables, by norm and on a deterministic sample of entries (the whole-table check with its zero pattern is
+    # test_separate_mode_field_bwd_with_cross_terms_8192 / test_prop_bwd_production_shape)
+    for name in arena.names():
+        if not name.endswith("hash_table") or p[name].grad is None:
+            continue
+        ref, got = p[name].grad, arena.grad_view(name).detach().cpu()
+        assert abs(float(got.double().norm()) - float(ref.double().norm())) <= 2e-3 * float(ref.double().norm()), name
+        ii = torch.from_numpy(np.random.default_rng(0).integers(0, ref.numel(), 200000))
+        dif = (got.reshape(-1)[ii] - ref.reshape(-1)[ii]).abs()
+        assert int((dif > 3e-4 * float(ref.abs().max())).sum()) <= 64, (name, int((dif > 3e-4 * float(ref.abs().max())).sum()))

@@ -346,3 +346,57 @@ def test_two_rank_bf16_transport_rounds_only_the_big_slices():
     for rank, err_table, err_rest in res:
         assert 0 < err_table < 2 ** -6, res   # bf16: 8 mantissa bits on each addend, then on the sum
         assert err_rest < 1e-6, res           # everything else travelled in fp32
+
+
+def test_schedule_guard_decides_from_measured_times():
+    """parallel.ScheduleGuard without a process group: the overlapped schedule is kept up to ratio x the plain step and dropped beyond."""
+    from nerfstudio_thermal_amd.parallel import ScheduleGuard
+
+    g = ScheduleGuard(1, ratio=1.5)
+    d = g.decide(0.80, 0.92)
+    assert d["schedule"] == "overlapped" and not d["stalled"] and abs(d["ratio"] - 1.15) < 1e-9
+    d = g.decide(0.80, 1.95)  # the ~0.9 ms stall of DESIGN.md section 8.0
+    assert d["schedule"] == "simple" and d["stalled"] and g.decision is d
+    assert ScheduleGuard(1).decide(0.8, float("nan"))["stalled"]  # a time that could not be measured is not a pass
+    assert ScheduleGuard(1, ratio=3.0).decide(0.80, 1.95)["schedule"] == "overlapped"
+    # with the simple schedule timed as well, the faster REAL schedule runs (the overlapped one keeps a 5 % benefit of the doubt):
+    assert g.decide(0.80, 1.50, 0.95)["schedule"] == "simple"          # the stall: one all-reduce behind the backward is faster
+    assert g.decide(0.80, 1.60, 1.80)["schedule"] == "overlapped"      # N = 2: beyond 1.5 x plain because the LINK is slow -- and still the better one
+    assert g.decide(0.80, 0.95, 0.93)["schedule"] == "overlapped" and g.decide(0.80, 0.95, 0.80)["schedule"] == "simple"
+    assert g.decide(0.80, float("nan"), 0.95)["schedule"] == "simple"
+
+
+def _guard_worker(rank, world, port, q):
+    from nerfstudio_thermal_amd.parallel import ScheduleGuard
+
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    for k, t in enumerate((arena.params, arena.exp_avg, arena.exp_avg_sq)):
+        t.copy_(torch.arange(arena.total, dtype=torch.float32) * (rank + 1) + k)  # every rank drifted on its own during the plain steps
+    guard = ScheduleGuard(world)
+    # only rank 1 sees the stall: both must leave the overlapped schedule (their collectives would no longer match otherwise)
+    dec = guard.decide(0.80, 0.95 if rank == 0 else 2.10, 1.0)
+    guard.resync(arena)
+    same = all(bool(torch.equal(t, torch.arange(arena.total, dtype=torch.float32) + k)) for k, t in enumerate((arena.params, arena.exp_avg, arena.exp_avg_sq)))
+    # and a second decision where nobody stalls
+    dec2 = ScheduleGuard(world).decide(0.80 + 0.01 * rank, 0.90)
+    q.put((rank, dec["schedule"], dec["overlapped_ms"], same, dec2["schedule"], dec2["plain_ms"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_schedule_guard_agrees_and_resyncs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sched, over, same, sched2, plain2 in res:
+        assert sched == "simple" and over == 2.10 and same, res
+        assert sched2 == "overlapped" and abs(plain2 - 0.81) < 1e-12, res
