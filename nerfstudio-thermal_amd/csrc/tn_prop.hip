@@ -172,74 +172,106 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
   }
   const float b1 = net.b1[0];
   int64_t P = N * (int64_t)S;
-  f32x4_t G = {0.f, 0.f, 0.f, 0.f};
+  // Two independent accumulators for the weight-gradient product: 16 MFMAs that accumulate into ONE register quad wait for each other (the
+  // pipe's depth, 16 times over); two interleaved chains of eight halve that (four chains spill at the 128 registers of 4 waves per SIMD).
+  f32x4_t G[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float dw1[4] = {0.f, 0.f, 0.f, 0.f}, sum_dout = 0.0f;
-  for (int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64; base < P; base += (int64_t)gridDim.x * blockDim.x) {
-    {
-      const int64_t i = base + lane;
-      const bool live = i < P;
-      const int64_t ic = live ? i : P - 1;
-      int64_t ray = tn_div_index(ic, S, P);
-      int s = (int)(ic - ray * S);
-      const float* o = origins + ray * 3;
-      const float* d = directions + ray * 3;
-      const float* eb = e_bins + ray * (S + 1) + s;
-      Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
-      const float dd = (live && c.sel) ? d_density[ic] : 0.0f;
-      float enc[PF];
+  // A trip = 64 samples.  The wave is ONE in-order instruction stream and each trip used to be a chain: global loads -> LDS -> MFMAs ->
+  // shuffles -> exp -> MFMAs -> stores -> LDS -> MFMAs; with ~4 trips per wave at level 0 the loads' latency was paid four times over
+  // (66 us for 1 M samples against ~13 us of vector / matrix work).  Now the NEXT trip's inputs are requested before this trip's matrix work
+  // (11 registers), and the four 16-sample blocks of a trip run as four interleaved chains instead of one after the other.
+  float n_enc[PF], n_dd = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  auto fetch = [&](int64_t b0) {
+    const int64_t i = b0 + lane;
+    const bool live = i < P;
+    const int64_t ic = live ? i : P - 1;
+    int64_t ray = tn_div_index(ic, S, P);
+    int s = (int)(ic - ray * S);
+    const float* o = origins + ray * 3;
+    const float* d = directions + ray * 3;
+    const float* eb = e_bins + ray * (S + 1) + s;
+    Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+    n_dd = (live && c.sel) ? d_density[ic] : 0.0f;
 #pragma unroll
-      for (int l = 0; l < PL; ++l) {
-        const float2 v = HAVE_ENC ? *reinterpret_cast<const float2*>(saved_enc + ((int64_t)l * P + ic) * 2)
-                                  : tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
-        enc[2 * l] = v.x;
-        enc[2 * l + 1] = v.y;
+    for (int l = 0; l < PL; ++l) {
+      const float2 v = HAVE_ENC ? *reinterpret_cast<const float2*>(saved_enc + ((int64_t)l * P + ic) * 2)
+                                : tn_encode_level(net.g.table, c.px, c.py, c.pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
+      n_enc[2 * l] = v.x;
+      n_enc[2 * l + 1] = v.y;
+    }
+  };
+  int64_t base = (blockIdx.x * (int64_t)(blockDim.x >> 6) + wv) * 64;
+  if (base < P) fetch(base);
+  for (; base < P; base += stride) {
+    *reinterpret_cast<float4*>(E + lane * PB_RS + 0) = make_float4(n_enc[0], n_enc[1], n_enc[2], n_enc[3]);
+    *reinterpret_cast<float4*>(E + lane * PB_RS + 4) = make_float4(n_enc[4], n_enc[5], n_enc[6], n_enc[7]);
+    *reinterpret_cast<float4*>(E + lane * PB_RS + 8) = make_float4(n_enc[8], n_enc[9], 1.0f, 0.0f);
+    DD[lane] = n_dd;
+    if (base + stride < P) fetch(base + stride);  // in flight during everything below
+    PB_WAVE_SYNC();
+    // ---- the four 16-sample blocks c of the trip, two at a time as two interleaved chains (four at a time spill at 128 registers)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // forward: pre-activations of the hidden units 4 g + r of sample 16 c + n
+      f32x4_t T[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          T[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], E[(16 * (2 * h + q) + n) * PB_RS + 4 * t + g], T[q], 0, 0, 0);
+      float part[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        part[q] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[q] = fmaf(w1q[r], fmaxf(T[q][r], 0.0f), part[q]);
       }
-      *reinterpret_cast<float4*>(E + lane * PB_RS + 0) = make_float4(enc[0], enc[1], enc[2], enc[3]);
-      *reinterpret_cast<float4*>(E + lane * PB_RS + 4) = make_float4(enc[4], enc[5], enc[6], enc[7]);
-      *reinterpret_cast<float4*>(E + lane * PB_RS + 8) = make_float4(enc[8], enc[9], 1.0f, 0.0f);
-      DD[lane] = dd;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) part[q] += __shfl_xor(part[q], 16, 64);  // the four rows hold the four quarters of the hidden layer
+#pragma unroll
+      for (int q = 0; q < 2; ++q) part[q] += __shfl_xor(part[q], 32, 64);
+      f32x4_t X[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      float da[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = 2 * h + q;
+        const float d_out = DD[16 * c + n] * expf(fminf(fmaxf(b1 + part[q], -15.0f), 15.0f));  // trunc_exp backward (the clamped exp is finite: 0 stays 0)
+        if (g == 0) sum_dout += d_out;  // (every row computes it: one of them counts)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dw1[r] = fmaf(d_out, fmaxf(T[q][r], 0.0f), dw1[r]);
+          da[q][r] = T[q][r] > 0.0f ? d_out * w1q[r] : 0.0f;
+        }
+      }
+      // d enc of sample 16 c + n, features 4 g .. 4 g + 3: K = hidden, k-step r <-> hidden 4 g + r, straight from the registers
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) X[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[r], da[q][r], X[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = 2 * h + q;
+        // dA[s][j] rows for the weight-gradient product
+        *reinterpret_cast<float4*>(DA + (16 * c + n) * PB_RS2 + 4 * g) = make_float4(da[q][0], da[q][1], da[q][2], da[q][3]);
+        const int64_t is = base + 16 * c + n;
+        if (is < P && g < 3) {  // level-major [PL][P] float2: 16 lanes write 128 consecutive bytes (the bin pass reads them the same way)
+          *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g) * P + is) * 2) = make_float2(X[q][0], X[q][1]);
+          if (g < 2) *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g + 1) * P + is) * 2) = make_float2(X[q][2], X[q][3]);
+        }
+      }
     }
     PB_WAVE_SYNC();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      // ---- forward: pre-activations of the hidden units 4 g + r of sample 16 c + n
-      f32x4_t T = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 3; ++t) T = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], E[(16 * c + n) * PB_RS + 4 * t + g], T, 0, 0, 0);
-      float part = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(w1q[r], fmaxf(T[r], 0.0f), part);
-      part += __shfl_xor(part, 16, 64);  // the four rows hold the four quarters of the hidden layer
-      part += __shfl_xor(part, 32, 64);
-      const float d_out = DD[16 * c + n] * expf(fminf(fmaxf(b1 + part, -15.0f), 15.0f));  // trunc_exp backward (the clamped exp is finite: 0 stays 0)
-      if (g == 0) sum_dout += d_out;  // (every row computes it: one of them counts)
-      float da[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dw1[r] = fmaf(d_out, fmaxf(T[r], 0.0f), dw1[r]);
-        da[r] = T[r] > 0.0f ? d_out * w1q[r] : 0.0f;
-      }
-      // ---- d enc of sample 16 c + n, features 4 g .. 4 g + 3: K = hidden, k-step r <-> hidden 4 g + r, straight from the registers
-      f32x4_t X = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[r], da[r], X, 0, 0, 0);
-      const int64_t is = base + 16 * c + n;
-      if (is < P && g < 3) {  // level-major [PL][P] float2: 16 lanes write 128 consecutive bytes (the bin pass reads them the same way)
-        *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g) * P + is) * 2) = make_float2(X[0], X[1]);
-        if (g < 2) *reinterpret_cast<float2*>(ws_denc + ((int64_t)(2 * g + 1) * P + is) * 2) = make_float2(X[2], X[3]);
-      }
-      // dA[s][j] rows for the weight-gradient product
-      *reinterpret_cast<float4*>(DA + (16 * c + n) * PB_RS2 + 4 * g) = make_float4(da[0], da[1], da[2], da[3]);
-    }
-    PB_WAVE_SYNC();
-    // ---- dW0 | db0 (transposed: [feature][hidden]): K = the wave's 64 samples, four at a time
+    // ---- dW0 | db0 (transposed: [feature][hidden]): K = the wave's 64 samples, four at a time; chain q takes the k-steps t = q (mod 2)
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const float e = n < PB_RS ? E[(4 * t + g) * PB_RS + n] : 0.0f;
-      G = __builtin_amdgcn_mfma_f32_16x16x4f32(e, DA[(4 * t + g) * PB_RS2 + n], G, 0, 0, 0);
+      G[t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(e, DA[(4 * t + g) * PB_RS2 + n], G[t & 1], 0, 0, 0);
     }
     PB_WAVE_SYNC();  // E, dA and dd have been read: the next trip may write them
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) G[0][r] = G[0][r] + G[1][r];
   // ---- block-level sum: every wave leaves its partial sums in its own LDS region, 273 threads add them up, one atomic per weight and block.
   // register r of lane (g, n) = G[feature 4 g + r][hidden n];  dw1[r] of lane (g, n) = this lane's samples' share of dW1[4 g + r]
 #pragma unroll
@@ -248,7 +280,7 @@ __global__ void __launch_bounds__(PB_THREADS) k_prop_bwd_mlp(PropK net, const fl
   {
     float* mine = E;  // [0..255] [feature][hidden] tile (rows 0..9 dW0^T, row 10 db0), [256..271] dW1, [272] db1
 #pragma unroll
-    for (int r = 0; r < 4; ++r) mine[(4 * g + r) * 16 + n] = G[r];
+    for (int r = 0; r < 4; ++r) mine[(4 * g + r) * 16 + n] = G[0][r];
     if (n == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[256 + 4 * g + r] = dw1[r];

@@ -60,11 +60,11 @@ class GradAllReducer:
         flat = arena.grads[lo:hi]
         n = flat.numel()
         step = (n + self.chunks - 1) // self.chunks
-        works = []
+        # async_op=False: ProcessGroupNCCL enqueues a synchronous collective on the CURRENT stream (torch >= 2.7; older versions run it on the
+        # communicator's stream and make the current one wait -- same result).  No stream beyond the plain step's takes part, so this schedule
+        # cannot meet the hardware-queue stall of DESIGN.md section 8.0 whatever GPU_MAX_HW_QUEUES says.  The host does not wait either way.
         for s in range(0, n, step):
-            works.append(dist.all_reduce(flat[s : s + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
-            w.wait()
+            dist.all_reduce(flat[s : s + step], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
         if self.world > 1:
             flat.mul_(1.0 / self.world)
 
@@ -117,6 +117,16 @@ class ScheduleGuard:
                 dist.broadcast(t, src=src, group=self.group)
 
 
+class _StreamWork:
+    """wait() of a collective that was enqueued synchronously on a stream of ours: the current stream waits for the event recorded behind it"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class OverlappedGradReducer:
     """The same mean all-reduce, issued in pieces WHILE the backward pass is still running (what DDP's bucketed reducer does for the
     reference, pipelines/base_pipeline.py:281-283, laid out for this path's gradient arena and xGMI):
@@ -158,6 +168,7 @@ class OverlappedGradReducer:
         self.level_chunks = level_chunks
         self.dense_exchange = dense_exchange
         self._side_group = side_group
+        self._comm_stream = None
         self._works: List = []
         self._ranges: List[Tuple[int, int]] = []
         self._arena = None
@@ -202,13 +213,33 @@ class OverlappedGradReducer:
             self._side_group = dist.new_group() if dist.is_initialized() else None
         return self._side_group
 
+    def _comm(self):
+        """The stream the collectives run on (RCCL backend): ONE stream of this object's own, created once.  A synchronous collective is
+        enqueued on the current stream (torch >= 2.7), so issuing it inside `with torch.cuda.stream(comm)` puts RCCL's kernels where this
+        schedule wants them instead of on the communicator's internal stream -- the step's stream set is then exactly {main, proposal side
+        stream, this one}, all from torch's pool.  TN_DP_COMM_STREAM=0: the communicator's own stream (async_op=True), as before round 5."""
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        return self._comm_stream
+
     def _issue(self, tensor, group=None) -> None:
         if dist.is_initialized():  # a 1-process group still goes through the backend (GPU tests drive RCCL that way)
             if self.transport_dtype is not None and tensor.numel() >= (1 << 20):
                 wire = tensor.to(self.transport_dtype)
                 self._casts[len(self._works)] = (tensor, wire)  # converted back when the collective has been waited for (finish_iter)
                 tensor = wire
-            self._works.append(dist.all_reduce(tensor, op=self._op(), group=group if group is not None else self.group, async_op=True))
+            grp = group if group is not None else self.group
+            if tensor.is_cuda and dist.get_backend(grp) == "nccl" and os.environ.get("TN_DP_COMM_STREAM", "1") != "0":
+                cs, cur = self._comm(), torch.cuda.current_stream()
+                cs.wait_stream(cur)  # ordered after everything already enqueued on the current stream
+                tensor.record_stream(cs)
+                with torch.cuda.stream(cs):
+                    dist.all_reduce(tensor, op=self._op(), group=grp, async_op=False)
+                    ev = torch.cuda.Event()
+                    ev.record(cs)
+                self._works.append(_StreamWork(ev))
+            else:
+                self._works.append(dist.all_reduce(tensor, op=self._op(), group=grp, async_op=True))
         else:
             self._works.append(None)
 

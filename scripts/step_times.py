@@ -4,7 +4,11 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from nerfstudio_thermal_amd import _lib
+if os.environ.get("TN_LIB"):  # A/B timing against another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["TN_LIB"])
 import bench
+import numpy as np
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = torch.device("cuda", 0)
 cfg, arena, eng = bench.build_engine(dev)
@@ -28,3 +32,8 @@ for s in range(n):
 torch.cuda.synchronize()
 for s in range(n):
     print(f"step {s:3d} upd {upd[s]} device {evs[s].elapsed_time(evs[s+1]):7.3f} ms  host enqueue {host[s]:7.3f} ms  segments {segs[s]}")
+
+dev_ms = np.array([evs[s].elapsed_time(evs[s + 1]) for s in range(n)])
+u = np.array(upd, dtype=bool)
+skip = 12  # every step below 10 updates the proposal networks, and the first steps allocate
+print(f"[{os.environ.get('TN_LIB', 'default lib')}] median device ms: update steps {np.median(dev_ms[skip:][u[skip:]]):.4f}  other steps {np.median(dev_ms[skip:][~u[skip:]]):.4f}  all {np.median(dev_ms[skip:]):.4f}")
