@@ -603,7 +603,8 @@ __device__ __forceinline__ f32x16 load_enc_lm(const float* __restrict__ enc, int
 #ifndef FWD_THREADS
 #define FWD_THREADS 256
 #endif
-// FWD_ABLATE (compile-time, timing diagnostics only -- the backward is wrong with it): 1 no activation stores
+// FWD_ABLATE (compile-time, timing diagnostics only -- results are wrong with any bit set): 1 no activation stores, 2 no per-ray loads (sh table,
+// camhead row), 4 no encoding loads, 8 no last layer / sigmoid / output stores, 16 no density / base-output stores (scripts/fwd_ablation.sh)
 #ifndef FWD_ABLATE
 #define FWD_ABLATE 0
 #endif
@@ -632,7 +633,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
   f32x16 nin;  // the next tile's encoding, requested one tile ahead -- the first one before the weights are staged (a wave makes three trips)
   if (wave < ntiles) {
     const int64_t p0 = wave * TILE + j;
-    nin = load_enc_lm(encs, PT, p0 < P ? p0 : P - 1, h, L);
+    nin = (FWD_ABLATE & 4) ? f32x16{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f} : load_enc_lm(encs, PT, p0 < P ? p0 : P - 1, h, L);
   }
   for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
     *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
@@ -656,34 +657,35 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     {
       const int64_t tn = tile + nwaves < ntiles ? tile + nwaves : tile;
       const int64_t pn = tn * TILE + j;
-      nin = load_enc_lm(encs, PT, pn < P ? pn : P - 1, h, L);
+      if (!(FWD_ABLATE & 4)) nin = load_enc_lm(encs, PT, pn < P ? pn : P - 1, h, L);
     }
     __builtin_amdgcn_sched_barrier(0);
     a0 = relu16(a0); a1 = relu16(a1);
-    if (TRAIN && !FWD_ABLATE) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
+    if (TRAIN && !(FWD_ABLATE & 1)) { store_frag(h1s, tile, 2, 0, lane, a0); store_frag(h1s, tile, 2, 1, lane, a1); }
     f32x16 bo = bias_tile(lbias, 1, 0, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 0, r), a0[r], bo);
 #pragma unroll
     for (int r = 0; r < 16; ++r) bo = MFMA(AF(1, 0, 1, r), a1[r], bo);
     __builtin_amdgcn_sched_barrier(0);
-    if (valid && h == 0) {
+    if (valid && h == 0 && !(FWD_ABLATE & 16)) {
       float pre = bo[0];
       density[p] = expf(pre) * sl;  // average_init_density (=1.0) * trunc_exp(pre) * selector
       if (density_pre) density_pre[p] = pre;
     }
-    if (TRAIN && !FWD_ABLATE) store_bo(hins, tile, lane, bo);  // whole tiles: lanes past the end hold the (finite) values of the last sample
+    if (TRAIN && !(FWD_ABLATE & 1)) store_bo(hins, tile, lane, bo);  // whole tiles: lanes past the end hold the (finite) values of the last sample
     // ---------------- head input in slot space: tile 0 = sh[R(r,h)] (r<8) | base_out rows (r>=8), tile 1 = embedding
     f32x16 hi0, hi1;
     {
-      const float4 s0 = *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8), s1 = *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8 + 4);
+      const float4 zz = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+      const float4 s0 = (FWD_ABLATE & 2) ? zz : *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8), s1 = (FWD_ABLATE & 2) ? zz : *reinterpret_cast<const float4*>(shtab + ray * 16 + h * 8 + 4);
       hi0[0] = s0.x; hi0[1] = s0.y; hi0[2] = s0.z; hi0[3] = s0.w; hi0[4] = s1.x; hi0[5] = s1.y; hi0[6] = s1.z; hi0[7] = s1.w;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) hi0[8 + r] = bo[r];
     f32x16 c0 = bias_tile(lbias, 2, 0, h), c1 = bias_tile(lbias, 2, 1, h);
     constexpr bool CAMHEAD = TRAIN && !FWD_EMB_MFMA;  // (the training launch is the one with per-camera embeddings: use_cam_emb == TRAIN)
-    if (CAMHEAD) {
+    if (CAMHEAD && !(FWD_ABLATE & 2)) {
       // the camera's embedding enters head layer 0 as the per-camera vector camhead[cam] (built with the fragments): no MFMA for slots 32..63
       int64_t cam = cam_idx[ray];
       if (cam < 0 || cam >= num_images) cam = 0;
@@ -694,7 +696,7 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
         c0[4 * gq] += u0.x; c0[4 * gq + 1] += u0.y; c0[4 * gq + 2] += u0.z; c0[4 * gq + 3] += u0.w;
         c1[4 * gq] += u1.x; c1[4 * gq + 1] += u1.y; c1[4 * gq + 2] += u1.z; c1[4 * gq + 3] += u1.w;
       }
-    } else {
+    } else if (!CAMHEAD) {
       const float* ebp;
       if (use_cam_emb) {
         int64_t cam = cam_idx[ray];
@@ -712,13 +714,13 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     // ---------------- head layer 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 0, r), hi0[r], c0); c1 = MFMA(AF(2, 1, 0, r), hi0[r], c1); }
-    if (!CAMHEAD) {  // (inference: the mean embedding goes through the matrix cores as before)
+    if (!CAMHEAD && !(FWD_ABLATE & 2)) {  // (inference: the mean embedding goes through the matrix cores as before)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
     }
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
-    if (TRAIN && !FWD_ABLATE) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
+    if (TRAIN && !(FWD_ABLATE & 1)) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
     // ---------------- head layer 1
     f32x16 d0 = bias_tile(lbias, 3, 0, h), d1 = bias_tile(lbias, 3, 1, h);
 #pragma unroll
@@ -727,13 +729,14 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
-    if (TRAIN && !FWD_ABLATE) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
+    if (TRAIN && !(FWD_ABLATE & 1)) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 2 + sigmoid.  Linear(64, C <= 4) on the VECTOR ALU: as a 32-row MFMA tile it spent 32 matrix instructions
     // (2 064 cycles of the 14.4 k per tile) on 4 useful rows.  Lane (j, h) holds 32 of its sample's 64 inputs (tiles 0 / 1, registers r <->
     // features 32 t + R(r, h)); the weights of the four outputs for that feature are lanes 32 h + 0..3 of the layer's forward fragment
     // (Af[4][0][t][r][32 h + c] = W[c][32 t + R(r, h)]): one broadcast ds_read_b128 per (t, r), four FMAs, then the two halves are added.
     float e[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FWD_ABLATE & 8) { if (d0[0] + d1[5] == 1.2345e-30f) rgb[p] = d0[3]; continue; }
 #if FWD_HEAD2_MFMA
     {
       f32x16 em = bias_tile(lbias, 4, 0, h);
