@@ -30,7 +30,7 @@ import torch  # noqa: E402
 
 RAYS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc.json")
 
 
 def source_hash() -> str:
@@ -209,7 +209,7 @@ def time_ms(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters
 
 
-# bench row -> kernels of profiles/r04_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only.
+# bench row -> kernels of profiles/r05_pmc.json ("<kernel> <grid X>x<grid Y>"), N = 4096 shared only.
 # The DOMINANT row (the top-level `roofline` object) is derived from the measured stand-alone times x launches per step (rows of kernel_roofline:
 # proposal-grid rows count only on update steps), not named here.
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X (256 CUs x 4 x 64 FLOP/cycle/SIMD... MI355X_MICROARCH.md); scripts/microbench/mfma_rate.hip sustains 155
@@ -238,11 +238,11 @@ def pmc_lookup(pmc, prefixes):
 def load_pmc():
     """PMC figures measured by scripts/pmc_passes.sh, or (None, why) when they were taken on other kernel sources than the ones running."""
     if not os.path.exists(PMC_JSON):
-        return None, "no profiles/r04_pmc.json"
+        return None, "no profiles/r05_pmc.json"
     with open(PMC_JSON) as f:
         j = json.load(f)
     if j.get("source_hash") != source_hash():
-        return None, f"profiles/r04_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
+        return None, f"profiles/r05_pmc.json was measured on kernel sources {j.get('source_hash')}, running {source_hash()}: re-run scripts/pmc_passes.sh"
     return j["kernels"], None
 
 
@@ -893,7 +893,7 @@ def main():
         if pmc is not None and pmc_lookup(pmc, PMC_KEYS.get(name, ["?"])) is not None:
             traffic = sum(v["traffic_bytes"] for v in pmc_lookup(pmc, PMC_KEYS[name]))
         elif pmc is not None:
-            why = f"profiles/r04_pmc.json holds no (single) entry for {PMC_KEYS.get(name)}"
+            why = f"profiles/r05_pmc.json holds no (single) entry for {PMC_KEYS.get(name)}"
         upd = updates / max(args.steps, 1)
         step_bytes = step_algorithmic_bytes(arena, args.mode, rays, upd, args.nerf_samples)
         step_gbs = step_bytes / (dt / args.steps) / 1e9
@@ -918,7 +918,7 @@ def main():
                                                if pmc_lookup(pmc, ks) is not None}
             roofline["mfma_busy_frac"] = {k.split(" ")[0]: v["mfma_busy_frac"] for k, v in pmc.items()
                                           if k.split(" ")[0] in ("k_field_mlp_fwd<true>", "k_field_bwd_fused<false>") and "mfma_busy_frac" in v}
-            roofline["pmc_source"] = "profiles/r04_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
+            roofline["pmc_source"] = "profiles/r05_pmc.json (read bytes = FETCH_SIZE x the calibrated factor of the kernel's read shape, scripts/pmc_summary.py)"
         result = {
             "metric": "train rays/sec (4096-ray batch, 96 samples/ray)",
             "value": world * rays * args.steps / dt,

@@ -29,8 +29,11 @@
  *      TN_SCATTER_MODE=0          the round-1 global-atomic scatter with dense replicas instead of the binned scatter (A/B timing)
  *      TN_SCATTER_REPLICAS=n, TN_SCATTER_SPARSE_CHUNK=n, TN_SCATTER_MERGE_RES=n      tuning knobs of the two scatter paths
  *      TN_FOLD_TRACE=1 [TN_FOLD_TRACE_FILE=path]   per-block timing of the fold pass (synchronises and prints: diagnostics only)
- *    The Python package adds GPU_MAX_HW_QUEUES=8 (unless set) before the first HIP call and TN_FUSE_SMALL=0 (one launch per reference seam
- *    instead of the fused small kernels: test aid).
+ *      TN_BIN_LEVEL_GROUPS=n      force the number of level groups of the bin pass (diagnostic: n = levels -> one level per block)
+ *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
+ *                                 half of the output features; a measured experiment that is correct and slower (profiles/r05_experiments.md)
+ *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid) and writes
+ *    nothing into the environment (rounds 2-4 set GPU_MAX_HW_QUEUES=8 at import: the schedules now fit the runtime's default of four).
  */
 #ifndef THERMAL_NERF_HIP_H
 #define THERMAL_NERF_HIP_H

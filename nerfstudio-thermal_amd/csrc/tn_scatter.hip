@@ -509,6 +509,29 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_grid_bin(GridK g, const floa
       }
     }
     __syncthreads();
+    if (li1 - li0 == 1) {
+      // a round of ONE level (the main grid's fine levels: nothing merges, a level fills the staging area): wave-uniform array bases and 32-bit
+      // record offsets -- ~10 vector instructions per record less than the general loop below, on the levels that stage the most records
+      const int li = li0;
+      const int l = blockIdx.y + li * level_groups;
+      uint16_t* __restrict__ idx_l = bk.idx + (size_t)l * bk.level_stride;
+      float2* __restrict__ val_l = bk.val + (size_t)l * bk.level_stride;
+      for (uint32_t j = tid; j < round_total; j += BIN_THREADS) {
+        const uint32_t id = s_idx[j] & 0xffffffu;
+        const float2 v = s_val[j];
+        const uint2 dl = s_dl[li * ns + (id >> bk.slice_log2)];
+        if (j < dl.y) {
+          const uint32_t at = j + dl.x;
+          idx_l[at] = (uint16_t)(id & smask);
+          val_l[at] = v;
+        } else {  // bucket full: add straight into the gradient
+          float* dst = reinterpret_cast<float*>(g.grad + (size_t)l * g.tsize + id);
+          if (v.x != 0.0f) unsafeAtomicAdd(dst, v.x);
+          if (v.y != 0.0f) unsafeAtomicAdd(dst + 1, v.y);
+          if (g.nonfinite != nullptr && ((v.x - v.x) + (v.y - v.y)) != 0.0f) *g.nonfinite = 1.0f;
+        }
+      }
+    } else
     for (uint32_t J = tid; J < round_total; J += BIN_THREADS) {
       const uint32_t tagged = s_idx[J];
       const float2 v = s_val[J];
@@ -800,6 +823,10 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
   int level_groups = 1;
   while (level_groups < L && ((int64_t)blocks * level_groups < 256 * 6 || tn_cdiv(L, level_groups) * bk.nslices > BIN_MAX_COUNTERS)) level_groups *= 2;
   level_groups = std::min(level_groups, L);
+  {  // TN_BIN_LEVEL_GROUPS (diagnostic): force the number of level groups (L = one level per block: the level's corner slots are evaluated once)
+    static const int forced = env_int("TN_BIN_LEVEL_GROUPS", 0, 0, TN_MAX_LEVELS);
+    if (forced > 0 && tn_cdiv(L, std::min(forced, L)) * bk.nslices <= BIN_MAX_COUNTERS) level_groups = std::min(forced, L);
+  }
   if (d_origins != nullptr)
     hipLaunchKernelGGL(k_grid_bin<true>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S,
                        d_origins, d_directions, level_groups, bk);

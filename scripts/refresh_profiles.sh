@@ -1,11 +1,19 @@
-# Everything under profiles/r04_* in one gpurun call (tests, PMC passes, bench lines, kernel stats, timelines):
+# Everything under profiles/<round>_* in one gpurun call (tests, PMC passes, bench lines, kernel stats, timelines):
 #   gpurun --timeout 1200 -- 'bash scripts/refresh_profiles.sh > gpurun_out/refresh.log 2>&1'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r04
+R=${R:-r05}
 mkdir -p gpurun_out/$R
+PART=${PART:-all}   # 1: tests, PMC passes, hardware-queue sweep, forward ablation, microbenchmark; 2: bench lines, kernel stats, timelines (two gpurun calls: each stays under the 20-minute limit)
+if [ "$PART" != "2" ]; then
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/$R/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/$R/tests.log
 bash scripts/pmc_passes.sh gpurun_out/pmc | tail -12
 python scripts/pmc_summary.py gpurun_out/pmc profiles/$R > gpurun_out/$R/pmc_summary.log 2>&1 && cp profiles/${R}_pmc.json profiles/${R}_pmc_summary.md gpurun_out/$R/
+bash scripts/dp_hwq_sweep.sh $R 2> gpurun_out/$R/sweep.err | tail -20
+bash scripts/fwd_ablation.sh gpurun_out/$R/fwd_ablation > gpurun_out/$R/fwd_ablation.log 2>&1; grep -E '^==' gpurun_out/$R/fwd_ablation.log
+find gpurun_out/$R/fwd_ablation -name '*.csv' ! -name '*kernel_stats.csv' -delete; find gpurun_out/$R/fwd_ablation -name '*.db' -delete
+timeout -k 5 120 scripts/microbench/mfma_valu_overlap > gpurun_out/$R/mfma_valu_overlap.txt 2>&1; tail -18 gpurun_out/$R/mfma_valu_overlap.txt
+fi
+if [ "$PART" = "1" ]; then exit 0; fi
 last() { grep '^{' "$1" | tail -1 > "$1.tmp"; mv "$1.tmp" "$1"; }
 b() { out=gpurun_out/$R/bench_$1.json; shift; python bench.py "$@" > $out 2>/dev/null; last $out; }
 b n1_driver_invocation --steps 20 --warmup 5
@@ -18,6 +26,8 @@ b n1_model_api_no_scaler --path model-api --no-grad-scaler --no-cpu-baseline --s
 b n1_model_api_torch_adam --path model-api --api-optimizer torch --no-cpu-baseline --steps 200 --warmup 60
 b n1_no_grad_scaler --no-grad-scaler --no-cpu-baseline --no-extras
 b n1_force_dp --force-dp --no-cpu-baseline --no-extras
+b n1_force_dp_overlapped --force-dp --no-dp-guard --no-cpu-baseline --no-extras
+b n1_force_dp_overlapped_sum --force-dp --no-dp-guard --force-dp-sum --no-cpu-baseline --no-extras
 b n1_force_dp_sharded --force-dp --dp-shard-optimizer --no-grad-scaler --no-cpu-baseline --no-extras
 b n1_1024rays --rays 1024 --no-cpu-baseline
 b n1_96samples --nerf-samples 96 --no-cpu-baseline
@@ -26,7 +36,7 @@ python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1ran
 rm -rf gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep
 # (the last 20 steps of a fused / separate run are the in-step measurement, which issues the backward phase by phase: the timelines show steps of the timed region)
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_a.log 2>&1
-rocprofv3 --kernel-trace -d gpurun_out/prof_dp -o dp -- python3 bench.py --force-dp --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_dp.log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/prof_dp -o dp -- python3 bench.py --force-dp --no-dp-guard --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_dp.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_sep -o sep -- python3 bench.py --mode separate --rays 8192 --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_sep.log 2>&1
 python scripts/rocpd_stats.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/bench_n1_kernel_stats.csv --split-grid --tail 10 > gpurun_out/$R/bench_n1_kernel_stats_tail.txt 2>&1
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --step-from-end 26 > /dev/null 2> gpurun_out/$R/timeline.err
