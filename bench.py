@@ -546,7 +546,8 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
         opt_in = {"single_thread_backward": {"ms_per_step": dt1 / steps * 1e3, "rays_per_s": rays * steps / dt1,
                                              "note": "torch.autograd.set_multithreading_enabled(False) (nerfstudio_thermal_amd.configure_host, opt-in); "
                                                      "ms_per_step above is with torch's defaults"}}
-    name, ms, nbytes = next(r for r in kernel_roofline(eng, cam_t, idx) if r[0] == DOMINANT)
+    # (the main grid's scatter entry point on THIS workload: the headline line's dominant kernel, for comparison across the legs)
+    name, ms, nbytes = next(r for r in kernel_roofline(eng, cam_t, idx)[0] if r[0] == "scatter(main grid)")
     how = {"model-api": " (autocast + torch.amp.GradScaler + HipFusedAdam: the reference Trainer's sequence, engine/trainer.py:455-499)",
            "fused-trainer": " (the reference Trainer's loop body -- callbacks, train_iteration, callbacks -- with train_iteration on the fused step: "
                             "trainer.FusedTrainerMixin, what the method plugin's TrainerConfig._target runs)"}.get(path, " (device-side GradScaler)")

@@ -1,0 +1,39 @@
+"""bench.py's default line on the GPU, end to end: one subprocess run with few steps, every object the contract and DESIGN.md section 5 name is
+there and NO extra leg failed (an extra's exception is caught into {"error": ...} so that it never costs the headline -- which also means nothing
+else notices it: round 5 shipped a NameError in all four legs for an hour)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_line_has_every_object_and_no_failed_leg():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--long-steps", "8", "--cpu-steps", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "long_run", "parity", "extra"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["kernel"] in rf["all_kernels"] and rf["kernel"] == max(rf["dominant_by"]["ms_per_step"], key=rf["dominant_by"]["ms_per_step"].get)
+    assert "traffic" in rf and (rf["traffic"] is not None or "traffic_unavailable" in rf)
+    m = rf["mfma"]
+    assert m["peak"] == 157.3 and 0.1 < m["frac"] < 1.0 and abs(m["frac"] - m["achieved_tflops"] / m["peak"]) < 1e-12 and m["flop_per_launch"] == 2 * 4096 * 48 * 22912
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    p = d["parity"]
+    assert "error" not in p and p["max_abs_rgb"] <= 1e-3 and p["max_abs_thermal"] <= 1e-3, p
+    assert 0 < p["density_err_over_1ulp_response"] <= 6.0 and 0 <= p["bins_beyond_64ulp_share"] <= 0.02, p
+    for name, leg in d["extra"].items():
+        assert "error" not in leg, (name, leg)
+        assert leg["ms_per_step"] > 0 and leg["rays_per_s"] > 0, (name, leg)
+    assert set(d["extra"]) == {"separate_8192", "nerf_samples_96", "model_api_amp", "fused_trainer"}
