@@ -213,12 +213,12 @@ def time_ms(fn, iters=10, warmup=2):
 # The DOMINANT row (the top-level `roofline` object) is derived from the measured stand-alone times x launches per step (rows of kernel_roofline:
 # proposal-grid rows count only on update steps), not named here.
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X (256 CUs x 4 x 64 FLOP/cycle/SIMD... MI355X_MICROARCH.md); scripts/microbench/mfma_rate.hip sustains 155
-# kernel name + points of the launch; the key in the PMC file also carries the grid's y extent (level groups: "k_grid_bin<false> 196608x4"),
+# kernel name + points of the launch; the key in the PMC file also carries the grid's y extent (level groups: "k_seg_bin<false> 196608x4"),
 # which changes with the block size of the bin pass -- matched by prefix
 PMC_KEYS = {
-    "scatter(main grid)": ["k_grid_bin<false> 196608x", "k_grid_fold 196608x"],
-    "scatter(prop0 grid)": ["k_grid_bin<true> 1048576x", "k_grid_fold 1048576x"],
-    "scatter(prop1 grid)": ["k_grid_bin<true> 393216x", "k_grid_fold 393216x"],
+    "scatter(main grid)": ["k_seg_bin<false> 196608x", "k_seg_fold 196608x"],
+    "scatter(prop0 grid)": ["k_seg_bin<true> 1048576x", "k_seg_fold 1048576x"],
+    "scatter(prop1 grid)": ["k_seg_bin<true> 393216x", "k_seg_fold 393216x"],
     "k_prop_fwd(level0)": ["k_prop_fwd 1048576x"],
     "k_prop_fwd(level1)": ["k_prop_fwd 393216x"],
 }
@@ -904,7 +904,7 @@ def main():
                     "in_step_schedule": "phased backward: tn_field_bwd_phase(MLP) / HIP event / SCATTER / HIP event / JOIN in 20 EXTRA steps after the timed "
                                         "region -- the timed `value` runs the one-call backward (tn_render_rays_train_bwd), which cannot take events",
                     "frac_in_step": None if in_step is None else nbytes / (in_step["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "the main grid's scatter entry point = k_grid_bin + k_grid_fold as the field backward calls it (d position comes from "
+                    "note": "the main grid's scatter entry point = k_seg_bin + k_seg_fold as the field backward calls it (d position comes from "
                             "k_field_dpos); the bin pass is bound by instruction issue, the fold streams its records into double-precision LDS atomics",
                     "dominant_by": {"rule": "stand-alone ms x launches per step at this run's proposal-update fraction", "ms_per_step": shares},
                     "all_kernels": {n: {"ms": m, "GB/s": bts / (m * 1e-3) / 1e9, "frac": bts / (m * 1e-3) / 1e9 / HBM_PEAK_GBS} for n, m, bts in rows},

@@ -26,7 +26,9 @@
  *    caller's gradient arena (nerfstudio_thermal_amd/parallel.py), exactly where the reference has torch DDP.
  *  - Environment switches, read once per process, all tuning / diagnostic aids whose defaults are the product path:
  *      TN_NO_FORK=1               no companion streams (everything on the caller's stream)
- *      TN_SCATTER_MODE=0          the round-1 global-atomic scatter with dense replicas instead of the binned scatter (A/B timing)
+ *      TN_SCATTER_MODE=2|1|0      table-gradient scatter: 2 = segmented (default: block-private record regions, no global atomics), 1 = binned
+ *                                 (rounds 2-5: per-bucket arrays with reservations), 0 = the round-1 global-atomic scatter with dense replicas.
+ *                                 Read on every call; the bin and fold launches of one backward must see the same value.
  *      TN_SCATTER_REPLICAS=n, TN_SCATTER_SPARSE_CHUNK=n, TN_SCATTER_MERGE_RES=n      tuning knobs of the two scatter paths
  *      TN_FOLD_TRACE=1 [TN_FOLD_TRACE_FILE=path]   per-block timing of the fold pass (synchronises and prints: diagnostics only)
  *      TN_BIN_LEVEL_GROUPS=n      force the number of level groups of the bin pass (diagnostic: n = levels -> one level per block)

@@ -709,6 +709,354 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
   }
 }
 
+// ======================================================================================================================================
+// Segmented path (TN_SCATTER_MODE=2): block-private record regions, no counting pass, no reservations.
+//
+// The binned path above evaluates every level's 8 corner slots TWICE per sample (phase A counts the records per bucket so that phase B can
+// stage them in bucket order and one returning global atomic per bucket can reserve their run in the bucket's global array) and its copy-out
+// looks every record's bucket up again.  The pass is bound by vector-ALU issue (profiles/r05_experiments.md), and keeping phase A while
+// evaluating the slots once loses to the reservation latency (k_grid_bin_p, one level per block: measured, removed).  So the reservation
+// goes: a bin block OWNS a region of the record arrays per level -- [level][bin block][BIN_THREADS * 8 records], as many as it can ever
+// produce -- writes its records there sorted by bucket (rank = the value an LDS atomic returns while the slots are still in registers, bucket
+// offsets = one 128-entry prefix per level) as ONE linear, vectorised copy, and leaves a header {offset, count} per bucket.  The fold block of a
+// bucket walks the segments the bin blocks left for it.  No global atomics, no counters to zero, no overflow path (a region cannot overflow).
+struct SegK {
+  uint16_t* idx;   // [L][NB][SEG_CAP] slot inside the bucket, records of a (level, bin block) sorted by bucket
+  float2* val;     // same shape
+  uint32_t* hdr;   // [L][nslices][NB]: offset | count << 16 of the bucket's segment inside the (level, bin block) region
+  uint32_t NB;     // bin blocks per level (blockIdx.x extent of the bin pass)
+  int slice_log2, nslices;
+  uint32_t merge_mask;
+  uint32_t segc;    // segments (bin blocks) per fold block
+  uint32_t chunks;  // fold blocks per bucket = ceil(NB / segc)
+};
+#define SEG_CAP (BIN_THREADS * 8)
+#ifndef SEG_FOLD_ABLATE
+#define SEG_FOLD_ABLATE 0
+#endif
+
+template <bool WANT_DPOS>
+__global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
+                                                         const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
+                                                         float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, SegK sk) {
+  __shared__ uint32_t s_cnt[TN_BIN_MAX_SLICES];      // records per bucket of the level being ranked (zero between levels)
+  __shared__ uint32_t s_off[TN_BIN_MAX_SLICES + 1];  // exclusive prefix; [nslices] = the level's record count
+  __shared__ __attribute__((aligned(16))) uint16_t s_i16[SEG_CAP];
+  __shared__ __attribute__((aligned(16))) float2 s_val[SEG_CAP];
+  const int lane = tn_lane();
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int ns = sk.nslices;
+  const int64_t P = N * (int64_t)S;
+  int64_t i = (int64_t)blockIdx.x * BIN_THREADS + tid;
+  const bool live = i < P;
+  if (!live) i = P - 1;
+  int64_t ray;
+  int s;
+  tn_patch_order(i, N, S, ray, s);
+  const int64_t p = ray * S + s;
+  const float* o = origins + ray * 3;
+  const float* d = directions + ray * 3;
+  const float* eb = e_bins + ray * (S + 1) + s;
+  const float st = eb[0], en = eb[1];
+  const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
+  const int nlev = (g.L - (int)blockIdx.y + level_groups - 1) / level_groups;  // levels of this block: blockIdx.y + li * level_groups
+  constexpr int GVP = WANT_DPOS ? 0 : 5;  // d enc of the first levels, requested up front (the d-position variant has no registers for it)
+  float2 gvp[GVP + 1];
+#pragma unroll
+  for (int li = 0; li < GVP; ++li) {
+    const int l = blockIdx.y + li * level_groups;
+    gvp[li] = (live && li < nlev) ? *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p) : make_float2(0.f, 0.f);
+  }
+  for (int t = tid; t < ns; t += BIN_THREADS) s_cnt[t] = 0;
+  __syncthreads();
+  const uint32_t smask = (1u << sk.slice_log2) - 1u;
+  float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+#pragma unroll 1
+  for (int li = 0; li < nlev; ++li) {
+    const int l = blockIdx.y + li * level_groups;
+    const float res = g.res[l];
+    const bool merge = (sk.merge_mask >> l) & 1u;
+    BinLevel b;
+    bin_level(c, res, g.mask, merge, live, lane, b);
+    // rank of every record inside its bucket: the value the counting atomic returns (the slots stay in registers until they are staged)
+    // (kept in bits 20+ of the slot's own register -- slots have at most 20 bits on this path, a rank at most 12: no registers of its own)
+    if (b.emit) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) b.idx[k] |= atomicAdd(&s_cnt[b.idx[k] >> sk.slice_log2], 1u) << 20;
+    }
+    __syncthreads();  // every record of the level is counted
+    if (wv == (li & (BIN_THREADS / 64 - 1))) {
+      // one wave (a different one per level): exclusive prefix over the buckets, the headers, and the counters back to zero
+      uint32_t run = 0;
+      uint32_t* hdr = sk.hdr + ((size_t)l * ns) * sk.NB + blockIdx.x;
+      for (int base = 0; base < ns; base += 64) {
+        const int sl = base + lane;
+        const uint32_t cnt = sl < ns ? s_cnt[sl] : 0u;
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+          const uint32_t t = __shfl_up(inc, o2, 64);
+          if (lane >= o2) inc += t;
+        }
+        if (sl < ns) {
+          const uint32_t off = run + inc - cnt;
+          s_off[sl] = off;
+          s_cnt[sl] = 0u;
+          hdr[(size_t)sl * sk.NB] = off | (cnt << 16);
+        }
+        run += __shfl(inc, 63, 64);
+      }
+      if (lane == 0) s_off[ns] = run;
+    }
+    // (everybody, beside the prefix: this level's values)
+    float2 gv = make_float2(0.f, 0.f);
+    if (li < GVP) {
+#pragma unroll
+      for (int q = 0; q < GVP; ++q)
+        if (q == li) gv = gvp[q];
+    } else if (live) {
+      gv = *reinterpret_cast<const float2*>(ld > 0 ? g_enc + p * ld + 2 * l : g_enc + (int64_t)l * 2 * P + 2 * p);
+    }
+    if (WANT_DPOS) {
+      // d enc / d position from the corner values: s_k = <g, table[corner k]>, then the three one-sided differences of the trilinear form
+      const float2* tb = g.table + (size_t)l * g.tsize;
+      float sk8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 t = tb[b.idx[k] & 0xfffffu];
+        sk8[k] = gv.x * t.x + gv.y * t.y;
+      }
+      float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ax += b.wy[u] * b.wz[v] * (sk8[1 + 2 * u + 4 * v] - sk8[0 + 2 * u + 4 * v]);
+          ay += b.wx[u] * b.wz[v] * (sk8[u + 2 + 4 * v] - sk8[u + 0 + 4 * v]);
+          az += b.wx[u] * b.wy[v] * (sk8[u + 2 * v + 4] - sk8[u + 2 * v + 0]);
+        }
+      dpx += ax * res;
+      dpy += ay * res;
+      dpz += az * res;
+    }
+    float vx[8], vy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = b.wx[k & 1] * b.wy[(k >> 1) & 1] * b.wz[k >> 2];
+      vx[k] = w * gv.x;
+      vy[k] = w * gv.y;
+    }
+    if (merge && b.maxlen > 1) bin_run_sums(vx, vy, lane, b);  // the run's last lane ends up with the run's sums
+    __syncthreads();  // the bucket offsets are known
+    if (b.emit) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint32_t pos = s_off[(b.idx[k] & 0xfffffu) >> sk.slice_log2] + (b.idx[k] >> 20);
+        s_i16[pos] = (uint16_t)(b.idx[k] & smask);
+        s_val[pos] = make_float2(vx[k], vy[k]);
+      }
+    }
+    __syncthreads();  // staged
+    // linear copy of the staged records into the block's region of the level: 16 bytes per lane and instruction
+    const uint32_t total = s_off[ns];
+    const size_t reg = ((size_t)l * sk.NB + blockIdx.x) * SEG_CAP;
+    {
+      float4* __restrict__ dv = reinterpret_cast<float4*>(sk.val + reg);
+      const float4* sv = reinterpret_cast<const float4*>(s_val);
+      for (uint32_t j = tid; j < (total + 1) / 2; j += BIN_THREADS) dv[j] = sv[j];
+      uint4* __restrict__ di = reinterpret_cast<uint4*>(sk.idx + reg);
+      const uint4* si = reinterpret_cast<const uint4*>(s_i16);
+      for (uint32_t j = tid; j < (total + 7) / 8; j += BIN_THREADS) di[j] = si[j];
+    }
+    // (no barrier here: the next level's ranking touches s_cnt only, which the prefix wave left zeroed before the barrier above; its staging
+    // waits behind two more barriers, which nobody passes before everybody has finished this copy)
+  }
+  if (WANT_DPOS) {
+    float wxg, wyg, wzg;
+    tn_contract_bwd(c, dpx, dpy, dpz, wxg, wyg, wzg);
+    if (!live) { wxg = wyg = wzg = 0.0f; }
+    const float tm = (st + en) / 2.0f;
+    float v[6] = {wxg, wyg, wzg, wxg * tm, wyg * tm, wzg * tm};
+    // patch order: lanes 4 apart are consecutive depths of one ray when the group holds 4 rays
+    const int r32 = (int)ray;
+    const int lead = __shfl(r32, lane & 3, 64);
+    if (__all(r32 == lead)) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float r = v[k];
+        r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 8, 64);
+        r += __shfl_xor(r, 16, 64);
+        r += __shfl_xor(r, 32, 64);
+        if (lane < 4 && r != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), r);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (v[k] != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), v[k]);
+    }
+  }
+}
+
+// Fold of the segmented path: block = (level, bucket, chunk of bin blocks).  It reads the headers the bin blocks left for its bucket, then its
+// waves walk the segments -- PACK segments per wave and iteration (64 / PACK lanes each: a segment of a fine main-grid level holds ~32 records,
+// of a proposal grid ~60, of a merged coarse level a handful; PACK follows the block's average), lane = record, two loads per record, two
+// double-precision LDS adds (see k_grid_fold) -- and the bucket's image goes to the table gradient as in k_grid_fold.
+__global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uint32_t level_begin, uint32_t grad_zero_promise) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [slots] double x, [slots] double y, then [segc] headers, [segc] running counts, 16 words
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t ns = (uint32_t)sk.nslices, per_level = ns * sk.chunks;
+  const uint32_t l = level_begin + blockIdx.x / per_level, rel = blockIdx.x % per_level;
+  // chunk-major inside a level.  Blocks go to the 8 XCDs round-robin by index; the segments of buckets s and s+1 of one bin block are neighbours in
+  // memory (they share cache lines: a segment of a fine main-grid level is 64 B of slots and 256 B of values at an arbitrary offset), so groups
+  // of 4 consecutive buckets are given to ONE XCD, as consecutive blocks of it: the shared lines are then hits in that XCD's L2.
+  const uint32_t ch = rel / ns, p = rel % ns;
+  const uint32_t sl = (ns % 32u == 0u) ? ((p >> 5) << 5) + ((p & 7u) << 2) + ((p >> 3) & 3u) : p;
+  const uint32_t slots = 1u << sk.slice_log2;
+  double* ax = reinterpret_cast<double*>(s_mem);
+  double* ay = ax + slots;
+  uint32_t* s_h = reinterpret_cast<uint32_t*>(s_mem + 4 * slots);
+  uint32_t* s_pre = s_h + sk.segc;    // [segc] records before the segment, counted from the first segment of its wave's 64
+  uint32_t* s_tot = s_pre + sk.segc;  // [FOLD_THREADS / 64] record counts of the waves' headers
+  const uint32_t b0 = ch * sk.segc, nseg = min(sk.segc, sk.NB - b0);
+  // the headers (at most FOLD_THREADS: seg_plan) are in flight while the image is cleared
+  const uint32_t my_h = (uint32_t)tid < nseg ? sk.hdr[((size_t)l * ns + sl) * sk.NB + b0 + tid] : 0u;
+  {
+    float4* z = reinterpret_cast<float4*>(s_mem);
+    for (uint32_t t = tid; t < slots; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);  // 4 floats = 16 B per slot
+  }
+  {
+    const uint32_t c = my_h >> 16;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if ((uint32_t)tid < nseg) { s_h[tid] = my_h; s_pre[tid] = inc - c; }
+    if (lane == 63) s_tot[wave] = inc;
+  }
+  __syncthreads();
+  uint32_t total = 0;
+#pragma unroll
+  for (int w = 0; w < FOLD_THREADS / 64; ++w) total += s_tot[w];
+  if (total == 0) return;  // whole block leaves together
+  const bool split = sk.chunks > 1;
+  const bool store = grad_zero_promise && !split;
+  // The LDS adds are what this kernel's time is made of, and a ds_add_f64 costs the same with 20 lanes enabled as with 64 (one segment per wave
+  // instruction, the first version: 768 half-empty adds per main-grid block instead of the binned fold's 384 full ones, 88 us instead of 70 --
+  // unchanged by deeper prefetch, hoisted header loads or bucket-to-XCD grouping).  So the lanes are kept full: the block's records, segment after
+  // segment, are ONE stream of `total` records, cut into equal shares for groups of `gw` lanes; a group walks its share gw records at a time,
+  // stepping over segment boundaries in the middle of a step (per lane: segment, offset inside it; a boundary costs the lane one header read
+  // from LDS).  Equal shares in RECORDS: with equal shares in segments the slowest of the 64 groups had ~17 % more than the mean (81 us).
+  const uint32_t avg = total / nseg;
+  const int gw_log2 = avg >= 128 ? 6 : (avg >= 48 ? 5 : 4);  // (16, 32 or 64 lanes: no measurable difference on any of the three grids)
+  const uint32_t gw = 1u << gw_log2, ngroups = FOLD_THREADS >> gw_log2;
+  const uint32_t share = (((total + ngroups - 1) / ngroups) + gw - 1) & ~(gw - 1);
+  const uint32_t r_begin = ((uint32_t)tid >> gw_log2) * share, r_end = min(total, r_begin + share);
+  uint32_t rr = r_begin + ((uint32_t)tid & (gw - 1));  // the lane's next record of the stream
+  const size_t lvl_base = (size_t)l * sk.NB + b0;
+  uint32_t sg = 0, t = 0, cnt = 0;
+  size_t base = 0;
+  auto open_seg = [&]() {
+    const uint32_t h = s_h[sg];
+    cnt = h >> 16;
+    base = (lvl_base + sg) * SEG_CAP + (h & 0xffffu);
+  };
+  if (r_begin < total) {
+    // the segment that holds record r_begin: first the wave's 64 headers it lies in, then a binary search on their running counts
+    uint32_t before = 0, w = 0;
+#pragma unroll
+    for (int i = 0; i < FOLD_THREADS / 64; ++i) {
+      const uint32_t c = s_tot[i];
+      if (i == (int)w && r_begin >= before + c) { before += c; ++w; }
+    }
+    const uint32_t want = r_begin - before;  // < s_tot[w]
+    uint32_t lo = w * 64, hi = min(nseg, lo + 64);  // answer: the last segment in [lo, hi) with s_pre <= want (empty segments in front of it share that value)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_pre[mid] <= want) lo = mid; else hi = mid;
+    }
+    sg = lo;
+    open_seg();
+    t = want - s_pre[sg] + ((uint32_t)tid & (gw - 1));
+  }
+  struct FoldRec { uint32_t id; float2 v; bool ok; };
+  auto fetch = [&](FoldRec& r) {  // the lane's next record (ok = false once the share is used up, and from then on)
+    r.ok = rr < r_end;
+    r.id = 0;
+    r.v = make_float2(0.f, 0.f);
+    if (r.ok) {
+      while (t >= cnt) {  // (a record with index < total exists: the walk ends inside the headers)
+        t -= cnt;
+        ++sg;
+        open_seg();
+      }
+#if SEG_FOLD_ABLATE & 2  // (timing experiments: no record loads)
+      r.id = (uint32_t)(base + t) & (slots - 1);
+      r.v = make_float2(1.0f, 1.0f);
+#else
+      r.id = sk.idx[base + t];
+      r.v = sk.val[base + t];
+#endif
+    }
+    t += gw;
+    rr += gw;
+  };
+  constexpr int FOLD_D = 4;  // records in flight per lane
+  FoldRec q[FOLD_D];
+#pragma unroll
+  for (int d = 0; d < FOLD_D; ++d) fetch(q[d]);
+  while (__any(q[0].ok)) {
+#pragma unroll
+    for (int d = 0; d < FOLD_D; ++d) {
+      const FoldRec c = q[d];
+      fetch(q[d]);
+#if SEG_FOLD_ABLATE & 1  // (timing experiments: no LDS adds -- the loads stay alive through a store that never happens)
+      if (c.ok && c.v.x == 123.456f && c.id == 77u) ax[c.id] = (double)c.v.y;
+#else
+      if (c.ok) {
+        if (c.v.x != 0.0f) unsafeAtomicAdd(&ax[c.id], (double)c.v.x);
+        if (c.v.y != 0.0f) unsafeAtomicAdd(&ay[c.id], (double)c.v.y);
+      }
+#endif
+    }
+  }
+  __syncthreads();
+#if SEG_FOLD_ABLATE & 4  // (timing experiments: no flush)
+  if (total != 0xffffffffu) return;
+#endif
+  float2* dst = g.grad + (size_t)l * g.tsize + ((size_t)sl << sk.slice_log2);
+  for (uint32_t tt = 0; tt < slots; tt += FOLD_THREADS * 8) {
+    float2 w[8], cv[8];
+    bool nz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // every load first (one round trip for the 8 slots of a thread), then the stores
+      const uint32_t t = tt + u * FOLD_THREADS + tid;
+      nz[u] = false;
+      if (t < slots) {
+        w[u] = make_float2((float)ax[t], (float)ay[t]);
+        nz[u] = w[u].x != 0.0f || w[u].y != 0.0f;  // untouched slots keep an exactly-zero gradient
+        if (nz[u] && !split) cv[u] = store ? make_float2(0.f, 0.f) : dst[t];  // (the caller vouches for zeros: nothing to read back)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t t = tt + u * FOLD_THREADS + tid;
+      if (!nz[u]) continue;
+      if (!split) {
+        const float2 r = make_float2(cv[u].x + w[u].x, cv[u].y + w[u].y);
+        dst[t] = r;
+        if (g.nonfinite != nullptr && ((r.x - r.x) + (r.y - r.y)) != 0.0f) *g.nonfinite = 1.0f;  // GradScaler's found_inf on the FINAL value
+      } else {
+        if (w[u].x != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t), w[u].x);
+        if (w[u].y != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(dst + t) + 1, w[u].y);
+        if (g.nonfinite != nullptr && ((w[u].x - w[u].x) + (w[u].y - w[u].y)) != 0.0f) *g.nonfinite = 1.0f;
+      }
+    }
+  }
+}
+
 static int env_int(const char* name, int dflt, int lo, int hi) {
   const char* e = getenv(name);
   int v = e ? atoi(e) : dflt;
@@ -750,8 +1098,42 @@ static int64_t plan_replicas(const TnGrid& grid, int64_t P, ReplicaK& rk) {
   return used;
 }
 
-// TN_SCATTER_MODE: 1 = binned (default), 0 = atomics with dense replicas (the round-1 path; also what the dense data-parallel exchange uses)
-static int scatter_mode() { static int m = env_int("TN_SCATTER_MODE", 1, 0, 1); return m; }
+// TN_SCATTER_MODE: 2 = segmented (default), 1 = binned (rounds 2-5: per-bucket global arrays with reservations), 0 = atomics with dense replicas
+// (the round-1 path; also what the dense data-parallel exchange uses).  Read on every call (tests compare the three in one process); the bin and
+// the fold launches of one backward must see the same value.
+static int scatter_mode() { return env_int("TN_SCATTER_MODE", 2, 0, 2); }
+static bool seg_mode() { return scatter_mode() == 2; }
+static int merge_res();
+
+// layout of the segmented path for (grid, P, scratch): a pure function of its arguments (the bin pass and the fold launches of a phased backward
+// agree on it without any state).  It lives inside the binned path's scratch: 8 records per sample and level instead of 16.
+static int seg_plan(const TnGrid& grid, int64_t P, void* scratch, SegK& sk) {
+  const int L = grid.num_levels;
+  sk = SegK{};
+  sk.slice_log2 = std::min(TN_BIN_SLICE_LOG2, grid.log2_hashmap_size);
+  sk.nslices = 1 << (grid.log2_hashmap_size - sk.slice_log2);
+  TN_REQUIRE(sk.nslices <= TN_BIN_MAX_SLICES, "tn_grid_scatter: table too large for the segmented path");
+  const int64_t NB = tn_cdiv(P, BIN_THREADS);
+  sk.NB = (uint32_t)NB;
+  const int64_t recs = (int64_t)L * NB * SEG_CAP;
+  char* base = reinterpret_cast<char*>(scratch) + 256;
+  sk.val = reinterpret_cast<float2*>(base);
+  sk.idx = reinterpret_cast<uint16_t*>(base + recs * 8);
+  sk.hdr = reinterpret_cast<uint32_t*>(base + recs * 10);
+  TN_REQUIRE(256 + recs * 10 + (int64_t)L * sk.nslices * NB * 4 <= tn_scatter_scratch_bytes(P, L), "tn_grid_scatter: segmented layout exceeds the scatter scratch");
+  for (int l = 0; l < L; ++l)
+    if (grid.res[l] <= (float)merge_res()) sk.merge_mask |= 1u << l;
+  // fold blocks: a bucket's bin blocks are cut into chunks of `segc` (<= 1024 = FOLD_THREADS: one header per thread).  A grid with many buckets
+  // (the main grid: 16 x 128) gets one block per bucket while the headers fit -- chunks flush with float atomics; a grid with few (the proposal
+  // grids: 5 x 32) is cut into chunks of 8 x nslices bin blocks, ~32 K records per fold block (first proposal grid, 2048 bin blocks: 128 per
+  // chunk 67.7 us, 256 57.4, 512 66.6; second, 768 bin blocks: 37.3 / 33.1 / 46.5)
+  int64_t segc = (int64_t)L * sk.nslices >= 1024 ? 1024 : std::max<int64_t>(64, std::min<int64_t>(1024, 8 * sk.nslices));
+  segc = std::min<int64_t>(segc, NB);
+  segc = tn_cdiv(NB, tn_cdiv(NB, segc));  // equal chunks
+  sk.segc = (uint32_t)segc;
+  sk.chunks = (uint32_t)tn_cdiv(NB, segc);
+  return TN_OK;
+}
 static int fold_chunk_sparse() { static int r = env_int("TN_SCATTER_SPARSE_CHUNK", 16384, 1024, 32768) & ~1023; return r; }
 // Same-cell runs of consecutive samples are summed before they are written (bin_run_sums) on every level whose resolution is at most this.
 // Default: every level.  (Until the end of round 4 the default was 256 -- the finer levels of the main grid were thought to hold too few runs
@@ -798,6 +1180,7 @@ void tn_grid_scatter_counters(const TnGrid& grid, int64_t P, void* scratch, uint
   *ptr = nullptr;
   *words = 0;
   if (P <= 0 || !tn_grid_scatter_is_binned(grid, P, scratch)) return;
+  if (seg_mode()) return;  // the segmented path has no counters (no global atomics at all)
   BinK bk;
   uint32_t nblk;
   if (bin_plan(grid, P, scratch, bk, nblk) != TN_OK) return;
@@ -809,6 +1192,24 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
                         int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed) {
   const int64_t P = N * (int64_t)S;
   const int L = grid.num_levels;
+  if (seg_mode()) {
+    SegK sk;
+    int rc = seg_plan(grid, P, scratch, sk);
+    if (rc) return rc;
+    GridK gk = make_gridk(grid);
+    const int blocks = (int)sk.NB;
+    int level_groups = 1;  // enough resident work for every CU: split the levels over blockIdx.y while the batch alone gives fewer than ~6 blocks per CU
+    while (level_groups < L && (int64_t)blocks * level_groups < 256 * 6) level_groups *= 2;
+    level_groups = std::min(level_groups, L);
+    if (d_origins != nullptr)
+      hipLaunchKernelGGL(k_seg_bin<true>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
+                         d_directions, level_groups, sk);
+    else
+      hipLaunchKernelGGL(k_seg_bin<false>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
+                         d_directions, level_groups, sk);
+    TN_CHECK_LAUNCH("tn_grid_scatter(bin, segmented)");
+    return TN_OK;
+  }
   BinK bk;
   uint32_t nblk;
   int rc = bin_plan(grid, P, scratch, bk, nblk);
@@ -841,6 +1242,19 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
 int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream) {
   const int L = grid.num_levels;
   TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= L, "tn_grid_scatter_fold: bad level range");
+  if (seg_mode()) {
+    SegK sk;
+    int rc = seg_plan(grid, P, scratch, sk);
+    if (rc) return rc;
+    GridK gk = make_gridk(grid);
+    const size_t shmem = (size_t)(2u << sk.slice_log2) * sizeof(double) + (size_t)sk.segc * 8 + (FOLD_THREADS / 64) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2u << TN_BIN_SLICE_LOG2) * sizeof(double) + 1024 * 8 + (FOLD_THREADS / 64) * 4));
+    const uint32_t nblk = (uint32_t)(level_end - level_begin) * (uint32_t)sk.nslices * sk.chunks;
+    hipLaunchKernelGGL(k_seg_fold, dim3(nblk), dim3(FOLD_THREADS), shmem, stream, gk, sk, (uint32_t)level_begin, (uint32_t)(gk.grad_zero ? 1 : 0));
+    TN_CHECK_LAUNCH("tn_grid_scatter(fold, segmented)");
+    return TN_OK;
+  }
   BinK bk;
   uint32_t nblk_all;
   int rc = bin_plan(grid, P, scratch, bk, nblk_all);
@@ -890,7 +1304,7 @@ int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level
 }
 
 bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratch) {
-  return scratch != nullptr && scatter_mode() == 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 && P * 8 < (1ll << 31);
+  return scratch != nullptr && scatter_mode() >= 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 && P * 8 < (1ll << 31);
 }
 
 static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,

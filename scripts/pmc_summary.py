@@ -3,7 +3,7 @@
 
     python scripts/pmc_summary.py gpurun_out/pmc profiles/r03
 
-Per-launch means of every counter, keyed by kernel and grid (X x Y threads); a k_grid_fold launch is filed under the k_grid_bin launch it
+Per-launch means of every counter, keyed by kernel and grid (X x Y threads); a fold launch (k_seg_fold / k_grid_fold) is filed under the bin launch (k_seg_bin / k_grid_bin) it
 follows (the two kernels + nothing else make one tn_hash_scatter call).
 
 HBM-side bytes (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE counts the L2's memory-side read requests at 64 B each, but a wide coalesced
@@ -31,6 +31,8 @@ READ_SHAPE = {
     "k_grid_fold": "read16",            # (u32 slot pair + float4 value pair) per lane
     "k_field_bwd_fused": "read16", "k_field_dpos": "read16", "k_field_density_only": "read16",
     "k_grid_bin": "gather8",            # 8-B pieces: d enc per lane and level, the 8 corner fetches when it computes d position (64-B requests)
+    "k_seg_bin": "gather8",             # (the same reads; segmented path)
+    "k_seg_fold": "read8",              # u16 slot + float2 value per lane, 16-lane pieces
     "k_field_encode_xcd": "gather8", "k_prop_fwd": "gather8", "k_prop_bwd_mlp": "gather8",
     "k_field_mlp_fwd": "read8",         # level-major encoding: 8 B per lane and level
     "k_field_prep": "read8",
@@ -55,9 +57,9 @@ def collect(root, sub):
                 dims[row["Dispatch_Id"]] = (short(row["Kernel_Name"]), f'{row["Grid_Size_X"]}x{row["Grid_Size_Y"]}', int(row["Start_Timestamp"]))
         owner, last_bin = {}, None
         for did, (name, grid, _) in sorted(dims.items(), key=lambda kv: kv[1][2]):
-            if name.startswith("k_grid_bin"):
+            if name.startswith(("k_grid_bin", "k_seg_bin")):
                 last_bin = grid
-            owner[did] = (name, last_bin if name.startswith("k_grid_fold") else grid)
+            owner[did] = (name, last_bin if name.startswith(("k_grid_fold", "k_seg_fold")) else grid)
         with open(path) as f:
             for row in csv.DictReader(f):
                 if row["Dispatch_Id"] not in owner:

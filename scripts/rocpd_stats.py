@@ -35,7 +35,7 @@ def main():
         # Only the kernels bench.py launches ALONE after the steps (kernel_roofline: the proposal forward, the three table scatters, the main field's
         # forward launch group and its backward MLP phase) have a stand-alone tail; for every other kernel the last launches are in-step launches
         # (round 4 printed those under the same heading: profiles/r04_bench_n1_kernel_stats_tail.txt lists k_prop_bwd_mlp at 191.7 us there).
-        alone = ("k_prop_fwd", "k_grid_bin", "k_grid_fold", "k_field_prep", "k_field_encode_xcd", "k_field_mlp_fwd", "k_field_bwd_fused", "k_field_pack",
+        alone = ("k_prop_fwd", "k_grid_bin", "k_grid_fold", "k_seg_bin", "k_seg_fold", "k_field_prep", "k_field_encode_xcd", "k_field_mlp_fwd", "k_field_bwd_fused", "k_field_pack",
                  "k_field_emb_finish")
         is_alone = lambda name: any(a in name for a in alone)  # noqa: E731
 

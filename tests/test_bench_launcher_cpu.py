@@ -44,12 +44,12 @@ def test_pmc_figures_are_only_quoted_for_the_kernels_they_were_measured_on(tmp_p
     sys.path.insert(0, ROOT)
     import bench
 
-    pmc = {"k_grid_bin<false> 196608x4": {"traffic_bytes": 220e6}, "k_grid_fold 196608x4": {"traffic_bytes": 260e6},
-           "k_grid_bin<true> 1048576x1": {"traffic_bytes": 1.0}, "k_grid_fold 1048576x1": {"traffic_bytes": 2.0}}
+    pmc = {"k_seg_bin<false> 196608x4": {"traffic_bytes": 220e6}, "k_seg_fold 196608x4": {"traffic_bytes": 260e6},
+           "k_seg_bin<true> 1048576x1": {"traffic_bytes": 1.0}, "k_seg_fold 1048576x1": {"traffic_bytes": 2.0}}
     hit = bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(main grid)"])
     assert hit is not None and sum(v["traffic_bytes"] for v in hit) == 480e6
     assert bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(prop1 grid)"]) is None  # not measured: no figure, never a guess
-    pmc["k_grid_fold 196608x2"] = {"traffic_bytes": 1.0}
+    pmc["k_seg_fold 196608x2"] = {"traffic_bytes": 1.0}
     assert bench.pmc_lookup(pmc, bench.PMC_KEYS["scatter(main grid)"]) is None  # two candidates (stale + fresh entry): ambiguous, refused
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps({"source_hash": "0" * 16, "kernels": pmc}))

@@ -993,6 +993,37 @@ def test_field_fwd_bwd_many_cameras():
     assert float(gemb[I - 40:].abs().max()) == 0.0  # cameras without a ray keep an exactly-zero embedding gradient
 
 
+@pytest.mark.parametrize("shape", ["main", "proposal"])
+def test_hash_scatter_paths_agree(monkeypatch, shape):
+    """TN_SCATTER_MODE=2 (segmented: block-private record regions, the default), 1 (binned: per-bucket arrays with reservations) and 0 (atomics +
+    dense replicas) are three ways to the same sums: table gradient and d origins / d directions at the production shapes of the main grid
+    (one fold block per bucket) and of the first proposal grid (buckets cut into chunks that flush with float atomics)."""
+    L, log2T, N, S, max_res = (16, 19, 4096, 48, 2048) if shape == "main" else (5, 17, 4096, 256, 128)
+    res = ops.level_resolutions(L, 16, max_res)
+    r = rays(N)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    s, e = sample_level(N, S, nears, fars)
+    table = torch.from_numpy(synth.uniform("hst", (L * 2**log2T, 2), seed=SEED)).to(DEV)
+    g_enc = g(torch.from_numpy(synth.uniform("hsg", (L, N * S, 2), seed=SEED)) * 1e-3)
+    out = {}
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("TN_SCATTER_MODE", mode)
+        for zero in (False, True):
+            tg = torch.zeros((L * 2**log2T, 2), device=DEV)
+            d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
+            ops.hash_scatter(table, tg, L, log2T, res, g(r["origins"]), g(r["directions"]), g(e), g_enc, d_o, d_d, grad_is_zero=zero)
+            torch.cuda.synchronize()
+            out[mode, zero] = (tg, d_o, d_d)
+    ref = out["1", False]
+    scale = [float(t.abs().max()) for t in ref]
+    assert min(scale) > 0
+    for key, got in out.items():
+        assert torch.equal(got[0] == 0, ref[0] == 0), key
+        for t, rt, sc, name in zip(got, ref, scale, ("table_grad", "d_origins", "d_directions")):
+            # double-precision sums per bucket rounded once (modes 1, 2) against float atomics (mode 0, chunk flushes, the d position sums)
+            assert float((t - rt).abs().max()) <= (1e-5 if name == "table_grad" else 1e-4) * sc, (key, name, float((t - rt).abs().max()), sc)
+
+
 def test_hash_scatter_store_variant_equals_the_adding_one():
     """TnGrid.table_grad_is_zero: with the promise kept (zeros in table_grad) the storing fold gives what the adding one gives -- same non-zero
     pattern, same values up to the order of the fold's double-precision atomics -- at the production shape of the main grid."""
