@@ -32,6 +32,8 @@
  *      TN_SCATTER_REPLICAS=n, TN_SCATTER_SPARSE_CHUNK=n, TN_SCATTER_MERGE_RES=n      tuning knobs of the two scatter paths
  *      TN_FOLD_TRACE=1 [TN_FOLD_TRACE_FILE=path]   per-block timing of the fold pass (synchronises and prints: diagnostics only)
  *      TN_BIN_LEVEL_GROUPS=n      force the number of level groups of the bin pass (diagnostic: n = levels -> one level per block)
+ *      TN_FUSE_RENDER=1           (read per call) tn_train_step with tn_render_fwd / tn_train_losses / tn_render_bwd as ONE launch,
+ *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
  *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
  *                                 half of the output features; a measured experiment that is correct and slower (profiles/r05_experiments.md)
  *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid) and writes
@@ -283,7 +285,7 @@ int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp
  * depth.  Results are bit-identical to tn_weights_fwd + tn_minmax_init + tn_composite_fwd + tn_clip_depth (two launches, not four, and no
  * atomics).  scratch: TN_RENDER_SCRATCH_FLOATS floats of device memory, contents irrelevant (required when depth_expected is given; one
  * buffer per stream that may run this concurrently).  accumulation / depth_median / depth_expected may be NULL. */
-#define TN_RENDER_SCRATCH_FLOATS 1024
+#define TN_RENDER_SCRATCH_FLOATS 4096
 int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
                   float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
                   tn_stream_t stream);
@@ -395,6 +397,22 @@ int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t
                     const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
                     const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult, float* d_pred_rgb, float* d_pred_thermal,
                     float* loss_lines, tn_stream_t stream);
+/* tn_render_fwd(training) + tn_train_losses + tn_render_bwd of the shared-density model's last level in ONE launch (the renderers of
+ * model_components/renderers.py:118-133,547-576, the loss terms of models/thermal_nerfacto.py:284-368 + model_components/losses.py:57-158 and the
+ * renderers' backward): three wave-per-ray kernels over the same rays, each latency-bound alone.  A block renders one 2x2 patch (4 rays), hands
+ * the four composites around in LDS for the pixel terms, adds the distortion term and runs the renderers' backward with the weights still in
+ * registers; the interlevel terms run beside it in blocks of their own (they recompute the fine weights with the same instructions).
+ * Arguments as the three entry points: C must be 4 (RGB + thermal composite; pred_rgb = comp, pred_thermal = comp + 3, d_comp [N,4] likewise),
+ * N a multiple of 4; d_weights_fine [N,S] and d_comp [N,4] are accumulators (read, term added, written), d_weights_prop[i] too (or NULL);
+ * d_rgb [N,S,4] and d_density [N,S] are written.  clip_depth = 0 leaves depth_expected unclipped and the per-block min / max of the sample
+ * midpoints in `scratch` (tn_render_fwd's clip launch is then the caller's to issue).  Every per-element result equals the three calls' bit for
+ * bit; the loss sums (loss_lines) are added up in another order, so they agree to rounding -- as two runs of tn_train_losses do. */
+int tn_render_losses_bwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, float* weights,
+                         float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
+                         const float* s_bins_fine, int32_t num_props, const float* const* s_bins_prop, const float* const* weights_prop,
+                         const int32_t* S_prop, float* const* d_weights_prop, float distortion_mult, float interlevel_mult,
+                         float* d_weights_fine, const float* image, const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult,
+                         float* d_comp, float* loss_lines, float* d_rgb, float* d_density, int32_t clip_depth, tn_stream_t stream);
 int tn_losses_finish(const float* loss_lines, float* losses16, const float* pose_adjustment, int32_t num_cameras, float trans_pen,
                      float rot_pen, float scale, float* reg_out, float* grad_pose, tn_stream_t stream);
 /* tn_pose_apply_bwd + tn_losses_finish for the same pose tensor in one launch (the end of an iteration's backward); loss_lines / losses16 may
@@ -474,11 +492,14 @@ int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp
 int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
 /* ---- Trainer.train_iteration (engine/trainer.py:455-499) for the shared-density model with a camera optimiser, as ONE call: what
- * RenderEngine.train_step enqueues through five calls of this ABI, in the same order on the same streams, bit for bit --
+ * RenderEngine.train_step enqueues through five calls of this ABI, in the same order on the same streams --
  *   tn_render_rays_train      forward of the branch (pose correction, proposal sampling, field, renderers); the accumulators in `acc` are cleared
  *                             inside the field's first launch
  *   tn_train_losses           pixel terms + distortion + both interlevel terms (value and gradient), sums spread over loss_lines
  *   tn_render_rays_train_bwd  renderer backward, field backward (d position, table scatter), both proposal networks when prop_grad != 0
+ *                             (with TN_FUSE_RENDER=1 the renderers at the end of the first, the losses and the renderer backward at the head of the
+ *                             third are ONE launch, tn_render_losses_bwd: every gradient and output bit for bit either way, the loss sums to
+ *                             rounding)
  *   tn_pose_bwd_finish_check  pose gradient + camera regulariser + loss sums into losses16, GradScaler's found_inf for the pose and the small
  *                             ranges no table scatter sees
  *   tn_adam_step_ranges_amp_update   Adam over the stepped groups (skip / bias correction / LR schedule decided on the device), GradScaler.update()

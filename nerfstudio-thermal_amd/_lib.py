@@ -11,10 +11,10 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 303  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 304  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
-TN_RENDER_SCRATCH_FLOATS = 1024
+TN_RENDER_SCRATCH_FLOATS = 4096
 TN_LOSS_LINES = 64
 TN_RENDER_TRAIN_OFFSETS = 25
 TN_BWD_MLP, TN_BWD_SCATTER, TN_BWD_JOIN, TN_BWD_SCATTER_BIN, TN_BWD_SCATTER_FOLD, TN_BWD_FORK_DPOS, TN_BWD_COUNTERS_CLEAN = 1, 2, 4, 8, 16, 32, 64
@@ -133,6 +133,8 @@ SIGNATURES = {
     "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
     "tn_proposal_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_render_losses_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _f, _f, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p,
+                                       _i32, _p]),
     "tn_train_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _i32, _p, _i32, _p, _p, _f, _f, _f, _p, _p, _p, _p]),
     "tn_losses_finish": (C.c_int, [_p, _p, _p, _i32, _f, _f, _f, _p, _p, _p]),
     "tn_l1_loss": (C.c_int, [_p, _p, _i64, _f, _f, _p, _p, _p, _p]),

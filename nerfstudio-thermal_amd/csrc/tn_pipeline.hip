@@ -105,13 +105,14 @@ extern "C" int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t
   return TN_OK;
 }
 
-extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
-                                    const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
-                                    const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
-                                    int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
-                                    const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
-                                    int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
-                                    int32_t save_prop_enc, tn_stream_t stream) {
+// with_render = false: everything up to and including the field's forward (tn_train_step renders inside tn_render_losses_bwd)
+static int render_rays_train_impl(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
+                                  const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
+                                  const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
+                                  int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
+                                  const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
+                                  int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
+                                  int32_t save_prop_enc, bool with_render, tn_stream_t stream) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -155,8 +156,20 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
   if ((rc = tn_field_fwd_ex(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, field_workspace_bytes, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, 1,
                             zero_fill, zero_fill_bytes, stream)))
     return rc;
+  if (!with_render) return TN_OK;
   return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
                        at(TRO_SCRATCH), stream);
+}
+extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
+                                    const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
+                                    const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
+                                    int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
+                                    const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
+                                    int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
+                                    int32_t save_prop_enc, tn_stream_t stream) {
+  return render_rays_train_impl(prop0, prop1, field, pose_adjustment, frozen, num_cameras, origins_in, directions_in, camera_indices, nears, fars, N, S0, S1, S2,
+                                anneal, jitter0, jitter1, jitter2, lin_spaced0, lin_pdf1, lin_pdf2, field_workspace, field_workspace_bytes, out,
+                                wait_event_before_field, zero_fill, zero_fill_bytes, save_prop_enc, true, stream);
 }
 
 // ---- the TRAINING backward of one branch as one call: everything behind d(composite) / d(weights) of the losses -- tn_render_bwd (get_weights +
@@ -172,13 +185,14 @@ extern "C" int64_t tn_render_rays_train_bwd_tmp_floats(int64_t N, int32_t S0, in
   auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
   return up(N * (int64_t)S2 * C) + up(N * (int64_t)S2) + up(N * (int64_t)S0) + up(N * (int64_t)S1);
 }
-extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
-                                        const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
-                                        const float* fwd_out, const float* d_comp, const float* d_weights0,
-                                        const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
-                                        int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
-                                        int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
-                                        tn_stream_t stream) {
+// render_bwd_done: d_rgb / d_density at the head of `tmp` are there already (tn_render_losses_bwd wrote them)
+static int render_rays_train_bwd_impl(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+                                      const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
+                                      const float* fwd_out, const float* d_comp, const float* d_weights0,
+                                      const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
+                                      int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
+                                      int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
+                                      bool render_bwd_done, tn_stream_t stream) {
   if (N == 0) return TN_OK;
   TN_REQUIRE(field && origins && directions && camera_indices && fwd_out && d_comp && d_weights2 && field_workspace && tmp,
              "tn_render_rays_train_bwd: null pointer");
@@ -201,7 +215,8 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
   const float* d = directions;
   hipStream_t st = tn_s(stream);
   int rc;
-  if ((rc = tn_render_bwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), at(TRO_W2), d_comp, d_weights2, N, S2, C, d_rgb, d_dens, stream))) return rc;
+  if (!render_bwd_done && (rc = tn_render_bwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), at(TRO_W2), d_comp, d_weights2, N, S2, C, d_rgb, d_dens, stream)))
+    return rc;
   if (d_density_extra != nullptr) {  // the density loss's gradient on this branch's own density (separate mode)
     const int64_t n = N * (int64_t)S2;
     hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)std::min<int64_t>(tn_cdiv(n, 256), 4096)), dim3(256), 0, st, d_dens, d_density_extra, n);
@@ -226,6 +241,17 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
                           TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | (prop_grad ? TN_BWD_FORK_DPOS : 0), 0, field->grid.num_levels, stream);
   if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
   return rc ? rc : (rc0 ? rc0 : rc1);
+}
+extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+                                        const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
+                                        const float* fwd_out, const float* d_comp, const float* d_weights0,
+                                        const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
+                                        int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
+                                        int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
+                                        tn_stream_t stream) {
+  return render_rays_train_bwd_impl(prop0, prop1, field, origins, directions, camera_indices, N, S0, S1, S2, fwd_out, d_comp, d_weights0, d_weights1, d_weights2,
+                                    d_density_extra, field_workspace, field_workspace_bytes, prop_workspace0, prop_workspace_bytes0, prop_workspace1,
+                                    prop_workspace_bytes1, tmp, d_origins, d_directions, prop_enc_saved, false, stream);
 }
 
 
@@ -270,28 +296,43 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   int64_t off[TRO_COUNT];
   train_layout(a->N, a->S0, a->S1, a->S2, C, off);
   int rc;
-  if ((rc = tn_render_rays_train(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
-                                 a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
-                                 a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
-                                 a->acc_bytes, a->prop_grad ? 1 : 0, stream)))
+  // TN_FUSE_RENDER=1 (read per call): the renderers, the losses and the renderers' backward as ONE launch, tn_render_losses_bwd, instead of their
+  // three entry points.  A measured experiment, off by default: these per-ray stages are bound by vector-instruction issue (4096 rays = 4 waves
+  // per SIMD, ~4 k instructions per ray), not by launches or latency, so the one launch takes what the three take together (41 vs 37 us).
+  const char* fr = getenv("TN_FUSE_RENDER");
+  const bool fuse_render = fr && fr[0] == '1' && a->N % 4 == 0;
+  if ((rc = render_rays_train_impl(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
+                                   a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
+                                   a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
+                                   a->acc_bytes, a->prop_grad ? 1 : 0, !fuse_render, stream)))
     return rc;
-  const float* out = a->fwd_out;
+  float* out = a->fwd_out;
   const float* sprop[2] = {out + off[TRO_S0], out + off[TRO_S1]};
   const float* wprop[2] = {out + off[TRO_W0], out + off[TRO_W1]};
   const int32_t Sprop[2] = {a->S0, a->S1};
   float* dwprop[2] = {a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr};
   const float* comp = out + off[TRO_COMP];
-  // pixel terms on the RGB columns / the thermal column of the one RGBT composite (models/thermal_nerfacto.py:425-428)
-  if ((rc = tn_train_losses(out + off[TRO_S2], out + off[TRO_W2], a->S2, 2, sprop, wprop, Sprop, dwprop, a->N, a->distortion_mult, a->interlevel_mult,
-                            a->d_weights2, comp, C, comp + 3, C, a->image, a->is_thermal, a->thermal_mult, a->tv_mult, a->cross_mult, a->d_comp, a->d_comp + 3,
-                            a->loss_lines, stream)))
+  if (fuse_render) {
+    float* d_rgb = a->bwd_tmp;  // the layout tn_render_rays_train_bwd gives its `tmp`
+    float* d_dens = d_rgb + (a->N * (int64_t)a->S2 * C + 63) / 64 * 64;
+    if ((rc = tn_render_losses_bwd(out + off[TRO_E2], out + off[TRO_D2], out + off[TRO_RGB_SAMPLES], a->N, a->S2, C, out + off[TRO_W2], out + off[TRO_COMP],
+                                   out + off[TRO_ACC], out + off[TRO_DEPTH], out + off[TRO_EXPECTED], out + off[TRO_SCRATCH], out + off[TRO_S2], 2, sprop, wprop,
+                                   Sprop, dwprop, a->distortion_mult, a->interlevel_mult, a->d_weights2, a->image, a->is_thermal, a->thermal_mult, a->tv_mult,
+                                   a->cross_mult, a->d_comp, a->loss_lines, d_rgb, d_dens, 1, stream)))
+      return rc;
+  } else if ((rc = tn_train_losses(out + off[TRO_S2], out + off[TRO_W2], a->S2, 2, sprop, wprop, Sprop, dwprop, a->N, a->distortion_mult, a->interlevel_mult,
+                                   a->d_weights2, comp, C, comp + 3, C, a->image, a->is_thermal, a->thermal_mult, a->tv_mult, a->cross_mult, a->d_comp,
+                                   a->d_comp + 3, a->loss_lines, stream))) {
+    // pixel terms on the RGB columns / the thermal column of the one RGBT composite (models/thermal_nerfacto.py:425-428)
     return rc;
-  if ((rc = tn_render_rays_train_bwd(a->prop_grad ? a->prop0 : nullptr, a->prop_grad ? a->prop1 : nullptr, a->field, out + off[TRO_ORIGINS],
-                                     out + off[TRO_DIRECTIONS], a->camera_indices, a->N, a->S0, a->S1, a->S2, out, a->d_comp,
-                                     a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr, a->d_weights2, nullptr,
-                                     a->field_workspace, a->field_workspace_bytes, a->prop_grad ? a->prop_workspace0 : nullptr,
-                                     a->prop_grad ? a->prop_workspace_bytes0 : 0, a->prop_grad ? a->prop_workspace1 : nullptr,
-                                     a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, a->prop_grad ? 1 : 0, stream)))
+  }
+  if ((rc = render_rays_train_bwd_impl(a->prop_grad ? a->prop0 : nullptr, a->prop_grad ? a->prop1 : nullptr, a->field, out + off[TRO_ORIGINS],
+                                       out + off[TRO_DIRECTIONS], a->camera_indices, a->N, a->S0, a->S1, a->S2, out, a->d_comp,
+                                       a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr, a->d_weights2, nullptr,
+                                       a->field_workspace, a->field_workspace_bytes, a->prop_grad ? a->prop_workspace0 : nullptr,
+                                       a->prop_grad ? a->prop_workspace_bytes0 : 0, a->prop_grad ? a->prop_workspace1 : nullptr,
+                                       a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, a->prop_grad ? 1 : 0,
+                                       fuse_render, stream)))
     return rc;
   if ((rc = tn_pose_bwd_finish_check(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N,
                                      a->num_cameras, a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11,

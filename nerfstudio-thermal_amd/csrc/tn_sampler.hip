@@ -32,11 +32,37 @@ extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const 
 
 // ------------------------------------------------------------------------------------------------ weights
 // lane l owns samples [l*ITEMS, (l+1)*ITEMS) of its ray.
+// The per-ray bodies come in two halves: the LOADS of the ray's data (bins, density, colours) and the arithmetic on registers.  The one-launch
+// kernels call them back to back; tn_render_losses_bwd requests everything a ray's chain of stages will need up front (each stage's first
+// touch of new data is an HBM round trip of ~2 us -- five of them in a row were most of that kernel) and keeps it for the backward.
 template <int ITEMS>
-__device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, const float* __restrict__ density, int S, int64_t ray,
-                                             float* __restrict__ weights, float* __restrict__ median_depth, int lane, float (&w)[ITEMS]) {
+__device__ __forceinline__ void ray_load_bins(const float* __restrict__ e_bins, const float* __restrict__ density, int S, int64_t ray, int lane,
+                                              float (&st)[ITEMS], float (&en)[ITEMS], float (&dn)[ITEMS]) {
   const float* eb = e_bins + ray * (S + 1);
-  const float* dn = density + ray * S;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    st[k] = en[k] = dn[k] = 0.0f;
+    if (i < S) {
+      st[k] = eb[i]; en[k] = eb[i + 1];
+      if (density != nullptr) dn[k] = density[ray * S + i];
+    }
+  }
+}
+template <int ITEMS, int C>
+__device__ __forceinline__ void ray_load_rgb(const float* __restrict__ rgb, int S, int64_t ray, int lane, float (&v)[ITEMS][C], float (&last)[C]) {
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[k][c] = (i < S) ? rgb[(ray * S + i) * C + c] : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) last[c] = rgb[(ray * S + (S - 1)) * C + c];
+}
+template <int ITEMS>
+__device__ __forceinline__ void weights_compute(const float (&st)[ITEMS], const float (&en)[ITEMS], const float (&dn)[ITEMS], int S, int64_t ray,
+                                                float* __restrict__ weights, float* __restrict__ median_depth, int lane, float (&w)[ITEMS]) {
   float dd[ITEMS], mid[ITEMS];
   double loc = 0.0;
 #pragma unroll
@@ -44,9 +70,8 @@ __device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, c
     int i = lane * ITEMS + k;
     dd[k] = 0.0f; mid[k] = 0.0f;
     if (i < S) {
-      float st = eb[i], en = eb[i + 1];
-      dd[k] = (en - st) * dn[i];
-      mid[k] = (st + en) / 2.0f;
+      dd[k] = (en[k] - st[k]) * dn[k];
+      mid[k] = (st[k] + en[k]) / 2.0f;
     }
     loc += (double)dd[k];
   }
@@ -60,8 +85,8 @@ __device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, c
     float a = 1.0f - expf(-dd[k]);
     float T = expf(-trans);
     w[k] = tn_nan_to_num(a * T);
-    if (i < S) weights[ray * S + i] = w[k];
-    else w[k] = 0.0f;
+    if (i >= S) w[k] = 0.0f;
+    else if (weights != nullptr) weights[ray * S + i] = w[k];
     run += (double)dd[k];
     wloc += (double)w[k];
   }
@@ -89,6 +114,13 @@ __device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, c
     best = __shfl(v, owner, 64);
     if (lane == 0) median_depth[ray] = best;
   }
+}
+template <int ITEMS>
+__device__ __forceinline__ void weights_body(const float* __restrict__ e_bins, const float* __restrict__ density, int S, int64_t ray,
+                                             float* __restrict__ weights, float* __restrict__ median_depth, int lane, float (&w)[ITEMS]) {
+  float st[ITEMS], en[ITEMS], dn[ITEMS];
+  ray_load_bins<ITEMS>(e_bins, density, S, ray, lane, st, en, dn);
+  weights_compute<ITEMS>(st, en, dn, S, ray, weights, median_depth, lane, w);
 }
 template <int ITEMS>
 __global__ void __launch_bounds__(BLOCK) k_weights_fwd(const float* __restrict__ e_bins, const float* __restrict__ density, int64_t N, int S,
@@ -175,12 +207,31 @@ extern "C" int tn_weights_bwd(const float* e_bins, const float* density, const f
 // ------------------------------------------------------------------------------------------------ PDF resample
 // w_raw[k] = weight of sample lane*ITEMS + k of the previous level (0 beyond Sp): from memory (k_pdf_resample) or straight from the
 // registers of weights_body (k_weights_pdf).
-template <int ITEMS>
-__device__ __forceinline__ void pdf_body(const float (&w_raw)[ITEMS], const float* __restrict__ s_bins_prev, int Sp, float anneal,
-                                         const float* __restrict__ u_lin, const float* __restrict__ jitter, const float* __restrict__ nears,
-                                         const float* __restrict__ fars, int S, int64_t ray, float* __restrict__ s_bins, float* __restrict__ e_bins,
-                                         float* cdf, float* pb, int lane) {
+// what pdf_body reads from memory, requested in ONE go by pdf_load (k_weights_pdf: before get_weights, whose stores the compiler will not move
+// loads across; written where they are used, the bins' copy into LDS alone was five round trips in a row, the ray's near / far / jitter and
+// the first u another one behind the CDF)
+struct PdfLoads {
+  float bp[TN_MAX_SAMPLES / 64 + 1];  // the previous level's s-space bins, i = lane + 64 k
+  float u0[TN_MAX_SAMPLES / 64 + 1];  // u_lin[j], j = lane + 64 k
+  float near, far, jit;
+};
+__device__ __forceinline__ void pdf_load(const float* __restrict__ s_bins_prev, int Sp, const float* __restrict__ u_lin,
+                                         const float* __restrict__ jitter, const float* __restrict__ nears, const float* __restrict__ fars, int S,
+                                         int64_t ray, int lane, PdfLoads& L) {
   const float* bp = s_bins_prev + ray * (Sp + 1);
+#pragma unroll
+  for (int k = 0; k <= TN_MAX_SAMPLES / 64; ++k) {
+    const int i = lane + 64 * k;
+    L.bp[k] = (i <= Sp) ? bp[i] : 0.0f;
+    L.u0[k] = (i <= S) ? u_lin[i] : 0.0f;
+  }
+  L.near = nears[ray];
+  L.far = fars[ray];
+  L.jit = jitter != nullptr ? jitter[ray] : 0.0f;
+}
+template <int ITEMS>
+__device__ __forceinline__ void pdf_body(const float (&w_raw)[ITEMS], const PdfLoads& L, int Sp, float anneal, bool jittered, int S, int64_t ray,
+                                         float* __restrict__ s_bins, float* __restrict__ e_bins, float* cdf, float* pb, int lane) {
   float w[ITEMS];
   double loc = 0.0;
 #pragma unroll
@@ -194,7 +245,9 @@ __device__ __forceinline__ void pdf_body(const float (&w_raw)[ITEMS], const floa
     }
     loc += (double)w[k];
   }
-  for (int i = lane; i <= Sp; i += 64) pb[i] = bp[i];
+#pragma unroll
+  for (int k = 0; k <= TN_MAX_SAMPLES / 64; ++k)
+    if (lane + 64 * k <= Sp) pb[lane + 64 * k] = L.bp[k];
   float w_sum = (float)tn_wave_sum_d(loc);
   float padding = fmaxf(1e-5f - w_sum, 0.0f);
   float pad_each = padding / (float)Sp;
@@ -218,12 +271,15 @@ __device__ __forceinline__ void pdf_body(const float (&w_raw)[ITEMS], const floa
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
-  float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
+  float s_near = tn_spacing(L.near), s_far = tn_spacing(L.far);
   int nb = S + 1;
-  for (int j = lane; j < nb; j += 64) {
+#pragma unroll
+  for (int kk = 0; kk <= TN_MAX_SAMPLES / 64; ++kk) {
+    const int j = lane + 64 * kk;
+    if (j >= nb) continue;
     float u;
-    if (jitter != nullptr) u = u_lin[j] + jitter[ray] / (float)nb;
-    else u = u_lin[j] + (float)(1.0 / (2.0 * (double)nb));
+    if (jittered) u = L.u0[kk] + L.jit / (float)nb;
+    else u = L.u0[kk] + (float)(1.0 / (2.0 * (double)nb));
     // searchsorted(cdf, u, side="right"): number of cdf entries <= u
     int lo = 0, hi = Sp + 1;
     while (lo < hi) {
@@ -258,7 +314,9 @@ __global__ void __launch_bounds__(BLOCK) k_pdf_resample(const float* __restrict_
     int i = lane * ITEMS + k;
     w_raw[k] = (i < Sp) ? weights_prev[ray * Sp + i] : 0.0f;
   }
-  pdf_body<ITEMS>(w_raw, s_bins_prev, Sp, anneal, u_lin, jitter, nears, fars, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
+  PdfLoads L;
+  pdf_load(s_bins_prev, Sp, u_lin, jitter, nears, fars, S, ray, lane, L);
+  pdf_body<ITEMS>(w_raw, L, Sp, anneal, jitter != nullptr, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
 }
 // RaySamples.get_weights of a proposal level and the PDF resampling it feeds, one wave per ray, the weights handed over in registers
 // (the two are always called back to back by ProposalNetworkSampler.generate_ray_samples, ray_samplers.py:593-611).
@@ -276,8 +334,10 @@ __global__ void __launch_bounds__(BLOCK) k_weights_pdf(const float* __restrict__
   int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
   if (ray >= N) return;
   float w[ITEMS];
+  PdfLoads L;
+  pdf_load(s_bins_prev, Sp, u_lin, jitter, nears, fars, S, ray, lane, L);  // in flight beside the loads of get_weights
   weights_body<ITEMS>(e_bins_prev, density_prev, Sp, ray, weights_prev, median_prev, lane, w);
-  pdf_body<ITEMS>(w, s_bins_prev, Sp, anneal, u_lin, jitter, nears, fars, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
+  pdf_body<ITEMS>(w, L, Sp, anneal, jitter != nullptr, S, ray, s_bins, e_bins, sh_cdf[wv], sh_bins[wv], lane);
 }
 
 extern "C" int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
@@ -316,10 +376,10 @@ extern "C" int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream) {
 
 // one ray of the renderers: w[k] = weight of sample lane*ITEMS + k (0 beyond S); mn / mx take the ray's smallest / largest midpoint
 template <int ITEMS, int C>
-__device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const float* __restrict__ rgb, const float* __restrict__ e_bins, int S,
-                                              int64_t ray, int training, float* __restrict__ comp, float* __restrict__ accumulation,
-                                              float* __restrict__ depth_median, float* __restrict__ depth_expected, int lane, float& mn, float& mx) {
-  const float* eb = e_bins + ray * (S + 1);
+__device__ __forceinline__ void composite_compute(const float (&w)[ITEMS], const float (&st)[ITEMS], const float (&en)[ITEMS], const float (&rv)[ITEMS][C],
+                                                  const float (&lastc)[C], int S, int64_t ray, int training, float* __restrict__ comp,
+                                                  float* __restrict__ accumulation, float* __restrict__ depth_median, float* __restrict__ depth_expected,
+                                                  int lane, float& mn, float& mx, float* comp_out = nullptr) {  // comp_out: [C], valid on lane 0
   float acc_c[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc_c[c] = 0.0f;
@@ -332,11 +392,11 @@ __device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const flo
     int i = lane * ITEMS + k;
     mid[k] = 0.0f;
     if (i < S) {
-      mid[k] = (eb[i] + eb[i + 1]) / 2.0f;
+      mid[k] = (st[k] + en[k]) / 2.0f;
       mn = fminf(mn, mid[k]); mx = fmaxf(mx, mid[k]);
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        float v = rgb[(ray * S + i) * C + c];
+        float v = rv[k][c];
         if (!training) v = tn_nan_to_num(v);
         acc_c[c] += w[k] * v;
       }
@@ -352,11 +412,12 @@ __device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const flo
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      float last = rgb[(ray * S + (S - 1)) * C + c];
+      float last = lastc[c];
       if (!training) last = tn_nan_to_num(last);
       float v = acc_c[c] + last * (1.0f - wsum);
       if (!training) v = fminf(fmaxf(v, 0.0f), 1.0f);
       comp[ray * C + c] = v;
+      if (comp_out != nullptr) comp_out[c] = v;
     }
     if (accumulation) accumulation[ray] = wsum;
     if (depth_expected) depth_expected[ray] = wmid / (wsum + 1e-10f);
@@ -381,6 +442,16 @@ __device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const flo
     v = __shfl(v, owner, 64);
     if (lane == 0) depth_median[ray] = v;
   }
+}
+
+template <int ITEMS, int C>
+__device__ __forceinline__ void composite_ray(const float (&w)[ITEMS], const float* __restrict__ rgb, const float* __restrict__ e_bins, int S,
+                                              int64_t ray, int training, float* __restrict__ comp, float* __restrict__ accumulation,
+                                              float* __restrict__ depth_median, float* __restrict__ depth_expected, int lane, float& mn, float& mx) {
+  float st[ITEMS], en[ITEMS], dn[ITEMS], rv[ITEMS][C], lastc[C];
+  ray_load_bins<ITEMS>(e_bins, nullptr, S, ray, lane, st, en, dn);
+  ray_load_rgb<ITEMS, C>(rgb, S, ray, lane, rv, lastc);
+  composite_compute<ITEMS, C>(w, st, en, rv, lastc, S, ray, training, comp, accumulation, depth_median, depth_expected, lane, mn, mx);
 }
 
 template <int ITEMS, int C>
@@ -454,11 +525,12 @@ __global__ void __launch_bounds__(BLOCK) k_render_fwd(const float* __restrict__ 
     scratch[RENDER_MAX_BLOCKS + blockIdx.x] = b;
   }
 }
-// every block reduces the nblk (<= 512) pairs itself (4 KB out of L2), then clips its share of the rays
-__global__ void __launch_bounds__(512) k_clip_depth_blocks(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int64_t N) {
+// every block reduces the nblk pairs itself (a few KB out of L2), then clips its share of the rays; the maxima start at scratch[hi_off]
+__global__ void __launch_bounds__(512) k_clip_depth_blocks(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int hi_off, int64_t N) {
   __shared__ float sh_lo[8], sh_hi[8];
   const int t = threadIdx.x;
-  float lo = t < nblk ? scratch[t] : INFINITY, hi = t < nblk ? scratch[RENDER_MAX_BLOCKS + t] : 0.0f;
+  float lo = INFINITY, hi = 0.0f;
+  for (int i = t; i < nblk; i += 512) { lo = fminf(lo, scratch[i]); hi = fmaxf(hi, scratch[hi_off + i]); }
   lo = tn_wave_min(lo); hi = tn_wave_max(hi);
   if ((t & 63) == 0) { sh_lo[t >> 6] = lo; sh_hi[t >> 6] = hi; }
   __syncthreads();
@@ -496,7 +568,7 @@ extern "C" int tn_render_fwd(const float* e_bins, const float* density, const fl
 #undef LAUNCH_R
   TN_CHECK_LAUNCH("tn_render_fwd");
   if (depth_expected != nullptr) {
-    hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, st, depth_expected, scratch, nblk, N);
+    hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, st, depth_expected, scratch, nblk, RENDER_MAX_BLOCKS, N);
     TN_CHECK_LAUNCH("tn_render_fwd(clip)");
   }
   return TN_OK;
@@ -604,24 +676,17 @@ extern "C" int tn_composite_bwd(const float* rgb, const float* weights, const fl
 
 // backward of tn_render_fwd in one launch: composite_bwd, then weights_bwd on d_weights_in + the compositing term (held in registers;
 // d_weights_in is NOT updated).  Same arithmetic, same order as tn_composite_bwd followed by tn_weights_bwd.
+// one ray: wk = the ray's weights (lane * ITEMS + k; 0 beyond S), g = d composite, gw_in = d weights of the ray as handed in (any address space);
+// st / en / dn / rv / lastc = the ray's data (ray_load_bins, ray_load_rgb)
 template <int ITEMS, int C>
-__global__ void __launch_bounds__(BLOCK) k_render_bwd(const float* __restrict__ e_bins, const float* __restrict__ density,
-                                                      const float* __restrict__ rgb, const float* __restrict__ weights,
-                                                      const float* __restrict__ d_comp, const float* __restrict__ d_weights_in, int64_t N, int S,
-                                                      float* __restrict__ d_rgb, float* __restrict__ d_density) {
-  int lane = tn_lane();
-  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
-  if (ray >= N) return;
-  const float* eb = e_bins + ray * (S + 1);
-  float g[C], last[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) { g[c] = d_comp[ray * C + c]; last[c] = rgb[(ray * S + (S - 1)) * C + c]; }
-  float dd[ITEMS], delta[ITEMS], gw[ITEMS], wk[ITEMS];
+__device__ __forceinline__ void render_bwd_compute(const float (&st)[ITEMS], const float (&en)[ITEMS], const float (&dn)[ITEMS], const float (&rv)[ITEMS][C],
+                                                   const float (&last)[C], const float (&wk)[ITEMS], const float (&g)[C], const float* gw_in, int64_t ray,
+                                                   int S, float* __restrict__ d_rgb, float* __restrict__ d_density, int lane) {
+  float dd[ITEMS], delta[ITEMS], gw[ITEMS];
   float wsum = 0.0f;
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     int i = lane * ITEMS + k;
-    wk[k] = (i < S) ? weights[ray * S + i] : 0.0f;
     if (i < S) wsum += wk[k];
   }
   wsum = tn_wave_sum(wsum);
@@ -635,15 +700,15 @@ __global__ void __launch_bounds__(BLOCK) k_render_bwd(const float* __restrict__ 
       float dw = 0.0f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        float v = rgb[(ray * S + i) * C + c];
+        float v = rv[k][c];
         dw += g[c] * (v - last[c]);
         float dr = wk[k] * g[c];
         if (i == S - 1) dr += (1.0f - wsum) * g[c];
         d_rgb[(ray * S + i) * C + c] = dr;
       }
-      gw[k] = d_weights_in[ray * S + i] + dw;
-      delta[k] = eb[i + 1] - eb[i];
-      dd[k] = delta[k] * density[ray * S + i];
+      gw[k] = gw_in[i] + dw;
+      delta[k] = en[k] - st[k];
+      dd[k] = delta[k] * dn[k];
     }
     loc += (double)dd[k];
     sloc += gw[k] * wk[k];
@@ -662,6 +727,33 @@ __global__ void __launch_bounds__(BLOCK) k_render_bwd(const float* __restrict__ 
     if (i < S) d_density[ray * S + i] = gg * delta[k];
     suffix += gw[k] * wk[k];
   }
+}
+template <int ITEMS, int C>
+__device__ __forceinline__ void render_bwd_ray(const float* __restrict__ e_bins, const float* __restrict__ density, const float* __restrict__ rgb,
+                                               const float (&wk)[ITEMS], const float (&g)[C], const float* gw_in, int64_t ray, int S,
+                                               float* __restrict__ d_rgb, float* __restrict__ d_density, int lane) {
+  float st[ITEMS], en[ITEMS], dn[ITEMS], rv[ITEMS][C], lastc[C];
+  ray_load_bins<ITEMS>(e_bins, density, S, ray, lane, st, en, dn);
+  ray_load_rgb<ITEMS, C>(rgb, S, ray, lane, rv, lastc);
+  render_bwd_compute<ITEMS, C>(st, en, dn, rv, lastc, wk, g, gw_in, ray, S, d_rgb, d_density, lane);
+}
+template <int ITEMS, int C>
+__global__ void __launch_bounds__(BLOCK) k_render_bwd(const float* __restrict__ e_bins, const float* __restrict__ density,
+                                                      const float* __restrict__ rgb, const float* __restrict__ weights,
+                                                      const float* __restrict__ d_comp, const float* __restrict__ d_weights_in, int64_t N, int S,
+                                                      float* __restrict__ d_rgb, float* __restrict__ d_density) {
+  int lane = tn_lane();
+  int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  float g[C], wk[ITEMS];
+#pragma unroll
+  for (int c = 0; c < C; ++c) g[c] = d_comp[ray * C + c];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    int i = lane * ITEMS + k;
+    wk[k] = (i < S) ? weights[ray * S + i] : 0.0f;
+  }
+  render_bwd_ray<ITEMS, C>(e_bins, density, rgb, wk, g, d_weights_in + ray * S, ray, S, d_rgb, d_density, lane);
 }
 
 extern "C" int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
@@ -691,6 +783,55 @@ extern "C" int tn_render_bwd(const float* e_bins, const float* density, const fl
 // LDS of the loss bodies: ONE buffer per block, carved up by whichever body the block runs (a block of the fused launch runs exactly one),
 // small enough for 8 blocks per CU -- the whole grid of tn_train_losses is resident at once.
 #define LOSS_SMEM_BYTES (RAYS_PER_BLOCK * 3600 + 16)
+// one ray; returns the lane's share of L.  tlo / thi / dwf: s_bins[i], s_bins[i + 1] and the handed-in d weights for i = lane + 64 k; the ray's
+// weights are in sh_w.  d_w_row (may be NULL) receives dwf + this term, gw_out (LDS row, may be NULL) the same values.
+template <int DK>
+__device__ __forceinline__ float distortion_compute(const float (&tlo)[DK], const float (&thi)[DK], const float (&dwf)[DK], int S, float scale,
+                                                    float* __restrict__ d_w_row, float* gw_out, float* sh_w, float* sh_m, int lane) {
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    const int i = lane + 64 * k;
+    if (i < S) sh_m[i] = (thi[k] + tlo[k]) / 2.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  float total = 0.0f;
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    const int i = lane + 64 * k;
+    if (i < S) {
+      float wi = sh_w[i], mi = sh_m[i];
+      float inner = 0.0f;
+      for (int j = 0; j < S; ++j) inner += sh_w[j] * fabsf(mi - sh_m[j]);
+      float width = thi[k] - tlo[k];
+      total += wi * inner + wi * wi * width / 3.0f;
+      if (d_w_row != nullptr) {
+        const float v = dwf[k] + scale * (2.0f * inner + 2.0f * wi * width / 3.0f);
+        d_w_row[i] = v;
+        if (gw_out != nullptr) gw_out[i] = v;
+      }
+    }
+  }
+  __threadfence_block();
+  return total;
+}
+__device__ __forceinline__ float distortion_ray(const float* __restrict__ t, const float* __restrict__ w_row, int S, float scale,
+                                                float* __restrict__ d_w_row, float* sh_w, float* sh_m, int lane) {
+  constexpr int DK = TN_MAX_SAMPLES / 64;
+  float tlo[DK], thi[DK], dwf[DK];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    const int i = lane + 64 * k;
+    tlo[k] = thi[k] = dwf[k] = 0.0f;
+    if (i < S) {
+      sh_w[i] = w_row[i];
+      tlo[k] = t[i]; thi[k] = t[i + 1];
+      if (d_w_row != nullptr) dwf[k] = d_w_row[i];
+    }
+  }
+  return distortion_compute<DK>(tlo, thi, dwf, S, scale, d_w_row, nullptr, sh_w, sh_m, lane);
+}
 __device__ __forceinline__ void distortion_body(const float* __restrict__ s_bins, const float* __restrict__ weights, int64_t N, int S, float mult,
                                                 float* __restrict__ loss_out, float* __restrict__ d_weights, unsigned char* smem) {
   float (*sh_w)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem);
@@ -701,27 +842,8 @@ __device__ __forceinline__ void distortion_body(const float* __restrict__ s_bins
   int wv = threadIdx.x >> 6;
   float wave_total = 0.0f;
   float scale = mult / (float)N;
-  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
-  const float* t = s_bins + ray * (S + 1);
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < S; i += 64) {
-    sh_w[wv][i] = weights[ray * S + i];
-    sh_m[wv][i] = (t[i + 1] + t[i]) / 2.0f;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  float total = 0.0f;
-  for (int i = lane; i < S; i += 64) {
-    float wi = sh_w[wv][i], mi = sh_m[wv][i];
-    float inner = 0.0f;
-    for (int j = 0; j < S; ++j) inner += sh_w[wv][j] * fabsf(mi - sh_m[wv][j]);
-    float width = t[i + 1] - t[i];
-    total += wi * inner + wi * wi * width / 3.0f;
-    if (d_weights != nullptr) d_weights[ray * S + i] += scale * (2.0f * inner + 2.0f * wi * width / 3.0f);
-  }
-  wave_total += tn_wave_sum(total);
-  __threadfence_block();
-  }  // ray loop
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK)
+    wave_total += tn_wave_sum(distortion_ray(s_bins + ray * (S + 1), weights + ray * S, S, scale, d_weights ? d_weights + ray * S : nullptr, sh_w[wv], sh_m[wv], lane));
   if (lane == 0) sh_part[wv] = wave_total;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -757,33 +879,42 @@ extern "C" int tn_distortion_loss(const float* s_bins, const float* weights, int
 //   d wp_k = sum_i ([lo_i <= k <= hi_i] - [hi_i < k < lo_i]) * g_i,   g_i = -2 clip(w_i - w_outer_i,0) / (w_i + eps) / (N*S_f)
 // The gradient is summed directly over the covering fine intervals (all g_i have one sign): no difference-array / prefix-sum, whose
 // cancellation residue (1e-16) would become full-size Adam steps on table entries whose true gradient is exactly 0.
-__device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
-                                                const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N, float mult,
-                                                float* __restrict__ loss_out, float* __restrict__ d_w_prop, unsigned char* smem) {
-  // per wave: cp[257] cy[257] g[256] floats, lo[256] hi[256] bytes (proposal-bin indices < 256) = 3592 bytes
-  struct WaveLds { float cp[TN_MAX_SAMPLES + 1]; float cy[TN_MAX_SAMPLES + 1]; float g[TN_MAX_SAMPLES]; uint8_t lo[TN_MAX_SAMPLES]; uint8_t hi[TN_MAX_SAMPLES]; };
-  static_assert(sizeof(WaveLds) <= 3600 && TN_MAX_SAMPLES <= 256, "loss smem");
-  int lane = tn_lane();
-  int wv = threadIdx.x >> 6;
-  WaveLds& wl = *reinterpret_cast<WaveLds*>(smem + wv * 3600);
-  float* sh_part = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600);
-  float wave_total = 0.0f;
-  float scale = mult / ((float)N * (float)Sf);
-  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+// per wave: cp[257] cy[257] g[256] floats, lo[256] hi[256] bytes (proposal-bin indices < 256) = 3592 bytes
+struct InterlevelLds { float cp[TN_MAX_SAMPLES + 1]; float cy[TN_MAX_SAMPLES + 1]; float g[TN_MAX_SAMPLES]; uint8_t lo[TN_MAX_SAMPLES]; uint8_t hi[TN_MAX_SAMPLES]; };
+static_assert(sizeof(InterlevelLds) <= 3600 && TN_MAX_SAMPLES <= 256, "loss smem");
+// one ray: c / wf = the fine level's s-space bins and weights (wf in any address space), cp / wp = the proposal level's, d_wp = its d weights
+// (accumulated; may be NULL).  Returns the lane's share of the loss sum.
+__device__ __forceinline__ float interlevel_ray(const float* __restrict__ c, const float* wf, int Sf, const float* __restrict__ cp,
+                                                const float* __restrict__ wp, int Sp, float scale, float* __restrict__ d_wp, InterlevelLds& wl,
+                                                int lane) {
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
-  const float* cp = p_bins + ray * (Sp + 1);
-  const float* c = c_bins + ray * (Sf + 1);
-  // cumsum of wp (torch CPU: double accumulate, float per element); lane owns 4 contiguous entries (Sp<=256)
+  // every load of the ray first: the stages below each start with data nobody has touched yet, and written where they are used each is a
+  // round trip of its own (the proposal bins' copy into LDS alone was five in a row)
+  constexpr int DK = TN_MAX_SAMPLES / 64;
   const int ITEMS = 4;
-  float v[ITEMS];
-  double loc = 0.0;
+  float v[ITEMS], cpv[DK + 1], t0v[DK], t1v[DK], wfv[DK], dwv[DK];
 #pragma unroll
   for (int k = 0; k < ITEMS; ++k) {
     int i = lane * ITEMS + k;
-    v[k] = (i < Sp) ? w_prop[ray * Sp + i] : 0.0f;
-    loc += (double)v[k];
+    v[k] = (i < Sp) ? wp[i] : 0.0f;
   }
+#pragma unroll
+  for (int k = 0; k <= DK; ++k) {
+    const int i = lane + 64 * k;
+    cpv[k] = (i <= Sp) ? cp[i] : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    const int i = lane + 64 * k;
+    t0v[k] = t1v[k] = wfv[k] = dwv[k] = 0.0f;
+    if (i < Sf) { t0v[k] = c[i]; t1v[k] = c[i + 1]; wfv[k] = wf[i]; }
+    if (d_wp != nullptr && i < Sp) dwv[k] = d_wp[i];
+  }
+  // cumsum of wp (torch CPU: double accumulate, float per element); lane owns 4 contiguous entries (Sp<=256)
+  double loc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) loc += (double)v[k];
   double incl = tn_wave_incl_scan_d(loc, lane);
   double run = tn_excl_from_incl_d(incl, lane);
   if (lane == 0) wl.cy[0] = 0.0f;
@@ -793,12 +924,17 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
     run += (double)v[k];
     if (i < Sp) wl.cy[i + 1] = (float)run;
   }
-  for (int i = lane; i <= Sp; i += 64) wl.cp[i] = cp[i];
+#pragma unroll
+  for (int k = 0; k <= DK; ++k)
+    if (lane + 64 * k <= Sp) wl.cp[lane + 64 * k] = cpv[k];
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   float total = 0.0f;
-  for (int i = lane; i < Sf; i += 64) {
-    float t0 = c[i], t1 = c[i + 1];
+#pragma unroll
+  for (int kk = 0; kk < DK; ++kk) {
+    const int i = lane + 64 * kk;
+    if (i >= Sf) continue;
+    float t0 = t0v[kk], t1 = t1v[kk];
     int lo = 0, hi = Sp;  // searchsorted right over the starts cp[0..Sp-1]
     while (lo < hi) { int m = (lo + hi) >> 1; if (wl.cp[m] <= t0) lo = m + 1; else hi = m; }
     int ilo = lo - 1; ilo = ilo < 0 ? 0 : (ilo > Sp - 1 ? Sp - 1 : ilo);
@@ -806,7 +942,7 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
     while (lo < hi) { int m = (lo + hi) >> 1; if (wl.cp[m + 1] <= t1) lo = m + 1; else hi = m; }
     int ihi = lo > Sp - 1 ? Sp - 1 : lo;
     float w_outer = wl.cy[ihi + 1] - wl.cy[ilo];
-    float w = w_fine[ray * Sf + i];
+    float w = wfv[kk];
     float d = w - w_outer;
     if (d < 0.0f) d = 0.0f;
     total += d * d / (w + 1.0e-7f);
@@ -814,8 +950,7 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
     wl.lo[i] = (uint8_t)ilo;
     wl.hi[i] = (uint8_t)ihi;
   }
-  wave_total += tn_wave_sum(total);
-  if (d_w_prop != nullptr) {
+  if (d_wp != nullptr) {
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     // lo_i and hi_i do not decrease with i (the fine bins are sorted), so the fine intervals that cover proposal bin k are ONE run
@@ -826,7 +961,10 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
     for (int i = lane; i < Sf; i += 64)
       if (i > 0 && (wl.lo[i] < wl.lo[i - 1] || wl.hi[i] < wl.hi[i - 1])) mono = false;
     if (__all(mono)) {
-      for (int k = lane; k < Sp; k += 64) {
+#pragma unroll
+      for (int kk = 0; kk < DK; ++kk) {
+        const int k = lane + 64 * kk;
+        if (k >= Sp) continue;
         int l = 0, h = Sf;
         while (l < h) { int m = (l + h) >> 1; if (wl.lo[m] <= k) l = m + 1; else h = m; }
         const int A = l;
@@ -836,7 +974,7 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
         float acc = 0.0f;
         if (B < A) { for (int i = B; i < A; ++i) acc += wl.g[i]; }
         else { for (int i = A; i < B; ++i) acc -= wl.g[i]; }
-        if (acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
+        if (acc != 0.0f) d_wp[k] = dwv[kk] + acc;
       }
     } else {
     // unsorted fine bins (never from the samplers): walk every interval with a non-zero g_i (wave-uniform bit masks, 64 intervals per word)
@@ -855,11 +993,24 @@ __device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins
           else if (b < k && k < a) acc -= gi;
         }
       }
-      if (k < Sp && acc != 0.0f) d_w_prop[ray * Sp + k] += acc;
+      if (k < Sp && acc != 0.0f) d_wp[k] += acc;
     }
     }
   }
-  }  // ray loop
+  return total;
+}
+__device__ __forceinline__ void interlevel_body(const float* __restrict__ c_bins, const float* __restrict__ w_fine, int Sf,
+                                                const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int64_t N, float mult,
+                                                float* __restrict__ loss_out, float* __restrict__ d_w_prop, unsigned char* smem) {
+  int lane = tn_lane();
+  int wv = threadIdx.x >> 6;
+  InterlevelLds& wl = *reinterpret_cast<InterlevelLds*>(smem + wv * 3600);
+  float* sh_part = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600);
+  float wave_total = 0.0f;
+  float scale = mult / ((float)N * (float)Sf);
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK)
+    wave_total += tn_wave_sum(interlevel_ray(c_bins + ray * (Sf + 1), w_fine + ray * Sf, Sf, p_bins + ray * (Sp + 1), w_prop + ray * Sp, Sp, scale,
+                                             d_w_prop ? d_w_prop + ray * Sp : nullptr, wl, lane));
   if (lane == 0) sh_part[wv] = wave_total;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -998,6 +1149,269 @@ extern "C" int tn_train_losses(const float* s_bins_fine, const float* weights_fi
   return launch_train_losses("tn_train_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
                              distortion_mult, interlevel_mult, nullptr, nullptr, d_weights_fine, pred_rgb, rgb_stride, pred_thermal, thermal_stride,
                              image, is_thermal, thermal_mult, tv_mult, cross_mult, nullptr, d_pred_rgb, d_pred_thermal, loss_lines, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ renderer + losses + renderer backward
+// tn_render_losses_bwd: tn_render_fwd(training) + tn_train_losses + tn_render_bwd of the shared-density model's last level in ONE launch.
+// The three are wave-per-ray kernels over the same rays, each latency-bound on its own (10 + 24 + 5 us with two launch gaps between them):
+//   blockIdx.y = 0      per 2x2 patch (4 rays = the 4 waves of a block): get_weights + the renderers, then -- composites exchanged through
+//                       LDS -- the pixel terms of the patch, the distortion loss of each ray, and the renderers' backward with the weights,
+//                       d composite and d weights still in registers / LDS;
+//   blockIdx.y = 1 + i  the interlevel loss against proposal level i.  It needs the fine level's weights: recomputed here with the function
+//                       slice 0 uses (same inputs, same instructions: the same bits), instead of waiting for slice 0 to publish them.
+// Every per-element result is what the three calls give (same expressions in the same order); the loss SUMS are added up in another order
+// (per block, then one float atomic per term and block -- as before they differ from run to run in the last bits).
+#define RT_SMEM_BYTES (RAYS_PER_BLOCK * 3600 + RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4 + 64)
+#ifndef RT_ABLATE
+#define RT_ABLATE 0  // (timing experiments: 1 no distortion stage, 2 no pixel stage, 4 no renderer backward, 8 no renderers)
+#endif
+#define RT_MAX_BLOCKS 2048  // one patch per block up to 8192 rays: every wave renders ONE ray (no second trip on the chain)
+static_assert(TN_RENDER_SCRATCH_FLOATS >= 2 * RT_MAX_BLOCKS, "render scratch");
+struct RenderTrainArgs {
+  const float* e_bins; const float* density; const float* rgb; int64_t N; int S;
+  float* weights; float* comp; float* accumulation; float* depth_median; float* depth_expected; float* scratch;
+  const float* s_bins_fine; float distortion_mult, interlevel_mult; float* d_w_fine;
+  int num_props;
+  const float* s_bins_prop[TN_MAX_PROP_LEVELS]; const float* w_prop[TN_MAX_PROP_LEVELS]; float* d_w_prop[TN_MAX_PROP_LEVELS]; int Sp[TN_MAX_PROP_LEVELS];
+  const float* image; const float* is_thermal; float thermal_mult, tv_mult, cross_mult; float* d_comp;
+  float* loss_lines; float* d_rgb; float* d_density;
+};
+template <int ITEMS>
+__global__ void __launch_bounds__(BLOCK, ITEMS == 1 ? 6 : 3) k_render_train(RenderTrainArgs a) {
+  constexpr int C = 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RT_SMEM_BYTES];
+  static_assert(3 * RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4 + 64 * 4 <= RT_SMEM_BYTES, "render-train smem");
+  const int lane = tn_lane(), wv = threadIdx.x >> 6;
+  const int S = a.S;
+  const int64_t N = a.N;
+  float* line = a.loss_lines + 16 * (blockIdx.x & (TN_LOSS_LINES - 1));
+  if (blockIdx.y > 0) {
+    const int pi = (int)blockIdx.y - 1, Sp = a.Sp[pi];
+    InterlevelLds& wl = *reinterpret_cast<InterlevelLds*>(smem + wv * 3600);
+    float* sh_wf = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600) + wv * TN_MAX_SAMPLES;
+    float* sh_part = reinterpret_cast<float*>(smem + RAYS_PER_BLOCK * 3600 + RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4);
+    const float scale = a.interlevel_mult / ((float)N * (float)S);
+    float wave_total = 0.0f;
+    for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+      float w[ITEMS];
+      weights_body<ITEMS>(a.e_bins, a.density, S, ray, nullptr, nullptr, lane, w);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k)
+        if (lane * ITEMS + k < S) sh_wf[lane * ITEMS + k] = w[k];
+      wave_total += tn_wave_sum(interlevel_ray(a.s_bins_fine + ray * (S + 1), sh_wf, S, a.s_bins_prop[pi] + ray * (Sp + 1), a.w_prop[pi] + ray * Sp, Sp, scale,
+                                               a.d_w_prop[pi] ? a.d_w_prop[pi] + ray * Sp : nullptr, wl, lane));
+    }
+    if (lane == 0) sh_part[wv] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+      for (int w = 0; w < RAYS_PER_BLOCK; ++w) t += sh_part[w];
+      if (t != 0.0f) atomicAdd(line + 8, t * scale);
+    }
+    return;
+  }
+  float (*sh_w)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem);
+  float (*sh_m)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem + RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4);
+  float (*sh_gw)[TN_MAX_SAMPLES] = reinterpret_cast<float (*)[TN_MAX_SAMPLES]>(smem + 2 * RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4);
+  float* sh_comp = reinterpret_cast<float*>(smem + 3 * RAYS_PER_BLOCK * TN_MAX_SAMPLES * 4);  // [4 rays][4 channels]
+  float* sh_cnt = sh_comp + 16;                                                               // [4]
+  float* sh_red = sh_cnt + 4;                                                                 // [4 waves][8]
+  // RGB rays of the batch (the patch terms' mean): every block counts them itself.  Requested here -- four 16-byte loads per thread up to 4096
+  // rays --, added up after the first composite (a scalar loop at this point was a chain of its own in front of the rendering)
+  float4 th4[4];
+  const bool th_vec = (reinterpret_cast<uintptr_t>(a.is_thermal) & 15) == 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i4 = (int64_t)u * BLOCK + threadIdx.x;
+    th4[u] = make_float4(1.f, 1.f, 1.f, 1.f);  // (thermal: not counted)
+    if (th_vec && i4 < N / 4) th4[u] = reinterpret_cast<const float4*>(a.is_thermal)[i4];
+  }
+  bool counted = false;
+  float blk_mn = INFINITY, blk_mx = 0.0f;
+  float l_rgb = 0.f, l_th = 0.f, l_tv = 0.f, l_cc = 0.f, dist_total = 0.0f, n_rgb_rays = 0.0f;
+  const float dscale = a.distortion_mult / (float)N;
+  // (N is a multiple of 4: the four waves of a block make the same trips, the block barriers inside are reached by all of them)
+  for (int64_t ray = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv; ray < N; ray += (int64_t)gridDim.x * RAYS_PER_BLOCK) {
+    // ---- every load the ray's chain of stages needs, requested now (each would otherwise be an HBM round trip in front of its stage)
+    float st[ITEMS], en[ITEMS], dn[ITEMS], rv[ITEMS][C], lastc[C];
+    ray_load_bins<ITEMS>(a.e_bins, a.density, S, ray, lane, st, en, dn);
+    ray_load_rgb<ITEMS, C>(a.rgb, S, ray, lane, rv, lastc);
+    const int64_t q4 = ray - wv;  // first ray of the 2x2 patch
+    float img_l = 0.0f, th_l = 0.0f, dc_l = 0.0f;
+    if (lane < 12) img_l = a.image[q4 * 3 + lane];
+    if (lane < 4) { th_l = a.is_thermal[q4 + lane]; dc_l = a.d_comp[ray * C + lane]; }
+    float tlo[ITEMS], thi[ITEMS], dwf[ITEMS];  // distortion: lane + 64 k order (ITEMS = ceil(S / 64))
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int i = lane + 64 * k;
+      tlo[k] = thi[k] = dwf[k] = 0.0f;
+      if (i < S) { tlo[k] = a.s_bins_fine[ray * (S + 1) + i]; thi[k] = a.s_bins_fine[ray * (S + 1) + i + 1]; dwf[k] = a.d_w_fine[ray * S + i]; }
+    }
+    // ---- get_weights + the renderers
+    float w[ITEMS], cv[C] = {0.f, 0.f, 0.f, 0.f};
+    float mn = 0.f, mx = 0.f;
+#if !(RT_ABLATE & 8)
+    weights_compute<ITEMS>(st, en, dn, S, ray, a.weights, nullptr, lane, w);
+    composite_compute<ITEMS, C>(w, st, en, rv, lastc, S, ray, 1, a.comp, a.accumulation, a.depth_median, a.depth_expected, lane, mn, mx, cv);
+#else
+    for (int k = 0; k < ITEMS; ++k) w[k] = st[k] + dn[k] + rv[k][0];
+#endif
+    blk_mn = fminf(blk_mn, tn_wave_min(mn));
+    blk_mx = fmaxf(blk_mx, tn_wave_max(mx));
+    if (!counted) {
+      counted = true;
+      float cnt = 0.0f;  // exact: a count of at most 2^24 ones
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        cnt += (th4[u].x == 0.0f ? 1.0f : 0.0f) + (th4[u].y == 0.0f ? 1.0f : 0.0f) + (th4[u].z == 0.0f ? 1.0f : 0.0f) + (th4[u].w == 0.0f ? 1.0f : 0.0f);
+      for (int64_t i = (th_vec ? (int64_t)16 * BLOCK : 0) + threadIdx.x; i < N; i += BLOCK) cnt += (a.is_thermal[i] == 0.0f) ? 1.0f : 0.0f;
+      cnt = tn_wave_sum(cnt);
+      if (lane == 0) sh_cnt[wv] = cnt;
+    }
+    __syncthreads();  // the previous patch's readers are done with sh_comp
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) sh_comp[wv * 4 + c] = cv[c];
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+      if (lane * ITEMS + k < S) sh_w[wv][lane * ITEMS + k] = w[k];
+    __syncthreads();  // the patch's four composites (and, first trip, the counts)
+    // ---- pixel terms (tn_pixel_loss.h: same expressions) of this wave's ray = pixel wv of the patch; every lane computes them, lane 0 keeps them
+    float g[C] = {0.f, 0.f, 0.f, 0.f};
+#if !(RT_ABLATE & 2)
+    {
+      n_rgb_rays = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+      const float n_patches = n_rgb_rays / 4.0f;
+      float pt[4], grey[4];
+      bool rgb_patch = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float th = __shfl(th_l, k, 64), nt = 1.0f - th;
+        if (th != 0.0f) rgb_patch = false;
+        float gsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float img = __shfl(img_l, 3 * k + c, 64);
+          const float gt = img * nt;
+          if (k == wv) {
+            const float aa = gt * nt, bb = sh_comp[k * 4 + c] * nt;
+            const float df = aa - bb;
+            if (lane == 0) l_rgb += df * df;
+            g[c] = __shfl(dc_l, c, 64) + (-2.0f * df * nt / ((float)N * 3.0f));
+          }
+          gsum += gt;
+        }
+        grey[k] = gsum / 3.0f;
+        const float p = sh_comp[k * 4 + 3];
+        pt[k] = p;
+        if (k == wv) {
+          const float gt_t = __shfl(img_l, 3 * k, 64) * th;
+          const float aa = gt_t * th, bb = p * th;
+          const float df = aa - bb;
+          if (lane == 0) l_th += df * df;
+          g[3] = __shfl(dc_l, 3, 64) + (a.thermal_mult * (-2.0f * df * th) / (float)N);
+        }
+      }
+      if (rgb_patch && n_patches > 0.0f) {
+        const int A[4] = {1, 2, 3, 3}, B[4] = {0, 0, 1, 2};
+        float dp[4] = {0.f, 0.f, 0.f, 0.f};
+        const float tvw = a.tv_mult * 0.25f / n_patches, ccw = a.cross_mult * 0.25f / n_patches;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dpt = pt[A[e]] - pt[B[e]];
+          const float dg = grey[A[e]] - grey[B[e]];
+          if (wv == 0 && lane == 0) { l_tv += fabsf(dpt); l_cc += fabsf(dpt - dg); }  // (the patch's sums once, not four times)
+          const float sg = tvw * sgn(dpt) + ccw * sgn(dpt - dg);
+          dp[A[e]] += sg;
+          dp[B[e]] -= sg;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == wv) g[3] += dp[k];
+      }
+      if (lane < C) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (c == lane) a.d_comp[ray * C + c] = g[c];
+      }
+    }
+#endif
+    // ---- distortion loss of the ray: d weights (handed-in accumulator + this term) to memory and to sh_gw
+#if !(RT_ABLATE & 1)
+    dist_total += tn_wave_sum(distortion_compute<ITEMS>(tlo, thi, dwf, S, dscale, a.d_w_fine + ray * S, sh_gw[wv], sh_w[wv], sh_m[wv], lane));
+#endif
+    __builtin_amdgcn_wave_barrier();
+    // ---- the renderers' backward on the registers of the forward
+#if !(RT_ABLATE & 4)
+    render_bwd_compute<ITEMS, C>(st, en, dn, rv, lastc, w, g, sh_gw[wv], ray, S, a.d_rgb, a.d_density, lane);
+#endif
+  }
+  if (lane == 0) {
+    float* r = sh_red + wv * 8;
+    r[0] = l_rgb; r[1] = l_th; r[2] = l_tv; r[3] = l_cc; r[4] = dist_total; r[5] = blk_mn; r[6] = blk_mx; r[7] = n_rgb_rays;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, mn = INFINITY, mx = 0.0f, n_rgb = 0.0f;
+    for (int w = 0; w < RAYS_PER_BLOCK; ++w) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] += sh_red[w * 8 + k];
+      mn = fminf(mn, sh_red[w * 8 + 5]);
+      mx = fmaxf(mx, sh_red[w * 8 + 6]);
+      n_rgb = fmaxf(n_rgb, sh_red[w * 8 + 7]);
+    }
+    if (a.depth_expected != nullptr) { a.scratch[blockIdx.x] = mn; a.scratch[RT_MAX_BLOCKS + blockIdx.x] = mx; }
+    const float n_patches = n_rgb / 4.0f;
+    if (t[0] != 0.0f) atomicAdd(line + 0, t[0] / ((float)N * 3.0f));
+    if (t[1] != 0.0f) atomicAdd(line + 1, a.thermal_mult * t[1] / (float)N);
+    if (n_patches > 0.0f) {
+      if (t[2] != 0.0f) atomicAdd(line + 2, a.tv_mult * 0.25f * t[2] / n_patches);
+      if (t[3] != 0.0f) atomicAdd(line + 3, a.cross_mult * 0.25f * t[3] / n_patches);
+    }
+    if (t[4] != 0.0f) atomicAdd(line + 9, t[4] * dscale);
+    if (blockIdx.x == 0) { line[4] = n_rgb; line[5] = (float)N - n_rgb; }  // ray counts per spectrum (PSNR metrics)
+  }
+}
+
+extern "C" int tn_render_losses_bwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, float* weights,
+                                    float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
+                                    const float* s_bins_fine, int32_t num_props, const float* const* s_bins_prop, const float* const* weights_prop,
+                                    const int32_t* S_prop, float* const* d_weights_prop, float distortion_mult, float interlevel_mult,
+                                    float* d_weights_fine, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
+                                    float cross_mult, float* d_comp, float* loss_lines, float* d_rgb, float* d_density, int32_t clip_depth,
+                                    tn_stream_t stream) {
+  if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
+  TN_REQUIRE(e_bins && density && rgb && weights && comp && s_bins_fine && d_weights_fine && image && is_thermal && d_comp && loss_lines && d_rgb && d_density,
+             "tn_render_losses_bwd: null pointer");
+  TN_REQUIRE(N > 0 && N % 4 == 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_render_losses_bwd: bad N=%lld (a multiple of 4: 2x2 patches) S=%d", (long long)N, S);
+  TN_REQUIRE(C == 4, "tn_render_losses_bwd: the shared-density model's RGB + thermal composite (4 channels), got %d", C);
+  TN_REQUIRE(depth_expected == nullptr || scratch != nullptr, "tn_render_losses_bwd: depth_expected needs the scratch buffer (TN_RENDER_SCRATCH_FLOATS)");
+  TN_REQUIRE(num_props >= 0 && num_props <= TN_MAX_PROP_LEVELS && (num_props == 0 || (s_bins_prop && weights_prop && S_prop && d_weights_prop)),
+             "tn_render_losses_bwd: bad proposal level list (num_props=%d, at most %d)", num_props, TN_MAX_PROP_LEVELS);
+  RenderTrainArgs a{};
+  a.e_bins = e_bins; a.density = density; a.rgb = rgb; a.N = N; a.S = S; a.weights = weights; a.comp = comp; a.accumulation = accumulation;
+  a.depth_median = depth_median; a.depth_expected = depth_expected; a.scratch = scratch; a.s_bins_fine = s_bins_fine;
+  a.distortion_mult = distortion_mult; a.interlevel_mult = interlevel_mult; a.d_w_fine = d_weights_fine; a.num_props = num_props;
+  for (int i = 0; i < num_props; ++i) {
+    TN_REQUIRE(s_bins_prop[i] && weights_prop[i] && S_prop[i] >= 1 && S_prop[i] <= TN_MAX_SAMPLES, "tn_render_losses_bwd: bad proposal level %d", i);
+    a.s_bins_prop[i] = s_bins_prop[i]; a.w_prop[i] = weights_prop[i]; a.Sp[i] = S_prop[i]; a.d_w_prop[i] = d_weights_prop[i];
+  }
+  a.image = image; a.is_thermal = is_thermal; a.thermal_mult = thermal_mult; a.tv_mult = tv_mult; a.cross_mult = cross_mult; a.d_comp = d_comp;
+  a.loss_lines = loss_lines; a.d_rgb = d_rgb; a.d_density = d_density;
+  const int nblk = (int)std::min<int64_t>(N / RAYS_PER_BLOCK, RT_MAX_BLOCKS);
+  dim3 grid((unsigned)nblk, (unsigned)(1 + num_props)), block(BLOCK);
+  hipStream_t st = tn_s(stream);
+  if (S <= 64) hipLaunchKernelGGL(k_render_train<1>, grid, block, 0, st, a);
+  else if (S <= 128) hipLaunchKernelGGL(k_render_train<2>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(k_render_train<4>, grid, block, 0, st, a);
+  TN_CHECK_LAUNCH("tn_render_losses_bwd");
+  if (depth_expected != nullptr && clip_depth) {
+    hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, st, depth_expected, scratch, nblk, RT_MAX_BLOCKS, N);
+    TN_CHECK_LAUNCH("tn_render_losses_bwd(clip)");
+  }
+  return TN_OK;
 }
 
 extern "C" int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,

@@ -1023,6 +1023,37 @@ def train_losses(s_fine: Tensor, w_fine: Tensor, props, distortion_mult: float, 
                                       _f32(loss_lines, "loss_lines", (LOSS_LINES, 16)), _stream()), "tn_train_losses")
 
 
+def render_losses_bwd(e_bins: Tensor, density: Tensor, rgb: Tensor, s_fine: Tensor, props, distortion_mult: float, interlevel_mult: float,
+                      d_w_fine: Tensor, image: Tensor, is_thermal: Tensor, thermal_mult: float, tv_mult: float, cross_mult: float, d_comp: Tensor,
+                      loss_lines: Tensor, clip_depth: bool = True):
+    """render_fwd(training) + train_losses + render_bwd of the shared-density model's last level in ONE launch (tn_render_losses_bwd).
+    rgb [N,S,4]; props as train_losses; d_w_fine [N,S], d_comp [N,4] and the props' d weights are accumulators.
+    -> weights, comp [N,4], accumulation, depth_median, depth_expected, d_rgb [N,S,4], d_density [N,S]."""
+    N, S, Cc = rgb.shape
+    dev = rgb.device
+    w = torch.empty((N, S), device=dev)
+    comp = torch.empty((N, Cc), device=dev)
+    acc = torch.empty((N, 1), device=dev)
+    med = torch.empty((N, 1), device=dev)
+    exp = torch.empty((N, 1), device=dev)
+    d_rgb = torch.empty((N, S, Cc), device=dev)
+    dd = torch.empty((N, S), device=dev)
+    st = _stream()
+    key = (dev.index, st.value)
+    scratch = _RENDER_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _RENDER_SCRATCH[key] = torch.empty(_lib.TN_RENDER_SCRATCH_FLOATS, device=dev)
+    n, sb, wp, sp, dw = _prop_level_arrays(props, N)
+    check(_lib.load().tn_render_losses_bwd(_f32(e_bins, "e_bins", (N, S + 1)), _f32(density, "density", (N, S)), _f32(rgb, "rgb", (N, S, Cc)), N, S, Cc,
+                                           _f32(w, "w"), _f32(comp, "comp"), _f32(acc, "acc"), _f32(med, "med"), _f32(exp, "exp"), _f32(scratch, "scratch"),
+                                           _f32(s_fine, "s_fine", (N, S + 1)), n, sb, wp, sp, dw, float(distortion_mult), float(interlevel_mult),
+                                           _f32(d_w_fine, "d_w_fine", (N, S)), _f32(image, "image", (N, 3)), _f32(is_thermal, "is_thermal", (N,)),
+                                           float(thermal_mult), float(tv_mult), float(cross_mult), _f32(d_comp, "d_comp", (N, Cc)),
+                                           _f32(loss_lines, "loss_lines", (LOSS_LINES, 16)), _f32(d_rgb, "d_rgb"), _f32(dd, "d_density"),
+                                           1 if clip_depth else 0, st), "tn_render_losses_bwd")
+    return w, comp, acc, med, exp, d_rgb, dd
+
+
 def losses_finish(loss_lines: Tensor, losses16: Tensor, pose: Optional[Tensor] = None, trans_pen: float = 0.0, rot_pen: float = 0.0,
                   scale: float = 0.0, reg_out: Optional[Tensor] = None, grad_pose: Optional[Tensor] = None) -> None:
     """losses16[k] += column sums of loss_lines; with `pose` also camera_reg(pose, ...) -> reg_out / grad_pose, same single-block launch."""

@@ -612,6 +612,63 @@ def test_train_losses_one_launch_equals_two():
     assert torch.equal(g1, g2) and float(L2[11]) == float(r1) and abs(float(L2[9]) - float(Lb[9]) - 0.25) <= 1e-7
 
 
+@pytest.mark.parametrize("S,prop_grad", [(48, True), (48, False), (100, True), (200, True)])
+def test_render_losses_bwd_is_the_three_launches(S, prop_grad):
+    """tn_render_losses_bwd = tn_render_fwd(training) + tn_train_losses + tn_render_bwd in one launch: every rendered output and every gradient
+    bit for bit (weights, composite, accumulation, both depths incl. the batch-wide clip, d composite, d weights of all three levels, d rgb,
+    d density); the loss sums up to the order of their additions.  N = 2080 rays: more patches than blocks (the ray loop runs twice for some),
+    accumulators that are NOT zero on entry, 48 samples (one per lane) and 100 / 200 (two / four per lane)."""
+    N = 2080
+    gen = torch.Generator().manual_seed(17)
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    j0, j1, j2 = (torch.from_numpy(j) for j in synth.synth_jitters(N))
+    sb, eb, ws = [], [], []
+    s_prev, w_prev = None, None
+    for i, Sl in enumerate((256, 96, S)):
+        if i == 0:
+            s_ = orc.spaced_bins(N, Sl, j0)
+        else:
+            s_ = orc.pdf_resample(s_prev, w_prev, Sl, (j1, j2)[i - 1])
+        e = orc.s_to_euclidean(s_, nears, fars)
+        w = orc.get_weights(orc.Samples(s_bins=s_, e_bins=e).deltas, (5.0 * torch.rand((N, Sl, 1), generator=gen)) ** 3)
+        sb.append(g(s_)); eb.append(g(e)); ws.append(g(w[..., 0]))
+        s_prev, w_prev = s_, w
+    dens = g((5.0 * torch.rand((N, S), generator=gen)) ** 3 * 0.01)
+    rgb = g(torch.rand((N, S, 4), generator=gen))
+    cams = synth.synth_cameras()
+    idx = synth.synth_ray_indices(cams, N)
+    img, is_th = synth.synth_gt(idx, cams)
+    img, is_th = g(torch.from_numpy(img)), g(torch.from_numpy(is_th))
+    acc0 = {k: g(torch.rand(shape, generator=gen) * 1e-3) for k, shape in (("d0", (N, 256)), ("d1", (N, 96)), ("d2", (N, S)), ("dc", (N, 4)))}
+
+    def run(fused: bool):
+        L = torch.zeros(16, device=DEV)
+        Lp = torch.zeros((ops.LOSS_LINES, 16), device=DEV)
+        d0, d1, d2, dc = (acc0[k].clone() for k in ("d0", "d1", "d2", "dc"))
+        props = [(sb[0], ws[0], d0 if prop_grad else None), (sb[1], ws[1], d1 if prop_grad else None)]
+        if fused:
+            w, c, a, m, x, d_rgb, dd = ops.render_losses_bwd(eb[2], dens, rgb, sb[2], props, 0.002, 1.0, d2, img, is_th, 100.0, 1e-3, 1e-3, dc, Lp)
+        else:
+            w, c, a, m, x = ops.render_fwd(eb[2], dens, rgb, True)
+            ops.train_losses(sb[2], w, props, 0.002, 1.0, d2, Lp, pixel=(c[:, :3], c[:, 3:], img, is_th, 100.0, 1e-3, 1e-3, dc[:, :3], dc[:, 3:]))
+            d_rgb, dd = ops.render_bwd(eb[2], dens, rgb, w, dc, d2)
+        ops.losses_finish(Lp, L)
+        torch.cuda.synchronize()
+        return L, dict(w=w, comp=c, acc=a, median=m, expected=x, d0=d0, d1=d1, d2=d2, d_comp=dc, d_rgb=d_rgb, d_density=dd)
+
+    La, A = run(False)
+    Lb, B = run(True)
+    for k in A:
+        assert torch.equal(A[k], B[k]), (k, float((A[k] - B[k]).abs().max()))
+    assert float(A["d_density"].abs().max()) > 0 and float(A["d2"].sub(acc0["d2"]).abs().max()) > 0
+    assert prop_grad == (float(A["d0"].sub(acc0["d0"]).abs().max()) > 0)
+    assert float((La - Lb).abs().max()) <= 2e-6 * float(La.abs().max()), (La, Lb)
+    assert float(Lb[4]) + float(Lb[5]) == N and all(float(Lb[k]) > 0 for k in (0, 1, 8, 9))
+    with pytest.raises(RuntimeError):  # 2x2 patches: N must be a multiple of 4
+        ops.render_losses_bwd(eb[2][:6], dens[:6], rgb[:6], sb[2][:6], [], 0.002, 1.0, acc0["d2"][:6].clone(), img[:6], is_th[:6], 100.0, 1e-3, 1e-3,
+                              acc0["dc"][:6].clone(), torch.zeros((ops.LOSS_LINES, 16), device=DEV))
+
+
 def test_interlevel_gradient_on_unsorted_bins_falls_back_to_the_full_walk():
     """The fast gradient path relies on sorted fine bins (lo_i, hi_i monotone); anything else takes the walk over every interval.  Checked
     against a direct evaluation of d wp_k = sum_i ([lo_i <= k <= hi_i] - [hi_i < k < lo_i]) g_i (csrc/tn_sampler.hip, interlevel_body)."""

@@ -476,3 +476,35 @@ def test_one_call_train_step_is_the_five_call_sequence(golden_dir, monkeypatch):
         assert [sA.num_skipped(i) for i in range(3)] == [sB.num_skipped(i) for i in range(3)]
         assert mA.arena.grads_clean and float(mA.arena.grads.abs().max()) == 0.0  # the launch consumed the gradients
     assert sA.get_scale() == 32768.0 and sA.schedule_lag() == 1
+
+
+def test_one_call_train_step_with_the_fused_renderer_launch(golden_dir, monkeypatch):
+    """TN_FUSE_RENDER=1: tn_train_step with tn_render_losses_bwd (renderers + losses + renderer backward in one launch; a measured experiment,
+    off by default) against the default tn_train_step: same losses to rounding, the same training state after every iteration -- with and
+    without a proposal update, and through a skipped (forced-inf) iteration."""
+    from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+    mA, _, rb, batch, jit = _setup(golden_dir, "shared")
+    mB, _, _, _, _ = _setup(golden_dir, "shared")
+    rays = (rb.origins.contiguous(), rb.directions.contiguous(), rb.camera_indices.reshape(-1).contiguous())
+    sA, sB = DeviceGradScaler(DEV), DeviceGradScaler(DEV)
+    bad = batch["image"].clone()
+    bad[:, :] = float("inf")
+    saw_plain = False
+    for step in range(13):
+        img = bad if step == 4 else batch["image"]
+        mB.arena.params.copy_(mA.arena.params); mB.arena.exp_avg.copy_(mA.arena.exp_avg); mB.arena.exp_avg_sq.copy_(mA.arena.exp_avg_sq)
+        monkeypatch.setenv("TN_FUSE_RENDER", "1")
+        lA = mA.engine.train_step(*rays, img, batch["is_thermal"], step, jit[0], None, grad_scaler=sA)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("TN_FUSE_RENDER")
+        lB = mB.engine.train_step(*rays, img, batch["is_thermal"], step, jit[0], None, grad_scaler=sB)
+        torch.cuda.synchronize()
+        saw_plain |= not mA.engine.last_updated
+        if step != 4:
+            for k in lA:
+                assert abs(float(lA[k]) - float(lB[k])) <= 1e-5 * abs(float(lB[k])) + 1e-12, (step, k, float(lA[k]), float(lB[k]))
+        assert_same_training_state(_snapshot(mA), _snapshot(mB), f"fused renderer launch vs the three launches, iteration {step}")
+        assert sA.get_scale() == sB.get_scale() and [sA.num_skipped(i) for i in range(3)] == [sB.num_skipped(i) for i in range(3)]
+    assert saw_plain  # an iteration without a proposal update was among them
+
