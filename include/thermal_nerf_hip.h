@@ -32,6 +32,8 @@
  *      TN_SCATTER_REPLICAS=n, TN_SCATTER_SPARSE_CHUNK=n, TN_SCATTER_MERGE_RES=n      tuning knobs of the two scatter paths
  *      TN_FOLD_TRACE=1 [TN_FOLD_TRACE_FILE=path]   per-block timing of the fold pass (synchronises and prints: diagnostics only)
  *      TN_BIN_LEVEL_GROUPS=n      force the number of level groups of the bin pass (diagnostic: n = levels -> one level per block)
+ *      TN_DPOS_COWORK=0           (read per call) the main field's d position pass as a launch of its own (forked with TN_BWD_FORK_DPOS) instead of
+ *                                 extra blocks of the table scatter's bin launch
  *      TN_FUSE_RENDER=1           (read per call) tn_train_step with tn_render_fwd / tn_train_losses / tn_render_bwd as ONE launch,
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
  *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
@@ -231,6 +233,8 @@ int tn_field_bwd(const TnField* field, const float* origins, const float* direct
  *                   d_origins is given, d position from the forward's saved
  *                   d enc / d offset (k_field_dpos); with TN_BWD_FORK_DPOS that second launch goes to a library-owned companion stream
  *                   beside the scatter -- worth it only when other streams are busy anyway (a second active queue costs more than it hides)
+ *                   (when TN_BWD_MLP and a TN_BWD_SCATTER over all levels come in ONE call and the scatter takes its segmented path, the pass
+ *                   gets no launch at all: it runs in extra blocks of the scatter's bin launch, d_origins / d_directions complete when that is)
  *   TN_BWD_SCATTER  table gradient of levels [level_begin, level_end); needs TN_BWD_MLP done
  *   TN_BWD_JOIN     make `stream` wait for the companion stream; required before d_origins / d_directions or the workspace are used again
  *   TN_BWD_SCATTER_BIN / TN_BWD_SCATTER_FOLD  the same scatter in its two passes: BIN writes the (slot, value) records of ALL levels once

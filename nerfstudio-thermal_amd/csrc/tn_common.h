@@ -370,9 +370,13 @@ struct ReplicaK {
 // scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
+// cowork: NULL, or the main field's d position pass (tn_field_dpos.h) to run in extra blocks of the bin launch -- only where
+// tn_grid_scatter_takes_cowork says so (the segmented path, no d position of the scatter's own)
+struct DposArgs;
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum = nullptr,
-                           bool counters_zeroed = false);
+                           bool counters_zeroed = false, const DposArgs* cowork = nullptr);
+bool tn_grid_scatter_takes_cowork(const TnGrid& grid, int64_t P, void* scratch);
 // The bin pass needs its bucket counters zero.  A separate hipMemsetAsync of those few KB costs 6-25 us on the launch stream (config 2 makes
 // seven of them per step): the kernel that produces d enc -- always the launch right before the scatter on the same stream -- zeroes them instead
 // (tn_zero_words, first thing block 0 does) and the scatter is told so (counters_zeroed).  *words = 0 when the binned path is not taken.
@@ -385,7 +389,8 @@ __device__ __forceinline__ void tn_zero_words(uint32_t* __restrict__ p, int word
 // whole grid once, the fold runs per level range.  Only valid when tn_grid_scatter_is_binned(grid, P, scratch).
 bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratch);
 int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
-                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed = false);
+                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed = false,
+                        const DposArgs* cowork = nullptr);
 int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream);
 int64_t tn_grid_dense_count(const TnGrid& grid, int64_t P);
 int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream);

@@ -19,6 +19,7 @@
 // h = lane>>5), accumulator register r in [0,16) holds feature row  R(r,h) = (r&3) + 8*(r>>2) + 4*h  of a 32-row tile.
 // Exact fp32: the MFMA is a k-ordered fmaf chain (no reduced precision), which the 1e-4 density tolerance needs.
 #include "tn_common.h"
+#include "tn_field_dpos.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -351,146 +352,19 @@ __global__ void __launch_bounds__(256) k_field_encode_xcd(GridK g, EncSched sc, 
   }
 }
 
-// What the per-camera sums cam_bias[cam][f] = sum over the camera's samples of gy_hh1[.][f] (k_field_bwd_fused) stand for.  The appearance
-// embedding is an input of head layer 0 that is constant over a camera's samples, so both of its gradients are linear in those sums
-// (hw0 = the head's first nn.Linear weight [64][63]; its columns 31..62 multiply the embedding: fields/nerfacto_field.py:288-300):
-//   gemb[cam][e]    += sum_f   hw0[f][31 + e] * cam_bias[cam][f]        job `cam` (threads 0..63 of a block)
-//   ghw0[f][31 + e] += sum_cam cam_bias[cam][f] * emb[cam][e]           jobs num_images .. num_images + 7 (256 of the 2048 entries each)
-// -- the fused kernel therefore neither computes d(head-input slots 32..63) nor the weight-gradient tile of those slots (64 MFMAs per tile less).
-// Jobs are dealt to the blocks of the launch round-robin; the last block to finish (one relaxed counter; every block's reads of cam_bias are
-// complete before it counts itself in) clears cam_bias and the counter for the next backward; blocks without a job do not take part.  The only writers of gemb and of those columns of
-// ghw0 on their stream at this point: plain read-modify-write.  Rides at the head of k_field_dpos when that launch follows, else k_field_emb_finish.
-__device__ __forceinline__ void emb_finish_jobs(float* __restrict__ cam_bias, uint32_t* __restrict__ counter, const float* __restrict__ hw0,
-                                                const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images,
-                                                float* sums /* 64 floats of LDS */, int* flag /* 1 int of LDS */) {
-  const int t = threadIdx.x;
-  const int njobs = num_images + 8;
-  if ((int)blockIdx.x >= njobs) return;  // only the blocks with a job count themselves in (one same-address atomic each: ~25 ns apiece)
-  const unsigned workers = (unsigned)njobs < gridDim.x ? (unsigned)njobs : gridDim.x;
-  for (int job = blockIdx.x; job < njobs; job += gridDim.x) {  // (block-uniform trip count)
-    if (job < num_images) {
-      const int cam = job;
-      float v = 0.0f;
-      if (t < 64) {
-        v = cam_bias[(int64_t)cam * 64 + t];
-        sums[t] = v;
-      }
-      __syncthreads();
-      if (t < 64 && __ballot(v != 0.0f) != 0ull) {  // (wave 0 as a whole; a camera without samples in this batch is skipped)
-        const int e = t & 31, half = t >> 5;
-        float a = 0.0f;
-        for (int f = 0; f < 32; ++f) a += hw0[(32 * half + f) * 63 + 31 + e] * sums[32 * half + f];
-        a += __shfl_xor(a, 32, 64);
-        if (half == 0 && a != 0.0f) gemb[(int64_t)cam * 32 + e] += a;
-      }
-      __syncthreads();
-    } else {
-      const int o = (job - num_images) * 256 + t;  // entry (f, e) of the embedding columns of d hw0
-      if (t < 256 && o < 2048) {
-        const int f = o >> 5, e = o & 31;
-        float a = 0.0f;
-        for (int cam = 0; cam < num_images; ++cam) {
-          const float b = cam_bias[(int64_t)cam * 64 + f];
-          if (b != 0.0f) a += b * emb[(int64_t)cam * 32 + e];
-        }
-        if (a != 0.0f) ghw0[f * 63 + 31 + e] += a;
-      }
-    }
-  }
-  __syncthreads();  // every thread of the block has consumed what it read from cam_bias
-  if (t == 0) *flag = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == workers - 1) ? 1 : 0;
-  __syncthreads();
-  if (*flag) {
-    for (int i = t; i < num_images * 64; i += blockDim.x) cam_bias[i] = 0.0f;
-    if (t == 0) *counter = 0u;
-  }
-}
+// (emb_finish_jobs, field_dpos_body: tn_field_dpos.h)
 __global__ void __launch_bounds__(256) k_field_emb_finish(float* __restrict__ cam_bias, uint32_t* __restrict__ counter, const float* __restrict__ hw0,
                                                           const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images) {
   __shared__ float sums[64];
   __shared__ int flag;
-  emb_finish_jobs(cam_bias, counter, hw0, emb, gemb, ghw0, num_images, sums, &flag);
+  emb_finish_jobs(cam_bias, counter, hw0, emb, gemb, ghw0, num_images, sums, &flag, blockIdx.x, gridDim.x);
 }
 
-// d position of every sample from d enc and the saved derivatives: dp_axis = sum_l sum_f g_enc[2l + f] * jac[l][f][axis]; then the
-// backward of contraction / frustum position and the per-ray sums into d origins / d directions (same arithmetic as the table scatter's
-// own d-position path, which stays for tn_hash_scatter and the proposal grids).  lane = (sample j of the tile, half h of the levels).
-__global__ void __launch_bounds__(256) k_field_dpos(const float* __restrict__ origins, const float* __restrict__ directions,
-                                                    const float* __restrict__ e_bins, const float* __restrict__ g_enc, const float* __restrict__ jac,
-                                                    int64_t N, int S, int L, int64_t PT, float* __restrict__ d_origins, float* __restrict__ d_directions,
-                                                    float* __restrict__ cam_bias, uint32_t* __restrict__ fin_counter, const float* __restrict__ hw0,
-                                                    const float* __restrict__ emb, float* __restrict__ gemb, float* __restrict__ ghw0, int num_images) {
+// d position of every sample (field_dpos_body) as a launch of its own
+__global__ void __launch_bounds__(256) k_field_dpos(DposArgs a) {
   __shared__ float emb_sums[64];
   __shared__ int emb_flag;
-  // (the embedding's gradients of the MLP phase before this launch, from its per-camera sums)
-  if (cam_bias != nullptr) emb_finish_jobs(cam_bias, fin_counter, hw0, emb, gemb, ghw0, num_images, emb_sums, &emb_flag);
-  const int64_t P = N * (int64_t)S;
-  const int64_t ntiles = tn_cdiv(P, 32);
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  typedef float v2f_t __attribute__((ext_vector_type(2)));
-  for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * (blockDim.x >> 6)) {
-    const int64_t p = tile * 32 + j;
-    const bool live = p < P;
-    const int64_t pc = live ? p : P - 1;
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float2 gl[2];
-      v2f_t jl[2][3];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int l = 4 * q + 2 * h + e;
-        if (l < L) {
-          gl[e] = *reinterpret_cast<const float2*>(g_enc + (int64_t)l * 2 * P + 2 * pc);  // level-major [16][P] float2
-          const v2f_t* jp = reinterpret_cast<const v2f_t*>(jac) + (int64_t)l * 3 * PT + pc;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) jl[e][k] = __builtin_nontemporal_load(jp + k * PT);
-        } else {
-          gl[e] = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) jl[e][k] = v2f_t{0.f, 0.f};
-        }
-      }
-      // plane k of a level = (d enc_0 / d o_k, d enc_1 / d o_k) * res
-      dx += gl[0].x * jl[0][0].x + gl[0].y * jl[0][0].y + gl[1].x * jl[1][0].x + gl[1].y * jl[1][0].y;
-      dy += gl[0].x * jl[0][1].x + gl[0].y * jl[0][1].y + gl[1].x * jl[1][1].x + gl[1].y * jl[1][1].y;
-      dz += gl[0].x * jl[0][2].x + gl[0].y * jl[0][2].y + gl[1].x * jl[1][2].x + gl[1].y * jl[1][2].y;
-    }
-    dx += __shfl_xor(dx, 32, 64); dy += __shfl_xor(dy, 32, 64); dz += __shfl_xor(dz, 32, 64);
-    const int64_t ray = tn_div_index(pc, S, P);
-    const int s = (int)(pc - ray * S);
-    const float* o = origins + ray * 3;
-    const float* d = directions + ray * 3;
-    const float* eb = e_bins + ray * (S + 1) + s;
-    const float st = eb[0], en = eb[1];
-    const Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], st, en);
-    float wx, wy, wz;
-    tn_contract_bwd(c, dx, dy, dz, wx, wy, wz);
-    if (!live || h != 0) { wx = wy = wz = 0.0f; }
-    const float tm = (st + en) / 2.0f;
-    float v[6] = {wx, wy, wz, wx * tm, wy * tm, wz * tm};
-    // segmented sums over the lanes of one ray (consecutive samples of a ray sit in consecutive lanes of a half-wave); the last lane of a
-    // segment adds the segment's sums
-    const int r32 = (int)ray;
-    const int prev = __shfl_up(r32, 1, 64);
-    const bool head = (j == 0) || (prev != r32);
-    const unsigned long long H = __ballot(head);
-    const int start = 63 - __clzll(H & (~0ull >> (63 - lane)));  // first lane of this lane's segment
-    const bool tail = (j == 31) || ((H >> (lane + 1)) & 1ull);
-#pragma unroll
-    for (int o2 = 1; o2 < 32; o2 <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const float t = __shfl_up(v[k], o2, 64);
-        if (lane - o2 >= start) v[k] += t;
-      }
-    }
-    if (live && h == 0 && tail) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (v[k] != 0.0f) atomicAdd((k < 3 ? d_origins : d_directions) + ray * 3 + (k % 3), v[k]);
-    }
-  }
+  field_dpos_body(a, blockIdx.x, gridDim.x, emb_sums, &emb_flag);
 }
 
 // ---- SH degree 4 on (d+1)/2, un-remapped (utils/math.py:45-78; fields/base_field.py:136-142) -------------------------------
@@ -1858,6 +1732,8 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
   const int C = field->num_channels;
   TN_REQUIRE(dens_only || !(phases & TN_BWD_MLP) || field->num_images <= FIELD_MAX_IMAGES,
              "tn_field_bwd: %d cameras, the per-camera sums of the appearance embedding's gradient are sized for %d", field->num_images, FIELD_MAX_IMAGES);
+  DposArgs dpos_args{};
+  bool dpos_cowork = false;
   if (phases & TN_BWD_MLP) {
     // chain + every weight gradient in one launch (k_field_bwd_fused)
     const size_t shmem = FB_LDS_FLOATS * sizeof(float);
@@ -1902,12 +1778,22 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
       // Forked to the companion stream only when the caller says other streams are busy anyway (TN_BWD_FORK_DPOS: the proposal networks'
       // backward runs beside this one).  On a step where the main stream is alone, a second active queue costs more than the ~25 us it hides:
       // measured 0.845 (forked) vs 0.815 ms (in line) per non-update step, 1.24 vs 1.39 ms per update step when nothing forks.
-      hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
-      const int64_t tiles = tn_cdiv(P, 32);
-      hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, origins, directions, e_bins,
-                         ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions, dens_only ? nullptr : ws.cam_bias,
-                         reinterpret_cast<uint32_t*>(ws.cam_bias + (int64_t)FIELD_MAX_IMAGES * 64), field->hw0, field->emb, field->gemb, field->ghw0,
-                         field->num_images);
+      dpos_args = DposArgs{origins, directions, e_bins, ws.g_enc, ws.jac, N, S, field->grid.num_levels, ws.PT, d_origins, d_directions,
+                           dens_only ? nullptr : ws.cam_bias, reinterpret_cast<uint32_t*>(ws.cam_bias + (int64_t)FIELD_MAX_IMAGES * 64), field->hw0, field->emb,
+                           field->gemb, field->ghw0, field->num_images};
+      // ... and when the whole table scatter follows in this call on its segmented path, the pass does not get a launch at all: it runs in extra
+      // blocks of the scatter's bin launch (tn_field_dpos.h) -- on iterations with and without the proposal networks' backward beside it
+      // (scripts/step_times.py, same box, launch of its own / forked vs co-work: other steps 0.6187-0.6239 -> 0.6115-0.6157 ms; co-work on the
+      // update steps too, where the pass used to fork: update steps 0.9008-0.9025 -> 0.8879-0.8927, other steps another 6-9 us less since the
+      // fourth queue never becomes active).  TN_DPOS_COWORK=0: a launch of its own, as before.
+      const char* cwe = getenv("TN_DPOS_COWORK");
+      dpos_cowork = (phases & TN_BWD_SCATTER) && level_begin == 0 && level_end == field->grid.num_levels && !(cwe && cwe[0] == '0') &&
+                    tn_grid_scatter_takes_cowork(field->grid, P, ws.scatter);
+      if (!dpos_cowork) {
+        hipStream_t side = (phases & TN_BWD_FORK_DPOS) ? tn_fork(st) : nullptr;
+        const int64_t tiles = tn_cdiv(P, 32);
+        hipLaunchKernelGGL(k_field_dpos, dim3((unsigned)std::min<int64_t>(tn_cdiv(tiles, 4), 256 * 8)), dim3(256), 0, side ? side : st, dpos_args);
+      }
       TN_CHECK_LAUNCH("tn_field_bwd(d position)");
     }
   }
@@ -1919,7 +1805,7 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     // (counters zeroed by the MLP phase: this call runs both, or the caller vouches for it -- and the scatter covers the whole grid in one go)
     const bool cz = (phases & (TN_BWD_MLP | TN_BWD_COUNTERS_CLEAN)) && level_begin == 0 && level_end == field->grid.num_levels;
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
-                                nullptr, cz);
+                                nullptr, cz, dpos_cowork ? &dpos_args : nullptr);
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");

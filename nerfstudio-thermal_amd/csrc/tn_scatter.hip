@@ -11,6 +11,7 @@
 //   * work items in patch order (tn_patch_order) and run-length merging across consecutive samples of the wave: samples in the same
 //     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
 #include "tn_common.h"
+#include "tn_field_dpos.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
@@ -738,16 +739,27 @@ struct SegK {
 template <bool WANT_DPOS>
 __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float* __restrict__ origins, const float* __restrict__ directions,
                                                          const float* __restrict__ e_bins, const float* __restrict__ g_enc, int ld, int64_t N, int S,
-                                                         float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, SegK sk) {
+                                                         float* __restrict__ d_origins, float* __restrict__ d_directions, int level_groups, SegK sk,
+                                                         DposArgs cw, int cw_blocks) {
   __shared__ uint32_t s_cnt[TN_BIN_MAX_SLICES];      // records per bucket of the level being ranked (zero between levels)
   __shared__ uint32_t s_off[TN_BIN_MAX_SLICES + 1];  // exclusive prefix; [nslices] = the level's record count
   __shared__ __attribute__((aligned(16))) uint16_t s_i16[SEG_CAP];
   __shared__ __attribute__((aligned(16))) float2 s_val[SEG_CAP];
+  // co-work blocks (the last cw_blocks of every grid row: dispatched between the bin blocks of consecutive level groups): the main field's d
+  // position pass, a streaming kernel, beside this pass, which is bound by vector-instruction issue -- in ONE launch, because a second active
+  // queue costs an iteration more than the pass takes (tn_field.hip).  (Spread evenly through the rows instead: no gain at all, 0.623 vs
+  // 0.616-0.622 ms per step without; at the row ends 0.6115 vs 0.6239.)
+  const unsigned bx = blockIdx.x;
+  if (!WANT_DPOS && bx >= sk.NB) {
+    field_dpos_body(cw, blockIdx.y * (unsigned)cw_blocks + (bx - sk.NB), (unsigned)cw_blocks * gridDim.y, reinterpret_cast<float*>(s_val),
+                    reinterpret_cast<int*>(s_cnt));
+    return;
+  }
   const int lane = tn_lane();
   const int tid = threadIdx.x, wv = tid >> 6;
   const int ns = sk.nslices;
   const int64_t P = N * (int64_t)S;
-  int64_t i = (int64_t)blockIdx.x * BIN_THREADS + tid;
+  int64_t i = (int64_t)bx * BIN_THREADS + tid;
   const bool live = i < P;
   if (!live) i = P - 1;
   int64_t ray;
@@ -788,7 +800,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
     if (wv == (li & (BIN_THREADS / 64 - 1))) {
       // one wave (a different one per level): exclusive prefix over the buckets, the headers, and the counters back to zero
       uint32_t run = 0;
-      uint32_t* hdr = sk.hdr + ((size_t)l * ns) * sk.NB + blockIdx.x;
+      uint32_t* hdr = sk.hdr + ((size_t)l * ns) * sk.NB + bx;
       for (int base = 0; base < ns; base += 64) {
         const int sl = base + lane;
         const uint32_t cnt = sl < ns ? s_cnt[sl] : 0u;
@@ -859,7 +871,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
     __syncthreads();  // staged
     // linear copy of the staged records into the block's region of the level: 16 bytes per lane and instruction
     const uint32_t total = s_off[ns];
-    const size_t reg = ((size_t)l * sk.NB + blockIdx.x) * SEG_CAP;
+    const size_t reg = ((size_t)l * sk.NB + bx) * SEG_CAP;
     {
       float4* __restrict__ dv = reinterpret_cast<float4*>(sk.val + reg);
       const float4* sv = reinterpret_cast<const float4*>(s_val);
@@ -1189,7 +1201,7 @@ void tn_grid_scatter_counters(const TnGrid& grid, int64_t P, void* scratch, uint
 }
 
 int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
-                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed) {
+                        int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed, const DposArgs* cowork) {
   const int64_t P = N * (int64_t)S;
   const int L = grid.num_levels;
   if (seg_mode()) {
@@ -1201,15 +1213,24 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
     int level_groups = 1;  // enough resident work for every CU: split the levels over blockIdx.y while the batch alone gives fewer than ~6 blocks per CU
     while (level_groups < L && (int64_t)blocks * level_groups < 256 * 6) level_groups *= 2;
     level_groups = std::min(level_groups, L);
-    if (d_origins != nullptr)
+    TN_REQUIRE(cowork == nullptr || d_origins == nullptr, "tn_grid_scatter: co-work only beside a bin pass without a d position path of its own");
+    if (d_origins != nullptr) {
       hipLaunchKernelGGL(k_seg_bin<true>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
-                         d_directions, level_groups, sk);
-    else
-      hipLaunchKernelGGL(k_seg_bin<false>, dim3(blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S, d_origins,
-                         d_directions, level_groups, sk);
+                         d_directions, level_groups, sk, DposArgs{}, 0);
+    } else {
+      // co-work: one tile of 32 samples per wave, BIN_THREADS / 64 tiles per block, spread over the rows of the grid
+      int cw_blocks = 0;
+      if (cowork != nullptr) {
+        const int64_t tiles = tn_cdiv(cowork->N * (int64_t)cowork->S, 32);
+        cw_blocks = (int)std::min<int64_t>(tn_cdiv(tn_cdiv(tiles, BIN_THREADS / 64), level_groups), 2048);
+      }
+      hipLaunchKernelGGL(k_seg_bin<false>, dim3(blocks + cw_blocks, level_groups), dim3(BIN_THREADS), 0, stream, gk, origins, directions, e_bins, g_enc, ld, N, S,
+                         d_origins, d_directions, level_groups, sk, cowork ? *cowork : DposArgs{}, cw_blocks);
+    }
     TN_CHECK_LAUNCH("tn_grid_scatter(bin, segmented)");
     return TN_OK;
   }
+  TN_REQUIRE(cowork == nullptr, "tn_grid_scatter: co-work needs the segmented path (tn_grid_scatter_takes_cowork)");
   BinK bk;
   uint32_t nblk;
   int rc = bin_plan(grid, P, scratch, bk, nblk);
@@ -1307,23 +1328,27 @@ bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratc
   return scratch != nullptr && scatter_mode() >= 1 && grid.log2_hashmap_size - TN_BIN_SLICE_LOG2 <= 8 && P * 8 < (1ll << 31);
 }
 
+bool tn_grid_scatter_takes_cowork(const TnGrid& grid, int64_t P, void* scratch) { return seg_mode() && tn_grid_scatter_is_binned(grid, P, scratch); }
+
 static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
-                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed) {
-  int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed);
+                               int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed,
+                               const DposArgs* cowork) {
+  int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed, cowork);
   if (rc) return rc;
   return tn_grid_scatter_fold(grid, N * (int64_t)S, scratch, 0, grid.num_levels, stream);
 }
 
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum,
-                           bool counters_zeroed) {
+                           bool counters_zeroed, const DposArgs* cowork) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && (ld >= 2 * grid.num_levels || ld == TN_LD_LEVEL_MAJOR),
              "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
   if (dense_sum == nullptr && tn_grid_scatter_is_binned(grid, P, scratch))
-    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed);
+    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed, cowork);
+  TN_REQUIRE(cowork == nullptr, "tn_grid_scatter: co-work needs the segmented path (tn_grid_scatter_takes_cowork)");
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
   // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups
   int level_groups = 1;

@@ -1141,3 +1141,41 @@ def test_field_bwd_pair_variant(monkeypatch):
             assert scale > 0, name
             assert md(res["1"][name], ref) <= 2e-5 * scale, (dens_only, name, md(res["1"][name], ref), scale)
             assert bool(((res["1"][name] == 0) == (ref == 0)).all()) or name in ("d_o", "d_d"), (name, "zero pattern")
+
+
+@pytest.mark.parametrize("scatter_mode", ["2", "1"])
+def test_field_bwd_d_position_as_co_work_of_the_bin_launch(monkeypatch, scatter_mode):
+    """The main field's d position pass runs in extra blocks of the table scatter's bin launch (tn_field_dpos.h; segmented path) or as a launch of
+    its own (TN_DPOS_COWORK=0, and always on the binned path): the same d origins / d directions up to the order of their float atomics, and
+    every other gradient of the field bit for bit (the embedding's finisher rides at the head of the pass either way)."""
+    ocfg, params, cfg, arena = setup_pair("shared")
+    N, S = 515, 48
+    r = rays(N)
+    cam = torch.arange(N) % ocfg.num_images
+    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
+    _, e = sample_level(N, S, nears, fars)
+    fld = field_params(arena, "field", cfg, with_grads=True)
+    gd = torch.from_numpy(synth.uniform("gpd", (N, S), seed=SEED))
+    gc = torch.from_numpy(synth.uniform("gpc", (N, S, fld.num_channels), seed=SEED))
+    k = orc.field_keys("field")
+    monkeypatch.setenv("TN_SCATTER_MODE", scatter_mode)
+    res = {}
+    for cw in ("1", "0"):
+        monkeypatch.setenv("TN_DPOS_COWORK", cw)
+        arena.zero_grad()
+        d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
+        ops.field_fwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), True)
+        ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), g(gd), g(gc), d_o, d_d)
+        torch.cuda.synchronize()
+        res[cw] = {s_: arena.grad_view(k[s_]).detach().clone() for s_ in ("table", "w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb")}
+        res[cw]["d_o"], res[cw]["d_d"] = d_o, d_d
+    for name, ref in res["0"].items():
+        scale = float(ref.abs().max())
+        assert scale > 0, name
+        if name in ("d_o", "d_d"):
+            assert md(res["1"][name], ref) <= 1e-5 * scale, (name, md(res["1"][name], ref), scale)
+        elif name == "table":
+            assert torch.equal(res["1"][name] == 0, ref == 0) and md(res["1"][name], ref) <= 1e-6 * scale, name  # (order of the fold's double atomics)
+        else:
+            assert md(res["1"][name], ref) <= 2e-6 * scale, (name, md(res["1"][name], ref), scale)
+
