@@ -370,6 +370,17 @@ struct ReplicaK {
 // scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
+// internal variants of tn_render_fwd / tn_train_losses for tn_train_step: the batch-wide clip of depth_expected not as a launch of its own behind
+// the renderers but as co-work blocks of the loss launch that follows (tn_sampler.hip)
+int tn_render_fwd_ex(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training, float* weights,
+                     float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch, bool launch_clip, int* clip_nblk,
+                     tn_stream_t stream);
+int tn_train_losses_clip(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props, const float* const* s_bins_prop,
+                         const float* const* weights_prop, const int32_t* S_prop, float* const* d_weights_prop, int64_t N, float distortion_mult,
+                         float interlevel_mult, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
+                         int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult,
+                         float* d_pred_rgb, float* d_pred_thermal, float* loss_lines, float* depth_expected, const float* scratch, int clip_nblk,
+                         tn_stream_t stream);
 // cowork: NULL, or the main field's d position pass (tn_field_dpos.h) to run in extra blocks of the bin launch -- only where
 // tn_grid_scatter_takes_cowork says so (the segmented path, no d position of the scatter's own)
 struct DposArgs;

@@ -112,7 +112,8 @@ static int render_rays_train_impl(const TnPropNet* prop0, const TnPropNet* prop1
                                   int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                   const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
                                   int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
-                                  int32_t save_prop_enc, bool with_render, tn_stream_t stream) {
+                                  int32_t save_prop_enc, int with_render, int* clip_nblk, tn_stream_t stream) {
+  if (clip_nblk) *clip_nblk = 0;
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
                  field_workspace && out,
@@ -156,9 +157,9 @@ static int render_rays_train_impl(const TnPropNet* prop0, const TnPropNet* prop1
   if ((rc = tn_field_fwd_ex(field, o, d, camera_indices, at(TRO_E2), N, S2, 1, field_workspace, field_workspace_bytes, at(TRO_D2), at(TRO_RGB_SAMPLES), nullptr, 1,
                             zero_fill, zero_fill_bytes, stream)))
     return rc;
-  if (!with_render) return TN_OK;
-  return tn_render_fwd(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
-                       at(TRO_SCRATCH), stream);
+  if (!with_render) return TN_OK;  // (with_render: 0 no renderers, 1 tn_render_fwd, 2 tn_render_fwd without its clip launch)
+  return tn_render_fwd_ex(at(TRO_E2), at(TRO_D2), at(TRO_RGB_SAMPLES), N, S2, C, 1, at(TRO_W2), at(TRO_COMP), at(TRO_ACC), at(TRO_DEPTH), at(TRO_EXPECTED),
+                          at(TRO_SCRATCH), with_render == 1, clip_nblk, stream);
 }
 extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
                                     const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
@@ -169,7 +170,7 @@ extern "C" int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* pro
                                     int32_t save_prop_enc, tn_stream_t stream) {
   return render_rays_train_impl(prop0, prop1, field, pose_adjustment, frozen, num_cameras, origins_in, directions_in, camera_indices, nears, fars, N, S0, S1, S2,
                                 anneal, jitter0, jitter1, jitter2, lin_spaced0, lin_pdf1, lin_pdf2, field_workspace, field_workspace_bytes, out,
-                                wait_event_before_field, zero_fill, zero_fill_bytes, save_prop_enc, true, stream);
+                                wait_event_before_field, zero_fill, zero_fill_bytes, save_prop_enc, 1, nullptr, stream);
 }
 
 // ---- the TRAINING backward of one branch as one call: everything behind d(composite) / d(weights) of the losses -- tn_render_bwd (get_weights +
@@ -301,10 +302,11 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   // per SIMD, ~4 k instructions per ray), not by launches or latency, so the one launch takes what the three take together (41 vs 37 us).
   const char* fr = getenv("TN_FUSE_RENDER");
   const bool fuse_render = fr && fr[0] == '1' && a->N % 4 == 0;
+  int clip_nblk = 0;  // (the batch-wide clip of the expected depth rides in the loss launch: tn_train_losses_clip)
   if ((rc = render_rays_train_impl(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
                                    a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
                                    a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
-                                   a->acc_bytes, a->prop_grad ? 1 : 0, !fuse_render, stream)))
+                                   a->acc_bytes, a->prop_grad ? 1 : 0, fuse_render ? 0 : 2, &clip_nblk, stream)))
     return rc;
   float* out = a->fwd_out;
   const float* sprop[2] = {out + off[TRO_S0], out + off[TRO_S1]};
@@ -320,9 +322,10 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
                                    Sprop, dwprop, a->distortion_mult, a->interlevel_mult, a->d_weights2, a->image, a->is_thermal, a->thermal_mult, a->tv_mult,
                                    a->cross_mult, a->d_comp, a->loss_lines, d_rgb, d_dens, 1, stream)))
       return rc;
-  } else if ((rc = tn_train_losses(out + off[TRO_S2], out + off[TRO_W2], a->S2, 2, sprop, wprop, Sprop, dwprop, a->N, a->distortion_mult, a->interlevel_mult,
-                                   a->d_weights2, comp, C, comp + 3, C, a->image, a->is_thermal, a->thermal_mult, a->tv_mult, a->cross_mult, a->d_comp,
-                                   a->d_comp + 3, a->loss_lines, stream))) {
+  } else if ((rc = tn_train_losses_clip(out + off[TRO_S2], out + off[TRO_W2], a->S2, 2, sprop, wprop, Sprop, dwprop, a->N, a->distortion_mult,
+                                        a->interlevel_mult, a->d_weights2, comp, C, comp + 3, C, a->image, a->is_thermal, a->thermal_mult, a->tv_mult,
+                                        a->cross_mult, a->d_comp, a->d_comp + 3, a->loss_lines, out + off[TRO_EXPECTED], out + off[TRO_SCRATCH], clip_nblk,
+                                        stream))) {
     // pixel terms on the RGB columns / the thermal column of the one RGBT composite (models/thermal_nerfacto.py:425-428)
     return rc;
   }

@@ -525,28 +525,35 @@ __global__ void __launch_bounds__(BLOCK) k_render_fwd(const float* __restrict__ 
     scratch[RENDER_MAX_BLOCKS + blockIdx.x] = b;
   }
 }
-// every block reduces the nblk pairs itself (a few KB out of L2), then clips its share of the rays; the maxima start at scratch[hi_off]
-__global__ void __launch_bounds__(512) k_clip_depth_blocks(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int hi_off, int64_t N) {
-  __shared__ float sh_lo[8], sh_hi[8];
-  const int t = threadIdx.x;
+// every block reduces the nblk pairs itself (a few KB out of L2), then clips its share of the rays; the maxima start at scratch[hi_off].
+// bid / nblocks stand in for blockIdx.x / gridDim.x (the clip also runs as co-work blocks of the loss launch: tn_train_losses_clip).
+__device__ __forceinline__ void clip_depth_body(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int hi_off, int64_t N, int bid, int nblocks,
+                                                float* sh_lo, float* sh_hi /* 8 floats of LDS each */) {
+  const int t = threadIdx.x, nw = blockDim.x >> 6;
   float lo = INFINITY, hi = 0.0f;
-  for (int i = t; i < nblk; i += 512) { lo = fminf(lo, scratch[i]); hi = fmaxf(hi, scratch[hi_off + i]); }
+  for (int i = t; i < nblk; i += blockDim.x) { lo = fminf(lo, scratch[i]); hi = fmaxf(hi, scratch[hi_off + i]); }
   lo = tn_wave_min(lo); hi = tn_wave_max(hi);
   if ((t & 63) == 0) { sh_lo[t >> 6] = lo; sh_hi[t >> 6] = hi; }
   __syncthreads();
   lo = sh_lo[0]; hi = sh_hi[0];
-#pragma unroll
-  for (int w = 1; w < 8; ++w) { lo = fminf(lo, sh_lo[w]); hi = fmaxf(hi, sh_hi[w]); }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + t; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int w = 1; w < nw; ++w) { lo = fminf(lo, sh_lo[w]); hi = fmaxf(hi, sh_hi[w]); }
+  for (int64_t i = bid * (int64_t)blockDim.x + t; i < N; i += (int64_t)nblocks * blockDim.x) {
     float v = d[i];
     if (v == v) v = fminf(fmaxf(v, lo), hi);  // torch.clip; NaN propagates
     d[i] = v;
   }
 }
+__global__ void __launch_bounds__(512) k_clip_depth_blocks(float* __restrict__ d, const float* __restrict__ scratch, int nblk, int hi_off, int64_t N) {
+  __shared__ float sh_lo[8], sh_hi[8];
+  clip_depth_body(d, scratch, nblk, hi_off, N, blockIdx.x, gridDim.x, sh_lo, sh_hi);
+}
 
-extern "C" int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
-                             float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
-                             tn_stream_t stream) {
+// launch_clip = false: the batch-wide clip of depth_expected is left to the caller (*clip_nblk = the number of min / max pairs in scratch,
+// maxima at scratch + RENDER_MAX_BLOCKS): tn_train_step runs it as co-work blocks of the loss launch that follows
+int tn_render_fwd_ex(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training, float* weights,
+                     float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch, bool launch_clip, int* clip_nblk,
+                     tn_stream_t stream) {
+  if (clip_nblk) *clip_nblk = 0;
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(e_bins && density && rgb && weights && comp, "tn_render_fwd: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_render_fwd: bad N=%lld S=%d", (long long)N, S);
@@ -567,11 +574,17 @@ extern "C" int tn_render_fwd(const float* e_bins, const float* density, const fl
 #undef LAUNCH_R_C
 #undef LAUNCH_R
   TN_CHECK_LAUNCH("tn_render_fwd");
-  if (depth_expected != nullptr) {
+  if (clip_nblk) *clip_nblk = nblk;
+  if (depth_expected != nullptr && launch_clip) {
     hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, st, depth_expected, scratch, nblk, RENDER_MAX_BLOCKS, N);
     TN_CHECK_LAUNCH("tn_render_fwd(clip)");
   }
   return TN_OK;
+}
+extern "C" int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
+                             float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
+                             tn_stream_t stream) {
+  return tn_render_fwd_ex(e_bins, density, rgb, N, S, C, training, weights, comp, accumulation, depth_median, depth_expected, scratch, true, nullptr, stream);
 }
 
 extern "C" int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
@@ -1050,6 +1063,9 @@ struct PropLossArgs {
   float thermal_mult, tv_mult, cross_mult;
   float* pixel_losses; float* d_pred_rgb; float* d_pred_th;
   float* loss_lines;  // NULL: every term adds into its own output; else [TN_LOSS_LINES][16], see k_proposal_losses
+  // co-work of the pixel slice's idle blocks (tn_train_losses_clip): the batch-wide clip of the expected depth the renderer launch before this
+  // one left undone; clip_d == NULL: none
+  float* clip_d; const float* clip_scratch; int clip_nblk, clip_hi_off, clip_blocks;
 };
 __global__ void __launch_bounds__(BLOCK, 6) k_proposal_losses(PropLossArgs a) {
   // Every block ends with one float atomic per loss term, and atomics into ONE 64-byte line execute one after the other (~25 ns each):
@@ -1062,7 +1078,12 @@ __global__ void __launch_bounds__(BLOCK, 6) k_proposal_losses(PropLossArgs a) {
   int slice = blockIdx.y;
   if (a.pred_rgb != nullptr) {
     if (slice == 0) {
-      if ((int)blockIdx.x >= a.pixel_blocks) return;  // whole block leaves together
+      if ((int)blockIdx.x >= a.pixel_blocks) {  // whole block leaves together
+        if (a.clip_d != nullptr && (int)blockIdx.x < a.pixel_blocks + a.clip_blocks)
+          clip_depth_body(a.clip_d, a.clip_scratch, a.clip_nblk, a.clip_hi_off, a.N, (int)blockIdx.x - a.pixel_blocks, a.clip_blocks,
+                          reinterpret_cast<float*>(smem), reinterpret_cast<float*>(smem) + 8);
+        return;
+      }
       pixel_losses_body(a.pred_rgb, a.rs, a.pred_th, a.ts, a.image, a.is_thermal, a.N, a.thermal_mult, a.tv_mult, a.cross_mult,
                         line ? line : a.pixel_losses, a.d_pred_rgb, a.d_pred_th, blockIdx.x, a.pixel_blocks);
       return;
@@ -1098,7 +1119,7 @@ static int launch_train_losses(const char* who, const float* s_bins_fine, const 
                                float* interlevel_out, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
                                int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult,
                                float cross_mult, float* pixel_losses_out, float* d_pred_rgb, float* d_pred_thermal, float* loss_lines,
-                               tn_stream_t stream) {
+                               tn_stream_t stream, float* clip_d = nullptr, const float* clip_scratch = nullptr, int clip_nblk = 0) {
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(s_bins_fine && weights_fine && ((distortion_out && interlevel_out) || loss_lines), "%s: null pointer", who);
   TN_REQUIRE(N > 0 && S_fine >= 1 && S_fine <= TN_MAX_SAMPLES, "%s: bad N=%lld S_fine=%d", who, (long long)N, S_fine);
@@ -1125,6 +1146,17 @@ static int launch_train_losses(const char* who, const float* s_bins_fine, const 
   }
   a.loss_lines = loss_lines;
   dim3 grid((unsigned)std::min<int64_t>(tn_cdiv(N, RAYS_PER_BLOCK), 512), slices);
+  if (clip_d != nullptr && clip_nblk > 0) {
+    TN_REQUIRE(pred_rgb != nullptr && clip_scratch != nullptr, "%s: the depth clip rides in the pixel slice", who);
+    const int cb = (int)std::min<int64_t>(tn_cdiv(N, BLOCK * 8), 64);
+    if (a.pixel_blocks + cb <= (int)grid.x) {
+      a.clip_d = clip_d; a.clip_scratch = clip_scratch; a.clip_nblk = clip_nblk; a.clip_hi_off = RENDER_MAX_BLOCKS; a.clip_blocks = cb;
+    } else {  // (tiny batches: no idle blocks in the slice)
+      hipLaunchKernelGGL(k_clip_depth_blocks, dim3((unsigned)std::min<int64_t>(tn_cdiv(N, 512 * 8), 1024)), dim3(512), 0, tn_s(stream), clip_d, clip_scratch, clip_nblk,
+                         RENDER_MAX_BLOCKS, N);
+      TN_CHECK_LAUNCH(who);
+    }
+  }
   hipLaunchKernelGGL(k_proposal_losses, grid, dim3(BLOCK), 0, tn_s(stream), a);
   TN_CHECK_LAUNCH(who);
   return TN_OK;
@@ -1412,6 +1444,20 @@ extern "C" int tn_render_losses_bwd(const float* e_bins, const float* density, c
     TN_CHECK_LAUNCH("tn_render_losses_bwd(clip)");
   }
   return TN_OK;
+}
+
+// tn_train_losses + the batch-wide clip of depth_expected (tn_render_fwd_ex(launch_clip = false) before it) as co-work blocks of the same launch
+int tn_train_losses_clip(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props, const float* const* s_bins_prop,
+                         const float* const* weights_prop, const int32_t* S_prop, float* const* d_weights_prop, int64_t N, float distortion_mult,
+                         float interlevel_mult, float* d_weights_fine, const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal,
+                         int32_t thermal_stride, const float* image, const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult,
+                         float* d_pred_rgb, float* d_pred_thermal, float* loss_lines, float* depth_expected, const float* scratch, int clip_nblk,
+                         tn_stream_t stream) {
+  TN_REQUIRE(loss_lines != nullptr, "tn_train_losses: null pointer (loss_lines)");
+  return launch_train_losses("tn_train_losses", s_bins_fine, weights_fine, S_fine, num_props, s_bins_prop, weights_prop, S_prop, d_weights_prop, N,
+                             distortion_mult, interlevel_mult, nullptr, nullptr, d_weights_fine, pred_rgb, rgb_stride, pred_thermal, thermal_stride,
+                             image, is_thermal, thermal_mult, tv_mult, cross_mult, nullptr, d_pred_rgb, d_pred_thermal, loss_lines, stream, depth_expected,
+                             scratch, clip_nblk);
 }
 
 extern "C" int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,

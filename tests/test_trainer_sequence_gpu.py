@@ -505,6 +505,18 @@ def test_one_call_train_step_with_the_fused_renderer_launch(golden_dir, monkeypa
             for k in lA:
                 assert abs(float(lA[k]) - float(lB[k])) <= 1e-5 * abs(float(lB[k])) + 1e-12, (step, k, float(lA[k]), float(lB[k]))
         assert_same_training_state(_snapshot(mA), _snapshot(mB), f"fused renderer launch vs the three launches, iteration {step}")
+        # everything the forward leaves in its buffer (samples, densities, weights, composite, depths) bit for bit -- among it the expected depth
+        # after the batch-wide clip, which the default path runs as co-work blocks of the loss launch and the fused path as a launch of its own
+        cA, cB = mA.engine._step_call, mB.engine._step_call
+        assert cA.off == cB.off
+        n = rays[0].shape[0]
+        S0, S1, S2 = cA.counts
+        # slots of tn_render_rays_train_layout in order (the regions are padded to 256 bytes: only their contents are compared)
+        sizes = [n * 3, n * 3, n * (S0 + 1), n * (S0 + 1), n * S0, n * S0, n, n * (S1 + 1), n * (S1 + 1), n * S1, n * S1, n, n * (S2 + 1), n * (S2 + 1), n * S2,
+                 n * S2, n * S2 * 4, n * 4, n, n, n]
+        for slot, size in enumerate(sizes):
+            o = cA.off[slot]
+            assert torch.equal(cA._keep[3][o:o + size], cB._keep[3][o:o + size]), (step, slot)
         assert sA.get_scale() == sB.get_scale() and [sA.num_skipped(i) for i in range(3)] == [sB.num_skipped(i) for i in range(3)]
     assert saw_plain  # an iteration without a proposal update was among them
 
