@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
 // offsets = one 128-entry prefix per level) as ONE linear, vectorised copy, and leaves a header {offset, count} per bucket.  The fold block of a
 // bucket walks the segments the bin blocks left for it.  No global atomics, no counters to zero, no overflow path (a region cannot overflow).
 struct SegK {
-  uint16_t* idx;   // [L][NB][SEG_CAP] slot inside the bucket, records of a (level, bin block) sorted by bucket
+  uint16_t* idx;   // [L][NB][SEG_REGION] slot inside the bucket, records of a (level, bin block) sorted by bucket, every bucket's run padded to an even count
   float2* val;     // same shape
   uint32_t* hdr;   // [L][nslices][NB]: offset | count << 16 of the bucket's segment inside the (level, bin block) region
   uint32_t NB;     // bin blocks per level (blockIdx.x extent of the bin pass)
@@ -732,6 +732,8 @@ struct SegK {
   uint32_t chunks;  // fold blocks per bucket = ceil(NB / segc)
 };
 #define SEG_CAP (BIN_THREADS * 8)
+// a block's region of a level: its records + one pad record (slot 0, value 0) behind every bucket with an odd count -- the fold reads PAIRS
+#define SEG_REGION (SEG_CAP + TN_BIN_MAX_SLICES)
 #ifndef SEG_FOLD_ABLATE
 #define SEG_FOLD_ABLATE 0
 #endif
@@ -743,8 +745,8 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
                                                          DposArgs cw, int cw_blocks) {
   __shared__ uint32_t s_cnt[TN_BIN_MAX_SLICES];      // records per bucket of the level being ranked (zero between levels)
   __shared__ uint32_t s_off[TN_BIN_MAX_SLICES + 1];  // exclusive prefix; [nslices] = the level's record count
-  __shared__ __attribute__((aligned(16))) uint16_t s_i16[SEG_CAP];
-  __shared__ __attribute__((aligned(16))) float2 s_val[SEG_CAP];
+  __shared__ __attribute__((aligned(16))) uint16_t s_i16[SEG_REGION];
+  __shared__ __attribute__((aligned(16))) float2 s_val[SEG_REGION];
   // co-work blocks (the last cw_blocks of every grid row: dispatched between the bin blocks of consecutive level groups): the main field's d
   // position pass, a streaming kernel, beside this pass, which is bound by vector-instruction issue -- in ONE launch, because a second active
   // queue costs an iteration more than the pass takes (tn_field.hip).  (Spread evenly through the rows instead: no gain at all, 0.623 vs
@@ -804,17 +806,22 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
       for (int base = 0; base < ns; base += 64) {
         const int sl = base + lane;
         const uint32_t cnt = sl < ns ? s_cnt[sl] : 0u;
-        uint32_t inc = cnt;
+        const uint32_t ce = (cnt + 1u) & ~1u;  // runs start at even offsets and hold an even number of records: the fold reads pairs
+        uint32_t inc = ce;
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) {
           const uint32_t t = __shfl_up(inc, o2, 64);
           if (lane >= o2) inc += t;
         }
         if (sl < ns) {
-          const uint32_t off = run + inc - cnt;
+          const uint32_t off = run + inc - ce;
           s_off[sl] = off;
           s_cnt[sl] = 0u;
-          hdr[(size_t)sl * sk.NB] = off | (cnt << 16);
+          hdr[(size_t)sl * sk.NB] = off | (ce << 16);
+          if (cnt & 1u) {  // the pad record (the staging area is free: the previous level's copy-out ended before the barrier above)
+            s_i16[off + cnt] = 0;
+            s_val[off + cnt] = make_float2(0.f, 0.f);
+          }
         }
         run += __shfl(inc, 63, 64);
       }
@@ -871,7 +878,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
     __syncthreads();  // staged
     // linear copy of the staged records into the block's region of the level: 16 bytes per lane and instruction
     const uint32_t total = s_off[ns];
-    const size_t reg = ((size_t)l * sk.NB + bx) * SEG_CAP;
+    const size_t reg = ((size_t)l * sk.NB + bx) * SEG_REGION;
     {
       float4* __restrict__ dv = reinterpret_cast<float4*>(sk.val + reg);
       const float4* sv = reinterpret_cast<const float4*>(s_val);
@@ -938,7 +945,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
     for (uint32_t t = tid; t < slots; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);  // 4 floats = 16 B per slot
   }
   {
-    const uint32_t c = my_h >> 16;
+    const uint32_t c = my_h >> 17;  // PAIRS of records (the runs are padded to even counts, at even offsets)
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -949,7 +956,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
     if (lane == 63) s_tot[wave] = inc;
   }
   __syncthreads();
-  uint32_t total = 0;
+  uint32_t total = 0;  // pairs
 #pragma unroll
   for (int w = 0; w < FOLD_THREADS / 64; ++w) total += s_tot[w];
   if (total == 0) return;  // whole block leaves together
@@ -958,25 +965,26 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
   // The LDS adds are what this kernel's time is made of, and a ds_add_f64 costs the same with 20 lanes enabled as with 64 (one segment per wave
   // instruction, the first version: 768 half-empty adds per main-grid block instead of the binned fold's 384 full ones, 88 us instead of 70 --
   // unchanged by deeper prefetch, hoisted header loads or bucket-to-XCD grouping).  So the lanes are kept full: the block's records, segment after
-  // segment, are ONE stream of `total` records, cut into equal shares for groups of `gw` lanes; a group walks its share gw records at a time,
-  // stepping over segment boundaries in the middle of a step (per lane: segment, offset inside it; a boundary costs the lane one header read
-  // from LDS).  Equal shares in RECORDS: with equal shares in segments the slowest of the 64 groups had ~17 % more than the mean (81 us).
-  const uint32_t avg = total / nseg;
-  const int gw_log2 = avg >= 128 ? 6 : (avg >= 48 ? 5 : 4);  // (16, 32 or 64 lanes: no measurable difference on any of the three grids)
+  // segment, are ONE stream, cut into equal shares for groups of `gw` lanes; a group walks its share gw PAIRS at a time (one 4-byte slot pair +
+  // one 16-byte value pair per lane), stepping over segment boundaries in the middle of a step (per lane: segment, offset inside it; a boundary
+  // costs the lane one header read from LDS).  Equal shares in RECORDS: with equal shares in segments the slowest of the 64 groups had ~17 % more
+  // than the mean.  Pairs: the walk (~40 vector instructions per step) was a quarter of the kernel with one record per lane and step.
+  const uint32_t avg = 2u * total / nseg;
+  const int gw_log2 = avg >= 256 ? 6 : (avg >= 96 ? 5 : 4);
   const uint32_t gw = 1u << gw_log2, ngroups = FOLD_THREADS >> gw_log2;
   const uint32_t share = (((total + ngroups - 1) / ngroups) + gw - 1) & ~(gw - 1);
   const uint32_t r_begin = ((uint32_t)tid >> gw_log2) * share, r_end = min(total, r_begin + share);
-  uint32_t rr = r_begin + ((uint32_t)tid & (gw - 1));  // the lane's next record of the stream
+  uint32_t rr = r_begin + ((uint32_t)tid & (gw - 1));  // the lane's next pair of the stream
   const size_t lvl_base = (size_t)l * sk.NB + b0;
   uint32_t sg = 0, t = 0, cnt = 0;
   size_t base = 0;
   auto open_seg = [&]() {
     const uint32_t h = s_h[sg];
-    cnt = h >> 16;
-    base = (lvl_base + sg) * SEG_CAP + (h & 0xffffu);
+    cnt = h >> 17;
+    base = (lvl_base + sg) * SEG_REGION + (h & 0xffffu);
   };
   if (r_begin < total) {
-    // the segment that holds record r_begin: first the wave's 64 headers it lies in, then a binary search on their running counts
+    // the segment that holds pair r_begin: first the wave's 64 headers it lies in, then a binary search on their running counts
     uint32_t before = 0, w = 0;
 #pragma unroll
     for (int i = 0; i < FOLD_THREADS / 64; ++i) {
@@ -993,29 +1001,29 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
     open_seg();
     t = want - s_pre[sg] + ((uint32_t)tid & (gw - 1));
   }
-  struct FoldRec { uint32_t id; float2 v; bool ok; };
-  auto fetch = [&](FoldRec& r) {  // the lane's next record (ok = false once the share is used up, and from then on)
+  struct FoldRec { uint32_t idp; float4 v; bool ok; };
+  auto fetch = [&](FoldRec& r) {  // the lane's next pair (ok = false once the share is used up, and from then on)
     r.ok = rr < r_end;
-    r.id = 0;
-    r.v = make_float2(0.f, 0.f);
+    r.idp = 0;
+    r.v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r.ok) {
-      while (t >= cnt) {  // (a record with index < total exists: the walk ends inside the headers)
+      while (t >= cnt) {  // (a pair with index < total exists: the walk ends inside the headers)
         t -= cnt;
         ++sg;
         open_seg();
       }
 #if SEG_FOLD_ABLATE & 2  // (timing experiments: no record loads)
-      r.id = (uint32_t)(base + t) & (slots - 1);
-      r.v = make_float2(1.0f, 1.0f);
+      r.idp = ((uint32_t)(base + 2 * t) & (slots - 1)) * 0x10001u;
+      r.v = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 #else
-      r.id = sk.idx[base + t];
-      r.v = sk.val[base + t];
+      r.idp = *reinterpret_cast<const uint32_t*>(sk.idx + base + 2 * (size_t)t);
+      r.v = *reinterpret_cast<const float4*>(sk.val + base + 2 * (size_t)t);
 #endif
     }
     t += gw;
     rr += gw;
   };
-  constexpr int FOLD_D = 4;  // records in flight per lane
+  constexpr int FOLD_D = 4;  // pairs in flight per lane
   FoldRec q[FOLD_D];
 #pragma unroll
   for (int d = 0; d < FOLD_D; ++d) fetch(q[d]);
@@ -1025,11 +1033,14 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
       const FoldRec c = q[d];
       fetch(q[d]);
 #if SEG_FOLD_ABLATE & 1  // (timing experiments: no LDS adds -- the loads stay alive through a store that never happens)
-      if (c.ok && c.v.x == 123.456f && c.id == 77u) ax[c.id] = (double)c.v.y;
+      if (c.ok && c.v.x == 123.456f && c.idp == 77u) ax[c.idp & 0xffffu] = (double)c.v.y;
 #else
       if (c.ok) {
-        if (c.v.x != 0.0f) unsafeAtomicAdd(&ax[c.id], (double)c.v.x);
-        if (c.v.y != 0.0f) unsafeAtomicAdd(&ay[c.id], (double)c.v.y);
+        const uint32_t i0 = c.idp & 0xffffu, i1 = c.idp >> 16;
+        if (c.v.x != 0.0f) unsafeAtomicAdd(&ax[i0], (double)c.v.x);
+        if (c.v.y != 0.0f) unsafeAtomicAdd(&ay[i0], (double)c.v.y);
+        if (c.v.z != 0.0f) unsafeAtomicAdd(&ax[i1], (double)c.v.z);
+        if (c.v.w != 0.0f) unsafeAtomicAdd(&ay[i1], (double)c.v.w);
       }
 #endif
     }
@@ -1127,7 +1138,7 @@ static int seg_plan(const TnGrid& grid, int64_t P, void* scratch, SegK& sk) {
   TN_REQUIRE(sk.nslices <= TN_BIN_MAX_SLICES, "tn_grid_scatter: table too large for the segmented path");
   const int64_t NB = tn_cdiv(P, BIN_THREADS);
   sk.NB = (uint32_t)NB;
-  const int64_t recs = (int64_t)L * NB * SEG_CAP;
+  const int64_t recs = (int64_t)L * NB * SEG_REGION;
   char* base = reinterpret_cast<char*>(scratch) + 256;
   sk.val = reinterpret_cast<float2*>(base);
   sk.idx = reinterpret_cast<uint16_t*>(base + recs * 8);
