@@ -9,8 +9,8 @@ cp gpurun_out/$R/rccl_1rank_latency.json profiles/${R}_rccl_1rank_latency.json
 cp gpurun_out/$R/${R}_pmc.json profiles/${R}_pmc.json
 cp gpurun_out/$R/${R}_pmc_summary.md profiles/${R}_pmc_summary.md
 cp gpurun_out/$R/dp_hwq_sweep.json profiles/${R}_dp_hwq_sweep.json
-cp gpurun_out/$R/mfma_valu_overlap.txt profiles/${R}_mfma_valu_overlap.txt
-grep -E '^==' gpurun_out/$R/fwd_ablation.log > profiles/${R}_fwd_ablation.txt
+[ -f gpurun_out/$R/mfma_valu_overlap.txt ] && cp gpurun_out/$R/mfma_valu_overlap.txt profiles/${R}_mfma_valu_overlap.txt
+[ -f gpurun_out/$R/fwd_ablation.log ] && grep -E '^==' gpurun_out/$R/fwd_ablation.log > profiles/${R}_fwd_ablation.txt
 python - <<PY
 import json, sys
 sys.path.insert(0, ".")

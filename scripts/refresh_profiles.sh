@@ -9,9 +9,11 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/$R/tests.log 2>&1; 
 bash scripts/pmc_passes.sh gpurun_out/pmc | tail -12
 python scripts/pmc_summary.py gpurun_out/pmc profiles/$R > gpurun_out/$R/pmc_summary.log 2>&1 && cp profiles/${R}_pmc.json profiles/${R}_pmc_summary.md gpurun_out/$R/
 bash scripts/dp_hwq_sweep.sh $R 2> gpurun_out/$R/sweep.err | tail -20
+if [ -z "$SKIP_ABLATION" ]; then  # (SKIP_ABLATION=1: the forward kernels and the microbenchmark are unchanged since the last run -- their files under profiles/ stay)
 bash scripts/fwd_ablation.sh gpurun_out/$R/fwd_ablation > gpurun_out/$R/fwd_ablation.log 2>&1; grep -E '^==' gpurun_out/$R/fwd_ablation.log
 find gpurun_out/$R/fwd_ablation -name '*.csv' ! -name '*kernel_stats.csv' -delete; find gpurun_out/$R/fwd_ablation -name '*.db' -delete
 timeout -k 5 120 scripts/microbench/mfma_valu_overlap > gpurun_out/$R/mfma_valu_overlap.txt 2>&1; tail -18 gpurun_out/$R/mfma_valu_overlap.txt
+fi
 fi
 if [ "$PART" = "1" ]; then exit 0; fi
 last() { grep '^{' "$1" | tail -1 > "$1.tmp"; mv "$1.tmp" "$1"; }
