@@ -1023,7 +1023,10 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
     t += gw;
     rr += gw;
   };
-  constexpr int FOLD_D = 4;  // pairs in flight per lane
+#ifndef SEG_FOLD_D
+#define SEG_FOLD_D 4
+#endif
+  constexpr int FOLD_D = SEG_FOLD_D;  // pairs in flight per lane (2 / 6 / 8: see profiles/r05_experiments.md)
   FoldRec q[FOLD_D];
 #pragma unroll
   for (int d = 0; d < FOLD_D; ++d) fetch(q[d]);
