@@ -117,7 +117,7 @@ extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
 // ------------------------------------------------------------------------------------------------ ray generation
 // Cameras._generate_rays_from_coords for PERSPECTIVE cameras with OPENCV distortion
 // (cameras/cameras.py:598-655,781-786,886-909; cameras/camera_utils.py:343-446,286-298).
-__device__ __forceinline__ void undistort(float xd, float yd, const float* __restrict__ k, float& xo, float& yo) {
+__device__ __forceinline__ void undistort(float xd, float yd, const float (&k)[6], float& xo, float& yo) {
   const float k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3], p1 = k[4], p2 = k[5];
   float x = xd, y = yd;
   for (int it = 0; it < 10; ++it) {
@@ -148,8 +148,11 @@ struct SamplePixelsArgs {
   const int64_t* image_idx; int num_images; const float* u; int64_t N; int ps; int64_t rays_per_image;
   int64_t* ray_indices; float* image; float* is_thermal_out; int64_t* camera_indices;
 };
-// one ray: which image / patch / pixel, its ground truth; returns (camera, y, x)
-__device__ __forceinline__ void sample_pixel_ray(const SamplePixelsArgs& a, int64_t r, int64_t& cam_out, int64_t& y_out, int64_t& x_out) {
+// one ray in two halves, so that a caller can put every load of the ray in front of its first store (the outputs may alias nothing, but the
+// compiler cannot know: written as one body the kernel was a chain of ten dependent round trips -- index, pixel channel, store, next channel, ...):
+// sample_pixel_pick = which image / patch / pixel + the address of its ground truth (loads only); sample_pixel_store = the outputs.
+struct PixelPick { int64_t cam, y, x; const float* px; float th; };
+__device__ __forceinline__ PixelPick sample_pixel_pick(const SamplePixelsArgs& a, int64_t r) {
   const int pp = a.ps * a.ps;
   int64_t i = a.rays_per_image > 0 ? r / a.rays_per_image : a.num_images - 1;  // every image holds rays_per_image rays, the last one the rest
   if (i > a.num_images - 1) i = a.num_images - 1;
@@ -158,26 +161,33 @@ __device__ __forceinline__ void sample_pixel_ray(const SamplePixelsArgs& a, int6
   int k = (int)(local - patch * pp);
   int dy = k / a.ps, dx = k - dy * a.ps;
   const float* up = a.u + (i * (a.rays_per_image / pp) + patch) * 3;
-  int H = a.heights[i], W = a.widths[i];
+  const float u1 = up[1], u2 = up[2];
+  const int H = a.heights[i], W = a.widths[i];
+  PixelPick p;
+  p.cam = a.image_idx[i];
+  p.th = a.is_thermal[i];
+  const int64_t off = a.image_offsets[i];
   // torch: floor(rand * [1, H - ps, W - ps]) in fp32 (float32 x int64 promotes to float32), then + patch offsets
-  int64_t y = (int64_t)floorf(up[1] * (float)(H - a.ps) + (float)dy);
-  int64_t x = (int64_t)floorf(up[2] * (float)(W - a.ps) + (float)dx);
-  const int64_t cam = a.image_idx[i];
-  a.ray_indices[r * 3 + 0] = cam;
-  if (a.camera_indices != nullptr) a.camera_indices[r] = cam;
-  a.ray_indices[r * 3 + 1] = y;
-  a.ray_indices[r * 3 + 2] = x;
-  const float* px = a.images + a.image_offsets[i] + (y * W + x) * 3;
-  a.image[r * 3 + 0] = px[0];
-  a.image[r * 3 + 1] = px[1];
-  a.image[r * 3 + 2] = px[2];
-  a.is_thermal_out[r] = a.is_thermal[i];
-  cam_out = cam; y_out = y; x_out = x;
+  p.y = (int64_t)floorf(u1 * (float)(H - a.ps) + (float)dy);
+  p.x = (int64_t)floorf(u2 * (float)(W - a.ps) + (float)dx);
+  p.px = a.images + off + (p.y * W + p.x) * 3;
+  return p;
+}
+__device__ __forceinline__ void sample_pixel_store(const SamplePixelsArgs& a, int64_t r, const PixelPick& p, float c0, float c1, float c2) {
+  a.ray_indices[r * 3 + 0] = p.cam;
+  if (a.camera_indices != nullptr) a.camera_indices[r] = p.cam;
+  a.ray_indices[r * 3 + 1] = p.y;
+  a.ray_indices[r * 3 + 2] = p.x;
+  a.image[r * 3 + 0] = c0;
+  a.image[r * 3 + 1] = c1;
+  a.image[r * 3 + 2] = c2;
+  a.is_thermal_out[r] = p.th;
 }
 __global__ void k_sample_pixels(SamplePixelsArgs a) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
-    int64_t cam, y, x;
-    sample_pixel_ray(a, r, cam, y, x);
+    const PixelPick p = sample_pixel_pick(a, r);
+    const float c0 = p.px[0], c1 = p.px[1], c2 = p.px[2];
+    sample_pixel_store(a, r, p, c0, c1, c2);
   }
 }
 
@@ -218,16 +228,30 @@ struct RaygenArgs {
   int any_distortion, num_cameras;
   float* origins; float* directions; float* pixel_area; float* directions_norm;
 };
-// one ray from (camera, pixel row, pixel column)
-__device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64_t cam, int64_t yi, int64_t xi) {
+// one ray from (camera, pixel row, pixel column), in two halves like the pixel sampler: the camera's parameters (loads only), then the arithmetic
+// and the stores
+struct CamParams { float fx, fy, cx, cy, R[12], k[6]; };
+__device__ __forceinline__ void raygen_load(const RaygenArgs& g, int64_t& cam, CamParams& c) {
   if (cam < 0 || cam >= g.num_cameras) cam = 0;  // host validates; keep the access in bounds regardless
+  c.fx = g.fx[cam]; c.fy = g.fy[cam]; c.cx = g.cx[cam]; c.cy = g.cy[cam];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) c.R[q] = g.c2w[cam * 12 + q];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) c.k[q] = 0.0f;
+  if (g.any_distortion) {  // (kernel-uniform; three 8-byte loads requested together)
+    const float2* dk = reinterpret_cast<const float2*>(g.distortion + cam * 6);
+    const float2 k01 = dk[0], k23 = dk[1], k45 = dk[2];
+    c.k[0] = k01.x; c.k[1] = k01.y; c.k[2] = k23.x; c.k[3] = k23.y; c.k[4] = k45.x; c.k[5] = k45.y;
+  }
+}
+__device__ __forceinline__ void raygen_compute(const RaygenArgs& g, int64_t i, const CamParams& cp, int64_t yi, int64_t xi) {
   float y = (float)yi + 0.5f;  // get_image_coords(pixel_offset=0.5)
   float x = (float)xi + 0.5f;
-  float fxc = g.fx[cam], fyc = g.fy[cam], cxc = g.cx[cam], cyc = g.cy[cam];
+  const float fxc = cp.fx, fyc = cp.fy, cxc = cp.cx, cyc = cp.cy;
   // coord, coord_x_offset, coord_y_offset
   float u[3] = {(x - cxc) / fxc, (x - cxc + 1.0f) / fxc, (x - cxc) / fxc};
   float v[3] = {(y - cyc) / fyc, (y - cyc) / fyc, (y - cyc + 1.0f) / fyc};
-  const float* R = g.c2w + cam * 12;
+  const float* R = cp.R;
   float dir[3][3];
   float nrm0 = 0.0f;
   const int nq = g.pixel_area ? 3 : 1;  // (the +1-pixel neighbours only serve pixel_area: two of the three Newton undistortions, the kernel's serial chain)
@@ -235,7 +259,7 @@ __device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64
   for (int q = 0; q < 3; ++q) {
     if (q >= nq) break;
     float a = u[q], b = v[q];
-    if (g.any_distortion) undistort(a, b, g.distortion + cam * 6, a, b);
+    if (g.any_distortion) undistort(a, b, cp.k, a, b);
     b = -b;  // OpenCV -> OpenGL
     float dz = -1.0f;
     // sum(d[None,:] * R, dim=-1): row r of R dotted with d
@@ -261,15 +285,66 @@ __device__ __forceinline__ void raygen_ray(const RaygenArgs& g, int64_t i, int64
   if (g.directions_norm) g.directions_norm[i] = nrm0;
 }
 __global__ void k_raygen(const int64_t* __restrict__ ray_indices, RaygenArgs g, int64_t N) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
-    raygen_ray(g, i, ray_indices[i * 3], ray_indices[i * 3 + 1], ray_indices[i * 3 + 2]);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cam = ray_indices[i * 3];
+    const int64_t y = ray_indices[i * 3 + 1], x = ray_indices[i * 3 + 2];
+    CamParams cp;
+    raygen_load(g, cam, cp);
+    raygen_compute(g, i, cp, y, x);
+  }
 }
-// datamanager.next_train in one launch: pixel sampling + ground-truth gather + ray generation (the pixel goes from one to the other in registers)
+// datamanager.next_train in one launch: pixel sampling + ground-truth gather + ray generation (the pixel goes from one to the other in registers).
+// FOUR lanes per ray: lane q of the quad runs the Newton undistortion of coordinate q (the pixel, its +1-column and its +1-row neighbour, which
+// only serve pixel_area; lane 3 idles) -- one thread per ray ran the three chains one after the other, ~2 000 dependent instructions on 64 waves
+// that each have a SIMD to themselves.  Same expressions per coordinate as raygen_compute.
 __global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) {
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
-    int64_t cam, y, x;
-    sample_pixel_ray(a, r, cam, y, x);
-    raygen_ray(g, r, cam, y, x);
+  const int lane = threadIdx.x & 63, q = lane & 3, quad0 = lane & ~3;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < a.N * 4; t += (int64_t)gridDim.x * blockDim.x) {  // (whole quads: blockDim % 4 == 0)
+    const int64_t r = t >> 2;
+    // two rounds of loads (index data; then the pixel and the camera's parameters together), then arithmetic and stores
+    const PixelPick p = sample_pixel_pick(a, r);
+    const float c0 = p.px[0], c1 = p.px[1], c2 = p.px[2];
+    int64_t cam = p.cam;
+    CamParams cp;
+    raygen_load(g, cam, cp);
+    if (q == 0) sample_pixel_store(a, r, p, c0, c1, c2);
+    const float y = (float)p.y + 0.5f, x = (float)p.x + 0.5f;  // get_image_coords(pixel_offset=0.5)
+    // coord, coord_x_offset, coord_y_offset
+    float ua = (q == 1) ? (x - cp.cx + 1.0f) / cp.fx : (x - cp.cx) / cp.fx;
+    float vb = (q == 2) ? (y - cp.cy + 1.0f) / cp.fy : (y - cp.cy) / cp.fy;
+    float dir[3] = {0.f, 0.f, 0.f}, nrm = 0.0f;
+    const int nq = g.pixel_area ? 3 : 1;
+    if (q < nq) {
+      float aa = ua, bb = vb;
+      if (g.any_distortion) undistort(aa, bb, cp.k, aa, bb);
+      bb = -bb;  // OpenCV -> OpenGL
+      const float dz = -1.0f;
+      const float* R = cp.R;
+      float w0 = aa * R[0] + bb * R[1] + dz * R[2];
+      float w1 = aa * R[4] + bb * R[5] + dz * R[6];
+      float w2 = aa * R[8] + bb * R[9] + dz * R[10];
+      float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+      n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
+      dir[0] = w0 / n; dir[1] = w1 / n; dir[2] = w2 / n;
+      nrm = n;
+    }
+    float d1[3], d2[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d1[c] = __shfl(dir[c], quad0 + 1, 64); d2[c] = __shfl(dir[c], quad0 + 2, 64); }
+    if (q == 0) {
+      g.origins[r * 3 + 0] = cp.R[3]; g.origins[r * 3 + 1] = cp.R[7]; g.origins[r * 3 + 2] = cp.R[11];
+      g.directions[r * 3 + 0] = dir[0]; g.directions[r * 3 + 1] = dir[1]; g.directions[r * 3 + 2] = dir[2];
+      if (g.pixel_area) {
+        float ddx = 0.0f, ddy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float da = dir[c] - d1[c], db = dir[c] - d2[c];
+          ddx += da * da; ddy += db * db;
+        }
+        g.pixel_area[r] = sqrtf(ddx) * sqrtf(ddy);
+      }
+      if (g.directions_norm) g.directions_norm[r] = nrm;
+    }
   }
 }
 
@@ -298,7 +373,7 @@ extern "C" int tn_sample_rays(const float* images, const int64_t* image_offsets,
   if (rc) return rc;
   TN_REQUIRE(c2w && fx && fy && cx && cy && origins && directions && num_cameras >= 1, "tn_sample_rays: bad camera arguments");  // (pixel_area may be NULL)
   RaygenArgs g{c2w, fx, fy, cx, cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, origins, directions, pixel_area, directions_norm};
-  hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays, 256), 2048)), dim3(256), 0, tn_s(stream), a, g);
+  hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays * 4, 256), 4096)), dim3(256), 0, tn_s(stream), a, g);  // 4 lanes per ray
   TN_CHECK_LAUNCH("tn_sample_rays");
   return TN_OK;
 }
