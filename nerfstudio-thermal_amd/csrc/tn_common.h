@@ -103,23 +103,28 @@ __device__ __forceinline__ int64_t tn_div_index(int64_t i, int64_t d, int64_t to
 }
 
 // (bid / nblk stand in for blockIdx.x / gridDim.x: tn_spaced_bins launches it alone, tn_pose_spaced_bins as one slice of a launch)
+// One WAVE per ray (bin j = lane + 64 k): the ray's near / far / jitter and their spacings once per ray instead of once per bin (three of the four
+// divisions of a bin were the ray's), consecutive lanes write consecutive bins.  Same expressions per bin as the reference's.
 __device__ __forceinline__ void tn_spaced_bins_body(const float* __restrict__ lin_bins, const float* __restrict__ jitter,
                                                     const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
                                                     float* __restrict__ s_bins, float* __restrict__ e_bins, int bid, int nblk) {
-  int64_t total = N * (int64_t)(S + 1);
-  for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nblk * blockDim.x) {
-    int64_t ray = tn_div_index(i, S + 1, total);
-    int j = (int)(i - ray * (S + 1));
-    float b = lin_bins[j];
-    if (jitter != nullptr) {
-      // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
-      float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
-      float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
-      b = lower + (upper - lower) * jitter[ray];
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (int64_t ray = (int64_t)bid * wpb + (threadIdx.x >> 6); ray < N; ray += (int64_t)nblk * wpb) {
+    const float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
+    const float jit = jitter != nullptr ? jitter[ray] : 0.0f;
+    float* sb = s_bins + ray * (S + 1);
+    float* eb = e_bins + ray * (S + 1);
+    for (int j = lane; j <= S; j += 64) {
+      float b = lin_bins[j];
+      if (jitter != nullptr) {
+        // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
+        float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
+        float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
+        b = lower + (upper - lower) * jit;
+      }
+      sb[j] = b;
+      eb[j] = tn_s_to_euclid(b, s_near, s_far);
     }
-    float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
-    s_bins[i] = b;
-    e_bins[i] = tn_s_to_euclid(b, s_near, s_far);
   }
 }
 

@@ -412,13 +412,17 @@ __device__ __forceinline__ void pose_fwd_body(const float* __restrict__ pose, co
     if (cam < 0 || cam >= C) cam = 0;
     float ox = o_in[i * 3], oy = o_in[i * 3 + 1], oz = o_in[i * 3 + 2];
     float dx = d_in[i * 3], dy = d_in[i * 3 + 1], dz = d_in[i * 3 + 2];
+    // (the camera's pose row is requested together with its frozen flag: one round trip, not two)
+    float prow[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) prow[q] = pose[cam * 6 + q];
     if (frozen != nullptr && frozen[cam]) {
       // identity transform: origins + 0, bmm(I, d)
       o_out[i * 3] = ox + 0.0f; o_out[i * 3 + 1] = oy + 0.0f; o_out[i * 3 + 2] = oz + 0.0f;
       d_out[i * 3] = dx; d_out[i * 3 + 1] = dy; d_out[i * 3 + 2] = dz;
       continue;
     }
-    Pose p = pose_exp(pose + cam * 6);
+    Pose p = pose_exp(prow);
     o_out[i * 3] = ox + p.t[0]; o_out[i * 3 + 1] = oy + p.t[1]; o_out[i * 3 + 2] = oz + p.t[2];
     d_out[i * 3 + 0] = p.R[0] * dx + p.R[1] * dy + p.R[2] * dz;
     d_out[i * 3 + 1] = p.R[3] * dx + p.R[4] * dy + p.R[5] * dz;
@@ -465,7 +469,7 @@ extern "C" int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* 
   TN_REQUIRE(pose_adjustment && camera_indices && origins_in && directions_in && origins_out && directions_out, "tn_pose_spaced_bins: null pointer");
   TN_REQUIRE(lin_bins && nears && fars && s_bins && e_bins, "tn_pose_spaced_bins: null pointer");
   TN_REQUIRE(N >= 0 && num_cameras >= 1 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_pose_spaced_bins: bad N=%lld C=%d S=%d", (long long)N, num_cameras, S);
-  const int bins_blocks = (int)std::min<int64_t>(tn_cdiv(N * (int64_t)(S + 1), 256), 4096);
+  const int bins_blocks = (int)std::min<int64_t>(tn_cdiv(N, 4), 4096);  // one wave per ray, 4 rays per block
   const int pose_blocks = (int)std::min<int64_t>(tn_cdiv(N, 256), (int64_t)bins_blocks);
   hipLaunchKernelGGL(k_pose_spaced_bins, dim3((unsigned)bins_blocks, 2), dim3(256), 0, tn_s(stream), pose_adjustment, frozen, camera_indices, origins_in,
                      directions_in, N, num_cameras, origins_out, directions_out, pose_blocks, lin_bins, jitter, nears, fars, S, s_bins, e_bins);

@@ -23,8 +23,7 @@ extern "C" int tn_spaced_bins(const float* lin_bins, const float* jitter, const 
   TN_REQUIRE(lin_bins && nears && fars && s_bins && e_bins, "tn_spaced_bins: null pointer");
   TN_REQUIRE(N >= 0 && S >= 1 && S <= TN_MAX_SAMPLES, "tn_spaced_bins: bad N=%lld S=%d", (long long)N, S);
   if (N == 0) return TN_OK;
-  int64_t total = N * (S + 1);
-  int grid = (int)std::min<int64_t>(tn_cdiv(total, 256), 4096);
+  int grid = (int)std::min<int64_t>(tn_cdiv(N, 4), 4096);  // one wave per ray, 4 rays per block
   hipLaunchKernelGGL(k_spaced_bins, dim3(grid), dim3(256), 0, tn_s(stream), lin_bins, jitter, nears, fars, N, S, s_bins, e_bins);
   TN_CHECK_LAUNCH("tn_spaced_bins");
   return TN_OK;
