@@ -1038,12 +1038,14 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
 #if SEG_FOLD_ABLATE & 1  // (timing experiments: no LDS adds -- the loads stay alive through a store that never happens)
       if (c.ok && c.v.x == 123.456f && c.idp == 77u) ax[c.idp & 0xffffu] = (double)c.v.y;
 #else
-      if (c.ok) {
+      // (one test per pair, not one per value: an add of +-0 changes nothing -- untouched slots stay exactly zero -- and an LDS add costs the same
+      // with a lane more or less; a step whose pairs are ALL zero is skipped as a whole)
+      if (c.ok && ((c.v.x != 0.0f) | (c.v.y != 0.0f) | (c.v.z != 0.0f) | (c.v.w != 0.0f))) {
         const uint32_t i0 = c.idp & 0xffffu, i1 = c.idp >> 16;
-        if (c.v.x != 0.0f) unsafeAtomicAdd(&ax[i0], (double)c.v.x);
-        if (c.v.y != 0.0f) unsafeAtomicAdd(&ay[i0], (double)c.v.y);
-        if (c.v.z != 0.0f) unsafeAtomicAdd(&ax[i1], (double)c.v.z);
-        if (c.v.w != 0.0f) unsafeAtomicAdd(&ay[i1], (double)c.v.w);
+        unsafeAtomicAdd(&ax[i0], (double)c.v.x);
+        unsafeAtomicAdd(&ay[i0], (double)c.v.y);
+        unsafeAtomicAdd(&ax[i1], (double)c.v.z);
+        unsafeAtomicAdd(&ay[i1], (double)c.v.w);
       }
 #endif
     }
