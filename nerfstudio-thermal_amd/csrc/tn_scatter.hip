@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_grid_fold(GridK g, BinK bk, ui
 // offsets = one 128-entry prefix per level) as ONE linear, vectorised copy, and leaves a header {offset, count} per bucket.  The fold block of a
 // bucket walks the segments the bin blocks left for it.  No global atomics, no counters to zero, no overflow path (a region cannot overflow).
 struct SegK {
-  uint16_t* idx;   // [L][NB][SEG_REGION] slot inside the bucket, records of a (level, bin block) sorted by bucket, every bucket's run padded to an even count
+  uint16_t* idx;   // [L][NB][SEG_REGION] slot inside the bucket, records of a (level, bin block) sorted by bucket, every bucket's run at an even offset
   float2* val;     // same shape
   uint32_t* hdr;   // [L][nslices][NB]: offset | count << 16 of the bucket's segment inside the (level, bin block) region
   uint32_t NB;     // bin blocks per level (blockIdx.x extent of the bin pass)
@@ -732,7 +732,7 @@ struct SegK {
   uint32_t chunks;  // fold blocks per bucket = ceil(NB / segc)
 };
 #define SEG_CAP (BIN_THREADS * 8)
-// a block's region of a level: its records + one pad record (slot 0, value 0) behind every bucket with an odd count -- the fold reads PAIRS
+// a block's region of a level: its records, every bucket's run at an EVEN offset (one unused slot behind an odd run) -- the fold reads PAIRS
 #define SEG_REGION (SEG_CAP + TN_BIN_MAX_SLICES)
 #ifndef SEG_FOLD_ABLATE
 #define SEG_FOLD_ABLATE 0
@@ -817,11 +817,8 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
           const uint32_t off = run + inc - ce;
           s_off[sl] = off;
           s_cnt[sl] = 0u;
-          hdr[(size_t)sl * sk.NB] = off | (ce << 16);
-          if (cnt & 1u) {  // the pad record (the staging area is free: the previous level's copy-out ended before the barrier above)
-            s_i16[off + cnt] = 0;
-            s_val[off + cnt] = make_float2(0.f, 0.f);
-          }
+          hdr[(size_t)sl * sk.NB] = off | (cnt << 16);  // (the REAL count: the fold ignores the second half of an odd run's last pair -- writing a
+                                                        // pad record here cost the d-position variant two spilled registers, 5 us on the 1 M-sample grid)
         }
         run += __shfl(inc, 63, 64);
       }
@@ -945,7 +942,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
     for (uint32_t t = tid; t < slots; t += FOLD_THREADS) z[t] = make_float4(0.f, 0.f, 0.f, 0.f);  // 4 floats = 16 B per slot
   }
   {
-    const uint32_t c = my_h >> 17;  // PAIRS of records (the runs are padded to even counts, at even offsets)
+    const uint32_t c = ((my_h >> 16) + 1u) >> 1;  // PAIRS of records (the runs start at even offsets; an odd run's last pair is half empty)
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -976,11 +973,12 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
   const uint32_t r_begin = ((uint32_t)tid >> gw_log2) * share, r_end = min(total, r_begin + share);
   uint32_t rr = r_begin + ((uint32_t)tid & (gw - 1));  // the lane's next pair of the stream
   const size_t lvl_base = (size_t)l * sk.NB + b0;
-  uint32_t sg = 0, t = 0, cnt = 0;
+  uint32_t sg = 0, t = 0, cnt = 0, cnt_rec = 0;
   size_t base = 0;
   auto open_seg = [&]() {
     const uint32_t h = s_h[sg];
-    cnt = h >> 17;
+    cnt_rec = h >> 16;
+    cnt = (cnt_rec + 1u) >> 1;
     base = (lvl_base + sg) * SEG_REGION + (h & 0xffffu);
   };
   if (r_begin < total) {
@@ -1019,6 +1017,7 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uin
       r.idp = *reinterpret_cast<const uint32_t*>(sk.idx + base + 2 * (size_t)t);
       r.v = *reinterpret_cast<const float4*>(sk.val + base + 2 * (size_t)t);
 #endif
+      if (2u * t + 1u >= cnt_rec) { r.idp &= 0xffffu; r.v.z = 0.0f; r.v.w = 0.0f; }  // the unused slot behind an odd run (whatever the staging area held)
     }
     t += gw;
     rr += gw;
