@@ -44,7 +44,7 @@ def main():
             d = [x[0] for x in con.execute(q, (r[0], r[1]) if split and gx else (r[0],))]
             return f"{r[0][:60]:<62}{(' [grid %d]' % r[1]) if split and gx else '':<16} tail_avg_us={sum(d) / len(d) / 1e3:9.1f}"
 
-        print(f"\nSTAND-ALONE launches (last {n} of each; kernels bench.py launches alone after the steps -- reproduces roofline.avg_launch_ms / roofline.mfma):")
+        print(f"\nSTAND-ALONE launches (last {n} of each; kernels bench.py launches alone after the steps -- reproduces roofline.avg_launch_ms / roofline.mfma; a k_seg_bin<false> row with a LARGER grid than the stand-alone one is the in-step launch that carries the d-position co-work blocks):")
         for r in [r for r in rows if is_alone(r[0])][:14]:
             print(tail(r))
         print(f"\nIN-STEP launches (last {n} of each; kernels that only ever run inside a training step, beside whatever the step runs on other streams -- NOT stand-alone):")
