@@ -1,4 +1,7 @@
 // Trilinear scatter-add of d(encoding) into a hash table's gradient (+ d position), shared by the proposal grids and the main grid.
+// Three paths, newest last in the file (TN_SCATTER_MODE): 0 = global float atomics with dense replicas (round 1; below), 1 = "binned": records
+// reserved into per-bucket global arrays, summed per bucket in LDS (rounds 2-5), 2 = "segmented" (round 5, the default): records in regions that
+// belong to one bin block, no global atomic at all, a fold that gathers its bucket's segment from every bin block.
 //
 // Global float atomics on MI355X are bound by 64-byte REQUESTS (~21 G requests/s, scripts/microbench/atomic_shapes.hip): lanes of one
 // wave-instruction that fall into the same 64-B line cost one request.  The kernel is laid out for that:
@@ -219,7 +222,8 @@ __global__ void __launch_bounds__(256) k_replica_reduce(GridK g, ReplicaK rk, fl
 }
 
 // ======================================================================================================================================
-// Atomic-free ("binned") path -- the default.  Global float atomics execute at the memory side at ~20 G 64-byte requests/s whatever the
+// Atomic-free ("binned") path -- TN_SCATTER_MODE=1; the segmented path further down is the default and shares its record format, bucket size and
+// LDS-image fold.  Global float atomics execute at the memory side at ~20 G 64-byte requests/s whatever the
 // kernel does (MI355X_MICROARCH.md, Global float atomics), plain coalesced stores run 4-5x faster, so every contribution is WRITTEN once
 // and summed on chip:
 //   pass 1  k_grid_bin : lane = sample (patch order).  Per level: 8 corner slots + values; runs of consecutive samples in one grid cell are
