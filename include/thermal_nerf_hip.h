@@ -34,6 +34,8 @@
  *      TN_BIN_LEVEL_GROUPS=n      force the number of level groups of the bin pass (diagnostic: n = levels -> one level per block)
  *      TN_DPOS_COWORK=0           (read per call) the main field's d position pass as a launch of its own (forked with TN_BWD_FORK_DPOS) instead of
  *                                 extra blocks of the table scatter's bin launch
+ *      TN_POSE_FINISH_COWORK=0    (read per call) tn_train_step's last backward launch (tn_pose_bwd_finish_check) always as a launch of its own instead of
+ *                                 the first blocks of the main grid's fold launch on iterations without a proposal update
  *      TN_FUSE_RENDER=1           (read per call) tn_train_step with tn_render_fwd / tn_train_losses / tn_render_bwd as ONE launch,
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
  *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning

@@ -388,11 +388,23 @@ int tn_train_losses_clip(const float* s_bins_fine, const float* weights_fine, in
                          tn_stream_t stream);
 // cowork: NULL, or the main field's d position pass (tn_field_dpos.h) to run in extra blocks of the bin launch -- only where
 // tn_grid_scatter_takes_cowork says so (the segmented path, no d position of the scatter's own)
+// fold_cowork: NULL, or the launch that ends an iteration's backward (tn_pose_finish.h) to run in the first blocks of the FOLD launch (same condition)
 struct DposArgs;
+struct PoseFinishArgs;
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum = nullptr,
-                           bool counters_zeroed = false, const DposArgs* cowork = nullptr);
+                           bool counters_zeroed = false, const DposArgs* cowork = nullptr, const PoseFinishArgs* fold_cowork = nullptr);
 bool tn_grid_scatter_takes_cowork(const TnGrid& grid, int64_t P, void* scratch);
+// tn_field_bwd_phase with the fold's co-work (tn_train_step); *fold_cowork_taken says whether the fold launch carried it (else the caller launches it)
+int tn_field_bwd_phase_ex(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                          const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
+                          float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, const PoseFinishArgs* fold_cowork,
+                          bool* fold_cowork_taken, tn_stream_t stream);
+int tn_pose_finish_args(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+                        const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose, const float* loss_lines,
+                        float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out, const float* grads, int32_t num_ranges,
+                        const int64_t* offsets, const int64_t* counts, const int32_t* flag_index, int32_t num_flags, float* found_inf, int32_t pose_flag,
+                        PoseFinishArgs& a);
 // The bin pass needs its bucket counters zero.  A separate hipMemsetAsync of those few KB costs 6-25 us on the launch stream (config 2 makes
 // seven of them per step): the kernel that produces d enc -- always the launch right before the scatter on the same stream -- zeroes them instead
 // (tn_zero_words, first thing block 0 does) and the scatter is told so (counters_zeroed).  *words = 0 when the binned path is not taken.
@@ -407,6 +419,7 @@ bool tn_grid_scatter_is_binned(const TnGrid& grid, int64_t P, const void* scratc
 int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld, int64_t N,
                         int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed = false,
                         const DposArgs* cowork = nullptr);
-int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream);
+int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream,
+                         const PoseFinishArgs* cowork = nullptr);
 int64_t tn_grid_dense_count(const TnGrid& grid, int64_t P);
 int tn_grid_dense_fold(const TnGrid& grid, int64_t P, const float* dense_sum, hipStream_t stream);

@@ -1709,6 +1709,14 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
                                   const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                                   int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end,
                                   tn_stream_t stream) {
+  return tn_field_bwd_phase_ex(field, origins, directions, camera_indices, e_bins, d_density, d_rgb, N, S, workspace, workspace_bytes, d_origins, d_directions,
+                               phases, level_begin, level_end, nullptr, nullptr, stream);
+}
+int tn_field_bwd_phase_ex(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+                          const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
+                          float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end, const PoseFinishArgs* fold_cowork,
+                          bool* fold_cowork_taken, tn_stream_t stream) {
+  if (fold_cowork_taken) *fold_cowork_taken = false;
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   int rc = check_field(field, "tn_field_bwd", true);
   if (rc) return rc;
@@ -1804,8 +1812,11 @@ extern "C" int tn_field_bwd_phase(const TnField* field, const float* origins, co
     TnGrid sub = level_range_grid(field->grid, level_begin, level_end);
     // (counters zeroed by the MLP phase: this call runs both, or the caller vouches for it -- and the scatter covers the whole grid in one go)
     const bool cz = (phases & (TN_BWD_MLP | TN_BWD_COUNTERS_CLEAN)) && level_begin == 0 && level_end == field->grid.num_levels;
+    // (the fold's co-work rides only where the d position pass does: the whole segmented scatter in this call)
+    const PoseFinishArgs* fcw = (fold_cowork != nullptr && dpos_cowork) ? fold_cowork : nullptr;
     rc = tn_grid_scatter_launch(sub, origins, directions, e_bins, ws.g_enc + (int64_t)level_begin * 2 * P, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
-                                nullptr, cz, dpos_cowork ? &dpos_args : nullptr);
+                                nullptr, cz, dpos_cowork ? &dpos_args : nullptr, fcw);
+    if (fold_cowork_taken && rc == TN_OK) *fold_cowork_taken = fcw != nullptr;
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
     TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");

@@ -3,6 +3,7 @@
 // call of the C ABI: the seven launches below are enqueued back to back by the library, nothing returns to the caller in between.
 // Every stage is the entry point a caller could also invoke on its own (same kernels, same results, bit for bit).
 #include "tn_common.h"
+#include "tn_pose_finish.h"
 
 namespace {
 struct EvalWs {
@@ -193,7 +194,8 @@ static int render_rays_train_bwd_impl(const TnPropNet* prop0, const TnPropNet* p
                                       const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
                                       int64_t field_workspace_bytes, void* prop_workspace0, int64_t prop_workspace_bytes0, void* prop_workspace1,
                                       int64_t prop_workspace_bytes1, float* tmp, float* d_origins, float* d_directions, int32_t prop_enc_saved,
-                                      bool render_bwd_done, tn_stream_t stream) {
+                                      bool render_bwd_done, const PoseFinishArgs* fold_cowork, bool* fold_cowork_taken, tn_stream_t stream) {
+  if (fold_cowork_taken) *fold_cowork_taken = false;
   if (N == 0) return TN_OK;
   TN_REQUIRE(field && origins && directions && camera_indices && fwd_out && d_comp && d_weights2 && field_workspace && tmp,
              "tn_render_rays_train_bwd: null pointer");
@@ -238,8 +240,10 @@ static int render_rays_train_bwd_impl(const TnPropNet* prop0, const TnPropNet* p
                                    prop_enc_saved ? at(TRO_PENC1) : nullptr, t1);
   }
   // (d position forks to its companion stream only when the proposal networks' backward keeps other queues busy anyway)
-  rc = tn_field_bwd_phase(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, field_workspace_bytes, d_origins, d_directions,
-                          TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | (prop_grad ? TN_BWD_FORK_DPOS : 0), 0, field->grid.num_levels, stream);
+  // (the fold's co-work only on iterations without the proposal networks' backward: their contributions to d origins / d directions arrive with the join below)
+  rc = tn_field_bwd_phase_ex(field, o, d, camera_indices, at(TRO_E2), d_dens, d_rgb, N, S2, field_workspace, field_workspace_bytes, d_origins, d_directions,
+                             TN_BWD_MLP | TN_BWD_SCATTER | TN_BWD_JOIN | (prop_grad ? TN_BWD_FORK_DPOS : 0), 0, field->grid.num_levels,
+                             prop_grad ? nullptr : fold_cowork, fold_cowork_taken, stream);
   if (prop_grad) { tn_join_n(st, 1); tn_join_n(st, 2); }
   return rc ? rc : (rc0 ? rc0 : rc1);
 }
@@ -252,7 +256,7 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
                                         tn_stream_t stream) {
   return render_rays_train_bwd_impl(prop0, prop1, field, origins, directions, camera_indices, N, S0, S1, S2, fwd_out, d_comp, d_weights0, d_weights1, d_weights2,
                                     d_density_extra, field_workspace, field_workspace_bytes, prop_workspace0, prop_workspace_bytes0, prop_workspace1,
-                                    prop_workspace_bytes1, tmp, d_origins, d_directions, prop_enc_saved, false, stream);
+                                    prop_workspace_bytes1, tmp, d_origins, d_directions, prop_enc_saved, false, nullptr, nullptr, stream);
 }
 
 
@@ -329,19 +333,32 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
     // pixel terms on the RGB columns / the thermal column of the one RGBT composite (models/thermal_nerfacto.py:425-428)
     return rc;
   }
+  // The launch that ends the backward (pose gradient, loss sums, regulariser, GradScaler's check of the small ranges) rides in the first blocks of
+  // the main grid's fold launch on iterations without a proposal update (TN_POSE_FINISH_COWORK=0: always a launch of its own)
+  PoseFinishArgs pf;
+  bool pf_taken = false;
+  const char* pfe = getenv("TN_POSE_FINISH_COWORK");
+  const bool pf_cowork = !a->prop_grad && !(pfe && pfe[0] == '0');
+  if (pf_cowork &&
+      (rc = tn_pose_finish_args(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N, a->num_cameras,
+                                a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11, a->grads, a->num_check,
+                                a->check_offsets, a->check_counts, a->check_flags, a->num_flags, a->found_inf, a->pose_flag, pf)))
+    return rc;
   if ((rc = render_rays_train_bwd_impl(a->prop_grad ? a->prop0 : nullptr, a->prop_grad ? a->prop1 : nullptr, a->field, out + off[TRO_ORIGINS],
                                        out + off[TRO_DIRECTIONS], a->camera_indices, a->N, a->S0, a->S1, a->S2, out, a->d_comp,
                                        a->prop_grad ? a->d_weights0 : nullptr, a->prop_grad ? a->d_weights1 : nullptr, a->d_weights2, nullptr,
                                        a->field_workspace, a->field_workspace_bytes, a->prop_grad ? a->prop_workspace0 : nullptr,
                                        a->prop_grad ? a->prop_workspace_bytes0 : 0, a->prop_grad ? a->prop_workspace1 : nullptr,
                                        a->prop_grad ? a->prop_workspace_bytes1 : 0, a->bwd_tmp, a->d_origins, a->d_directions, a->prop_grad ? 1 : 0,
-                                       fuse_render, stream)))
+                                       fuse_render, pf_cowork ? &pf : nullptr, &pf_taken, stream)))
     return rc;
-  if ((rc = tn_pose_bwd_finish_check(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N,
-                                     a->num_cameras, a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11,
-                                     a->grads, a->num_check, a->check_offsets, a->check_counts, a->check_flags, a->num_flags, a->found_inf, a->pose_flag,
-                                     stream)))
-    return rc;
+  if (!pf_taken) {
+    if ((rc = tn_pose_bwd_finish_check(a->pose_adjustment, a->frozen, a->camera_indices, a->directions_in, a->d_origins, a->d_directions, a->N,
+                                       a->num_cameras, a->grad_pose, a->loss_lines, a->losses16, a->trans_pen, a->rot_pen, a->pen_scale, a->losses16 + 11,
+                                       a->grads, a->num_check, a->check_offsets, a->check_counts, a->check_flags, a->num_flags, a->found_inf, a->pose_flag,
+                                       stream)))
+      return rc;
+  }
   if (a->num_ranges == 0) return TN_OK;
   return tn_adam_step_ranges_amp_update(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
                                         a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,

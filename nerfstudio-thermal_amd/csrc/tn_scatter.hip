@@ -15,6 +15,7 @@
 //     grid cell are summed in registers (stride-4 segmented scan) and only the run's last sample issues the atomics.
 #include "tn_common.h"
 #include "tn_field_dpos.h"
+#include "tn_pose_finish.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
@@ -922,11 +923,19 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
 // waves walk the segments -- PACK segments per wave and iteration (64 / PACK lanes each: a segment of a fine main-grid level holds ~32 records,
 // of a proposal grid ~60, of a merged coarse level a handful; PACK follows the block's average), lane = record, two loads per record, two
 // double-precision LDS adds (see k_grid_fold) -- and the bucket's image goes to the table gradient as in k_grid_fold.
-__global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uint32_t level_begin, uint32_t grad_zero_promise) {
+__global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uint32_t level_begin, uint32_t grad_zero_promise, PoseFinishArgs pf,
+                                                           uint32_t pf_blocks) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [slots] double x, [slots] double y, then [segc] headers, [segc] running counts, 16 words
+  // co-work blocks (the FIRST pf_blocks, a multiple of 8 so that the fold blocks keep their XCDs): the launch that ends the iteration's backward
+  // (tn_pose_finish.h) -- short latency chains beside a pass that is bound by its LDS adds, instead of 9 us in line behind it
+  if (blockIdx.x < pf_blocks) {
+    if ((int)blockIdx.x < pf.total_blocks) pose_finish_body(pf, (int)blockIdx.x);
+    return;
+  }
+  const uint32_t fb = blockIdx.x - pf_blocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t ns = (uint32_t)sk.nslices, per_level = ns * sk.chunks;
-  const uint32_t l = level_begin + blockIdx.x / per_level, rel = blockIdx.x % per_level;
+  const uint32_t l = level_begin + fb / per_level, rel = fb % per_level;
   // chunk-major inside a level.  Blocks go to the 8 XCDs round-robin by index; the segments of buckets s and s+1 of one bin block are neighbours in
   // memory (they share cache lines: a segment of a fine main-grid level is 64 B of slots and 256 B of values at an arbitrary offset), so groups
   // of 4 consecutive buckets are given to ONE XCD, as consecutive blocks of it: the shared lines are then hits in that XCD's L2.
@@ -1279,9 +1288,10 @@ int tn_grid_scatter_bin(const TnGrid& grid, const float* origins, const float* d
 }
 
 // fold of levels [level_begin, level_end) of a grid whose records tn_grid_scatter_bin has written (same grid, P and scratch)
-int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream) {
+int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level_begin, int level_end, hipStream_t stream, const PoseFinishArgs* cowork) {
   const int L = grid.num_levels;
   TN_REQUIRE(level_begin >= 0 && level_begin < level_end && level_end <= L, "tn_grid_scatter_fold: bad level range");
+  TN_REQUIRE(cowork == nullptr || seg_mode(), "tn_grid_scatter_fold: co-work needs the segmented path (tn_grid_scatter_takes_cowork)");
   if (seg_mode()) {
     SegK sk;
     int rc = seg_plan(grid, P, scratch, sk);
@@ -1291,7 +1301,9 @@ int tn_grid_scatter_fold(const TnGrid& grid, int64_t P, void* scratch, int level
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_fold), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((2u << TN_BIN_SLICE_LOG2) * sizeof(double) + 1024 * 8 + (FOLD_THREADS / 64) * 4));
     const uint32_t nblk = (uint32_t)(level_end - level_begin) * (uint32_t)sk.nslices * sk.chunks;
-    hipLaunchKernelGGL(k_seg_fold, dim3(nblk), dim3(FOLD_THREADS), shmem, stream, gk, sk, (uint32_t)level_begin, (uint32_t)(gk.grad_zero ? 1 : 0));
+    const uint32_t pfb = cowork ? ((uint32_t)cowork->total_blocks + 7u) & ~7u : 0u;
+    hipLaunchKernelGGL(k_seg_fold, dim3(nblk + pfb), dim3(FOLD_THREADS), shmem, stream, gk, sk, (uint32_t)level_begin, (uint32_t)(gk.grad_zero ? 1 : 0),
+                       cowork ? *cowork : PoseFinishArgs{}, pfb);
     TN_CHECK_LAUNCH("tn_grid_scatter(fold, segmented)");
     return TN_OK;
   }
@@ -1351,23 +1363,23 @@ bool tn_grid_scatter_takes_cowork(const TnGrid& grid, int64_t P, void* scratch) 
 
 static int grid_scatter_binned(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                                int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, bool counters_zeroed,
-                               const DposArgs* cowork) {
+                               const DposArgs* cowork, const PoseFinishArgs* fold_cowork) {
   int rc = tn_grid_scatter_bin(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed, cowork);
   if (rc) return rc;
-  return tn_grid_scatter_fold(grid, N * (int64_t)S, scratch, 0, grid.num_levels, stream);
+  return tn_grid_scatter_fold(grid, N * (int64_t)S, scratch, 0, grid.num_levels, stream, fold_cowork);
 }
 
 int tn_grid_scatter_launch(const TnGrid& grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int ld,
                            int64_t N, int S, float* d_origins, float* d_directions, void* scratch, hipStream_t stream, float* dense_sum,
-                           bool counters_zeroed, const DposArgs* cowork) {
+                           bool counters_zeroed, const DposArgs* cowork, const PoseFinishArgs* fold_cowork) {
   TN_REQUIRE(grid.table && grid.table_grad && origins && directions && e_bins && g_enc, "tn_grid_scatter: null pointer");
   TN_REQUIRE(grid.num_levels >= 1 && grid.num_levels <= TN_MAX_LEVELS && (ld >= 2 * grid.num_levels || ld == TN_LD_LEVEL_MAJOR),
              "tn_grid_scatter: bad level count / row stride");
   int64_t P = N * (int64_t)S;
   if (P == 0) return TN_OK;
   if (dense_sum == nullptr && tn_grid_scatter_is_binned(grid, P, scratch))
-    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed, cowork);
-  TN_REQUIRE(cowork == nullptr, "tn_grid_scatter: co-work needs the segmented path (tn_grid_scatter_takes_cowork)");
+    return grid_scatter_binned(grid, origins, directions, e_bins, g_enc, ld, N, S, d_origins, d_directions, scratch, stream, counters_zeroed, cowork, fold_cowork);
+  TN_REQUIRE(cowork == nullptr && fold_cowork == nullptr, "tn_grid_scatter: co-work needs the segmented path (tn_grid_scatter_takes_cowork)");
   int grid_dim = (int)std::min<int64_t>(tn_cdiv(P, 64), 256 * 32);
   // resident capacity is 256 CUs x 8 blocks: when the items do not fill a whole number of rounds, split the levels into 2 interleaved groups
   int level_groups = 1;
