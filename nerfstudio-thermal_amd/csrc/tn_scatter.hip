@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(BIN_THREADS, 4) k_seg_bin(GridK g, const float
 // waves walk the segments -- PACK segments per wave and iteration (64 / PACK lanes each: a segment of a fine main-grid level holds ~32 records,
 // of a proposal grid ~60, of a merged coarse level a handful; PACK follows the block's average), lane = record, two loads per record, two
 // double-precision LDS adds (see k_grid_fold) -- and the bucket's image goes to the table gradient as in k_grid_fold.
-__global__ void __launch_bounds__(FOLD_THREADS) k_seg_fold(GridK g, SegK sk, uint32_t level_begin, uint32_t grad_zero_promise, PoseFinishArgs pf,
+__global__ void __launch_bounds__(FOLD_THREADS, 8) k_seg_fold(GridK g, SegK sk, uint32_t level_begin, uint32_t grad_zero_promise, PoseFinishArgs pf,
                                                            uint32_t pf_blocks) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [slots] double x, [slots] double y, then [segc] headers, [segc] running counts, 16 words
   // co-work blocks (the FIRST pf_blocks, a multiple of 8 so that the fold blocks keep their XCDs): the launch that ends the iteration's backward
