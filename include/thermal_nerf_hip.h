@@ -40,7 +40,8 @@
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
  *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
  *                                 half of the output features; a measured experiment that is correct and slower (profiles/r05_experiments.md)
- *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid) and writes
+ *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid), TN_DM_PREFETCH=0 (the
+ *    device data manager launches every batch itself instead of handing the next one to tn_train_step: A/B timing) and writes
  *    nothing into the environment (rounds 2-4 set GPU_MAX_HW_QUEUES=8 at import: the schedules now fit the runtime's default of four).
  */
 #ifndef THERMAL_NERF_HIP_H
@@ -134,6 +135,16 @@ int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, con
  * RayGenerator): arguments of tn_sample_pixels followed by those of tn_raygen without ray_indices (the sampled pixel is handed over in
  * registers; ray_indices is still written).  Same results as the two calls. 
  * pixel_area may be NULL (a trainer whose model does not read it: the two extra undistortions per ray that only serve it are skipped). */
+/* The arguments of tn_sample_rays as a block: TnTrainStep::next_sample hands the NEXT iteration's batch to tn_train_step, which samples it in
+ * co-work blocks of its optimiser launch (the last launch of the iteration: an HBM-bound pass beside a short, latency-bound one). */
+typedef struct TnSampleRays {
+  const float* images; const int64_t* image_offsets; const int32_t* heights; const int32_t* widths; const float* is_thermal; const int64_t* image_idx;
+  int32_t num_images; const float* u; int64_t num_rays; int32_t patch_size;
+  int64_t* ray_indices; float* image; float* is_thermal_out; int64_t* camera_indices;
+  const float* c2w; const float* fx; const float* fy; const float* cx; const float* cy; const float* distortion; int32_t num_cameras;
+  float* origins; float* directions; float* pixel_area; float* directions_norm;
+} TnSampleRays;
+int tn_sample_rays_args(const TnSampleRays* args, tn_stream_t stream); /* tn_sample_rays on the block */
 int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                    const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
                    int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
@@ -548,6 +559,9 @@ typedef struct TnTrainStep {
   double beta1, beta2, eps;
   float* found_inf; int32_t num_flags; int32_t* skipped; int32_t lag_index;
   float* scale; int32_t* growth_tracker; uint32_t* done_counter; double growth_factor, backoff_factor; int32_t growth_interval;
+  /* NULL, or the NEXT iteration's batch (HOST struct): sampled in co-work blocks of the optimiser launch; ignored (the caller's to launch,
+   * tn_sample_rays_args) when num_ranges == 0 -- *next_sample_taken (HOST, may be NULL) says which */
+  const TnSampleRays* next_sample; int32_t* next_sample_taken;
 } TnTrainStep;
 int tn_train_step(const TnTrainStep* step, tn_stream_t stream);
 /* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 304  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 305  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 4096
@@ -54,6 +54,14 @@ TN_TRAIN_STEP_MAX_RANGES = 8
 _R = TN_TRAIN_STEP_MAX_RANGES
 
 
+class TnSampleRays(C.Structure):
+    """include/thermal_nerf_hip.h: the arguments of tn_sample_rays as a block (TnTrainStep.next_sample)"""
+    _fields_ = [("images", _p), ("image_offsets", _p), ("heights", _p), ("widths", _p), ("is_thermal", _p), ("image_idx", _p), ("num_images", _i32),
+                ("u", _p), ("num_rays", _i64), ("patch_size", _i32), ("ray_indices", _p), ("image", _p), ("is_thermal_out", _p), ("camera_indices", _p),
+                ("c2w", _p), ("fx", _p), ("fy", _p), ("cx", _p), ("cy", _p), ("distortion", _p), ("num_cameras", _i32), ("origins", _p),
+                ("directions", _p), ("pixel_area", _p), ("directions_norm", _p)]
+
+
 class TnTrainStep(C.Structure):
     """The argument block of tn_train_step: field for field the struct of include/thermal_nerf_hip.h (tests/test_abi_cpu.py compares the two)."""
     _fields_ = [
@@ -77,6 +85,7 @@ class TnTrainStep(C.Structure):
         ("beta1", _d), ("beta2", _d), ("eps", _d),
         ("found_inf", _p), ("num_flags", _i32), ("skipped", _p), ("lag_index", _i32),
         ("scale", _p), ("growth_tracker", _p), ("done_counter", _p), ("growth_factor", _d), ("backoff_factor", _d), ("growth_interval", _i32),
+        ("next_sample", C.POINTER(TnSampleRays)), ("next_sample_taken", C.POINTER(_i32)),
     ]
 
 
@@ -133,6 +142,7 @@ SIGNATURES = {
     "tn_interlevel_loss": (C.c_int, [_p, _p, _i32, _p, _p, _i32, _i64, _f, _p, _p, _p]),
     "tn_proposal_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _p, _p]),
     "tn_pixel_losses": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _i64, _f, _f, _f, _p, _p, _p, _p]),
+    "tn_sample_rays_args": (C.c_int, [C.POINTER(TnSampleRays), _p]),
     "tn_render_losses_bwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _f, _f, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p,
                                        _i32, _p]),
     "tn_train_losses": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p, _p, _i64, _f, _f, _p, _p, _i32, _p, _i32, _p, _p, _f, _f, _f, _p, _p, _p, _p]),

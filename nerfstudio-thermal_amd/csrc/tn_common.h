@@ -375,6 +375,14 @@ struct ReplicaK {
 // scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
+// tn_adam_step_ranges_amp_update with the next iteration's tn_sample_rays in co-work blocks of the launch (next may be NULL)
+int tn_adam_step_ranges_amp_update_cw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                      const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                      const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps, const float* inv_scale,
+                                      float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped, int32_t lag_index,
+                                      int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker, uint32_t* done_counter,
+                                      double growth_factor, double backoff_factor, int32_t growth_interval, const TnSampleRays* next, bool* next_taken,
+                                      tn_stream_t stream);
 // internal variants of tn_render_fwd / tn_train_losses for tn_train_step: the batch-wide clip of depth_expected not as a launch of its own behind
 // the renderers but as co-work blocks of the loss launch that follows (tn_sampler.hip)
 int tn_render_fwd_ex(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training, float* weights,

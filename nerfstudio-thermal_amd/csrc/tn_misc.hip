@@ -105,7 +105,7 @@ extern "C" int tn_shutdown(void) {
   return rc;
 }
 
-extern "C" int tn_version(void) { return 304; }  // 304 (round 5): tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
+extern "C" int tn_version(void) { return 305; }  // 305 (round 5): TnSampleRays, TnTrainStep::next_sample; 304: tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
   TN_REQUIRE(ptr != nullptr && bytes >= 0, "tn_fill_zero: bad argument");
@@ -298,9 +298,9 @@ __global__ void k_raygen(const int64_t* __restrict__ ray_indices, RaygenArgs g, 
 // FOUR lanes per ray: lane q of the quad runs the Newton undistortion of coordinate q (the pixel, its +1-column and its +1-row neighbour, which
 // only serve pixel_area; lane 3 idles) -- one thread per ray ran the three chains one after the other, ~2 000 dependent instructions on 64 waves
 // that each have a SIMD to themselves.  Same expressions per coordinate as raygen_compute.
-__global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) {
+__device__ __forceinline__ void sample_rays_body(const SamplePixelsArgs& a, const RaygenArgs& g, unsigned bid, unsigned nblk) {
   const int lane = threadIdx.x & 63, q = lane & 3, quad0 = lane & ~3;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < a.N * 4; t += (int64_t)gridDim.x * blockDim.x) {  // (whole quads: blockDim % 4 == 0)
+  for (int64_t t = bid * (int64_t)blockDim.x + threadIdx.x; t < a.N * 4; t += (int64_t)nblk * blockDim.x) {  // (whole quads: blockDim % 4 == 0)
     const int64_t r = t >> 2;
     // two rounds of loads (index data; then the pixel and the camera's parameters together), then arithmetic and stores
     const PixelPick p = sample_pixel_pick(a, r);
@@ -348,6 +348,7 @@ __global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) {
     }
   }
 }
+__global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) { sample_rays_body(a, g, blockIdx.x, gridDim.x); }
 
 extern "C" int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy,
                          const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions, float* pixel_area,
@@ -376,6 +377,28 @@ extern "C" int tn_sample_rays(const float* images, const int64_t* image_offsets,
   RaygenArgs g{c2w, fx, fy, cx, cy, distortion, distortion != nullptr ? 1 : 0, num_cameras, origins, directions, pixel_area, directions_norm};
   hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(num_rays * 4, 256), 4096)), dim3(256), 0, tn_s(stream), a, g);  // 4 lanes per ray
   TN_CHECK_LAUNCH("tn_sample_rays");
+  return TN_OK;
+}
+// validated kernel arguments of a TnSampleRays block (shared by tn_sample_rays_args and the optimiser launch's co-work)
+static int sample_rays_build(const char* who, const TnSampleRays* s, SamplePixelsArgs& a, RaygenArgs& g) {
+  TN_REQUIRE(s != nullptr && s->num_rays > 0, "%s: null / empty TnSampleRays", who);
+  int rc = sample_pixels_args(who, s->images, s->image_offsets, s->heights, s->widths, s->is_thermal, s->image_idx, s->num_images, s->u, s->num_rays,
+                              s->patch_size, s->ray_indices, s->image, s->is_thermal_out, s->camera_indices, a);
+  if (rc) return rc;
+  TN_REQUIRE(s->c2w && s->fx && s->fy && s->cx && s->cy && s->origins && s->directions && s->num_cameras >= 1, "%s: bad camera arguments", who);
+  g = RaygenArgs{s->c2w, s->fx, s->fy, s->cx, s->cy, s->distortion, s->distortion != nullptr ? 1 : 0, s->num_cameras, s->origins, s->directions, s->pixel_area,
+                 s->directions_norm};
+  return TN_OK;
+}
+extern "C" int tn_sample_rays_args(const TnSampleRays* s, tn_stream_t stream) {
+  TN_REQUIRE(s != nullptr, "tn_sample_rays_args: null pointer");
+  if (s->num_rays == 0) return TN_OK;
+  SamplePixelsArgs a;
+  RaygenArgs g;
+  int rc = sample_rays_build("tn_sample_rays_args", s, a, g);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sample_rays, dim3((unsigned)std::min<int64_t>(tn_cdiv(s->num_rays * 4, 256), 4096)), dim3(256), 0, tn_s(stream), a, g);
+  TN_CHECK_LAUNCH("tn_sample_rays_args");
   return TN_OK;
 }
 
@@ -954,10 +977,21 @@ __device__ __forceinline__ void adam_block_done(const ScalerUpdate& su, float* f
     }
   }
 }
+struct SampleCoWork { SamplePixelsArgs a; RaygenArgs g; int blocks; };
 __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
                                   double beta1, double beta2, float eps, const float* __restrict__ inv_scale, float* __restrict__ found_inf,
-                                  int32_t* __restrict__ skipped, int count_skip, int zero_g, ScalerUpdate su) {
-  const int k = blockIdx.y;
+                                  int32_t* __restrict__ skipped, int count_skip, int zero_g, ScalerUpdate su, SampleCoWork cw) {
+  int k = blockIdx.y;
+  if (cw.blocks > 0) {
+    // co-work row (row 0, dispatched first): the NEXT iteration's pixel sampling + ray generation -- a short latency-bound pass beside this
+    // HBM-bound one, instead of 7 us at the head of the next iteration.  Its blocks count themselves in like every block of the launch.
+    if (k == 0) {
+      if (blockIdx.x < (unsigned)cw.blocks) sample_rays_body(cw.a, cw.g, blockIdx.x, (unsigned)cw.blocks);
+      adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
+      return;
+    }
+    --k;
+  }
   const int fl = r.flag[k];
   float* gz = const_cast<float*>(g);  // zero_g: the gradients are consumed (set to zero behind the read): no zero-fill launch before the next backward
   // schedule lag = iterations so far in which the scale dropped; maintained by tn_grad_scaler_update AFTER this launch (stream order)
@@ -1047,7 +1081,9 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
                                const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                                const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                                const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
-                               int32_t lag_index, int32_t count_skip, int32_t zero_grads, ScalerUpdate su, tn_stream_t stream) {
+                               int32_t lag_index, int32_t count_skip, int32_t zero_grads, ScalerUpdate su, tn_stream_t stream,
+                               const TnSampleRays* next = nullptr, bool* next_taken = nullptr) {
+  if (next_taken) *next_taken = false;
   if (num_ranges == 0) return TN_OK;
   TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges_amp: null pointer");
   TN_REQUIRE(num_ranges > 0 && num_ranges <= TN_ADAM_MAX_RANGES, "tn_adam_step_ranges_amp: %d ranges (at most %d)", num_ranges, TN_ADAM_MAX_RANGES);
@@ -1074,8 +1110,15 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
   r.num_flags = num_flags;
   r.lag_index = lag_index;
   int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(max_n4, 256), 256 * 16));
-  hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
-                     const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su);
+  SampleCoWork cw{};
+  if (next != nullptr && next->num_rays > 0) {
+    int rc = sample_rays_build("tn_train_step(next_sample)", next, cw.a, cw.g);
+    if (rc) return rc;
+    cw.blocks = (int)std::min<int64_t>(tn_cdiv(next->num_rays * 4, 256), grid);  // 4 lanes per ray; the row has `grid` blocks
+    if (next_taken) *next_taken = true;
+  }
+  hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n + (cw.blocks > 0 ? 1 : 0)), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2,
+                     (float)eps, inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, cw);
   TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
   return TN_OK;
 }
@@ -1099,6 +1142,20 @@ extern "C" int tn_adam_step_ranges_amp_update(float* params, const float* grads,
   ScalerUpdate su{scale, growth_tracker, done_counter, (float)growth_factor, (float)backoff_factor, (int32_t)growth_interval};
   return adam_ranges_amp_impl(params, grads, exp_avg, exp_avg_sq, num_ranges, offsets, counts, steps, lrs, lr_finals, sched_max_steps, sched_step, beta1, beta2,
                               eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, su, stream);
+}
+
+int tn_adam_step_ranges_amp_update_cw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+                                      const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
+                                      const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps, const float* inv_scale,
+                                      float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped, int32_t lag_index,
+                                      int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker, uint32_t* done_counter,
+                                      double growth_factor, double backoff_factor, int32_t growth_interval, const TnSampleRays* next, bool* next_taken,
+                                      tn_stream_t stream) {
+  TN_REQUIRE(found_inf && scale && growth_tracker && done_counter && growth_interval >= 1, "tn_adam_step_ranges_amp_update: bad scaler arguments");
+  TN_REQUIRE(num_ranges > 0, "tn_adam_step_ranges_amp_update: the fused scale update needs at least one range (use tn_grad_scaler_update otherwise)");
+  ScalerUpdate su{scale, growth_tracker, done_counter, (float)growth_factor, (float)backoff_factor, (int32_t)growth_interval};
+  return adam_ranges_amp_impl(params, grads, exp_avg, exp_avg_sq, num_ranges, offsets, counts, steps, lrs, lr_finals, sched_max_steps, sched_step, beta1, beta2,
+                              eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, su, stream, next, next_taken);
 }
 
 // GradScaler.update() (torch/amp/grad_scaler.py -> amp_update_scale_cuda_kernel) for the fused step, one thread: backoff when any of the

@@ -264,6 +264,7 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
 // calls, in its order, on the caller's stream.  Nothing here launches a kernel of its own.
 extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   TN_REQUIRE(a != nullptr, "tn_train_step: null argument block");
+  if (a->next_sample_taken) *a->next_sample_taken = 0;  // (set once the optimiser launch carries it: any earlier return leaves the batch to the caller)
   if (a->N == 0) return TN_OK;
   TN_REQUIRE(a->prop0 && a->prop1 && a->field && a->origins_in && a->directions_in && a->camera_indices && a->image && a->is_thermal && a->nears &&
                  a->fars && a->fwd_out && a->bwd_tmp && a->acc && a->losses16 && a->loss_lines && a->d_comp && a->d_weights2,
@@ -360,8 +361,11 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
       return rc;
   }
   if (a->num_ranges == 0) return TN_OK;
-  return tn_adam_step_ranges_amp_update(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
-                                        a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,
-                                        a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter, a->growth_factor, a->backoff_factor,
-                                        a->growth_interval, stream);
+  bool taken = false;
+  rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
+                                         a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,
+                                         a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter, a->growth_factor, a->backoff_factor,
+                                         a->growth_interval, a->next_sample, &taken, stream);
+  if (a->next_sample_taken) *a->next_sample_taken = taken ? 1 : 0;
+  return rc;
 }

@@ -320,6 +320,54 @@ def sample_rays(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patc
     return o, d, cam, img, is_th, idx
 
 
+# A batch whose sampling has been handed to the NEXT tn_train_step: that call runs it in co-work blocks of its optimiser launch (TnTrainStep.next_sample);
+# if no such call comes first, flush_pending_sample() launches it as a kernel of its own.  One slot per process: the training loop has one data manager.
+_PENDING_SAMPLE: Optional[tuple] = None
+
+
+def sample_rays_deferred(cache: ImageCache, num_rays: int, u: Tensor, cameras: dict, patch_size: int = 2):
+    """The arguments of sample_rays as a TnSampleRays block WITHOUT a launch -> origins, directions, camera_indices, image, is_thermal, ray_indices,
+    pixel_area, directions_norm (the tensors sample_rays(with_bundle_extras=True) returns), filled once the next tn_train_step (TrainStepCall.run
+    picks the pending block up) or flush_pending_sample() has run.  An older block nobody took is launched first."""
+    global _PENDING_SAMPLE
+    flush_pending_sample()
+    n_img = cache.offsets.shape[0]
+    dev = cache.buffer.device
+    if u.device != dev or u.dtype != torch.float32 or not u.is_contiguous() or tuple(u.shape) != (num_rays // (patch_size * patch_size), 3):
+        raise ValueError(f"u must be a contiguous fp32 [{num_rays // (patch_size * patch_size)}, 3] tensor on {dev}")
+    idx = torch.empty((num_rays, 3), dtype=torch.int64, device=dev)
+    cam = torch.empty((num_rays,), dtype=torch.int64, device=dev)
+    img, is_th, o, d, area, nrm = (torch.empty((num_rays, 3), device=dev), torch.empty((num_rays,), device=dev), torch.empty((num_rays, 3), device=dev),
+                                   torch.empty((num_rays, 3), device=dev), torch.empty((num_rays, 1), device=dev), torch.empty((num_rays, 1), device=dev))
+    c2w = cameras["c2w"]
+    Cn = c2w.shape[0]
+    st = _lib.TnSampleRays()
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st.images, st.image_offsets, st.heights, st.widths = p(cache.buffer), p(cache.offsets), p(cache.heights), p(cache.widths)
+    st.is_thermal, st.image_idx, st.num_images = p(cache.is_thermal), p(cache.image_idx), n_img
+    st.u, st.num_rays, st.patch_size = p(u), num_rays, patch_size
+    st.ray_indices, st.image, st.is_thermal_out, st.camera_indices = p(idx), p(img), p(is_th), p(cam)
+    st.c2w = _f32(c2w, "c2w", (Cn, 3, 4))
+    st.fx, st.fy = _f32(cameras["fx"], "fx", (Cn,)), _f32(cameras["fy"], "fy", (Cn,))
+    st.cx, st.cy = _f32(cameras["cx"], "cx", (Cn,)), _f32(cameras["cy"], "cy", (Cn,))
+    st.distortion = _f32(cameras.get("distortion"), "distortion", (Cn, 6), optional=True)
+    st.num_cameras = Cn
+    st.origins, st.directions, st.pixel_area, st.directions_norm = p(o), p(d), p(area), p(nrm)
+    outs = (o, d, cam, img, is_th, idx, area, nrm)
+    _PENDING_SAMPLE = (st, (u, cameras, cache) + outs)
+    return outs
+
+
+def flush_pending_sample() -> None:
+    """launches a batch handed over by sample_rays_deferred that no tn_train_step has taken (tn_sample_rays_args, current stream)"""
+    global _PENDING_SAMPLE
+    pend = _PENDING_SAMPLE
+    if pend is None:
+        return
+    _PENDING_SAMPLE = None
+    check(_lib.load().tn_sample_rays_args(C.byref(pend[0]), _stream()), "tn_sample_rays_args")
+
+
 # ------------------------------------------------------------------------------------------------ a1 / a4
 def raygen(ray_indices: Tensor, c2w: Tensor, fx: Tensor, fy: Tensor, cx: Tensor, cy: Tensor, distortion: Optional[Tensor]):
     N, Cn = ray_indices.shape[0], c2w.shape[0]
@@ -869,8 +917,18 @@ class TrainStepCall:
         # run) changes them, and the five-call path reads fused_update_args() per step too -- the two paths must keep agreeing after a resume.
         _, _, _, gf, bf, gi = self.scaler.fused_update_args()
         st.growth_factor, st.backoff_factor, st.growth_interval = float(gf), float(bf), int(gi)
-        self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters)  # alive until the next call replaces them
+        # the next iteration's batch, when the data manager has handed one over (sample_rays_deferred): sampled inside this call's optimiser launch
+        global _PENDING_SAMPLE
+        pend = _PENDING_SAMPLE
+        taken = C.c_int32(0)
+        if pend is not None and len(ranges) > 0:
+            st.next_sample, st.next_sample_taken = C.pointer(pend[0]), C.pointer(taken)
+        else:
+            st.next_sample, st.next_sample_taken = C.POINTER(_lib.TnSampleRays)(), C.POINTER(C.c_int32)()
+        self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters, pend)  # alive until the next call replaces them
         check(_lib.load().tn_train_step(C.byref(st), _stream()), "tn_train_step")
+        if taken.value:
+            _PENDING_SAMPLE = None  # (else it stays pending: the data manager launches it itself before it hands the batch out)
         return buf
 
 

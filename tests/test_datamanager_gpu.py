@@ -105,3 +105,67 @@ def test_adapter_feeds_the_fused_trainer(scene):
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and set(loss_dict) >= {"rgb_loss", "thermal_loss", "interlevel_loss", "distortion_loss"}
     assert dm.train_count == 3 and not torch.equal(before, model.arena.params)
+
+
+def test_next_batch_is_sampled_inside_the_training_step(scene):
+    """prefetch="cowork" (the default): the batch of iteration k + 1 is sampled in co-work blocks of iteration k's optimiser launch
+    (TnTrainStep.next_sample) -- the same batches, bit for bit, as a manager that launches tn_sample_rays itself draws from the same seed, and
+    the pending block is gone after the step (taken), not launched a second time."""
+    import types
+
+    from nerfstudio_thermal_amd import ops
+    from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+    from nerfstudio_thermal_amd.datamanager import HipDataManagerConfig
+    from nerfstudio_thermal_amd.dataparser import ThermalNerfDataParserConfig
+    from nerfstudio_thermal_amd.optim import HipFusedAdam, Optimizers
+    from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
+
+    def manager(prefetch):
+        import random
+
+        random.seed(5)  # (the batch order is a random permutation of the images)
+        dm = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=256).setup(device="cuda:0")
+        dm._train_src._dm.prefetch = prefetch
+        return dm
+
+    dm = manager("cowork")
+    cfg = ThermalNerfactoModelConfig(density_mode="shared", log2_hashmap_size=12)
+    for a in cfg.proposal_net_args_list:
+        a["log2_hashmap_size"] = 10
+    model = cfg.setup(scene_box=dm.train_dataset.scene_box, num_train_data=len(dm.train_dataset), metadata=dm.train_dataset.metadata, device="cuda:0")
+    model.train()
+    seen = []
+
+    class _Base:
+        def train_iteration(self, step):
+            raise AssertionError("fell through to the reference iteration")
+
+    class _T(FusedTrainerMixin, _Base):
+        pass
+
+    t = _T()
+    orig_next = dm.next_train
+
+    def spy(step):
+        rb, batch = orig_next(step)
+        seen.append((rb.origins, rb.directions, rb.camera_indices, batch["image"], batch["indices"], batch["is_thermal"], rb.pixel_area))
+        return rb, batch
+
+    t.pipeline = types.SimpleNamespace(model=model, datamanager=types.SimpleNamespace(next_train=spy))
+    t.optimizers = Optimizers(model.get_param_groups(), optimizer_cls=HipFusedAdam)
+    t.mixed_precision, t.grad_scaler = True, torch.amp.GradScaler("cuda")
+    t.gradient_accumulation_steps = {}
+    t.config = types.SimpleNamespace(log_gradients=False)
+    torch.manual_seed(23)  # (the manager's uniforms come from ONE torch.rand per 32 batches, drawn at its first batch)
+    for step in range(4):
+        t.train_iteration(step)
+        assert ops._PENDING_SAMPLE is None, step  # the step's optimiser launch took the next batch
+    torch.cuda.synchronize()
+    ref = manager(False)
+    torch.manual_seed(23)
+    for step, got in enumerate(seen):
+        rb, batch = ref.next_train(step)
+        want = (rb.origins, rb.directions, rb.camera_indices, batch["image"], batch["indices"], batch["is_thermal"], rb.pixel_area)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), step
+

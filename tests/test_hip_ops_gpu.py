@@ -997,7 +997,7 @@ def test_device_data_manager_batches(golden_dir):
     cache = ops.ImageCache.build(b["images"], b["is_thermal"], b["image_idx"], DEV)
     cams = synth.synth_cameras()
     cam_t = {k: g(torch.from_numpy(cams[k])) for k in ("c2w", "fx", "fy", "cx", "cy", "distortion")}
-    for prefetch in (False, True):
+    for prefetch in (False, True, "cowork"):  # ("cowork" without a training step in between: every batch is launched just before it is handed out)
         torch.manual_seed(11)
         dm = DeviceDataManager(cache, cam_t, 256, 2, prefetch=prefetch)
         got = [dm.next_train(i) for i in range(3)]
@@ -1010,6 +1010,7 @@ def test_device_data_manager_batches(golden_dir):
             o_r, d_r, _, _ = ops.raygen(idx, cam_t["c2w"], cam_t["fx"], cam_t["fy"], cam_t["cx"], cam_t["cy"], cam_t["distortion"])
             for a, r in ((o, o_r), (d, d_r), (cam, cam_r), (img, img_r), (is_th, th_r)):
                 assert torch.equal(a, r), prefetch
+        ops.flush_pending_sample()  # (the batch the "cowork" manager prepared last: nobody will take it)
         assert not torch.equal(got[0][2], got[1][2]) or not torch.equal(got[0][3], got[1][3])  # a new batch every call
 
 
