@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${R:-r05}
 mkdir -p gpurun_out/$R
-PART=${PART:-all}   # 1: tests, PMC passes, hardware-queue sweep, forward ablation, microbenchmark; 2: bench lines, kernel stats, timelines (two gpurun calls: each stays under the 20-minute limit)
-if [ "$PART" != "2" ]; then
+PART=${PART:-all}   # 3: kernel traces / timelines only; 1: tests, PMC passes, hardware-queue sweep, forward ablation, microbenchmark; 2: bench lines, kernel stats, timelines (two gpurun calls: each stays under the 20-minute limit)
+if [ "$PART" != "2" ] && [ "$PART" != "3" ]; then
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/$R/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/$R/tests.log
 bash scripts/pmc_passes.sh gpurun_out/pmc | tail -12
 python scripts/pmc_summary.py gpurun_out/pmc profiles/$R > gpurun_out/$R/pmc_summary.log 2>&1 && cp profiles/${R}_pmc.json profiles/${R}_pmc_summary.md gpurun_out/$R/
@@ -16,6 +16,7 @@ timeout -k 5 120 scripts/microbench/mfma_valu_overlap > gpurun_out/$R/mfma_valu_
 fi
 fi
 if [ "$PART" = "1" ]; then exit 0; fi
+if [ "$PART" != "3" ]; then  # (PART=3: only the kernel traces / timelines below)
 last() { grep '^{' "$1" | tail -1 > "$1.tmp"; mv "$1.tmp" "$1"; }
 b() { out=gpurun_out/$R/bench_$1.json; shift; python bench.py "$@" > $out 2>/dev/null; last $out; }
 b n1_driver_invocation --steps 20 --warmup 5
@@ -35,6 +36,7 @@ b n1_1024rays --rays 1024 --no-cpu-baseline
 b n1_96samples --nerf-samples 96 --no-cpu-baseline
 b n1_splat_1080p --workload splat
 python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1rank_latency.json
+fi
 rm -rf gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep
 # (the last 20 steps of a fused / separate run are the in-step measurement, which issues the backward phase by phase: the timelines show steps of the timed region)
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_a.log 2>&1
@@ -43,6 +45,9 @@ rocprofv3 --kernel-trace -d gpurun_out/prof_sep -o sep -- python3 bench.py --mod
 python scripts/rocpd_stats.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/bench_n1_kernel_stats.csv --split-grid --tail 10 > gpurun_out/$R/bench_n1_kernel_stats_tail.txt 2>&1
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --step-from-end 26 > /dev/null 2> gpurun_out/$R/timeline.err
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline_update_step.md --step-from-end 25 > /dev/null 2>> gpurun_out/$R/timeline.err
+# (which of two consecutive steps updates the proposal networks depends on the run: the one with fewer launches is the step without an update)
+na=$(head -1 gpurun_out/$R/fused_timeline.md | sed 's/step of \([0-9]*\) kernels.*/\1/'); nb=$(head -1 gpurun_out/$R/fused_timeline_update_step.md | sed 's/step of \([0-9]*\) kernels.*/\1/')
+if [ "$na" -gt "$nb" ]; then mv gpurun_out/$R/fused_timeline.md gpurun_out/$R/tmp.md; mv gpurun_out/$R/fused_timeline_update_step.md gpurun_out/$R/fused_timeline.md; mv gpurun_out/$R/tmp.md gpurun_out/$R/fused_timeline_update_step.md; fi
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_dp -name '*.db' | head -1) gpurun_out/$R/dp_timeline.md --step-from-end 4 > /dev/null 2>> gpurun_out/$R/timeline.err
 python scripts/rocpd_timeline.py $(find gpurun_out/prof_sep -name '*.db' | head -1) gpurun_out/$R/separate_timeline.md --step-from-end 25 > /dev/null 2>> gpurun_out/$R/timeline.err
 find gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep -name '*.db' -delete
