@@ -1819,7 +1819,7 @@ int tn_field_bwd_phase_ex(const TnField* field, const float* origins, const floa
     if (fold_cowork_taken && rc == TN_OK) *fold_cowork_taken = fcw != nullptr;
   }
   if (phases & (TN_BWD_SCATTER_BIN | TN_BWD_SCATTER_FOLD)) {
-    TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs the binned path (TN_SCATTER_MODE=1, table <= 2^20 slots)");
+    TN_REQUIRE(tn_grid_scatter_is_binned(field->grid, P, ws.scatter), "tn_field_bwd: the two-step scatter needs a record-based path (TN_SCATTER_MODE=2 or 1 -- not 0 --, a scatter workspace, table <= 2^20 slots)");
     if (phases & TN_BWD_SCATTER_BIN)
       rc = tn_grid_scatter_bin(field->grid, origins, directions, e_bins, ws.g_enc, TN_LD_LEVEL_MAJOR, N, S, sc_do, sc_dd, ws.scatter, st,
                                (phases & (TN_BWD_MLP | TN_BWD_COUNTERS_CLEAN)) != 0);
