@@ -156,34 +156,36 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = [f[0] for f in L.TnTrainStep._fields_]
-    src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n  printf("%%zu\\n", sizeof(TnTrainStep));\n%s  return 0;\n}\n'
-                   % (os.path.join(root, "include", "thermal_nerf_hip.h"),
-                      "".join('  printf("%s %%zu\\n", offsetof(TnTrainStep, %s));\n' % (n, n) for n in names)))
-    exe = tmp_path / "layout"
-    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
-    assert int(out[0]) == C.sizeof(L.TnTrainStep)
-    seen = {}
-    for line in out[1:]:
-        if line:
-            n, o = line.split()
-            seen[n] = int(o)
-    assert seen == {n: getattr(L.TnTrainStep, n).offset for n in names}
-    # and the header declares no field the mirror lacks
     hdr = open(os.path.join(root, "include", "thermal_nerf_hip.h")).read()
-    body = hdr[hdr.index("typedef struct TnTrainStep {"):hdr.index("} TnTrainStep;")]
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    decl = set()
-    for stmt in body.split(";"):
-        stmt = stmt.replace("typedef struct TnTrainStep {", "").strip()
-        if not stmt:
-            continue
-        for part in stmt.split(","):
-            m = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip())
-            decl.add(m.group(1))
-    assert decl == set(names), (decl ^ set(names))
+    for struct in ("TnTrainStep", "TnSampleRays"):  # (TnSampleRays: the next iteration's batch, TnTrainStep::next_sample)
+        mirror = getattr(L, struct)
+        names = [f[0] for f in mirror._fields_]
+        src = tmp_path / f"layout_{struct}.c"
+        src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) {\n  printf("%%zu\\n", sizeof(%s));\n%s  return 0;\n}\n'
+                       % (os.path.join(root, "include", "thermal_nerf_hip.h"), struct,
+                          "".join('  printf("%s %%zu\\n", offsetof(%s, %s));\n' % (n, struct, n) for n in names)))
+        exe = tmp_path / f"layout_{struct}"
+        subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+        out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+        assert int(out[0]) == C.sizeof(mirror), struct
+        seen = {}
+        for line in out[1:]:
+            if line:
+                n, o = line.split()
+                seen[n] = int(o)
+        assert seen == {n: getattr(mirror, n).offset for n in names}, struct
+        # and the header declares no field the mirror lacks
+        body = hdr[hdr.index("typedef struct %s {" % struct):hdr.index("} %s;" % struct)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        decl = set()
+        for stmt in body.split(";"):
+            stmt = stmt.replace("typedef struct %s {" % struct, "").strip()
+            if not stmt:
+                continue
+            for part in stmt.split(","):
+                m = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", part.strip())
+                decl.add(m.group(1))
+        assert decl == set(names), (struct, decl ^ set(names))
 
 
 def test_train_step_argument_block_is_validated_before_any_launch(lib):
