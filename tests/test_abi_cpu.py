@@ -201,3 +201,20 @@ def test_train_step_argument_block_is_validated_before_any_launch(lib):
     a.N = 4096
     assert lib.tn_train_step(C.byref(a), None) == -22
     assert b"null pointer" in lib.tn_last_error()
+
+
+def test_sample_rays_block_is_validated_on_the_host(lib):
+    """tn_sample_rays_args (the TnSampleRays form of tn_sample_rays; the block tn_train_step takes as next_sample): a missing block is refused, an
+    empty batch touches nothing, a block without its arrays is refused before any launch."""
+    import ctypes as C
+
+    from nerfstudio_thermal_amd import _lib as L
+
+    assert lib.tn_sample_rays_args(None, None) == -22
+    assert b"null pointer" in lib.tn_last_error()
+    a = L.TnSampleRays()
+    assert lib.tn_sample_rays_args(C.byref(a), None) == 0  # num_rays == 0
+    a.num_rays, a.num_images, a.patch_size = 64, 4, 2
+    assert lib.tn_sample_rays_args(C.byref(a), None) == -22
+    assert b"null pointer" in lib.tn_last_error()
+
