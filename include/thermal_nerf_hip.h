@@ -53,6 +53,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported (tests/test_abi_cpu.py compares `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#define TN_API __attribute__((visibility("default")))
+#else
+#define TN_API
+#endif
+
 #define TN_OK 0
 #define TN_EINVAL (-22)   /* bad argument / unsupported shape */
 #define TN_ELAUNCH (-5)   /* hipLaunch / runtime error (see tn_last_error) */
@@ -100,15 +107,15 @@ typedef struct TnField {
   int32_t num_images;
 } TnField;
 
-const char* tn_last_error(void);
-int tn_version(void);
+TN_API const char* tn_last_error(void);
+TN_API int tn_version(void);
 /* bytes of device scratch tn_field_* need for `num_points` samples (packed weights + saved activations). */
-int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
+TN_API int64_t tn_field_workspace_bytes(int64_t num_points, int32_t training);
 /* Work plan of the field's hash-grid gather (HashEncoding.pytorch_fwd, field_components/encodings.py:401-461), for tests and diagnostics.
  * The gather is XCD-affine: workgroup b runs on XCD b % 8 and reads ONE level, so that a hashed level's table is served from that XCD's L2;
  * XCD x runs level x for all samples, then level x + 8.  out [8][2][3] int32: item i of XCD x = {level (-1: unused), first chunk,
  * chunk count}.  Returns the number of chunks per level (every level's chunks appear exactly once in the plan) or TN_EINVAL. */
-int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, int32_t* out);
+TN_API int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, int32_t* out);
 
 /* ---- N2  PatchPixelSampler.sample on a jagged image list + ground-truth gather (data/pixel_samplers.py:296-337 collate_image_dataset_batch_list,
  *          :389-441 PatchPixelSampler.sample_method without masks; what VanillaDataManager.next_train does on the host every step,
@@ -120,7 +127,7 @@ int32_t tn_field_encode_plan(const TnGrid* grid, int64_t num_points, int32_t* ou
  * (the reference asserts the same).  patch_size 1..8.
  * Outputs: ray_indices [N,3] int64 (camera,row,col), image [N,3], is_thermal_out [N], camera_indices [N] int64 (= ray_indices[:,0] as the
  * contiguous vector the field kernels take; may be NULL). */
-int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+TN_API int tn_sample_pixels(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                      const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
                      int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
                      tn_stream_t stream);
@@ -128,7 +135,7 @@ int tn_sample_pixels(const float* images, const int64_t* image_offsets, const in
 /* ---- a1  RayGenerator.forward -> Cameras._generate_rays_from_coords (model_components/ray_generators.py:40-55,
  *          cameras/cameras.py:598-655,781-786,886-909; undistortion cameras/camera_utils.py:409-446).
  * ray_indices [N,3] int64 (camera,row,col); c2w [C,3,4]; fx,fy,cx,cy [C]; distortion [C,6] (k1,k2,k3,k4,p1,p2) or NULL. */
-int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx,
+TN_API int tn_raygen(const int64_t* ray_indices, const float* c2w, const float* fx, const float* fy, const float* cx,
               const float* cy, const float* distortion, int32_t num_cameras, int64_t N, float* origins, float* directions,
               float* pixel_area, float* directions_norm, tn_stream_t stream);
 /* N2 + a1 in ONE launch (VanillaDataManager.next_train, data/datamanagers/base_datamanager.py:538-547: pixel sampler -> ground truth ->
@@ -144,8 +151,8 @@ typedef struct TnSampleRays {
   const float* c2w; const float* fx; const float* fy; const float* cx; const float* cy; const float* distortion; int32_t num_cameras;
   float* origins; float* directions; float* pixel_area; float* directions_norm;
 } TnSampleRays;
-int tn_sample_rays_args(const TnSampleRays* args, tn_stream_t stream); /* tn_sample_rays on the block */
-int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
+TN_API int tn_sample_rays_args(const TnSampleRays* args, tn_stream_t stream); /* tn_sample_rays on the block */
+TN_API int tn_sample_rays(const float* images, const int64_t* image_offsets, const int32_t* heights, const int32_t* widths,
                    const float* is_thermal, const int64_t* image_idx, int32_t num_images, const float* u, int64_t num_rays,
                    int32_t patch_size, int64_t* ray_indices, float* image, float* is_thermal_out, int64_t* camera_indices,
                    const float* c2w, const float* fx, const float* fy, const float* cx, const float* cy, const float* distortion,
@@ -153,21 +160,21 @@ int tn_sample_rays(const float* images, const int64_t* image_offsets, const int3
 
 /* ---- a4  CameraOptimizer(SO3xR3).apply_to_raybundle (cameras/camera_optimizers.py:130-176, cameras/lie_groups.py:24-58).
  * pose_adjustment [C,6]; frozen [C] uint8 (1 = non-trainable camera -> identity); camera_indices [N] int64. */
-int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+TN_API int tn_pose_apply_fwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
                       const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
                       tn_stream_t stream);
 /* backward: d_origins/d_directions [N,3] -> accumulates into grad_pose [C,6]. */
-int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+TN_API int tn_pose_apply_bwd(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
                       const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                       tn_stream_t stream);
 
 /* ---- a6  UniformLinDispPiecewiseSampler / SpacedSampler.generate_ray_samples (model_components/ray_samplers.py:78-128,225-248).
  * lin_bins [S+1] = torch.linspace(0,1,S+1) supplied by the host; jitter [N] or NULL (eval). Outputs s_bins,e_bins [N,S+1]. */
-int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
+TN_API int tn_spaced_bins(const float* lin_bins, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
                    float* s_bins, float* e_bins, tn_stream_t stream);
 /* tn_pose_apply_fwd and tn_spaced_bins (the two independent first steps of a training render) in one launch; arguments of the former, then of
  * the latter without N. */
-int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
+TN_API int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* origins_in,
                         const float* directions_in, int64_t N, int32_t num_cameras, float* origins_out, float* directions_out,
                         const float* lin_bins, const float* jitter, const float* nears, const float* fars, int32_t S, float* s_bins,
                         float* e_bins, tn_stream_t stream);
@@ -175,14 +182,14 @@ int tn_pose_spaced_bins(const float* pose_adjustment, const uint8_t* frozen, con
 /* ---- a8/a9/a10  Field.density_fn -> HashMLPDensityField.get_density (fields/base_field.py:48-68, fields/density_fields.py:95-118,
  *          field_components/encodings.py:401-461, field_components/mlp.py:159-178, field_components/activations.py:28-41).
  * positions = origins + directions * (e_bins[s]+e_bins[s+1])/2 (cameras/rays.py:49-58). density [N,S]. */
-int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
+TN_API int tn_prop_density_fwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins, int64_t N,
                         int32_t S, float* density, tn_stream_t stream);
 /* backward of the above: d_density [N,S] -> table/MLP gradients (accumulated) and, if non-NULL, d_origins/d_directions [N,3] (accumulated).
  * workspace: tn_prop_workspace_bytes(N*S) bytes of device scratch (d enc for the table scatter + the scatter's records); workspace_bytes = the size
  * of the buffer behind it: a shorter one is refused with TN_EINVAL (every workspace_bytes argument below works the same way -- the scratch of
  * a backward pass is hundreds of MB, and a short buffer would be a device out-of-bounds write the callee could not see). */
-int64_t tn_prop_workspace_bytes(int64_t num_points);
-int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
+TN_API int64_t tn_prop_workspace_bytes(int64_t num_points);
+TN_API int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float* directions, const float* e_bins,
                         const float* d_density, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
                         float* d_directions, tn_stream_t stream);
 
@@ -194,27 +201,27 @@ int tn_prop_density_bwd(const TnPropNet* net, const float* origins, const float*
  *          With it the scatter is atomic-free: every contribution is written once as a (slot, value) record into the bucket of its
  *          2^12-slot table slice and the buckets are summed in LDS (coarse levels are pre-merged in registers); NULL adds every
  *          contribution straight into table_grad with global float atomics (same result up to summation order, several times slower). */
-int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t num_levels);
-int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
+TN_API int64_t tn_hash_scatter_workspace_bytes(int64_t num_points, int32_t num_levels);
+TN_API int tn_hash_scatter(const TnGrid* grid, const float* origins, const float* directions, const float* e_bins, const float* g_enc, int32_t ld,
                     int64_t N, int32_t S, float* d_origins, float* d_directions, void* workspace, int64_t workspace_bytes, tn_stream_t stream);
 
 /* ---- a11 RaySamples.get_weights (cameras/rays.py:128-150) and, optionally, DepthRenderer("median") of the same level
  *          (model_components/renderers.py:547-557; used for prop_depth_i, models/nerfacto.py:351-352). median_depth may be NULL. */
-int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
+TN_API int tn_weights_fwd(const float* e_bins, const float* density, int64_t N, int32_t S, float* weights, float* median_depth,
                    tn_stream_t stream);
-int tn_weights_bwd(const float* e_bins, const float* density, const float* weights, const float* d_weights, int64_t N, int32_t S,
+TN_API int tn_weights_bwd(const float* e_bins, const float* density, const float* weights, const float* d_weights, int64_t N, int32_t S,
                    float* d_density, tn_stream_t stream);
 
 /* ---- a7  PDFSampler.generate_ray_samples incl. the anneal pow of ProposalNetworkSampler (model_components/ray_samplers.py:276-372,602).
  * u_lin [S+1] = torch.linspace(0, 1-1/(S+1), S+1) supplied by the host (eval adds 1/(2(S+1)), train adds jitter/(S+1)). */
-int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
+TN_API int tn_pdf_resample(const float* s_bins_prev, const float* weights_prev, int32_t S_prev, float anneal, const float* u_lin,
                     const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S, float* s_bins, float* e_bins,
                     tn_stream_t stream);
 
 /* a11 + a7 back to back, as ProposalNetworkSampler.generate_ray_samples always calls them (ray_samplers.py:593-611): the weights of the
  * previous level (written to weights_prev [N,S_prev]; median_prev [N] optional) and the bins of the next level, one launch, the weights
  * handed over in registers.  Bit-identical to tn_weights_fwd followed by tn_pdf_resample. */
-int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,
+TN_API int tn_weights_resample(const float* e_bins_prev, const float* density_prev, const float* s_bins_prev, int32_t S_prev, float anneal,
                         const float* u_lin, const float* jitter, const float* nears, const float* fars, int64_t N, int32_t S,
                         float* weights_prev, float* median_prev, float* s_bins, float* e_bins, tn_stream_t stream);
 
@@ -224,8 +231,8 @@ int tn_weights_resample(const float* e_bins_prev, const float* density_prev, con
  * Outputs: density [N,S], rgb [N,S,C], optional density_before_activation [N,S] (may be NULL).
  * workspace: device scratch of tn_field_workspace_bytes(N*S, training) bytes; when training!=0 it keeps the activations
  * tn_field_bwd consumes, so the same pointer must be passed to both. */
-int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t stream);
-int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+TN_API int tn_field_pack_weights(const TnField* field, void* workspace, tn_stream_t stream);
+TN_API int tn_field_fwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                  int64_t N, int32_t S, int32_t training, void* workspace, int64_t workspace_bytes, float* density, float* rgb,
                  float* density_pre, tn_stream_t stream);
 /* backward: d_density [N,S], d_rgb [N,S,C] -> all TnField gradients (accumulated); d_origins/d_directions optional (accumulated).
@@ -235,7 +242,7 @@ int tn_field_fwd(const TnField* field, const float* origins, const float* direct
  * per-camera vector instead of multiplying the embedding per sample): num_images <= TN_FIELD_MAX_IMAGES, refused with TN_EINVAL beyond.  The forward (training != 0) clears
  * those sums and the backward leaves them cleared: the workspace may come from an uninitialised allocation. */
 #define TN_FIELD_MAX_IMAGES 4096
-int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
+TN_API int tn_field_bwd(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices, const float* e_bins,
                  const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, float* d_origins,
                  float* d_directions, tn_stream_t stream);
 /* The same backward in phases, for data-parallel training: the table gradient of a level range is final as soon as its scatter has run,
@@ -259,7 +266,7 @@ int tn_field_bwd(const TnField* field, const float* origins, const float* direct
  *                   pass's bucket counters zeroed; without the flag a phase-by-phase backward pays a memset launch for them. */
 enum { TN_BWD_MLP = 1, TN_BWD_SCATTER = 2, TN_BWD_JOIN = 4, TN_BWD_SCATTER_BIN = 8, TN_BWD_SCATTER_FOLD = 16, TN_BWD_FORK_DPOS = 32,
        TN_BWD_COUNTERS_CLEAN = 64 };
-int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
+TN_API int tn_field_bwd_phase(const TnField* field, const float* origins, const float* directions, const int64_t* camera_indices,
                        const float* e_bins, const float* d_density, const float* d_rgb, int64_t N, int32_t S, void* workspace,
                        int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t phases, int32_t level_begin, int32_t level_end,
                        tn_stream_t stream);
@@ -271,16 +278,16 @@ int tn_field_bwd_phase(const TnField* field, const float* origins, const float* 
  *                                                     accumulated) and the table gradient of the range is left untouched
  *   (all-reduce dense_sum)
  *   tn_field_dense_fold(field, N*S, lb, le, dense_sum) hashes the sums into the table gradient (accumulating), as the plain scatter would have. */
-int64_t tn_field_dense_count(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end);
-int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+TN_API int64_t tn_field_dense_count(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end);
+TN_API int tn_field_bwd_scatter_dense(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                                void* workspace, int64_t workspace_bytes, float* d_origins, float* d_directions, int32_t level_begin, int32_t level_end,
                                float* dense_sum, tn_stream_t stream);
-int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
+TN_API int tn_field_dense_fold(const TnField* field, int64_t num_points, int32_t level_begin, int32_t level_end, const float* dense_sum,
                         tn_stream_t stream);
 /* density only (cross-evaluation density2 / density2_thermal, models/thermal_nerfacto.py:447-458): get_density without get_outputs.
  * training != 0 keeps what the backward needs in `workspace` (sized with tn_field_workspace_bytes(N*S, 1)); that backward is
  * tn_field_bwd / tn_field_bwd_phase with d_rgb = NULL: the colour head, its three weight gradients and the appearance embedding are skipped. */
-int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
+TN_API int tn_field_density_fwd(const TnField* field, const float* origins, const float* directions, const float* e_bins, int64_t N, int32_t S,
                          int32_t training, void* workspace, int64_t workspace_bytes, float* density, tn_stream_t stream);
 
 /* ---- a15/a16  RGBRenderer / RGBTRenderer (background "last_sample"), AccumulationRenderer, DepthRenderer median+expected
@@ -288,13 +295,13 @@ int tn_field_density_fwd(const TnField* field, const float* origins, const float
  * rgb [N,S,C]; outputs comp [N,C], accumulation [N], depth_median [N], depth_expected [N] (unclipped) and
  * steps_minmax [2] (running min/max of the sample midpoints as ordered uint32 bit patterns; initialise with tn_minmax_init,
  * then call tn_clip_depth to apply the batch-global clip of renderers.py:574). */
-int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream);
-int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
+TN_API int tn_minmax_init(uint32_t* steps_minmax, tn_stream_t stream);
+TN_API int tn_composite_fwd(const float* rgb, const float* weights, const float* e_bins, int64_t N, int32_t S, int32_t C, int32_t training,
                      float* comp, float* accumulation, float* depth_median, float* depth_expected, uint32_t* steps_minmax,
                      tn_stream_t stream);
-int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N, tn_stream_t stream);
+TN_API int tn_clip_depth(float* depth_expected, const uint32_t* steps_minmax, int64_t N, tn_stream_t stream);
 /* backward (train mode): d_comp [N,C] -> d_rgb [N,S,C] (written) and d_weights [N,S] (accumulated). */
-int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
+TN_API int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp, int64_t N, int32_t S, int32_t C, float* d_rgb,
                      float* d_weights, tn_stream_t stream);
 
 /* a11 + a15 + a16 of the last sampling level in ONE launch: RaySamples.get_weights (cameras/rays.py:128-150) followed by every renderer above
@@ -303,12 +310,12 @@ int tn_composite_bwd(const float* rgb, const float* weights, const float* d_comp
  * atomics).  scratch: TN_RENDER_SCRATCH_FLOATS floats of device memory, contents irrelevant (required when depth_expected is given; one
  * buffer per stream that may run this concurrently).  accumulation / depth_median / depth_expected may be NULL. */
 #define TN_RENDER_SCRATCH_FLOATS 4096
-int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
+TN_API int tn_render_fwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training,
                   float* weights, float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
                   tn_stream_t stream);
 /* its backward: tn_composite_bwd followed by tn_weights_bwd in one launch.  d_weights_in [N,S] = gradient that reaches the weights from the
  * losses (read only: the compositing term is added in registers); d_rgb [N,S,C] and d_density [N,S] are written. */
-int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
+TN_API int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, const float* weights, const float* d_comp,
                   const float* d_weights_in, int64_t N, int32_t S, int32_t C, float* d_rgb, float* d_density, tn_stream_t stream);
 
 /* ---- a5..a17 in ONE call: the no-grad render of one branch (a sampler with two proposal networks + a field), i.e.
@@ -320,8 +327,8 @@ int tn_render_bwd(const float* e_bins, const float* density, const float* rgb, c
  * them on the host; anneal = the sampler's current histogram-padding exponent.  Outputs: rgb [N,C], density [N,S2] (required);
  * accumulation, depth_median, depth_expected, prop_depth0/1 [N], e_bins_out [N,S2+1], rgb_samples_out [N,S2,C] (each may be NULL).
  * workspace: tn_render_rays_eval_workspace_bytes(N, S0, S1, S2, C) bytes, 256-byte aligned. */
-int64_t tn_render_rays_eval_workspace_bytes(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
-int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+TN_API int64_t tn_render_rays_eval_workspace_bytes(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
+TN_API int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
                         const float* directions, const int64_t* camera_indices, const float* nears, const float* fars, int64_t N,
                         int32_t S0, int32_t S1, int32_t S2, float anneal, const float* lin_spaced0, const float* lin_pdf1,
                         const float* lin_pdf2, void* workspace, int64_t workspace_bytes, float* rgb, float* accumulation, float* depth_median,
@@ -345,8 +352,8 @@ int tn_render_rays_eval(const TnPropNet* prop0, const TnPropNet* prop1, const Tn
  * first launch): the caller's zero-initialised accumulators of the iteration -- loss sums, d(composite), d(weights), d origins / d directions --
  * without a fill launch of their own. */
 #define TN_RENDER_TRAIN_OFFSETS 25
-int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
-int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
+TN_API int tn_render_rays_train_layout(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C, int64_t* offsets, int32_t num_offsets);
+TN_API int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* pose_adjustment,
                          const uint8_t* frozen, int32_t num_cameras, const float* origins_in, const float* directions_in,
                          const int64_t* camera_indices, const float* nears, const float* fars, int64_t N, int32_t S0, int32_t S1,
                          int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
@@ -364,8 +371,8 @@ int tn_render_rays_train(const TnPropNet* prop0, const TnPropNet* prop1, const T
  * joins: same launches and results as those calls made one by one.  tmp: tn_render_rays_train_bwd_tmp_floats(...) floats of scratch;
  * prop_workspace_k: tn_prop_workspace_bytes(N*S_k) (may be NULL without d_weights).  d_origins / d_directions [N,3] accumulate (or both NULL).
  * prop_enc_saved != 0: fwd_out holds the proposal levels' encodings (tn_render_rays_train(save_prop_enc != 0) on this buffer). */
-int64_t tn_render_rays_train_bwd_tmp_floats(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
-int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
+TN_API int64_t tn_render_rays_train_bwd_tmp_floats(int64_t num_rays, int32_t S0, int32_t S1, int32_t S2, int32_t C);
+TN_API int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, const TnField* field, const float* origins,
                              const float* directions, const int64_t* camera_indices, int64_t N, int32_t S0, int32_t S1, int32_t S2,
                              const float* fwd_out, const float* d_comp, const float* d_weights0,
                              const float* d_weights1, const float* d_weights2, const float* d_density_extra, void* field_workspace,
@@ -375,9 +382,9 @@ int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet* prop1, con
 
 /* ---- a18  interlevel_loss / distortion_loss (model_components/losses.py:57-158), forward value + gradient in one pass.
  * loss_out[0] += mult * mean_over_rays(...); d_weights accumulated (may be NULL to skip the gradient). */
-int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
+TN_API int tn_distortion_loss(const float* s_bins, const float* weights, int64_t N, int32_t S, float mult, float* loss_out, float* d_weights,
                        tn_stream_t stream);
-int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
+TN_API int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, const float* s_bins_prop,
                        const float* weights_prop, int32_t S_prop, int64_t N, float mult, float* loss_out, float* d_weights_prop,
                        tn_stream_t stream);
 
@@ -385,7 +392,7 @@ int tn_interlevel_loss(const float* s_bins_fine, const float* weights_fine, int3
  * the num_props (<= TN_MAX_PROP_LEVELS) proposal levels.  s_bins_prop / weights_prop / S_prop / d_weights_prop are HOST arrays of num_props
  * entries (device pointers / sizes); d_weights_prop[i] and d_weights_fine may be NULL.  Same accumulation semantics as the single calls. */
 #define TN_MAX_PROP_LEVELS 4
-int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+TN_API int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
                        const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
                        float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* distortion_out,
                        float* interlevel_out, float* d_weights_fine, tn_stream_t stream);
@@ -395,7 +402,7 @@ int tn_proposal_losses(const float* s_bins_fine, const float* weights_fine, int3
  * pred_rgb [N,3], pred_thermal [N,1] (for shared mode both are views of one [N,4] buffer: pass strides in floats),
  * image [N,3], is_thermal [N] float.  losses_out[0..3] += {rgb, thermal, tv_pixel, cross_channel}; losses_out must have room for 8 floats
  * (entry 4 is scratch: the number of RGB rays); d_pred_* accumulated. */
-int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
+TN_API int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
                     const float* is_thermal, int64_t N, float thermal_mult, float tv_mult, float cross_mult, float* losses_out,
                     float* d_pred_rgb, float* d_pred_thermal, tn_stream_t stream);
 /* The proposal losses of one branch AND (pred_rgb != NULL) the pixel terms above in ONE launch: they are independent, and each alone is a
@@ -408,7 +415,7 @@ int tn_pixel_losses(const float* pred_rgb, int32_t rgb_stride, const float* pred
  * regulariser of one pose tensor in the same single-block launch when pose_adjustment != NULL (arguments of tn_camera_reg; reg_out may be
  * one of the 16 slots). */
 #define TN_LOSS_LINES 64
-int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
+TN_API int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t S_fine, int32_t num_props,
                     const float* const* s_bins_prop, const float* const* weights_prop, const int32_t* S_prop,
                     float* const* d_weights_prop, int64_t N, float distortion_mult, float interlevel_mult, float* d_weights_fine,
                     const float* pred_rgb, int32_t rgb_stride, const float* pred_thermal, int32_t thermal_stride, const float* image,
@@ -424,17 +431,17 @@ int tn_train_losses(const float* s_bins_fine, const float* weights_fine, int32_t
  * d_rgb [N,S,4] and d_density [N,S] are written.  clip_depth = 0 leaves depth_expected unclipped and the per-block min / max of the sample
  * midpoints in `scratch` (tn_render_fwd's clip launch is then the caller's to issue).  Every per-element result equals the three calls' bit for
  * bit; the loss sums (loss_lines) are added up in another order, so they agree to rounding -- as two runs of tn_train_losses do. */
-int tn_render_losses_bwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, float* weights,
+TN_API int tn_render_losses_bwd(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, float* weights,
                          float* comp, float* accumulation, float* depth_median, float* depth_expected, float* scratch,
                          const float* s_bins_fine, int32_t num_props, const float* const* s_bins_prop, const float* const* weights_prop,
                          const int32_t* S_prop, float* const* d_weights_prop, float distortion_mult, float interlevel_mult,
                          float* d_weights_fine, const float* image, const float* is_thermal, float thermal_mult, float tv_mult, float cross_mult,
                          float* d_comp, float* loss_lines, float* d_rgb, float* d_density, int32_t clip_depth, tn_stream_t stream);
-int tn_losses_finish(const float* loss_lines, float* losses16, const float* pose_adjustment, int32_t num_cameras, float trans_pen,
+TN_API int tn_losses_finish(const float* loss_lines, float* losses16, const float* pose_adjustment, int32_t num_cameras, float trans_pen,
                      float rot_pen, float scale, float* reg_out, float* grad_pose, tn_stream_t stream);
 /* tn_pose_apply_bwd + tn_losses_finish for the same pose tensor in one launch (the end of an iteration's backward); loss_lines / losses16 may
  * both be NULL (regulariser only). */
-int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+TN_API int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
                        const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                        const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
                        tn_stream_t stream);
@@ -442,32 +449,32 @@ int tn_pose_bwd_finish(const float* pose_adjustment, const uint8_t* frozen, cons
  * when a contribution to the pose gradient is inf / NaN, and found_inf[flag_index[k]] when any of the `counts[k]` gradients at grads + offsets[k]
  * is (up to 8 SMALL ranges -- MLP weights, embeddings: at most 4 M floats each; offsets / counts / flag_index are HOST arrays).  With
  * TnGrid::nonfinite_flag on every grid this replaces tn_grad_nonfinite_ranges over the whole gradient arena. */
-int tn_pose_bwd_finish_check(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
+TN_API int tn_pose_bwd_finish_check(const float* pose_adjustment, const uint8_t* frozen, const int64_t* camera_indices, const float* directions_in,
                              const float* d_origins, const float* d_directions, int64_t N, int32_t num_cameras, float* grad_pose,
                              const float* loss_lines, float* losses16, float trans_pen, float rot_pen, float scale, float* reg_out,
                              const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
                              int32_t num_flags, float* found_inf, int32_t pose_flag, tn_stream_t stream);
 /* density L1 cross loss with the reference's detach asymmetry (models/thermal_nerfacto.py:328-344): loss += a*mean|x-y| with
  * gradient weight gx to x and gy to y (accumulated; either may be NULL). */
-int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
+TN_API int tn_l1_loss(const float* x, const float* y, int64_t count, float gx, float gy, float* loss_out, float* d_x, float* d_y,
                tn_stream_t stream);
 /* per-iteration metrics in one launch (models/thermal_nerfacto.py:262-270 PSNR per spectrum from the tn_pixel_losses sums losses[0,1,4,5];
  * cameras/camera_optimizers.py:197-202 pose norms): metrics_out[0] psnr_rgb, [1] psnr_thermal, [2],[3] |pose0[:, :3]|, |pose0[:, 3:]|,
  * [4],[5] the same for pose1; either pose may be NULL. */
-int tn_train_metrics(const float* losses, int64_t N, float thermal_mult, const float* pose0, int32_t num_cameras0, const float* pose1,
+TN_API int tn_train_metrics(const float* losses, int64_t N, float thermal_mult, const float* pose0, int32_t num_cameras0, const float* pose1,
                      int32_t num_cameras1, float* metrics_out, tn_stream_t stream);
 /* camera regulariser (cameras/camera_optimizers.py:189-195). */
-int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans_pen, float rot_pen, float scale, float* loss_out,
+TN_API int tn_camera_reg(const float* pose_adjustment, int32_t num_cameras, float trans_pen, float rot_pen, float scale, float* loss_out,
                   float* grad_pose, tn_stream_t stream);
 
 /* ---- N1  torch.optim.Adam(lr, eps) as engine/optimizers.py:73-210 builds it, fused over a flat fp32 arena.
  * step is 1-based. */
-int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
+TN_API int tn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t count, int32_t step, double lr,
                  double beta1, double beta2, double eps, tn_stream_t stream);
 /* The same for several ranges of one set of arenas in ONE launch: range k covers elements [offsets[k], offsets[k] + counts[k]) (offsets
  * multiples of 4) with its own 1-based step count and learning rate -- the optimiser groups of engine/optimizers.py:86-112.  offsets, counts,
  * steps, lrs are HOST arrays of num_ranges (<= 8) entries. */
-int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+TN_API int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                         const int64_t* counts, const int32_t* steps, const double* lrs, double beta1, double beta2, double eps,
                         tn_stream_t stream);
 /* GradScaler semantics without a host round trip (engine/trainer.py:470-495 -> torch/amp/grad_scaler.py; engine/optimizers.py:144-183).
@@ -484,29 +491,29 @@ int tn_adam_step_ranges(float* params, const float* grads, float* exp_avg, float
  *    (`grads` is then written): the optimizers.zero_grad_some() of the next iteration (engine/trainer.py:463-467) without a fill launch.
  *  - tn_grad_scaler_update is GradScaler.update() on the device (backoff / growth of *scale, growth tracker) and adds 1 to *lag (may be NULL)
  *    when any of the num_flags entries of found_inf is set; clear_found_inf != 0 zero-fills found_inf afterwards (ready for the next step). */
-int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream);
+TN_API int tn_grad_nonfinite(const float* grads, int64_t count, float* found_inf, tn_stream_t stream);
 /* the same for up to 8 ranges of one gradient arena in ONE launch: range k raises found_inf[flag_index[k]] (offsets, counts, flag_index: HOST arrays) */
-int tn_grad_nonfinite_ranges(const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
+TN_API int tn_grad_nonfinite_ranges(const float* grads, int32_t num_ranges, const int64_t* offsets, const int64_t* counts, const int32_t* flag_index,
                              int32_t num_flags, float* found_inf, tn_stream_t stream);
-int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+TN_API int tn_adam_step_ranges_amp(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                             const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                             const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                             const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
                             int32_t lag_index, int32_t count_skip, int32_t zero_grads, tn_stream_t stream);
-int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
+TN_API int tn_grad_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, int32_t num_flags, int32_t* lag,
                           double growth_factor, double backoff_factor, int32_t growth_interval, int32_t clear_found_inf, tn_stream_t stream);
 /* tn_adam_step_ranges_amp + tn_grad_scaler_update(clear_found_inf = 1) in ONE launch: the last block of the Adam launch to finish performs
  * GradScaler.update() -- every block has read found_inf / the schedule lag by then.  done_counter: TN_ADAM_DONE_WORDS zeroed uint32 on the device
  * (left zero; the blocks count themselves in on 64 counters in 64 different 64-byte lines: same-line atomics execute one after the other). */
 #define TN_ADAM_DONE_WORDS (65 * 16)
-int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
+TN_API int tn_adam_step_ranges_amp_update(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                                    const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                                    const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                                    const float* inv_scale, float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
                                    int32_t lag_index, int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker,
                                    uint32_t* done_counter, double growth_factor, double backoff_factor, int32_t growth_interval,
                                    tn_stream_t stream);
-int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
+TN_API int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
 
 /* ---- Trainer.train_iteration (engine/trainer.py:455-499) for the shared-density model with a camera optimiser, as ONE call: what
  * RenderEngine.train_step enqueues through five calls of this ABI, in the same order on the same streams --
@@ -527,6 +534,22 @@ int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream);
  * `acc` (acc_bytes, 16-byte aligned, multiple of 16): ONE allocation holding losses16 [16], loss_lines [TN_LOSS_LINES][16], d_comp [N,C],
  * d_weights2 [N,S2], d_weights0 [N,S0], d_weights1 [N,S1] (both only read when prop_grad != 0), d_origins, d_directions [N,3]; the call clears it. */
 #define TN_TRAIN_STEP_MAX_RANGES 8
+/* The NEXT iteration's sampling front -- everything tn_render_rays_train runs before the field: CameraOptimizer.apply_to_raybundle
+ * (cameras/camera_optimizers.py:130-176), the level-0 bins and twice density_fn -> get_weights -> PDFSampler (model_components/ray_samplers.py:577-618)
+ * -- for the batch TnTrainStep::next_sample describes, as co-work of THIS iteration's optimiser launch: five short launches (86 us at 4096 rays) that
+ * are bound by instruction issue leave the head of every iteration and run beside the Adam pass over the field, which is bound by HBM and touches
+ * none of their inputs.  One wave takes one ray through the whole chain (no ray depends on another); the optimiser groups the chain READS (the
+ * proposal networks, the pose corrections: whatever range of `params` holds prop0 / prop1 / pose_adjustment) are stepped by a launch of their own
+ * in front, so it sees this iteration's final parameters.  Results land in fwd_out exactly where tn_render_rays_train puts them (origins ... e_bins2,
+ * and the proposal encodings when prop_grad != 0), bit for bit.  Uses this call's nears / fars / lin_* tables / pose / frozen / networks and N rays.
+ * Taken only when next_sample is, next_sample->num_rays == N, 128 < S0 <= 256, 64 < S1 <= 128 (the sampler's default lane layouts) and at least one
+ * stepped range is not read by the chain. */
+typedef struct TnNextSampling {
+  float* fwd_out;                                                   /* the NEXT iteration's forward buffer (same layout: same N, S0, S1, S2) */
+  const float* jitter0; const float* jitter1; const float* jitter2; /* the NEXT iteration's jitter [N] (or NULL) */
+  float anneal;                                                     /* the NEXT iteration's histogram-padding exponent */
+  int32_t prop_grad;                                                /* the NEXT iteration's prop_grad: != 0 keeps the proposal encodings */
+} TnNextSampling;
 typedef struct TnTrainStep {
   const TnPropNet* prop0; const TnPropNet* prop1; const TnField* field;  /* HOST structs, gradient pointers set */
   /* the iteration's batch (datamanager.next_train): rays before the pose correction, ground truth */
@@ -562,10 +585,17 @@ typedef struct TnTrainStep {
   /* NULL, or the NEXT iteration's batch (HOST struct): sampled in co-work blocks of the optimiser launch; ignored (the caller's to launch,
    * tn_sample_rays_args) when num_ranges == 0 -- *next_sample_taken (HOST, may be NULL) says which */
   const TnSampleRays* next_sample; int32_t* next_sample_taken;
+  /* NULL, or (with next_sample) the NEXT iteration's sampling front (HOST struct, see TnNextSampling): run for that batch in the same co-work blocks.
+   * *next_sampling_taken (HOST, may be NULL) = 1 when the optimiser launch carried it: the next call then passes sampling_done = 1. */
+  const struct TnNextSampling* next_sampling; int32_t* next_sampling_taken;
+  /* != 0: the previous call's next_sampling has filled fwd_out up to the field's bins for THIS batch (origins_in / directions_in / camera_indices are
+   * next_sample's outputs), with this call's jitter, anneal and prop_grad, and no parameter of the proposal networks or the poses has changed
+   * since: the forward starts at the field. */
+  int32_t sampling_done;
 } TnTrainStep;
-int tn_train_step(const TnTrainStep* step, tn_stream_t stream);
+TN_API int tn_train_step(const TnTrainStep* step, tn_stream_t stream);
 /* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */
-int tn_shutdown(void);
+TN_API int tn_shutdown(void);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * N4: forward Gaussian-splat render, RGB + thermal colour per Gaussian.  Replaces the gsplat calls of
@@ -581,14 +611,14 @@ typedef struct TnSplatCamera {
   int32_t width, height;
 } TnSplatCamera;
 /* scratch for num_gaussians Gaussians and up to max_intersections (Gaussian, tile) pairs; num_tiles = ceil(W/16) * ceil(H/16) */
-int64_t tn_splat_workspace_bytes(int64_t num_gaussians, int64_t max_intersections, int32_t num_tiles);
+TN_API int64_t tn_splat_workspace_bytes(int64_t num_gaussians, int64_t max_intersections, int32_t num_tiles);
 /* project_gaussians + spherical_harmonics (splatfacto.py:739-777).  means [N,3], log_scales [N,3] (exponentiated inside), quats [N,4]
  * (w,x,y,z; normalised inside), opacities [N] (logits), features_dc [N,3], features_rest [N,K,3], thermal_dc [N,1], thermal_rest [N,K,1]
  * (K = num_rest_coeffs).  sh_degree 0..3 = degree evaluated this step (min(step // interval, sh_degree)); -1 = sigmoid(features_dc)
  * (config.sh_degree == 0).  antialiased != 0: opacity x compensation (rasterize_mode "antialiased").  Outputs as gsplat returns them:
  * xys [N,2], depths [N], radii [N] int32, conics [N,3], compensation [N], num_tiles_hit [N] int32, plus tile_box [N,4] int32
  * (x0, y0, x1, y1 in tiles).  Colours and opacities go into the workspace for tn_splat_raster. */
-int tn_splat_project(const TnSplatCamera* camera, const float* means, const float* log_scales, const float* quats, const float* opacities,
+TN_API int tn_splat_project(const TnSplatCamera* camera, const float* means, const float* log_scales, const float* quats, const float* opacities,
                      const float* features_dc, const float* features_rest, const float* thermal_dc, const float* thermal_rest,
                      int64_t num_gaussians, int32_t num_rest_coeffs, int32_t sh_degree, int32_t antialiased, float* xys, float* depths,
                      int32_t* radii, float* conics, float* compensation, int32_t* num_tiles_hit, int32_t* tile_box, void* workspace,
@@ -598,11 +628,11 @@ int tn_splat_project(const TnSplatCamera* camera, const float* means, const floa
  * the tiles where alpha >= 1/255 is reachable: exact, fewer pairs than sum(num_tiles_hit)).  Reads the pair count back to the host
  * (*num_intersections_out, a HOST pointer; one stream synchronisation, as gsplat's binning does); returns TN_EINVAL with the needed count
  * in *num_intersections_out when it exceeds max_intersections. */
-int tn_splat_bin(const TnSplatCamera* camera, const float* depths, int64_t num_gaussians, void* workspace, int64_t max_intersections,
+TN_API int tn_splat_bin(const TnSplatCamera* camera, const float* depths, int64_t num_gaussians, void* workspace, int64_t max_intersections,
                  int64_t* num_intersections_out, tn_stream_t stream);
 /* rasterize_gaussians, colour (RGB + thermal over background4) and depth in one pass (splatfacto.py:789-809): out_rgbt [H,W,4] clamped to
  * <= 1, out_depth [H,W] = depth / alpha where alpha > 0, else the maximum of the un-normalised depth image, out_alpha [H,W]. */
-int tn_splat_raster(const TnSplatCamera* camera, int64_t num_gaussians, void* workspace, int64_t max_intersections, const float* background4,
+TN_API int tn_splat_raster(const TnSplatCamera* camera, int64_t num_gaussians, void* workspace, int64_t max_intersections, const float* background4,
                     int32_t antialiased, float* out_rgbt, float* out_depth, float* out_alpha, tn_stream_t stream);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 305  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 306  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 4096
@@ -62,6 +62,11 @@ class TnSampleRays(C.Structure):
                 ("directions", _p), ("pixel_area", _p), ("directions_norm", _p)]
 
 
+class TnNextSampling(C.Structure):
+    """include/thermal_nerf_hip.h: the NEXT iteration's sampling front as co-work of this iteration's optimiser launch (TnTrainStep.next_sampling)"""
+    _fields_ = [("fwd_out", _p), ("jitter0", _p), ("jitter1", _p), ("jitter2", _p), ("anneal", _f), ("prop_grad", _i32)]
+
+
 class TnTrainStep(C.Structure):
     """The argument block of tn_train_step: field for field the struct of include/thermal_nerf_hip.h (tests/test_abi_cpu.py compares the two)."""
     _fields_ = [
@@ -86,6 +91,7 @@ class TnTrainStep(C.Structure):
         ("found_inf", _p), ("num_flags", _i32), ("skipped", _p), ("lag_index", _i32),
         ("scale", _p), ("growth_tracker", _p), ("done_counter", _p), ("growth_factor", _d), ("backoff_factor", _d), ("growth_interval", _i32),
         ("next_sample", C.POINTER(TnSampleRays)), ("next_sample_taken", C.POINTER(_i32)),
+        ("next_sampling", C.POINTER(TnNextSampling)), ("next_sampling_taken", C.POINTER(_i32)), ("sampling_done", _i32),
     ]
 
 

@@ -105,6 +105,29 @@ __device__ __forceinline__ int64_t tn_div_index(int64_t i, int64_t d, int64_t to
 // (bid / nblk stand in for blockIdx.x / gridDim.x: tn_spaced_bins launches it alone, tn_pose_spaced_bins as one slice of a launch)
 // One WAVE per ray (bin j = lane + 64 k): the ray's near / far / jitter and their spacings once per ray instead of once per bin (three of the four
 // divisions of a bin were the ray's), consecutive lanes write consecutive bins.  Same expressions per bin as the reference's.
+// the bins of ONE ray by its wave; e_keep (LDS, S + 1 floats) / s_keep (registers, bin j = lane + 64 k) : optional copies for stages that follow in the
+// same wave (tn_next_sampling.h)
+__device__ __forceinline__ void tn_spaced_bins_ray(const float* __restrict__ lin_bins, bool jittered, float jit, float s_near, float s_far, int S,
+                                                   float* __restrict__ sb, float* __restrict__ eb, int lane, float* e_keep = nullptr,
+                                                   float* s_keep = nullptr) {
+#pragma unroll
+  for (int k = 0; k <= TN_MAX_SAMPLES / 64; ++k) {
+    const int j = lane + 64 * k;
+    if (j > S) continue;
+    float b = lin_bins[j];
+    if (jittered) {
+      // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
+      float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
+      float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
+      b = lower + (upper - lower) * jit;
+    }
+    const float e = tn_s_to_euclid(b, s_near, s_far);
+    sb[j] = b;
+    eb[j] = e;
+    if (e_keep != nullptr) e_keep[j] = e;
+    if (s_keep != nullptr) s_keep[k] = b;
+  }
+}
 __device__ __forceinline__ void tn_spaced_bins_body(const float* __restrict__ lin_bins, const float* __restrict__ jitter,
                                                     const float* __restrict__ nears, const float* __restrict__ fars, int64_t N, int S,
                                                     float* __restrict__ s_bins, float* __restrict__ e_bins, int bid, int nblk) {
@@ -112,19 +135,7 @@ __device__ __forceinline__ void tn_spaced_bins_body(const float* __restrict__ li
   for (int64_t ray = (int64_t)bid * wpb + (threadIdx.x >> 6); ray < N; ray += (int64_t)nblk * wpb) {
     const float s_near = tn_spacing(nears[ray]), s_far = tn_spacing(fars[ray]);
     const float jit = jitter != nullptr ? jitter[ray] : 0.0f;
-    float* sb = s_bins + ray * (S + 1);
-    float* eb = e_bins + ray * (S + 1);
-    for (int j = lane; j <= S; j += 64) {
-      float b = lin_bins[j];
-      if (jitter != nullptr) {
-        // bin_centers = (bins[1:]+bins[:-1])/2 ; upper = cat(centers, last) ; lower = cat(first, centers)
-        float lower = (j == 0) ? lin_bins[0] : (lin_bins[j] + lin_bins[j - 1]) / 2.0f;
-        float upper = (j == S) ? lin_bins[S] : (lin_bins[j + 1] + lin_bins[j]) / 2.0f;
-        b = lower + (upper - lower) * jit;
-      }
-      sb[j] = b;
-      eb[j] = tn_s_to_euclid(b, s_near, s_far);
-    }
+    tn_spaced_bins_ray(lin_bins, jitter != nullptr, jit, s_near, s_far, S, s_bins + ray * (S + 1), e_bins + ray * (S + 1), lane);
   }
 }
 
@@ -375,14 +386,27 @@ struct ReplicaK {
 // scratch: tn_scatter_scratch_bytes(N*S, levels) of device memory or NULL (every level then adds straight into the hashed gradient).
 // dense_sum: NULL, or [tn_grid_dense_count(grid, N*S)] float2 that receive the per-cell sums INSTEAD of the hashed gradient (every level
 // of the grid must then be a dense-replica level); tn_grid_dense_fold adds such sums into the hashed gradient later.
-// tn_adam_step_ranges_amp_update with the next iteration's tn_sample_rays in co-work blocks of the launch (next may be NULL)
+// tn_adam_step_ranges_amp_update with the next iteration's tn_sample_rays in co-work blocks of the launch (next may be NULL) -- or, with `chain`,
+// the next iteration's whole sampling front for that batch (tn_next_sampling.h; needs `next`).  su_update = false: no GradScaler.update() in this
+// launch (a launch that is not the iteration's last optimiser launch).
+struct TnNextSamplingHost {
+  const TnPropNet *prop0, *prop1;
+  const float* pose; const uint8_t* frozen; int num_cameras;
+  const float *nears, *fars, *jit0, *jit1, *jit2, *lin0, *lin1, *lin2;
+  float anneal;
+  int S0, S1, S2;
+  int64_t N;
+  float *origins, *directions, *s0, *e0, *d0, *w0, *m0, *s1, *e1, *d1, *w1, *m1, *s2, *e2, *penc0, *penc1;  // the NEXT forward buffer's regions (penc: NULL = not kept)
+};
 int tn_adam_step_ranges_amp_update_cw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                                       const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                                       const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps, const float* inv_scale,
                                       float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped, int32_t lag_index,
                                       int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker, uint32_t* done_counter,
                                       double growth_factor, double backoff_factor, int32_t growth_interval, const TnSampleRays* next, bool* next_taken,
-                                      tn_stream_t stream);
+                                      tn_stream_t stream, const TnNextSamplingHost* chain = nullptr, bool su_update = true);
+// whether the chain supports these sample counts (the lane layouts of the default sampler: 4 / 2 samples per lane on the proposal levels)
+static inline bool tn_next_sampling_supported(int S0, int S1, int S2) { return S0 > 128 && S0 <= 256 && S1 > 64 && S1 <= 128 && S2 >= 1 && S2 <= 256; }
 // internal variants of tn_render_fwd / tn_train_losses for tn_train_step: the batch-wide clip of depth_expected not as a launch of its own behind
 // the renderers but as co-work blocks of the loss launch that follows (tn_sampler.hip)
 int tn_render_fwd_ex(const float* e_bins, const float* density, const float* rgb, int64_t N, int32_t S, int32_t C, int32_t training, float* weights,

@@ -105,7 +105,7 @@ extern "C" int tn_shutdown(void) {
   return rc;
 }
 
-extern "C" int tn_version(void) { return 305; }  // 305 (round 5): TnSampleRays, TnTrainStep::next_sample; 304: tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
+extern "C" int tn_version(void) { return 306; }  // 306 (round 6): TnNextSampling, TnTrainStep::next_sampling / sampling_done; 305 (round 5): TnSampleRays, TnTrainStep::next_sample; 304: tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
   TN_REQUIRE(ptr != nullptr && bytes >= 0, "tn_fill_zero: bad argument");
@@ -298,55 +298,65 @@ __global__ void k_raygen(const int64_t* __restrict__ ray_indices, RaygenArgs g, 
 // FOUR lanes per ray: lane q of the quad runs the Newton undistortion of coordinate q (the pixel, its +1-column and its +1-row neighbour, which
 // only serve pixel_area; lane 3 idles) -- one thread per ray ran the three chains one after the other, ~2 000 dependent instructions on 64 waves
 // that each have a SIMD to themselves.  Same expressions per coordinate as raygen_compute.
-__device__ __forceinline__ void sample_rays_body(const SamplePixelsArgs& a, const RaygenArgs& g, unsigned bid, unsigned nblk) {
-  const int lane = threadIdx.x & 63, q = lane & 3, quad0 = lane & ~3;
-  for (int64_t t = bid * (int64_t)blockDim.x + threadIdx.x; t < a.N * 4; t += (int64_t)nblk * blockDim.x) {  // (whole quads: blockDim % 4 == 0)
-    const int64_t r = t >> 2;
-    // two rounds of loads (index data; then the pixel and the camera's parameters together), then arithmetic and stores
-    const PixelPick p = sample_pixel_pick(a, r);
-    const float c0 = p.px[0], c1 = p.px[1], c2 = p.px[2];
-    int64_t cam = p.cam;
-    CamParams cp;
-    raygen_load(g, cam, cp);
-    if (q == 0) sample_pixel_store(a, r, p, c0, c1, c2);
-    const float y = (float)p.y + 0.5f, x = (float)p.x + 0.5f;  // get_image_coords(pixel_offset=0.5)
-    // coord, coord_x_offset, coord_y_offset
-    float ua = (q == 1) ? (x - cp.cx + 1.0f) / cp.fx : (x - cp.cx) / cp.fx;
-    float vb = (q == 2) ? (y - cp.cy + 1.0f) / cp.fy : (y - cp.cy) / cp.fy;
-    float dir[3] = {0.f, 0.f, 0.f}, nrm = 0.0f;
-    const int nq = g.pixel_area ? 3 : 1;
-    if (q < nq) {
-      float aa = ua, bb = vb;
-      if (g.any_distortion) undistort(aa, bb, cp.k, aa, bb);
-      bb = -bb;  // OpenCV -> OpenGL
-      const float dz = -1.0f;
-      const float* R = cp.R;
-      float w0 = aa * R[0] + bb * R[1] + dz * R[2];
-      float w1 = aa * R[4] + bb * R[5] + dz * R[6];
-      float w2 = aa * R[8] + bb * R[9] + dz * R[10];
-      float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
-      n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
-      dir[0] = w0 / n; dir[1] = w1 / n; dir[2] = w2 / n;
-      nrm = n;
-    }
-    float d1[3], d2[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { d1[c] = __shfl(dir[c], quad0 + 1, 64); d2[c] = __shfl(dir[c], quad0 + 2, 64); }
-    if (q == 0) {
-      g.origins[r * 3 + 0] = cp.R[3]; g.origins[r * 3 + 1] = cp.R[7]; g.origins[r * 3 + 2] = cp.R[11];
-      g.directions[r * 3 + 0] = dir[0]; g.directions[r * 3 + 1] = dir[1]; g.directions[r * 3 + 2] = dir[2];
-      if (g.pixel_area) {
-        float ddx = 0.0f, ddy = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float da = dir[c] - d1[c], db = dir[c] - d2[c];
-          ddx += da * da; ddy += db * db;
-        }
-        g.pixel_area[r] = sqrtf(ddx) * sqrtf(ddy);
-      }
-      if (g.directions_norm) g.directions_norm[r] = nrm;
-    }
+// ray r by the quad of lanes this lane belongs to (q = lane & 3); `store`: this lane writes the ray's outputs (a q == 0 lane).  Returns the ray
+// (origin, direction, camera; the direction is valid in q == 0 lanes) for a caller that goes on with it (tn_next_sampling.h).
+struct SampledRay { float o[3], d[3]; int64_t cam; };
+__device__ __forceinline__ SampledRay sample_ray_quad(const SamplePixelsArgs& a, const RaygenArgs& g, int64_t r, int lane, bool store) {
+  const int q = lane & 3, quad0 = lane & ~3;
+  // two rounds of loads (index data; then the pixel and the camera's parameters together), then arithmetic and stores
+  const PixelPick p = sample_pixel_pick(a, r);
+  const float c0 = p.px[0], c1 = p.px[1], c2 = p.px[2];
+  int64_t cam = p.cam;
+  CamParams cp;
+  raygen_load(g, cam, cp);
+  if (store) sample_pixel_store(a, r, p, c0, c1, c2);
+  const float y = (float)p.y + 0.5f, x = (float)p.x + 0.5f;  // get_image_coords(pixel_offset=0.5)
+  // coord, coord_x_offset, coord_y_offset
+  float ua = (q == 1) ? (x - cp.cx + 1.0f) / cp.fx : (x - cp.cx) / cp.fx;
+  float vb = (q == 2) ? (y - cp.cy + 1.0f) / cp.fy : (y - cp.cy) / cp.fy;
+  float dir[3] = {0.f, 0.f, 0.f}, nrm = 0.0f;
+  const int nq = g.pixel_area ? 3 : 1;
+  if (q < nq) {
+    float aa = ua, bb = vb;
+    if (g.any_distortion) undistort(aa, bb, cp.k, aa, bb);
+    bb = -bb;  // OpenCV -> OpenGL
+    const float dz = -1.0f;
+    const float* R = cp.R;
+    float w0 = aa * R[0] + bb * R[1] + dz * R[2];
+    float w1 = aa * R[4] + bb * R[5] + dz * R[6];
+    float w2 = aa * R[8] + bb * R[9] + dz * R[10];
+    float n = sqrtf(w0 * w0 + w1 * w1 + w2 * w2);
+    n = fmaxf(n, 8.881784197001252e-16f);  // np.finfo(float).eps * 4
+    dir[0] = w0 / n; dir[1] = w1 / n; dir[2] = w2 / n;
+    nrm = n;
   }
+  float d1[3], d2[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { d1[c] = __shfl(dir[c], quad0 + 1, 64); d2[c] = __shfl(dir[c], quad0 + 2, 64); }
+  if (store) {
+    g.origins[r * 3 + 0] = cp.R[3]; g.origins[r * 3 + 1] = cp.R[7]; g.origins[r * 3 + 2] = cp.R[11];
+    g.directions[r * 3 + 0] = dir[0]; g.directions[r * 3 + 1] = dir[1]; g.directions[r * 3 + 2] = dir[2];
+    if (g.pixel_area) {
+      float ddx = 0.0f, ddy = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float da = dir[c] - d1[c], db = dir[c] - d2[c];
+        ddx += da * da; ddy += db * db;
+      }
+      g.pixel_area[r] = sqrtf(ddx) * sqrtf(ddy);
+    }
+    if (g.directions_norm) g.directions_norm[r] = nrm;
+  }
+  SampledRay out;
+  out.o[0] = cp.R[3]; out.o[1] = cp.R[7]; out.o[2] = cp.R[11];
+  out.d[0] = dir[0]; out.d[1] = dir[1]; out.d[2] = dir[2];
+  out.cam = p.cam;  // (as stored: the caller clamps it against ITS table, like the kernels that read camera_indices)
+  return out;
+}
+__device__ __forceinline__ void sample_rays_body(const SamplePixelsArgs& a, const RaygenArgs& g, unsigned bid, unsigned nblk) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t t = bid * (int64_t)blockDim.x + threadIdx.x; t < a.N * 4; t += (int64_t)nblk * blockDim.x)  // (whole quads: blockDim % 4 == 0)
+    sample_ray_quad(a, g, t >> 2, lane, (lane & 3) == 0);
 }
 __global__ void k_sample_rays(SamplePixelsArgs a, RaygenArgs g) { sample_rays_body(a, g, blockIdx.x, gridDim.x); }
 
@@ -428,6 +438,21 @@ __device__ __forceinline__ Pose pose_exp(const float* __restrict__ p) {
   return o;
 }
 
+// one ray: prow = the camera's pose row, is_frozen = a non-trainable camera (identity)
+__device__ __forceinline__ void pose_apply_ray(const float (&prow)[6], bool is_frozen, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               float (&o)[3], float (&d)[3]) {
+  if (is_frozen) {
+    // identity transform: origins + 0, bmm(I, d)
+    o[0] = ox + 0.0f; o[1] = oy + 0.0f; o[2] = oz + 0.0f;
+    d[0] = dx; d[1] = dy; d[2] = dz;
+    return;
+  }
+  Pose p = pose_exp(prow);
+  o[0] = ox + p.t[0]; o[1] = oy + p.t[1]; o[2] = oz + p.t[2];
+  d[0] = p.R[0] * dx + p.R[1] * dy + p.R[2] * dz;
+  d[1] = p.R[3] * dx + p.R[4] * dy + p.R[5] * dz;
+  d[2] = p.R[6] * dx + p.R[7] * dy + p.R[8] * dz;
+}
 __device__ __forceinline__ void pose_fwd_body(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
                                               const float* __restrict__ o_in, const float* __restrict__ d_in, int64_t N, int C,
                                               float* __restrict__ o_out, float* __restrict__ d_out, int bid, int nblk) {
@@ -440,17 +465,10 @@ __device__ __forceinline__ void pose_fwd_body(const float* __restrict__ pose, co
     float prow[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) prow[q] = pose[cam * 6 + q];
-    if (frozen != nullptr && frozen[cam]) {
-      // identity transform: origins + 0, bmm(I, d)
-      o_out[i * 3] = ox + 0.0f; o_out[i * 3 + 1] = oy + 0.0f; o_out[i * 3 + 2] = oz + 0.0f;
-      d_out[i * 3] = dx; d_out[i * 3 + 1] = dy; d_out[i * 3 + 2] = dz;
-      continue;
-    }
-    Pose p = pose_exp(prow);
-    o_out[i * 3] = ox + p.t[0]; o_out[i * 3 + 1] = oy + p.t[1]; o_out[i * 3 + 2] = oz + p.t[2];
-    d_out[i * 3 + 0] = p.R[0] * dx + p.R[1] * dy + p.R[2] * dz;
-    d_out[i * 3 + 1] = p.R[3] * dx + p.R[4] * dy + p.R[5] * dz;
-    d_out[i * 3 + 2] = p.R[6] * dx + p.R[7] * dy + p.R[8] * dz;
+    float o[3], d[3];
+    pose_apply_ray(prow, frozen != nullptr && frozen[cam], ox, oy, oz, dx, dy, dz, o, d);
+    o_out[i * 3] = o[0]; o_out[i * 3 + 1] = o[1]; o_out[i * 3 + 2] = o[2];
+    d_out[i * 3] = d[0]; d_out[i * 3 + 1] = d[1]; d_out[i * 3 + 2] = d[2];
   }
 }
 __global__ void k_pose_fwd(const float* __restrict__ pose, const uint8_t* __restrict__ frozen, const int64_t* __restrict__ cam_idx,
@@ -978,20 +996,12 @@ __device__ __forceinline__ void adam_block_done(const ScalerUpdate& su, float* f
   }
 }
 struct SampleCoWork { SamplePixelsArgs a; RaygenArgs g; int blocks; };
-__global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
-                                  double beta1, double beta2, float eps, const float* __restrict__ inv_scale, float* __restrict__ found_inf,
-                                  int32_t* __restrict__ skipped, int count_skip, int zero_g, ScalerUpdate su, SampleCoWork cw) {
-  int k = blockIdx.y;
-  if (cw.blocks > 0) {
-    // co-work row (row 0, dispatched first): the NEXT iteration's pixel sampling + ray generation -- a short latency-bound pass beside this
-    // HBM-bound one, instead of 7 us at the head of the next iteration.  Its blocks count themselves in like every block of the launch.
-    if (k == 0) {
-      if (blockIdx.x < (unsigned)cw.blocks) sample_rays_body(cw.a, cw.g, blockIdx.x, (unsigned)cw.blocks);
-      adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
-      return;
-    }
-    --k;
-  }
+#include "tn_next_sampling.h"
+// one block of range k of the launch
+__device__ __forceinline__ void adam_range_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                const AdamRangesAmp& r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
+                                                float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g, const ScalerUpdate& su,
+                                                int k) {
   const int fl = r.flag[k];
   float* gz = const_cast<float*>(g);  // zero_g: the gradients are consumed (set to zero behind the read): no zero-fill launch before the next backward
   // schedule lag = iterations so far in which the scale dropped; maintained by tn_grad_scaler_update AFTER this launch (stream order)
@@ -1077,12 +1087,47 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
 #undef ADAM1
   adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
+__global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
+                                  double beta1, double beta2, float eps, const float* __restrict__ inv_scale, float* __restrict__ found_inf,
+                                  int32_t* __restrict__ skipped, int count_skip, int zero_g, ScalerUpdate su, SampleCoWork cw) {
+  int k = blockIdx.y;
+  if (cw.blocks > 0) {
+    // co-work row (row 0, dispatched first): the NEXT iteration's pixel sampling + ray generation -- a short latency-bound pass beside this
+    // HBM-bound one, instead of 7 us at the head of the next iteration.  Its blocks count themselves in like every block of the launch.
+    if (k == 0) {
+      if (blockIdx.x < (unsigned)cw.blocks) sample_rays_body(cw.a, cw.g, blockIdx.x, (unsigned)cw.blocks);
+      adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
+      return;
+    }
+    --k;
+  }
+  adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, k);
+}
+// The same launch with the NEXT iteration's whole sampling front (tn_next_sampling.h) in its co-work row: batch + pose correction + both proposal
+// levels, one wave per ray.  A kernel of its own: the chain's registers and 18 KB of LDS per block would otherwise be every Adam launch's.
+__global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                              AdamRangesAmp r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
+                                                              float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g,
+                                                              ScalerUpdate su, SampleCoWork cw, NextSamplingArgs ns) {
+  __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
+  if (blockIdx.y == 0) {
+    if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body(ns, cw.a, cw.g, blockIdx.x, (unsigned)ns.blocks, ns_lds);
+    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
+    return;
+  }
+  adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, (int)blockIdx.y - 1);
+}
+// (the chain alone, for register accounting and A/B timing: TN_NEXT_SAMPLING=2 launches it behind the optimiser launch instead of inside it)
+__global__ void __launch_bounds__(256) k_next_sampling(SampleCoWork cw, NextSamplingArgs ns) {
+  __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
+  next_sampling_body(ns, cw.a, cw.g, blockIdx.x, gridDim.x, ns_lds);
+}
 static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                                const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
                                const int32_t* sched_max_steps, int32_t sched_step, double beta1, double beta2, double eps,
                                const float* inv_scale, const float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped,
                                int32_t lag_index, int32_t count_skip, int32_t zero_grads, ScalerUpdate su, tn_stream_t stream,
-                               const TnSampleRays* next = nullptr, bool* next_taken = nullptr) {
+                               const TnSampleRays* next = nullptr, bool* next_taken = nullptr, const TnNextSamplingHost* chain = nullptr) {
   if (next_taken) *next_taken = false;
   if (num_ranges == 0) return TN_OK;
   TN_REQUIRE(params && grads && exp_avg && exp_avg_sq && offsets && counts && steps && lrs, "tn_adam_step_ranges_amp: null pointer");
@@ -1117,6 +1162,47 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
     cw.blocks = (int)std::min<int64_t>(tn_cdiv(next->num_rays * 4, 256), grid);  // 4 lanes per ray; the row has `grid` blocks
     if (next_taken) *next_taken = true;
   }
+  if (chain != nullptr) {
+    // the next iteration's sampling front for the batch `next` describes: one wave per ray, 4 rays per block and trip
+    TN_REQUIRE(cw.blocks > 0 && next->num_rays == chain->N, "tn_train_step(next_sampling): needs next_sample with the same number of rays");
+    TN_REQUIRE(tn_next_sampling_supported(chain->S0, chain->S1, chain->S2), "tn_train_step(next_sampling): unsupported sample counts (%d, %d, %d)", chain->S0,
+               chain->S1, chain->S2);
+    TN_REQUIRE(chain->prop0 && chain->prop1 && chain->pose && chain->nears && chain->fars && chain->lin0 && chain->lin1 && chain->lin2 && chain->origins &&
+                   chain->directions && chain->s0 && chain->e0 && chain->d0 && chain->w0 && chain->m0 && chain->s1 && chain->e1 && chain->d1 && chain->w1 &&
+                   chain->m1 && chain->s2 && chain->e2 && chain->num_cameras >= 1,
+               "tn_train_step(next_sampling): null pointer");
+    TN_REQUIRE(chain->prop0->grid.num_levels == PL && chain->prop1->grid.num_levels == PL && chain->prop0->grid.log2_hashmap_size >= 1 &&
+                   chain->prop0->grid.log2_hashmap_size <= 24 && chain->prop1->grid.log2_hashmap_size >= 1 && chain->prop1->grid.log2_hashmap_size <= 24,
+               "tn_train_step(next_sampling): proposal grids are built for %d levels", PL);
+    NextSamplingArgs ns{};
+    ns.p0 = PropK{make_gridk(chain->prop0->grid), chain->prop0->w0, chain->prop0->b0, chain->prop0->w1, chain->prop0->b1, nullptr, nullptr, nullptr, nullptr};
+    ns.p1 = PropK{make_gridk(chain->prop1->grid), chain->prop1->w0, chain->prop1->b0, chain->prop1->w1, chain->prop1->b1, nullptr, nullptr, nullptr, nullptr};
+    ns.pose = chain->pose; ns.frozen = chain->frozen; ns.num_cameras = chain->num_cameras;
+    ns.nears = chain->nears; ns.fars = chain->fars;
+    ns.jit0 = chain->jit0; ns.jit1 = chain->jit1; ns.jit2 = chain->jit2;
+    ns.lin0 = chain->lin0; ns.lin1 = chain->lin1; ns.lin2 = chain->lin2;
+    ns.anneal = chain->anneal;
+    ns.S0 = chain->S0; ns.S1 = chain->S1; ns.S2 = chain->S2; ns.N = chain->N;
+    ns.origins = chain->origins; ns.directions = chain->directions;
+    ns.s0 = chain->s0; ns.e0 = chain->e0; ns.d0 = chain->d0; ns.w0 = chain->w0; ns.m0 = chain->m0;
+    ns.s1 = chain->s1; ns.e1 = chain->e1; ns.d1 = chain->d1; ns.w1 = chain->w1; ns.m1 = chain->m1;
+    ns.s2 = chain->s2; ns.e2 = chain->e2; ns.penc0 = chain->penc0; ns.penc1 = chain->penc1;
+    ns.blocks = (int)std::min<int64_t>(tn_cdiv(chain->N, 4), grid);
+    const char* mode = getenv("TN_NEXT_SAMPLING");
+    if (mode && mode[0] == '2') {  // A/B timing: the chain as a launch of its own behind the optimiser launch (same results)
+      SampleCoWork none{};
+      hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
+                         const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, none);
+      TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
+      hipLaunchKernelGGL(k_next_sampling, dim3(ns.blocks), dim3(256), 0, tn_s(stream), cw, ns);
+      TN_CHECK_LAUNCH("tn_next_sampling");
+      return TN_OK;
+    }
+    hipLaunchKernelGGL(k_adam_ranges_amp_next, dim3(grid, n + 1), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps,
+                       inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, cw, ns);
+    TN_CHECK_LAUNCH("tn_adam_step_ranges_amp(next_sampling)");
+    return TN_OK;
+  }
   hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n + (cw.blocks > 0 ? 1 : 0)), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2,
                      (float)eps, inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, cw);
   TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
@@ -1150,12 +1236,13 @@ int tn_adam_step_ranges_amp_update_cw(float* params, const float* grads, float* 
                                       float* found_inf, const int32_t* flag_index, int32_t num_flags, int32_t* skipped, int32_t lag_index,
                                       int32_t count_skip, int32_t zero_grads, float* scale, int32_t* growth_tracker, uint32_t* done_counter,
                                       double growth_factor, double backoff_factor, int32_t growth_interval, const TnSampleRays* next, bool* next_taken,
-                                      tn_stream_t stream) {
+                                      tn_stream_t stream, const TnNextSamplingHost* chain, bool su_update) {
   TN_REQUIRE(found_inf && scale && growth_tracker && done_counter && growth_interval >= 1, "tn_adam_step_ranges_amp_update: bad scaler arguments");
   TN_REQUIRE(num_ranges > 0, "tn_adam_step_ranges_amp_update: the fused scale update needs at least one range (use tn_grad_scaler_update otherwise)");
   ScalerUpdate su{scale, growth_tracker, done_counter, (float)growth_factor, (float)backoff_factor, (int32_t)growth_interval};
   return adam_ranges_amp_impl(params, grads, exp_avg, exp_avg_sq, num_ranges, offsets, counts, steps, lrs, lr_finals, sched_max_steps, sched_step, beta1, beta2,
-                              eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, su, stream, next, next_taken);
+                              eps, inv_scale, found_inf, flag_index, num_flags, skipped, lag_index, count_skip, zero_grads, su_update ? su : ScalerUpdate{}, stream,
+                              next, next_taken, chain);
 }
 
 // GradScaler.update() (torch/amp/grad_scaler.py -> amp_update_scale_cuda_kernel) for the fused step, one thread: backoff when any of the

@@ -113,7 +113,7 @@ static int render_rays_train_impl(const TnPropNet* prop0, const TnPropNet* prop1
                                   int32_t S2, float anneal, const float* jitter0, const float* jitter1, const float* jitter2,
                                   const float* lin_spaced0, const float* lin_pdf1, const float* lin_pdf2, void* field_workspace,
                                   int64_t field_workspace_bytes, float* out, void* wait_event_before_field, void* zero_fill, int64_t zero_fill_bytes,
-                                  int32_t save_prop_enc, int with_render, int* clip_nblk, tn_stream_t stream) {
+                                  int32_t save_prop_enc, int with_render, int* clip_nblk, tn_stream_t stream, bool sampling_done = false) {
   if (clip_nblk) *clip_nblk = 0;
   if (N == 0) return TN_OK;  // empty batches are valid and touch nothing
   TN_REQUIRE(prop0 && prop1 && field && origins_in && directions_in && camera_indices && nears && fars && lin_spaced0 && lin_pdf1 && lin_pdf2 &&
@@ -129,25 +129,31 @@ static int render_rays_train_impl(const TnPropNet* prop0, const TnPropNet* prop1
   const float* o = origins_in;
   const float* d = directions_in;
   int rc;
-  if (pose_adjustment != nullptr) {  // CameraOptimizer.apply_to_raybundle and the first sampler level: independent, one launch
-    TN_REQUIRE(num_cameras >= 1, "tn_render_rays_train: bad num_cameras=%d", num_cameras);
-    if ((rc = tn_pose_spaced_bins(pose_adjustment, frozen, camera_indices, origins_in, directions_in, N, num_cameras, at(TRO_ORIGINS), at(TRO_DIRECTIONS),
-                                  lin_spaced0, jitter0, nears, fars, S0, at(TRO_S0), at(TRO_E0), stream)))
+  if (sampling_done) {
+    // the previous iteration's optimiser launch ran this batch's sampling front in its co-work blocks (TnTrainStep::next_sampling): pose-corrected
+    // rays, all three levels' bins, both proposal levels' densities / weights / median depths (and encodings) are in `out` already
+    if (pose_adjustment != nullptr) { o = at(TRO_ORIGINS); d = at(TRO_DIRECTIONS); }
+  } else {
+    if (pose_adjustment != nullptr) {  // CameraOptimizer.apply_to_raybundle and the first sampler level: independent, one launch
+      TN_REQUIRE(num_cameras >= 1, "tn_render_rays_train: bad num_cameras=%d", num_cameras);
+      if ((rc = tn_pose_spaced_bins(pose_adjustment, frozen, camera_indices, origins_in, directions_in, N, num_cameras, at(TRO_ORIGINS), at(TRO_DIRECTIONS),
+                                    lin_spaced0, jitter0, nears, fars, S0, at(TRO_S0), at(TRO_E0), stream)))
+        return rc;
+      o = at(TRO_ORIGINS);
+      d = at(TRO_DIRECTIONS);
+    } else if ((rc = tn_spaced_bins(lin_spaced0, jitter0, nears, fars, N, S0, at(TRO_S0), at(TRO_E0), stream))) {
       return rc;
-    o = at(TRO_ORIGINS);
-    d = at(TRO_DIRECTIONS);
-  } else if ((rc = tn_spaced_bins(lin_spaced0, jitter0, nears, fars, N, S0, at(TRO_S0), at(TRO_E0), stream))) {
-    return rc;
+    }
+    // save_prop_enc: the proposal networks take a gradient this iteration -- their encodings are kept for tn_render_rays_train_bwd
+    if ((rc = tn_prop_density_fwd_ex(prop0, o, d, at(TRO_E0), N, S0, at(TRO_D0), save_prop_enc ? at(TRO_PENC0) : nullptr, stream))) return rc;
+    if ((rc = tn_weights_resample(at(TRO_E0), at(TRO_D0), at(TRO_S0), S0, anneal, lin_pdf1, jitter1, nears, fars, N, S1, at(TRO_W0), at(TRO_M0), at(TRO_S1),
+                                  at(TRO_E1), stream)))
+      return rc;
+    if ((rc = tn_prop_density_fwd_ex(prop1, o, d, at(TRO_E1), N, S1, at(TRO_D1), save_prop_enc ? at(TRO_PENC1) : nullptr, stream))) return rc;
+    if ((rc = tn_weights_resample(at(TRO_E1), at(TRO_D1), at(TRO_S1), S1, anneal, lin_pdf2, jitter2, nears, fars, N, S2, at(TRO_W1), at(TRO_M1), at(TRO_S2),
+                                  at(TRO_E2), stream)))
+      return rc;
   }
-  // save_prop_enc: the proposal networks take a gradient this iteration -- their encodings are kept for tn_render_rays_train_bwd
-  if ((rc = tn_prop_density_fwd_ex(prop0, o, d, at(TRO_E0), N, S0, at(TRO_D0), save_prop_enc ? at(TRO_PENC0) : nullptr, stream))) return rc;
-  if ((rc = tn_weights_resample(at(TRO_E0), at(TRO_D0), at(TRO_S0), S0, anneal, lin_pdf1, jitter1, nears, fars, N, S1, at(TRO_W0), at(TRO_M0), at(TRO_S1),
-                                at(TRO_E1), stream)))
-    return rc;
-  if ((rc = tn_prop_density_fwd_ex(prop1, o, d, at(TRO_E1), N, S1, at(TRO_D1), save_prop_enc ? at(TRO_PENC1) : nullptr, stream))) return rc;
-  if ((rc = tn_weights_resample(at(TRO_E1), at(TRO_D1), at(TRO_S1), S1, anneal, lin_pdf2, jitter2, nears, fars, N, S2, at(TRO_W1), at(TRO_M1), at(TRO_S2),
-                                at(TRO_E2), stream)))
-    return rc;
   if (wait_event_before_field != nullptr) {
     // the previous iteration's Adam launch over the field's parameters may still be running on another stream (it overlaps the proposal
     // sampling above, which only reads the proposal networks): the field's first read of its parameters waits for it here
@@ -299,6 +305,21 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
                  (long long)a->prop_workspace_bytes1, (long long)need0, (long long)need1);
     }
   }
+  if (a->next_sampling_taken) *a->next_sampling_taken = 0;
+  if (a->next_sample != nullptr && a->num_ranges > 0) {  // what the optimiser launch's co-work would refuse, refused here too
+    const TnSampleRays* s = a->next_sample;
+    TN_REQUIRE(s->num_rays >= 0 && s->num_images >= 1 && s->patch_size >= 1 && s->patch_size <= 8, "tn_train_step(next_sample): bad num_rays=%lld num_images=%d patch_size=%d",
+               (long long)s->num_rays, s->num_images, s->patch_size);
+    if (s->num_rays > 0) {
+      const int64_t pp = (int64_t)s->patch_size * s->patch_size, per = ((s->num_rays / s->num_images) / pp) * pp, last = s->num_rays - (int64_t)(s->num_images - 1) * per;
+      TN_REQUIRE(last > 0 && last % pp == 0, "tn_train_step(next_sample): %lld rays over %d images do not split into whole patches", (long long)s->num_rays, s->num_images);
+      TN_REQUIRE(s->images && s->image_offsets && s->heights && s->widths && s->is_thermal && s->image_idx && s->u && s->ray_indices && s->image &&
+                     s->is_thermal_out && s->c2w && s->fx && s->fy && s->cx && s->cy && s->origins && s->directions && s->num_cameras >= 1,
+                 "tn_train_step(next_sample): null pointer / bad camera arguments");
+    }
+  }
+  if (a->next_sampling != nullptr) TN_REQUIRE(a->next_sampling->fwd_out != nullptr && ((uintptr_t)a->next_sampling->fwd_out % 256) == 0,
+                                              "tn_train_step(next_sampling): the next forward buffer must be given and 256-byte aligned");
   int64_t off[TRO_COUNT];
   train_layout(a->N, a->S0, a->S1, a->S2, C, off);
   int rc;
@@ -311,7 +332,7 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   if ((rc = render_rays_train_impl(a->prop0, a->prop1, a->field, a->pose_adjustment, a->frozen, a->num_cameras, a->origins_in, a->directions_in,
                                    a->camera_indices, a->nears, a->fars, a->N, a->S0, a->S1, a->S2, a->anneal, a->jitter0, a->jitter1, a->jitter2,
                                    a->lin_spaced0, a->lin_pdf1, a->lin_pdf2, a->field_workspace, a->field_workspace_bytes, a->fwd_out, nullptr, a->acc,
-                                   a->acc_bytes, a->prop_grad ? 1 : 0, fuse_render ? 0 : 2, &clip_nblk, stream)))
+                                   a->acc_bytes, a->prop_grad ? 1 : 0, fuse_render ? 0 : 2, &clip_nblk, stream, a->sampling_done != 0)))
     return rc;
   float* out = a->fwd_out;
   const float* sprop[2] = {out + off[TRO_S0], out + off[TRO_S1]};
@@ -362,10 +383,66 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   }
   if (a->num_ranges == 0) return TN_OK;
   bool taken = false;
-  rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
-                                         a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,
-                                         a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter, a->growth_factor, a->backoff_factor,
-                                         a->growth_interval, a->next_sample, &taken, stream);
+  // The next iteration's sampling front as co-work (TnTrainStep::next_sampling): the ranges it READS -- whatever holds the proposal networks or the
+  // pose corrections -- are stepped first, in a launch of their own (a few MB); the launch that carries the chain steps the rest (the field).
+  const TnNextSampling* nx = a->next_sampling;
+  const char* nse = getenv("TN_NEXT_SAMPLING");
+  bool chain = nx != nullptr && a->next_sample != nullptr && a->next_sample->num_rays == a->N && tn_next_sampling_supported(a->S0, a->S1, a->S2) &&
+               !(nse && nse[0] == '0');
+  int first[TN_TRAIN_STEP_MAX_RANGES], nfirst = 0, rest[TN_TRAIN_STEP_MAX_RANGES], nrest = 0;
+  if (chain) {
+    const float* reads[] = {a->prop0->grid.table, a->prop0->w0, a->prop0->b0, a->prop0->w1, a->prop0->b1, a->prop1->grid.table, a->prop1->w0,
+                            a->prop1->b0, a->prop1->w1, a->prop1->b1, a->pose_adjustment};
+    for (int k = 0; k < a->num_ranges; ++k) {
+      const float *lo = a->params + a->offsets[k], *hi = lo + a->counts[k];
+      bool hit = false;
+      for (const float* q : reads) hit = hit || (q >= lo && q < hi);
+      if (hit) first[nfirst++] = k; else if (a->counts[k] > 0) rest[nrest++] = k;
+    }
+    chain = nrest > 0;  // (nothing left to run beside: one launch, no chain)
+  }
+  if (!chain) {
+    rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
+                                           a->sched_max_steps, a->sched_step, a->beta1, a->beta2, a->eps, nullptr, a->found_inf, a->flag_index, a->num_flags,
+                                           a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter, a->growth_factor, a->backoff_factor,
+                                           a->growth_interval, a->next_sample, &taken, stream);
+  } else {
+    auto sub = [&](const int* idx, int n, int64_t* o, int64_t* c, int32_t* s, double* l, double* lf, int32_t* ms, int32_t* fl) {
+      for (int i = 0; i < n; ++i) {
+        const int k = idx[i];
+        o[i] = a->offsets[k]; c[i] = a->counts[k]; s[i] = a->steps[k]; l[i] = a->lrs[k]; lf[i] = a->lr_finals[k]; ms[i] = a->sched_max_steps[k]; fl[i] = a->flag_index[k];
+      }
+    };
+    int64_t o[TN_TRAIN_STEP_MAX_RANGES], c[TN_TRAIN_STEP_MAX_RANGES];
+    int32_t s[TN_TRAIN_STEP_MAX_RANGES], ms[TN_TRAIN_STEP_MAX_RANGES], fl[TN_TRAIN_STEP_MAX_RANGES];
+    double l[TN_TRAIN_STEP_MAX_RANGES], lf[TN_TRAIN_STEP_MAX_RANGES];
+    rc = TN_OK;
+    if (nfirst > 0) {  // (reads found_inf / the schedule lag like the second launch; GradScaler.update() comes with the second)
+      sub(first, nfirst, o, c, s, l, lf, ms, fl);
+      rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, nfirst, o, c, s, l, lf, ms, a->sched_step, a->beta1, a->beta2, a->eps,
+                                             nullptr, a->found_inf, fl, a->num_flags, a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter,
+                                             a->growth_factor, a->backoff_factor, a->growth_interval, nullptr, nullptr, stream, nullptr, false);
+    }
+    if (!rc) {
+      float* nout = nx->fwd_out;
+      auto at = [&](int slot) { return nout + off[slot]; };
+      TnNextSamplingHost h{};
+      h.prop0 = a->prop0; h.prop1 = a->prop1; h.pose = a->pose_adjustment; h.frozen = a->frozen; h.num_cameras = a->num_cameras;
+      h.nears = a->nears; h.fars = a->fars; h.jit0 = nx->jitter0; h.jit1 = nx->jitter1; h.jit2 = nx->jitter2;
+      h.lin0 = a->lin_spaced0; h.lin1 = a->lin_pdf1; h.lin2 = a->lin_pdf2; h.anneal = nx->anneal;
+      h.S0 = a->S0; h.S1 = a->S1; h.S2 = a->S2; h.N = a->N;
+      h.origins = at(TRO_ORIGINS); h.directions = at(TRO_DIRECTIONS);
+      h.s0 = at(TRO_S0); h.e0 = at(TRO_E0); h.d0 = at(TRO_D0); h.w0 = at(TRO_W0); h.m0 = at(TRO_M0);
+      h.s1 = at(TRO_S1); h.e1 = at(TRO_E1); h.d1 = at(TRO_D1); h.w1 = at(TRO_W1); h.m1 = at(TRO_M1);
+      h.s2 = at(TRO_S2); h.e2 = at(TRO_E2);
+      h.penc0 = nx->prop_grad ? at(TRO_PENC0) : nullptr; h.penc1 = nx->prop_grad ? at(TRO_PENC1) : nullptr;
+      sub(rest, nrest, o, c, s, l, lf, ms, fl);
+      rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, nrest, o, c, s, l, lf, ms, a->sched_step, a->beta1, a->beta2, a->eps,
+                                             nullptr, a->found_inf, fl, a->num_flags, a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter,
+                                             a->growth_factor, a->backoff_factor, a->growth_interval, a->next_sample, &taken, stream, &h, true);
+      if (!rc && a->next_sampling_taken) *a->next_sampling_taken = 1;
+    }
+  }
   if (a->next_sample_taken) *a->next_sample_taken = taken ? 1 : 0;
   return rc;
 }

@@ -4,30 +4,7 @@
 // Consecutive lanes are consecutive samples of one ray, so neighbouring lanes hit the same / adjacent grid cells on the
 // coarse levels (gathers coalesce in the texture-address unit) and the 772 B of MLP weights are wave-uniform scalar loads.
 #include "tn_common.h"
-
-#define PL 5     // levels
-#define PF 10    // PL * 2 features
-#define PH 16    // hidden width
-#define PROP_NW (PH * PF + PH + PH + 1)  // 193 weights: w0[16][10], b0[16], w1[16], b1
-
-struct PropK {
-  GridK g;
-  const float *w0, *b0, *w1, *b1;
-  float *gw0, *gb0, *gw1, *gb1;
-};
-
-// The 193 weights as rows of 12 floats per hidden unit, [w0[j][0..9] | b0[j] | w1[j]], staged in LDS once per block and read as three
-// broadcast ds_read_b128 per hidden unit (all lanes one address: no bank conflicts).  Read through the kernel's pointers they end up as
-// ~200 scalar registers the compiler spills into VGPR lanes: 698 v_readlane per sample made the kernel VALU-bound (45 us at level 0).
-#define PROP_WROW 12
-__device__ __forceinline__ void prop_stage_weights(const PropK& net, float* s_w) {  // s_w: PH * PROP_WROW + 4 floats, 16-B aligned
-  for (int t = threadIdx.x; t < PH * PROP_WROW; t += blockDim.x) {
-    const int j = t / PROP_WROW, k = t - j * PROP_WROW;
-    s_w[t] = k < PF ? net.w0[j * PF + k] : (k == PF ? net.b0[j] : net.w1[j]);
-  }
-  if (threadIdx.x == 0) s_w[PH * PROP_WROW] = net.b1[0];
-  __syncthreads();
-}
+#include "tn_prop_point.h"
 
 // SAVE_ENC (training iterations in which the proposal networks take a gradient): the 10 encoding features of every sample are kept
 // (level-major [5][P] float2) so that k_prop_bwd_mlp does not repeat the 40 gathers per sample.
@@ -45,6 +22,8 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
     const float* d = directions + ray * 3;
     const float* eb = e_bins + ray * (S + 1) + s;
     Contracted c = tn_contract(o[0], o[1], o[2], d[0], d[1], d[2], eb[0], eb[1]);
+    // (prop_density_sample of tn_prop_point.h, written out: called as a function the <false> instantiation is scheduled into 66 registers instead of
+    // 38 -- the two must stay the same arithmetic, tests/test_datamanager_gpu.py compares their results bit for bit)
     float enc[PF];
 #pragma unroll
     for (int l = 0; l < PL; ++l) {

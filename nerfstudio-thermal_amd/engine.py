@@ -27,6 +27,8 @@ _FUSE = os.environ.get("TN_FUSE_SMALL", "1") != "0"
 _ONE_CALL_BWD = os.environ.get("TN_ONE_CALL_BWD", "1") != "0"
 # TN_TRAIN_STEP_ONE_CALL=0: the fused step through its five library calls instead of tn_train_step (test / A-B aid: the two must agree)
 _ONE_CALL_STEP = os.environ.get("TN_TRAIN_STEP_ONE_CALL", "1") != "0"
+# TN_NEXT_SAMPLING=0: the one-call step does not run the NEXT iteration's sampling front in its optimiser launch (A/B timing, tests)
+_NEXT_SAMPLING = os.environ.get("TN_NEXT_SAMPLING", "1") != "0"
 
 
 @dataclass
@@ -111,6 +113,9 @@ class RenderEngine:
         # two launches on ONE stream cost nothing) -- see profiles/r03_experiments.md.  Kept as an option for runtimes where it pays.
         self.overlap_adam = False
         self._adam_event = None
+        # the one-call step runs the NEXT iteration's sampling front (pose correction + proposal sampling of the batch the device data manager has
+        # handed over) as co-work of its optimiser launch (TnTrainStep.next_sampling); False: every iteration samples in line
+        self.next_sampling = True
 
     def _side_stream(self, i: int = 0):
         side = self.__dict__.setdefault("_side", {})
@@ -139,14 +144,18 @@ class RenderEngine:
         x = e if step >= w else (0.0 if step <= 0 else (e / w) * step)  # (slope first, as np.interp evaluates it: bit-identical)
         return min(max(x, 1.0), e)
 
-    def set_anneal_for_step(self, step: int) -> None:
-        """set_anneal callback (models/nerfacto.py:271-281)."""
+    def anneal_for_step(self, step: int) -> float:
+        """the sampler's histogram-padding exponent at `step` (models/nerfacto.py:271-281)"""
         c = self.cfg
         if not c.use_proposal_weight_anneal:
-            return
+            return self.anneal
         frac = min(max(step / c.proposal_weights_anneal_max_num_iters, 0.0), 1.0)
         b = c.proposal_weights_anneal_slope
-        self.anneal = b * frac / ((b - 1) * frac + 1)
+        return b * frac / ((b - 1) * frac + 1)
+
+    def set_anneal_for_step(self, step: int) -> None:
+        """set_anneal callback (models/nerfacto.py:271-281)."""
+        self.anneal = self.anneal_for_step(step)
 
     def step_cb(self, step: int) -> None:
         self.sampler_step = step
@@ -794,7 +803,8 @@ class RenderEngine:
         if smp:
             self.steps_since_update, self.sampler_step, self.anneal = int(smp["steps_since_update"]), int(smp["step"]), float(smp["anneal"])
 
-    def _train_step_one_call(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, jitters, scaler) -> Dict[str, Tensor]:
+    def _train_step_one_call(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, jitters, scaler,
+                             step: Optional[int] = None) -> Dict[str, Tensor]:
         """The iteration of train_step (shared density, camera optimiser, device-side GradScaler, no data-parallel exchange) as ONE library call,
         tn_train_step: what get_outputs + loss_and_backward + optimizer_step enqueue through five calls, with their bookkeeping done here.
         The five-call path stays the reference (TN_TRAIN_STEP_ONE_CALL=0; tests/test_trainer_sequence_gpu.py compares the two)."""
@@ -811,9 +821,28 @@ class RenderEngine:
             self._step_gidx = gidx
         gidx = self._step_gidx
         nears, fars = self._nears_fars(N, True)
+        updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
+        # The previous call may have run THIS batch's sampling front (pose correction + both proposal levels) in its optimiser launch
+        # (TnTrainStep.next_sampling): valid when the batch is the one it was planned for, the sampler's state is what was predicted, and nobody has
+        # written the parameters through torch since (our kernels do not move the version counter; copy_ / load_state_dict do).
+        plan, fwd_buf = self.__dict__.pop("_planned", None), None
+        if plan is not None and jitters is None and plan["call"] is call and plan["N"] == N and plan["step"] == step \
+                and plan["ptrs"] == (origins.data_ptr(), directions.data_ptr(), cam.data_ptr()) and plan["anneal"] == float(self.anneal) \
+                and plan["updated"] == bool(updated) and plan["version"] == a.params._version:
+            jitters, fwd_buf = plan["jitters"], plan["buf"]
         if jitters is None:
             jitters = list(self._uniforms().take((3, N)).unbind(0))
-        updated = self.steps_since_update > self.update_schedule(self.sampler_step) or self.sampler_step < 10
+            drew = True
+        else:
+            drew = fwd_buf is not None
+        # ... and this call plans the next one: the batch the data manager has handed over (ops.sample_rays_deferred), the jitter of the next iteration
+        # (drawn now: the same sequence of draws, one iteration early), its anneal exponent and whether its proposal networks take a gradient
+        next_plan = None
+        pend = ops._PENDING_SAMPLE
+        if _NEXT_SAMPLING and self.next_sampling and drew and step is not None and pend is not None and int(pend[0].num_rays) == N and N % 4 == 0:
+            since = (0 if updated else self.steps_since_update) + 1  # (what step_cb leaves behind this iteration)
+            n_updated = since > self.update_schedule(step) or step < 10
+            next_plan = (list(self._uniforms().take((3, N)).unbind(0)), self.anneal_for_step(step + 1), bool(n_updated))
         keys, shapes = self._accumulator_spec(N, {"": bool(updated), "_thermal": False})
         views, flat = self._zeros_many(shapes, fill=False)  # cleared inside the field's first launch
         acc = {k[0]: v for k, v in zip(keys, views)}
@@ -834,9 +863,14 @@ class RenderEngine:
             ranges.append((lo, hi, group_steps[g], lr0, lr_final, max_steps, gidx[g]))
         self._set_grad_zero(True)  # (train_step made sure the arena's gradients are zero; shared mode: one scatter per table)
         try:
-            call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count)
+            call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count,
+                     fwd_buf=fwd_buf, next_plan=next_plan)
         finally:
             self._set_grad_zero(False)  # the promise holds for this call's scatters only -- also when the call was refused
+        if next_plan is not None and call.next_buf is not None:
+            o2, d2, c2 = pend[1][3], pend[1][4], pend[1][5]  # (sample_rays_deferred: (u, cameras, cache) + (origins, directions, camera_indices, ...))
+            self._planned = {"call": call, "N": N, "step": step + 1, "ptrs": (o2.data_ptr(), d2.data_ptr(), c2.data_ptr()), "anneal": float(next_plan[1]),
+                             "updated": next_plan[2], "jitters": next_plan[0], "buf": call.next_buf, "version": a.params._version}
         self.adam_step_count += 1
         self.group_steps = group_steps
         a.grads_clean = True  # the Adam launch consumed the gradients of every group that received any
@@ -906,7 +940,7 @@ class RenderEngine:
         if (_ONE_CALL_STEP and _FUSE and _ONE_CALL_BWD and kflags is not None and scheduled and not self.separate and self.pose is not None
                 and not self.overlap_adam and getattr(self, "scatter_events", None) is None
                 and self.field.num_channels == 4 and "camera_opt" in self.arena.optimised_groups):
-            losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler)
+            losses = self._train_step_one_call(origins, directions, cam, image, is_thermal, jitters, grad_scaler, step)
             self._set_grad_zero(False)  # the promise holds for this iteration's scatters only (anybody may call the ops on these grids next)
             if step_callback:
                 self.step_cb(step)

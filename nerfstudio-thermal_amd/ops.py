@@ -881,9 +881,13 @@ class TrainStepCall:
         self._N = N
 
     def run(self, origins: Tensor, directions: Tensor, cam: Tensor, image: Tensor, is_thermal: Tensor, nears: Tensor, fars: Tensor, anneal: float,
-            jitters: Sequence[Tensor], prop_grad: bool, acc_flat: Tensor, acc: dict, ranges, sched_step: int) -> Tensor:
+            jitters: Sequence[Tensor], prop_grad: bool, acc_flat: Tensor, acc: dict, ranges, sched_step: int, fwd_buf: Optional[Tensor] = None,
+            next_plan: Optional[tuple] = None) -> Tensor:
         """acc: name -> view of acc_flat for L [16], Lp [LOSS_LINES,16], d_comp, dw0, dw1 (prop_grad only), dw2, d_o, d_d.
-        ranges: [(lo, hi, adam step, lr_init, lr_final, max_steps, flag)] of the groups stepped this iteration.  -> the forward's buffer."""
+        ranges: [(lo, hi, adam step, lr_init, lr_final, max_steps, flag)] of the groups stepped this iteration.  -> the forward's buffer.
+        fwd_buf: the buffer the PREVIOUS call's next_plan filled up to the field's bins for this very batch (TnTrainStep.sampling_done).
+        next_plan = (jitters, anneal, prop_grad) of the NEXT iteration: its sampling front for the pending batch (sample_rays_deferred) runs as co-work of
+        this call's optimiser launch (TnTrainStep.next_sampling); self.next_buf is the buffer it filled, or None when the library did not take it."""
         N = origins.shape[0]
         dev = origins.device
         if N != self._N:
@@ -898,8 +902,11 @@ class TrainStepCall:
         st.nears, st.fars = _ray_scalar(nears, "nears", N), _ray_scalar(fars, "fars", N)
         st.anneal, st.prop_grad = float(anneal), 1 if prop_grad else 0
         st.jitter0, st.jitter1, st.jitter2 = (_ray_scalar(j, "jitter", N) for j in jitters)
-        buf = torch.empty(self.off[_lib.TN_RENDER_TRAIN_OFFSETS - 1], device=dev)
-        st.fwd_out = C.c_void_p(buf.data_ptr())
+        total = self.off[_lib.TN_RENDER_TRAIN_OFFSETS - 1]
+        if fwd_buf is not None and (fwd_buf.numel() != total or fwd_buf.device != dev):
+            raise ValueError("fwd_buf is not this batch's forward buffer")
+        buf = torch.empty(total, device=dev) if fwd_buf is None else fwd_buf
+        st.fwd_out, st.sampling_done = C.c_void_p(buf.data_ptr()), 0 if fwd_buf is None else 1
         st.acc, st.acc_bytes = C.c_void_p(acc_flat.data_ptr()), _nbytes(acc_flat)
         st.losses16, st.loss_lines = _f32(acc["L"], "losses16", (16,)), _f32(acc["Lp"], "loss_lines", (LOSS_LINES, 16))
         st.d_comp, st.d_weights2 = _f32(acc["d_comp"], "d_comp", (N, 4)), _f32(acc["dw2"], "d_weights2", (N, S2))
@@ -925,10 +932,25 @@ class TrainStepCall:
             st.next_sample, st.next_sample_taken = C.pointer(pend[0]), C.pointer(taken)
         else:
             st.next_sample, st.next_sample_taken = C.POINTER(_lib.TnSampleRays)(), C.POINTER(C.c_int32)()
-        self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters, pend)  # alive until the next call replaces them
+        # the next iteration's sampling front for that batch, in the same co-work blocks
+        ns_taken, nxt, next_buf = C.c_int32(0), None, None
+        self.next_buf = None
+        if next_plan is not None and pend is not None and len(ranges) > 0 and int(pend[0].num_rays) == N:
+            njit, nanneal, nprop = next_plan
+            next_buf = torch.empty(total, device=dev)
+            nxt = _lib.TnNextSampling()
+            nxt.fwd_out = C.c_void_p(next_buf.data_ptr())
+            nxt.jitter0, nxt.jitter1, nxt.jitter2 = (_ray_scalar(j, "jitter", N) for j in njit)
+            nxt.anneal, nxt.prop_grad = float(nanneal), 1 if nprop else 0
+            st.next_sampling, st.next_sampling_taken = C.pointer(nxt), C.pointer(ns_taken)
+        else:
+            st.next_sampling, st.next_sampling_taken = C.POINTER(_lib.TnNextSampling)(), C.POINTER(C.c_int32)()
+        self._keep = (p0, p1, f, buf, acc_flat, origins, directions, cam, image, is_thermal, jitters, pend, nxt, next_buf, next_plan)  # alive until the next call replaces them
         check(_lib.load().tn_train_step(C.byref(st), _stream()), "tn_train_step")
         if taken.value:
             _PENDING_SAMPLE = None  # (else it stays pending: the data manager launches it itself before it hands the batch out)
+        if ns_taken.value:
+            self.next_buf = next_buf
         return buf
 
 

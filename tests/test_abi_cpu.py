@@ -144,8 +144,21 @@ def test_field_camera_cap_is_the_documented_one():
     assert a == b == 4096
 
 
-def test_train_step_struct_layout_matches_the_header(tmp_path):
-    """The ctypes mirror of TnTrainStep (_lib.TnTrainStep) against the C compiler's layout of the header's struct: size and the offset of every
+def test_library_exports_exactly_the_header(lib):
+    """`nm -D` of the built library = the header's entry points, nothing else: the library is linked with a version script (csrc/exports.map) and
+    compiled with -fvisibility=hidden, so kernel handles and the helpers its translation units share stay local."""
+    import shutil
+    import subprocess
+
+    if shutil.which("nm") is None:
+        pytest.skip("no nm")
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == header_symbols(), exported ^ header_symbols()
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the header's structs against the C compiler's layout: size and the offset of every
     field (a field added on one side only, or in another order, would hand tn_train_step pointers in the wrong slots)."""
     import ctypes as C
     import shutil
@@ -157,7 +170,9 @@ def test_train_step_struct_layout_matches_the_header(tmp_path):
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "thermal_nerf_hip.h")).read()
-    for struct in ("TnTrainStep", "TnSampleRays"):  # (TnSampleRays: the next iteration's batch, TnTrainStep::next_sample)
+    # (TnSampleRays / TnNextSampling: the next iteration's batch and sampling front, TnTrainStep::next_sample / next_sampling; the others: every
+    # struct an entry point takes by pointer)
+    for struct in ("TnTrainStep", "TnSampleRays", "TnNextSampling", "TnGrid", "TnPropNet", "TnField", "TnSplatCamera"):
         mirror = getattr(L, struct)
         names = [f[0] for f in mirror._fields_]
         src = tmp_path / f"layout_{struct}.c"

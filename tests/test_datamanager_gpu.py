@@ -169,3 +169,83 @@ def test_next_batch_is_sampled_inside_the_training_step(scene):
         for a, b in zip(got, want):
             assert torch.equal(a, b), step
 
+
+
+@pytest.mark.parametrize("mode", ["cowork", "serial"])
+def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
+    """TnTrainStep.next_sampling: the sampling front of iteration k + 1 (pose correction, level-0 bins, both proposal levels' density -> weights ->
+    PDF resampling) runs in co-work blocks of iteration k's optimiser launch, behind a launch that steps the groups it reads.  Against the same run
+    with every iteration sampling in line (engine.next_sampling = False), from re-synchronised states as the other comparisons here: the forward's
+    buffer -- pose-corrected rays, all bins, proposal densities / weights / median depths, and everything the field and the renderers add -- bit for
+    bit, over 13 iterations that include proposal updates, iterations without one and a skipped (forced-inf) one; the same losses, scaler and
+    sampler bookkeeping.  mode "serial" (TN_NEXT_SAMPLING=2): the chain as a launch of its own behind the optimiser launch (the A/B timing aid)."""
+    import random
+
+    from nerfstudio_thermal_amd import ops
+    from nerfstudio_thermal_amd.config import ThermalNerfactoModelConfig
+    from nerfstudio_thermal_amd.datamanager import HipDataManagerConfig
+    from nerfstudio_thermal_amd.dataparser import ThermalNerfDataParserConfig
+    from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+    N = 256
+    if mode == "serial":
+        monkeypatch.setenv("TN_NEXT_SAMPLING", "2")
+
+    def run(chain: bool, states=None):
+        random.seed(5)
+        torch.manual_seed(29)
+        dm = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=N).setup(device="cuda:0")
+        cfg = ThermalNerfactoModelConfig(density_mode="shared", log2_hashmap_size=12)
+        for a in cfg.proposal_net_args_list:
+            a["log2_hashmap_size"] = 10
+        model = cfg.setup(scene_box=dm.train_dataset.scene_box, num_train_data=len(dm.train_dataset), metadata=dm.train_dataset.metadata, device="cuda:0")
+        model.train()
+        eng, ar = model.engine, model.arena
+        eng.next_sampling = chain
+        scaler = DeviceGradScaler("cuda:0", num_groups=len(ar.optimised_groups))
+        rec, used = [], 0
+        for step in range(13):
+            rb, batch = dm.next_train(step)
+            if step == 6:
+                batch["image"].fill_(float("inf"))  # in place: the batch tensors are the ones the previous iteration's co-work filled
+            if states is not None:  # the in-line run continues from the chained run's state (float atomics: two runs drift apart in the last bits)
+                with torch.no_grad():
+                    for dst, src in zip((ar.params, ar.exp_avg, ar.exp_avg_sq), states[step]):
+                        dst.copy_(src)
+            before = (ar.params.clone(), ar.exp_avg.clone(), ar.exp_avg_sq.clone())
+            planned = eng.__dict__.get("_planned") is not None
+            losses = model.train_iteration(rb, batch, step, grad_scaler=scaler)
+            call = eng._step_call
+            used += int(planned and call.st.sampling_done == 1)
+            torch.cuda.synchronize()
+            rec.append({"before": before, "buf": call._keep[3].clone(), "off": list(call.off), "losses": {k: float(v) for k, v in losses.items()},
+                        "updated": eng.last_updated, "since": eng.steps_since_update, "scale": scaler.get_scale(),
+                        "skipped": [scaler.num_skipped(i) for i in range(3)], "lag": scaler.schedule_lag(), "counts": call.counts})
+            assert ops._PENDING_SAMPLE is None, step
+        return rec, used
+
+    A, usedA = run(True)
+    assert usedA == 12  # every iteration but the first started at the field
+    B, usedB = run(False, [r["before"] for r in A])
+    assert usedB == 0
+    saw_plain = saw_update = False
+    for step, (a, b) in enumerate(zip(A, B)):
+        assert a["off"] == b["off"]
+        S0, S1, S2 = a["counts"]
+        sizes = [N * 3, N * 3, N * (S0 + 1), N * (S0 + 1), N * S0, N * S0, N, N * (S1 + 1), N * (S1 + 1), N * S1, N * S1, N, N * (S2 + 1), N * (S2 + 1), N * S2,
+                 N * S2, N * S2 * 4, N * 4, N, N, N]
+        for slot, size in enumerate(sizes):
+            o = a["off"][slot]
+            assert torch.equal(a["buf"][o:o + size], b["buf"][o:o + size]), (step, slot)
+        if a["updated"]:  # the proposal levels' encodings are kept on update iterations
+            for slot, size in ((22, N * S0 * 10), (23, N * S1 * 10)):
+                o = a["off"][slot]
+                assert torch.equal(a["buf"][o:o + size], b["buf"][o:o + size]), (step, slot)
+        saw_plain |= not a["updated"]
+        saw_update |= a["updated"] and step > 0
+        for k in ("updated", "since", "scale", "skipped", "lag"):
+            assert a[k] == b[k], (step, k)
+        if step != 6:
+            for k, v in a["losses"].items():
+                assert abs(v - b["losses"][k]) <= 1e-5 * abs(b["losses"][k]) + 1e-12, (step, k)
+    assert saw_plain and saw_update and A[-1]["skipped"][1] == 1
