@@ -392,11 +392,14 @@ struct ReplicaK {
 struct TnNextSamplingHost {
   const TnPropNet *prop0, *prop1;
   const float* pose; const uint8_t* frozen; int num_cameras;
+  const float *rays_o, *rays_d; const int64_t* cam;  // the batch (an earlier launch has sampled it)
   const float *nears, *fars, *jit0, *jit1, *jit2, *lin0, *lin1, *lin2;
   float anneal;
   int S0, S1, S2;
   int64_t N;
-  float *origins, *directions, *s0, *e0, *d0, *w0, *m0, *s1, *e1, *d1, *w1, *m1, *s2, *e2, *penc0, *penc1;  // the NEXT forward buffer's regions (penc: NULL = not kept)
+  float* out;       // the NEXT forward buffer
+  int64_t off[16];  // float offsets of its regions: origins, directions | s0 e0 d0 w0 m0 | s1 e1 d1 w1 m1 | s2 e2 | penc0 penc1
+  int save_enc;     // keep the proposal levels' encodings
 };
 int tn_adam_step_ranges_amp_update_cw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                                       const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,

@@ -1103,24 +1103,24 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
   }
   adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, k);
 }
-// The same launch with the NEXT iteration's whole sampling front (tn_next_sampling.h) in its co-work row: batch + pose correction + both proposal
-// levels, one wave per ray.  A kernel of its own: the chain's registers and 18 KB of LDS per block would otherwise be every Adam launch's.
+// The same launch with the NEXT iteration's sampling front (tn_next_sampling.h) in its co-work row: pose correction + both proposal levels, one
+// wave per ray.  A kernel of its own: the chain's registers and 18 KB of LDS per block would otherwise be every Adam launch's.
 __global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                              AdamRangesAmp r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
-                                                              float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g,
-                                                              ScalerUpdate su, SampleCoWork cw, NextSamplingArgs ns) {
+                                                                 AdamRangesAmp r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
+                                                                 float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g,
+                                                                 ScalerUpdate su, NextSamplingArgs ns) {
   __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
   if (blockIdx.y == 0) {
-    if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body(ns, cw.a, cw.g, blockIdx.x, (unsigned)ns.blocks, ns_lds);
+    if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body(ns, blockIdx.x, (unsigned)ns.blocks, ns_lds);
     adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
     return;
   }
   adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, (int)blockIdx.y - 1);
 }
 // (the chain alone, for register accounting and A/B timing: TN_NEXT_SAMPLING=2 launches it behind the optimiser launch instead of inside it)
-__global__ void __launch_bounds__(256) k_next_sampling(SampleCoWork cw, NextSamplingArgs ns) {
+__global__ void __launch_bounds__(256) k_next_sampling(NextSamplingArgs ns) {
   __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
-  next_sampling_body(ns, cw.a, cw.g, blockIdx.x, gridDim.x, ns_lds);
+  next_sampling_body(ns, blockIdx.x, gridDim.x, ns_lds);
 }
 static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t num_ranges, const int64_t* offsets,
                                const int64_t* counts, const int32_t* steps, const double* lrs, const double* lr_finals,
@@ -1163,43 +1163,55 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
     if (next_taken) *next_taken = true;
   }
   if (chain != nullptr) {
-    // the next iteration's sampling front for the batch `next` describes: one wave per ray, 4 rays per block and trip
-    TN_REQUIRE(cw.blocks > 0 && next->num_rays == chain->N, "tn_train_step(next_sampling): needs next_sample with the same number of rays");
+    // the next iteration's sampling front for the batch chain->rays_* hold (sampled by an earlier launch): one wave per ray, 4 rays per block and trip
+    TN_REQUIRE(next == nullptr, "tn_train_step(next_sampling): the launch that carries the chain does not sample the batch");
+    TN_REQUIRE(chain->N > 0 && chain->N % 4 == 0 && chain->N < (1ll << 30), "tn_train_step(next_sampling): %lld rays (a multiple of 4 is needed)", (long long)chain->N);
     TN_REQUIRE(tn_next_sampling_supported(chain->S0, chain->S1, chain->S2), "tn_train_step(next_sampling): unsupported sample counts (%d, %d, %d)", chain->S0,
                chain->S1, chain->S2);
-    TN_REQUIRE(chain->prop0 && chain->prop1 && chain->pose && chain->nears && chain->fars && chain->lin0 && chain->lin1 && chain->lin2 && chain->origins &&
-                   chain->directions && chain->s0 && chain->e0 && chain->d0 && chain->w0 && chain->m0 && chain->s1 && chain->e1 && chain->d1 && chain->w1 &&
-                   chain->m1 && chain->s2 && chain->e2 && chain->num_cameras >= 1,
+    TN_REQUIRE(chain->prop0 && chain->prop1 && chain->pose && chain->nears && chain->fars && chain->lin0 && chain->lin1 && chain->lin2 && chain->out &&
+                   chain->rays_o && chain->rays_d && chain->cam && chain->num_cameras >= 1,
                "tn_train_step(next_sampling): null pointer");
     TN_REQUIRE(chain->prop0->grid.num_levels == PL && chain->prop1->grid.num_levels == PL && chain->prop0->grid.log2_hashmap_size >= 1 &&
                    chain->prop0->grid.log2_hashmap_size <= 24 && chain->prop1->grid.log2_hashmap_size >= 1 && chain->prop1->grid.log2_hashmap_size <= 24,
                "tn_train_step(next_sampling): proposal grids are built for %d levels", PL);
     NextSamplingArgs ns{};
-    ns.p0 = PropK{make_gridk(chain->prop0->grid), chain->prop0->w0, chain->prop0->b0, chain->prop0->w1, chain->prop0->b1, nullptr, nullptr, nullptr, nullptr};
-    ns.p1 = PropK{make_gridk(chain->prop1->grid), chain->prop1->w0, chain->prop1->b0, chain->prop1->w1, chain->prop1->b1, nullptr, nullptr, nullptr, nullptr};
+    auto prop = [](const TnPropNet* q) {
+      NsProp o{};
+      o.table = reinterpret_cast<const float2*>(q->grid.table);
+      o.tsize = 1u << q->grid.log2_hashmap_size; o.mask = o.tsize - 1u;
+      for (int l = 0; l < PL; ++l) o.res[l] = q->grid.res[l];
+      o.w0 = q->w0; o.b0 = q->b0; o.w1 = q->w1; o.b1 = q->b1;
+      return o;
+    };
+    TN_REQUIRE(chain->prop0->grid.table && chain->prop0->w0 && chain->prop0->b0 && chain->prop0->w1 && chain->prop0->b1 && chain->prop1->grid.table &&
+                   chain->prop1->w0 && chain->prop1->b0 && chain->prop1->w1 && chain->prop1->b1, "tn_train_step(next_sampling): null parameter pointer");
+    ns.p0 = prop(chain->prop0); ns.p1 = prop(chain->prop1);
     ns.pose = chain->pose; ns.frozen = chain->frozen; ns.num_cameras = chain->num_cameras;
+    ns.rays_o = chain->rays_o; ns.rays_d = chain->rays_d; ns.cam = chain->cam;
     ns.nears = chain->nears; ns.fars = chain->fars;
     ns.jit0 = chain->jit0; ns.jit1 = chain->jit1; ns.jit2 = chain->jit2;
     ns.lin0 = chain->lin0; ns.lin1 = chain->lin1; ns.lin2 = chain->lin2;
     ns.anneal = chain->anneal;
-    ns.S0 = chain->S0; ns.S1 = chain->S1; ns.S2 = chain->S2; ns.N = chain->N;
-    ns.origins = chain->origins; ns.directions = chain->directions;
-    ns.s0 = chain->s0; ns.e0 = chain->e0; ns.d0 = chain->d0; ns.w0 = chain->w0; ns.m0 = chain->m0;
-    ns.s1 = chain->s1; ns.e1 = chain->e1; ns.d1 = chain->d1; ns.w1 = chain->w1; ns.m1 = chain->m1;
-    ns.s2 = chain->s2; ns.e2 = chain->e2; ns.penc0 = chain->penc0; ns.penc1 = chain->penc1;
-    ns.blocks = (int)std::min<int64_t>(tn_cdiv(chain->N, 4), grid);
+    ns.S0 = chain->S0; ns.S1 = chain->S1; ns.S2 = chain->S2; ns.N = (int)chain->N;
+    ns.out = chain->out;
+    for (int k = 0; k < NS_SLOTS; ++k) {
+      TN_REQUIRE(chain->off[k] >= 0 && chain->off[k] < (1ll << 32), "tn_train_step(next_sampling): forward buffer region %d out of range", k);
+      ns.off[k] = (uint32_t)chain->off[k];
+    }
+    ns.save_enc = chain->save_enc;
+    ns.blocks = (int)std::min<int64_t>(chain->N / 4, grid);
     const char* mode = getenv("TN_NEXT_SAMPLING");
     if (mode && mode[0] == '2') {  // A/B timing: the chain as a launch of its own behind the optimiser launch (same results)
       SampleCoWork none{};
       hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
                          const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, none);
       TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
-      hipLaunchKernelGGL(k_next_sampling, dim3(ns.blocks), dim3(256), 0, tn_s(stream), cw, ns);
+      hipLaunchKernelGGL(k_next_sampling, dim3(ns.blocks), dim3(256), 0, tn_s(stream), ns);
       TN_CHECK_LAUNCH("tn_next_sampling");
       return TN_OK;
     }
     hipLaunchKernelGGL(k_adam_ranges_amp_next, dim3(grid, n + 1), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps,
-                       inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, cw, ns);
+                       inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, ns);
     TN_CHECK_LAUNCH("tn_adam_step_ranges_amp(next_sampling)");
     return TN_OK;
   }

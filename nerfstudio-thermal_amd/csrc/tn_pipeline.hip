@@ -387,8 +387,8 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   // pose corrections -- are stepped first, in a launch of their own (a few MB); the launch that carries the chain steps the rest (the field).
   const TnNextSampling* nx = a->next_sampling;
   const char* nse = getenv("TN_NEXT_SAMPLING");
-  bool chain = nx != nullptr && a->next_sample != nullptr && a->next_sample->num_rays == a->N && tn_next_sampling_supported(a->S0, a->S1, a->S2) &&
-               !(nse && nse[0] == '0');
+  bool chain = nx != nullptr && a->next_sample != nullptr && a->next_sample->num_rays == a->N && a->next_sample->camera_indices != nullptr && a->N % 4 == 0 &&
+               tn_next_sampling_supported(a->S0, a->S1, a->S2) && !(nse && nse[0] == '0');
   int first[TN_TRAIN_STEP_MAX_RANGES], nfirst = 0, rest[TN_TRAIN_STEP_MAX_RANGES], nrest = 0;
   if (chain) {
     const float* reads[] = {a->prop0->grid.table, a->prop0->w0, a->prop0->b0, a->prop0->w1, a->prop0->b1, a->prop1->grid.table, a->prop1->w0,
@@ -399,7 +399,7 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
       for (const float* q : reads) hit = hit || (q >= lo && q < hi);
       if (hit) first[nfirst++] = k; else if (a->counts[k] > 0) rest[nrest++] = k;
     }
-    chain = nrest > 0;  // (nothing left to run beside: one launch, no chain)
+    chain = nrest > 0 && nfirst > 0;  // (nothing left to run beside, or nothing to step first: one launch, no chain)
   }
   if (!chain) {
     rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->num_ranges, a->offsets, a->counts, a->steps, a->lrs, a->lr_finals,
@@ -417,29 +417,30 @@ extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
     int32_t s[TN_TRAIN_STEP_MAX_RANGES], ms[TN_TRAIN_STEP_MAX_RANGES], fl[TN_TRAIN_STEP_MAX_RANGES];
     double l[TN_TRAIN_STEP_MAX_RANGES], lf[TN_TRAIN_STEP_MAX_RANGES];
     rc = TN_OK;
-    if (nfirst > 0) {  // (reads found_inf / the schedule lag like the second launch; GradScaler.update() comes with the second)
-      sub(first, nfirst, o, c, s, l, lf, ms, fl);
-      rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, nfirst, o, c, s, l, lf, ms, a->sched_step, a->beta1, a->beta2, a->eps,
-                                             nullptr, a->found_inf, fl, a->num_flags, a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter,
-                                             a->growth_factor, a->backoff_factor, a->growth_interval, nullptr, nullptr, stream, nullptr, false);
-    }
+    // (the first launch reads found_inf / the schedule lag like the second; GradScaler.update() comes with the second.  It also carries the batch's
+    // pixel sampling + ray generation in its co-work row, as the one optimiser launch of other iterations does)
+    sub(first, nfirst, o, c, s, l, lf, ms, fl);
+    rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, nfirst, o, c, s, l, lf, ms, a->sched_step, a->beta1, a->beta2, a->eps,
+                                           nullptr, a->found_inf, fl, a->num_flags, a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter,
+                                           a->growth_factor, a->backoff_factor, a->growth_interval, a->next_sample, &taken, stream, nullptr, false);
+    if (!rc && !taken) rc = tn_sample_rays_args(a->next_sample, stream);  // (no range of the first launch was live: the batch as a launch of its own)
     if (!rc) {
-      float* nout = nx->fwd_out;
-      auto at = [&](int slot) { return nout + off[slot]; };
+      taken = true;
       TnNextSamplingHost h{};
       h.prop0 = a->prop0; h.prop1 = a->prop1; h.pose = a->pose_adjustment; h.frozen = a->frozen; h.num_cameras = a->num_cameras;
+      h.rays_o = a->next_sample->origins; h.rays_d = a->next_sample->directions; h.cam = a->next_sample->camera_indices;
       h.nears = a->nears; h.fars = a->fars; h.jit0 = nx->jitter0; h.jit1 = nx->jitter1; h.jit2 = nx->jitter2;
       h.lin0 = a->lin_spaced0; h.lin1 = a->lin_pdf1; h.lin2 = a->lin_pdf2; h.anneal = nx->anneal;
       h.S0 = a->S0; h.S1 = a->S1; h.S2 = a->S2; h.N = a->N;
-      h.origins = at(TRO_ORIGINS); h.directions = at(TRO_DIRECTIONS);
-      h.s0 = at(TRO_S0); h.e0 = at(TRO_E0); h.d0 = at(TRO_D0); h.w0 = at(TRO_W0); h.m0 = at(TRO_M0);
-      h.s1 = at(TRO_S1); h.e1 = at(TRO_E1); h.d1 = at(TRO_D1); h.w1 = at(TRO_W1); h.m1 = at(TRO_M1);
-      h.s2 = at(TRO_S2); h.e2 = at(TRO_E2);
-      h.penc0 = nx->prop_grad ? at(TRO_PENC0) : nullptr; h.penc1 = nx->prop_grad ? at(TRO_PENC1) : nullptr;
+      h.out = nx->fwd_out;
+      const int slots[16] = {TRO_ORIGINS, TRO_DIRECTIONS, TRO_S0, TRO_E0, TRO_D0, TRO_W0, TRO_M0, TRO_S1, TRO_E1, TRO_D1, TRO_W1, TRO_M1, TRO_S2, TRO_E2, TRO_PENC0,
+                             TRO_PENC1};
+      for (int k = 0; k < 16; ++k) h.off[k] = off[slots[k]];
+      h.save_enc = nx->prop_grad ? 1 : 0;
       sub(rest, nrest, o, c, s, l, lf, ms, fl);
       rc = tn_adam_step_ranges_amp_update_cw(a->params, a->grads, a->exp_avg, a->exp_avg_sq, nrest, o, c, s, l, lf, ms, a->sched_step, a->beta1, a->beta2, a->eps,
                                              nullptr, a->found_inf, fl, a->num_flags, a->skipped, a->lag_index, 1, 1, a->scale, a->growth_tracker, a->done_counter,
-                                             a->growth_factor, a->backoff_factor, a->growth_interval, a->next_sample, &taken, stream, &h, true);
+                                             a->growth_factor, a->backoff_factor, a->growth_interval, nullptr, nullptr, stream, &h, true);
       if (!rc && a->next_sampling_taken) *a->next_sampling_taken = 1;
     }
   }

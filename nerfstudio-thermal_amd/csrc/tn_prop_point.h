@@ -30,9 +30,9 @@ __device__ __forceinline__ void prop_stage_weights(const PropK& net, float* s_w)
 
 // density of ONE sample: 5-level hash gather + trilinear -> Linear(10,16) ReLU Linear(16,1) -> trunc_exp -> * selector.  s_w: the staged weight
 // rows of prop_stage_weights.  enc_out (SAVE_ENC): level-major [PL][P] float2, entry i.
-// LEVEL_FENCE: nothing is scheduled across the boundary between two levels (8 gathers in flight, not 40): the caller has a register budget
-// to keep (the optimiser launch's co-work) and time to spare.
-template <bool SAVE_ENC, bool LEVEL_FENCE = false>
+// LEVEL_FENCE: nothing is scheduled across the boundary between two levels (8 gathers in flight, not 40) -- measured: no fewer registers, more latency; unused.
+// OPTIONAL_ENC: enc_out may be NULL at run time (wave-uniform): one instantiation for both kinds of iteration.
+template <bool SAVE_ENC, bool LEVEL_FENCE = false, bool OPTIONAL_ENC = false>
 __device__ __forceinline__ float prop_density_sample(const PropK& net, const float* s_w, float px, float py, float pz, bool sel, int64_t i, int64_t P, float* enc_out) {
   float enc[PF];
 #pragma unroll
@@ -41,7 +41,7 @@ __device__ __forceinline__ float prop_density_sample(const PropK& net, const flo
     float2 v = tn_encode_level(net.g.table, px, py, pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
     enc[2 * l] = v.x;
     enc[2 * l + 1] = v.y;
-    if (SAVE_ENC && (!LEVEL_FENCE || enc_out != nullptr)) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;  // level-major [PL][P] float2: 512 contiguous bytes per wave and level
+    if (SAVE_ENC && (!OPTIONAL_ENC || enc_out != nullptr)) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;  // level-major [PL][P] float2: 512 contiguous bytes per wave and level
   }
   float out = s_w[PH * PROP_WROW];
 #pragma unroll 4

@@ -6,7 +6,7 @@ scatter launches of the data-parallel schedule (bench.py --force-dp).
     python scripts/rocpd_timeline.py gpurun_out/prof_dp/x_results.db [out.md] [--step-from-end 3]
 
 A step is delimited by consecutive launches of k_sample_pixels / k_sample_rays (the first kernel of every bench step), or of k_pose_spaced_bins
-when the pixel sampling rides in the previous step's optimiser launch.
+when the pixel sampling rides in the previous step's optimiser launch, or of k_field_prep when the whole sampling front does.
 """
 import re
 import sqlite3
@@ -26,6 +26,9 @@ def main():
         # the data manager hands the next batch to the training step (TnTrainStep.next_sample: sampled inside the optimiser launch): the first
         # kernel of an iteration is then the pose correction + level-0 bins
         marks = [i for i, r in enumerate(rows) if r[0].startswith("k_pose_spaced_bins")]
+    if len(marks) < back + 1:
+        # ... and with the sampling front in the previous step's optimiser launch too (TnTrainStep.next_sampling) an iteration starts at the field
+        marks = [i for i, r in enumerate(rows) if "k_field_prep" in r[0]]
     if len(marks) < back + 1:
         print("not enough steps in the trace", len(marks))
         return
