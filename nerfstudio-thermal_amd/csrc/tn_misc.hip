@@ -997,35 +997,33 @@ __device__ __forceinline__ void adam_block_done(const ScalerUpdate& su, float* f
 }
 struct SampleCoWork { SamplePixelsArgs a; RaygenArgs g; int blocks; };
 #include "tn_next_sampling.h"
-// one block of range k of the launch
+// block `bid` of the `nblk` blocks that walk range k of the launch (grid-stride)
 __device__ __forceinline__ void adam_range_body(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                 const AdamRangesAmp& r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
-                                                float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g, const ScalerUpdate& su,
-                                                int k) {
+                                                float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g, int k, int bid,
+                                                int nblk) {
   const int fl = r.flag[k];
   float* gz = const_cast<float*>(g);  // zero_g: the gradients are consumed (set to zero behind the read): no zero-fill launch before the next backward
   // schedule lag = iterations so far in which the scale dropped; maintained by tn_grad_scaler_update AFTER this launch (stream order)
   const int lag = (skipped != nullptr && r.lag_index >= 0) ? skipped[r.lag_index] : 0;
   const int64_t off = r.off[k], n = r.cnt[k], n4 = n / 4;
+  const int64_t stride = (int64_t)nblk * blockDim.x;
   if (found_inf != nullptr && found_inf[fl] != 0.0f) {  // uniform over the range's blocks
-    if (count_skip && skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (count_skip && skipped != nullptr && bid == 0 && threadIdx.x == 0) {
       bool first = true;  // ONE count per group and launch, however many ranges of the launch carry the group's flag
       for (int j = 0; j < k; ++j) first = first && r.flag[j] != fl;
       if (first) atomicAdd(&skipped[fl], 1);
     }
     if (zero_g) {  // the skipped step still consumes its (non-finite) gradients
-      for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+      for (int64_t i = bid * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride)
         reinterpret_cast<float4*>(gz + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - n4 * 4) gz[off + n4 * 4 + threadIdx.x] = 0.0f;
+      if (bid == 0 && (int64_t)threadIdx.x < n - n4 * 4) gz[off + n4 * 4 + threadIdx.x] = 0.0f;
     }
-    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
     return;
   }
-  if ((int64_t)blockIdx.x * blockDim.x >= n4 && blockIdx.x != 0) {
-    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
-    return;
-  }
+  if ((int64_t)bid * blockDim.x >= n4 && bid != 0) return;
   __shared__ float s_ns, s_bc;
+  __syncthreads();  // (a block that walks several ranges: the previous range's readers are done with s_ns / s_bc)
   if (threadIdx.x == 0) {
     const int sk = skipped ? skipped[fl] : 0;
     const int eff = r.step[k] - sk;
@@ -1056,28 +1054,35 @@ __device__ __forceinline__ void adam_range_body(float* __restrict__ p, const flo
     M = m_new_;                                   \
     V = v_new_;                                   \
   }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    v4f gg = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g4) + i);
-    v4f mm4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m4) + i);
-    v4f vv4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v4) + i);
-    // Entries that have never received a gradient (g, m and v all +0: on the coarse levels of a hash table most slots -- level 0 uses 4913 of
-    // 2^19) stay exactly as they are under Adam's arithmetic (m' = v' = 0, p' = p + step * 0 / eps = p): nothing to read further, nothing to write.
-    const v4u zb = __builtin_bit_cast(v4u, gg) | __builtin_bit_cast(v4u, mm4) | __builtin_bit_cast(v4u, vv4);
-    if ((zb.x | zb.y | zb.z | zb.w) == 0u) continue;
-    float4 pp = p4[i];
-    ADAM1(pp.x, gg.x, mm4.x, vv4.x)
-    ADAM1(pp.y, gg.y, mm4.y, vv4.y)
-    ADAM1(pp.z, gg.z, mm4.z, vv4.z)
-    ADAM1(pp.w, gg.w, mm4.w, vv4.w)
-    p4[i] = pp;
-    __builtin_nontemporal_store(mm4, reinterpret_cast<v4f*>(m4) + i);
-    __builtin_nontemporal_store(vv4, reinterpret_cast<v4f*>(v4) + i);
-    if (zero_g) { const v4f z = {0.f, 0.f, 0.f, 0.f}; __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(gz + off) + i); }
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  // Entries that have never received a gradient (g, m and v all +0: on the coarse levels of a hash table most slots -- level 0 uses 4913 of
+  // 2^19) stay exactly as they are under Adam's arithmetic (m' = v' = 0, p' = p + step * 0 / eps = p): nothing to read further, nothing to write.
+#define ADAM4(I, GG, MM, VV)                                                                                           \
+  {                                                                                                                    \
+    const v4u zb = __builtin_bit_cast(v4u, GG) | __builtin_bit_cast(v4u, MM) | __builtin_bit_cast(v4u, VV);          \
+    if ((zb.x | zb.y | zb.z | zb.w) != 0u) {                                                                           \
+      float4 pp = p4[I];                                                                                               \
+      ADAM1(pp.x, GG.x, MM.x, VV.x)                                                                                    \
+      ADAM1(pp.y, GG.y, MM.y, VV.y)                                                                                    \
+      ADAM1(pp.z, GG.z, MM.z, VV.z)                                                                                    \
+      ADAM1(pp.w, GG.w, MM.w, VV.w)                                                                                    \
+      p4[I] = pp;                                                                                                      \
+      __builtin_nontemporal_store(MM, reinterpret_cast<v4f*>(m4) + (I));                                               \
+      __builtin_nontemporal_store(VV, reinterpret_cast<v4f*>(v4) + (I));                                               \
+      if (zero_g) { const v4f z = {0.f, 0.f, 0.f, 0.f}; __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(gz + off) + (I)); } \
+    }                                                                                                                  \
   }
+  int64_t i0 = bid * (int64_t)blockDim.x + threadIdx.x;
+  for (; i0 < n4; i0 += stride) {
+    v4f gg = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g4) + i0);
+    v4f mm4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m4) + i0);
+    v4f vv4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v4) + i0);
+    ADAM4(i0, gg, mm4, vv4)
+  }
+#undef ADAM4
   const int tail = (int)(n - n4 * 4);
-  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
+  if (bid == 0 && (int)threadIdx.x < tail) {
     const int64_t i = off + n4 * 4 + threadIdx.x;
     float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
     ADAM1(pp, gg, mm, vv)
@@ -1085,7 +1090,6 @@ __device__ __forceinline__ void adam_range_body(float* __restrict__ p, const flo
     if (zero_g) gz[i] = 0.0f;
   }
 #undef ADAM1
-  adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
 __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamRangesAmp r,
                                   double beta1, double beta2, float eps, const float* __restrict__ inv_scale, float* __restrict__ found_inf,
@@ -1101,10 +1105,19 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
     }
     --k;
   }
-  adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, k);
+  adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, k, (int)blockIdx.x, (int)gridDim.x);
+  adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
-// The same launch with the NEXT iteration's sampling front (tn_next_sampling.h) in its co-work row: pose correction + both proposal levels, one
-// wave per ray.  A kernel of its own: the chain's registers and 18 KB of LDS per block would otherwise be every Adam launch's.
+// The optimiser launch that carries the NEXT iteration's sampling front (tn_next_sampling.h: pose correction + both proposal levels, one wave per
+// ray) in a co-work row in front of its range rows.  A kernel of its own: the chain's 127 registers and 18 KB of LDS per block would otherwise be
+// every Adam launch's.
+// What the launch gains (profiles/r06_next_sampling.md): the chain is bound by vector-instruction issue (~12 k wave-instructions per ray; 80 us for
+// 4096 rays when it has the chip to itself) and at 127 registers its 1024 blocks are exactly the chip's 4 waves per SIMD -- so the range rows
+// start as chain blocks retire and the launch takes 141 us for 80 + 78, not the ~85 us a perfect overlap would.  The launch still wins over the five
+// in-line launches it replaces (their gaps, the proposal update's larger first launch); two layouts that make room for both kinds at once -- 5 or 6
+// waves per SIMD with persistent Adam blocks (1 or 2 per CU, 4 x the loads in flight per lane) interleaved 1 : 4 / 2 : 4 with the chain blocks --
+// were built and measured SLOWER (177 / 196 us): the chain spills 26 / 47 registers there and HBM wants ~100 KB in flight per CU, which one or two
+// Adam waves per SIMD do not provide.
 __global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                                  AdamRangesAmp r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
                                                                  float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g,
@@ -1112,10 +1125,10 @@ __global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restri
   __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
   if (blockIdx.y == 0) {
     if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body(ns, blockIdx.x, (unsigned)ns.blocks, ns_lds);
-    adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
-    return;
+  } else {
+    adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, (int)blockIdx.y - 1, (int)blockIdx.x, (int)gridDim.x);
   }
-  adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, su, (int)blockIdx.y - 1);
+  adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
 // (the chain alone, for register accounting and A/B timing: TN_NEXT_SAMPLING=2 launches it behind the optimiser launch instead of inside it)
 __global__ void __launch_bounds__(256) k_next_sampling(NextSamplingArgs ns) {
@@ -1159,7 +1172,10 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
   if (next != nullptr && next->num_rays > 0) {
     int rc = sample_rays_build("tn_train_step(next_sample)", next, cw.a, cw.g);
     if (rc) return rc;
-    cw.blocks = (int)std::min<int64_t>(tn_cdiv(next->num_rays * 4, 256), grid);  // 4 lanes per ray; the row has `grid` blocks
+    // 4 lanes per ray.  The row has `grid` blocks: a launch over small ranges only (the pose corrections alone) is widened for its co-work row --
+    // the range rows' surplus blocks leave at once
+    grid = std::max(grid, (int)std::min<int64_t>(tn_cdiv(next->num_rays * 4, 256), 256));
+    cw.blocks = (int)std::min<int64_t>(tn_cdiv(next->num_rays * 4, 256), grid);
     if (next_taken) *next_taken = true;
   }
   if (chain != nullptr) {
@@ -1199,8 +1215,19 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
       ns.off[k] = (uint32_t)chain->off[k];
     }
     ns.save_enc = chain->save_enc;
+    grid = std::max(grid, (int)std::min<int64_t>(chain->N / 4, 1024));  // (a launch over small ranges only is widened for its co-work row)
     ns.blocks = (int)std::min<int64_t>(chain->N / 4, grid);
     const char* mode = getenv("TN_NEXT_SAMPLING");
+    if (mode && mode[0] == '3') {  // A/B timing: the chain on a companion stream beside the optimiser launch; tn_train_step joins it before the next field forward
+      hipStream_t side = tn_fork_n(tn_s(stream), 3);
+      hipLaunchKernelGGL(k_next_sampling, dim3(ns.blocks), dim3(256), 0, side ? side : tn_s(stream), ns);
+      TN_CHECK_LAUNCH("tn_next_sampling");
+      SampleCoWork none{};
+      hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,
+                         const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, none);
+      TN_CHECK_LAUNCH("tn_adam_step_ranges_amp");
+      return TN_OK;
+    }
     if (mode && mode[0] == '2') {  // A/B timing: the chain as a launch of its own behind the optimiser launch (same results)
       SampleCoWork none{};
       hipLaunchKernelGGL(k_adam_ranges_amp, dim3(grid, n), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps, inv_scale,

@@ -270,6 +270,7 @@ extern "C" int tn_render_rays_train_bwd(const TnPropNet* prop0, const TnPropNet*
 // calls, in its order, on the caller's stream.  Nothing here launches a kernel of its own.
 extern "C" int tn_train_step(const TnTrainStep* a, tn_stream_t stream) {
   TN_REQUIRE(a != nullptr, "tn_train_step: null argument block");
+  tn_join_n(tn_s(stream), 3);  // (TN_NEXT_SAMPLING=3: the previous call's sampling front ran on a companion stream; a no-op otherwise)
   if (a->next_sample_taken) *a->next_sample_taken = 0;  // (set once the optimiser launch carries it: any earlier return leaves the batch to the caller)
   if (a->N == 0) return TN_OK;
   TN_REQUIRE(a->prop0 && a->prop1 && a->field && a->origins_in && a->directions_in && a->camera_indices && a->image && a->is_thermal && a->nears &&

@@ -171,7 +171,7 @@ def test_next_batch_is_sampled_inside_the_training_step(scene):
 
 
 
-@pytest.mark.parametrize("mode", ["cowork", "serial"])
+@pytest.mark.parametrize("mode", ["cowork", "serial", "fork"])
 def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
     """TnTrainStep.next_sampling: the sampling front of iteration k + 1 (pose correction, level-0 bins, both proposal levels' density -> weights ->
     PDF resampling) runs in co-work blocks of iteration k's optimiser launch, behind a launch that steps the groups it reads.  Against the same run
@@ -188,8 +188,8 @@ def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
     from nerfstudio_thermal_amd.optim import DeviceGradScaler
 
     N = 256
-    if mode == "serial":
-        monkeypatch.setenv("TN_NEXT_SAMPLING", "2")
+    if mode != "cowork":  # (A/B timing aids: the chain as a launch of its own behind the optimiser launch / on a companion stream beside it)
+        monkeypatch.setenv("TN_NEXT_SAMPLING", "2" if mode == "serial" else "3")
 
     def run(chain: bool, states=None):
         random.seed(5)
