@@ -556,6 +556,85 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
             "dominant_kernel": name, "dominant_kernel_ms": ms, "dominant_kernel_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def eval_render_leg(device, reps=3, profile_path=None):
+    """TEST_RAYS_PER_SEC of the reference (utils/writer.py:55-56, engine/trainer.py:519-527): one full RGB image (640x480) + one full thermal image
+    (160x120) of the synthetic scene's cameras through `Model.get_outputs_for_camera` (models/base_model.py:165-205: chunks of
+    eval_num_rays_per_chunk = 32768 rays) -- and the same rays through `tn_render_rays_eval` directly, chunk by chunk.  Algorithmic bytes per ray =
+    the forward gather term of SURVEY 8d (161 792 B).  Never part of `value`."""
+    import types
+
+    from nerfstudio_thermal_amd import ops, synth
+
+    cfg, arena, model = build_model(device)
+    model.config.eval_num_rays_per_chunk = 1 << 15  # method_configs["thermal-nerfacto"] (configs/method_configs.py:255-310), as plugin.py sets it
+    model.eval()
+    cams = synth.synth_cameras()
+
+    def camera(i):
+        return types.SimpleNamespace(camera_to_worlds=torch.from_numpy(cams["c2w"][i]), fx=float(cams["fx"][i]), fy=float(cams["fy"][i]), cx=float(cams["cx"][i]),
+                                     cy=float(cams["cy"][i]), width=int(cams["width"][i]), height=int(cams["height"][i]),
+                                     distortion_params=torch.from_numpy(cams["distortion"][i]), camera_index=i)
+
+    pair = [camera(0), camera(4)]
+    rays = sum(c.width * c.height for c in pair)
+
+    def through_model():
+        outs = [model.get_outputs_for_camera(c) for c in pair]
+        return outs
+
+    through_model()  # warm-up: workspaces, lin tables
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        outs = through_model()
+    torch.cuda.synchronize()
+    dt_model = (time.perf_counter() - t0) / reps
+    assert all(bool(torch.isfinite(o["rgb"]).all()) for o in outs)
+
+    # the same rays through the C ABI's inference entry point, chunk by chunk (what get_outputs_for_camera_ray_bundle needs per chunk)
+    eng = model.engine
+    chunk = int(cfg.eval_num_rays_per_chunk)
+    bundles = []
+    for c in pair:
+        H, W = c.height, c.width
+        yy, xx = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+        idx = torch.stack([torch.zeros(H * W, dtype=torch.int64, device=device), yy.reshape(-1), xx.reshape(-1)], dim=1).contiguous()
+        g = lambda v: torch.as_tensor(v, dtype=torch.float32, device=device).reshape(-1)  # noqa: E731
+        o, d, _, _ = ops.raygen(idx, c.camera_to_worlds.to(device).reshape(1, 3, 4).contiguous(), g(c.fx), g(c.fy), g(c.cx), g(c.cy),
+                                c.distortion_params.to(device).reshape(1, 6).contiguous())
+        bundles.append((o, d, torch.full((H * W,), c.camera_index, dtype=torch.int64, device=device)))
+
+    def direct():
+        for o, d, cam in bundles:
+            for i in range(0, o.shape[0], chunk):
+                n = min(chunk, o.shape[0] - i)
+                nears, fars = eng._nears_fars(n, False)
+                ops.render_rays_eval(eng.props, eng.field, o[i:i + n], d[i:i + n], cam[i:i + n], nears, fars, eng.counts, eng.anneal)
+
+    direct()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        direct()
+    torch.cuda.synchronize()
+    dt_direct = (time.perf_counter() - t0) / reps
+    if profile_path:
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            through_model()
+            torch.cuda.synchronize()
+        with open(profile_path, "w") as f:
+            f.write(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40))
+    bytes_ray = 161792.0
+    return {"workload": "one 640x480 RGB + one 160x120 thermal image of the synthetic scene (326 400 rays), shared density, eval mode, chunks of %d rays" % chunk,
+            "rays": rays, "reps": reps,
+            "get_outputs_for_camera": {"ms": dt_model * 1e3, "rays_per_s": rays / dt_model, "frac_of_hbm_roofline": rays / dt_model * bytes_ray / 1e9 / HBM_PEAK_GBS},
+            "tn_render_rays_eval": {"ms": dt_direct * 1e3, "rays_per_s": rays / dt_direct, "frac_of_hbm_roofline": rays / dt_direct * bytes_ray / 1e9 / HBM_PEAK_GBS},
+            "algorithmic_bytes_per_ray": bytes_ray,
+            "note": "the reference's TEST_RAYS_PER_SEC (utils/writer.py:55-56); gather term only, no cache credit: the proposal tables are L2-resident"}
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves, as the reference's launcher does
     (scripts/train.py:138-151,204-209: mp.spawn of one process per device).  The parent has made NO HIP call at this point (torch is imported,
@@ -746,6 +825,14 @@ def main():
             return one_step_api(model, optimizers, cam_t, cache, rays, step, scaler, call=ddp)
         return one_step(eng, cam_t, cache, rays, step, hook, scaler)
 
+    # The "render PSNR vs ref" half of the metric, on the untouched synthetic weights the reference golden was rendered with (before any training
+    # step changes them -- the schedule guard's timing steps below included --, outside every timed region)
+    parity = None
+    if rank == 0 and world == 1 and not api and args.mode == "shared" and args.nerf_samples == 48 and not args.no_extras:
+        try:
+            parity = parity_vs_reference(eng, device)
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
+            parity = {"error": repr(e)}
     # ---- parallel.ScheduleGuard: the overlapped data-parallel schedule against the plain step, measured here, before the warm-up.  A stall of the
     # overlapped schedule switches the run to the simple one IN PROCESS; the JSON says which schedule ran and why.
     dp_info = None
@@ -776,7 +863,7 @@ def main():
             over_ms = timed(hook)
             simple_ms = timed(simple_hook)
             dec = guard.decide(plain_ms, over_ms, simple_ms)
-            guard.resync(arena)           # ... and is brought back to rank 0's parameters and Adam moments here
+            guard.resync(arena, grad_scaler=scaler)  # ... and is brought back to rank 0's parameters, Adam moments and loss-scale state here
             dp_info["guard"] = dec
             if dec["schedule"] == "simple":
                 hook = simple_hook
@@ -784,14 +871,6 @@ def main():
                     dec["overlapped_ms"], dec["simple_ms"], dec["plain_ms"])
                 print("bench.py: " + dp_info["schedule"], file=sys.stderr)
 
-    # The "render PSNR vs ref" half of the metric, on the untouched synthetic weights the reference golden was rendered with (before any training
-    # step changes them, outside every timed region)
-    parity = None
-    if rank == 0 and world == 1 and not api and args.mode == "shared" and args.nerf_samples == 48 and not args.no_extras:
-        try:
-            parity = parity_vs_reference(eng, device)
-        except Exception as e:  # noqa: BLE001  (an extra must never cost the headline line)
-            parity = {"error": repr(e)}
     step = 0
     for _ in range(args.warmup):
         run(step)
@@ -960,6 +1039,11 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     result["extra"][key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            try:  # the eval / render side of the metric: full images through get_outputs_for_camera and through tn_render_rays_eval
+                result["extra"]["eval_render"] = eval_render_leg(device, profile_path=os.environ.get("TN_EVAL_PROFILE"))
+            except Exception as e:  # noqa: BLE001
+                result["extra"]["eval_render"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.synchronize()
             cores = args.cpu_threads or min(os.cpu_count() or 1, 16)

@@ -61,7 +61,7 @@ class TrainRaySource:
     permutation of the dataset drawn once when all images are cached; `shuffle=False`: dataset order)."""
 
     def __init__(self, images: Sequence[Tensor], is_thermal: Sequence[float], cameras: Any, num_rays: int, patch_size: int, device,
-                 ray_bundle_cls: Callable[..., Any] = RayBundle, shuffle: bool = True):
+                 ray_bundle_cls: Callable[..., Any] = RayBundle, shuffle: bool = True, prefetch="cowork"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the device datamanager needs a GPU: pixel sampling and ray generation are HIP kernels (there is no CPU fallback)")
@@ -75,7 +75,10 @@ class TrainRaySource:
         self.num_rays = (int(num_rays) // self.patch_size ** 2) * self.patch_size ** 2  # PatchPixelSampler.set_num_rays_per_batch (data/pixel_samplers.py:380-386)
         if self.num_rays // self.patch_size ** 2 < n:
             raise ValueError(f"{num_rays} rays per batch cannot cover {n} images with {patch_size}x{patch_size} patches")
-        self._dm = DeviceDataManager(self.cache, self.cameras, self.num_rays, self.patch_size)
+        # prefetch="cowork" (TRAINING sources): the next batch is handed to the training step in between (ops.sample_rays_deferred: one pending
+        # block per process).  Eval sources launch their batches themselves: an eval batch parked in that slot would be sampled by the next TRAINING
+        # step and kept alive until the next evaluation, hundreds of iterations later, while the training batches lose their co-work.
+        self._dm = DeviceDataManager(self.cache, self.cameras, self.num_rays, self.patch_size, prefetch=prefetch)
         self._bundle = ray_bundle_cls
 
     def next(self, step: int = 0) -> Tuple[Any, Dict[str, Tensor]]:
@@ -174,9 +177,9 @@ class HipDataManager(torch.nn.Module):
         raise NotImplementedError
 
     @staticmethod
-    def _source(ds: DatasetView, num_rays: int, patch: int, device, shuffle: bool) -> TrainRaySource:
+    def _source(ds: DatasetView, num_rays: int, patch: int, device, shuffle: bool, prefetch="cowork") -> TrainRaySource:
         return TrainRaySource([ds.get_image_float32(i) for i in range(len(ds))], ds.metadata["is_thermal"], ds.cameras, num_rays, patch, device,
-                              shuffle=shuffle)
+                              shuffle=shuffle, prefetch=prefetch)
 
     def setup_train(self) -> None:
         self._train_src = self._source(self.train_dataset, self.config.train_num_rays_per_batch, self.config.patch_size, self.device,
@@ -186,7 +189,7 @@ class HipDataManager(torch.nn.Module):
         self._eval_next_image = 0
         if len(self.eval_dataset) and self.config.eval_num_rays_per_batch // self.config.patch_size ** 2 >= len(self.eval_dataset):
             self._eval_src = self._source(self.eval_dataset, self.config.eval_num_rays_per_batch, self.config.patch_size, self.device,
-                                          self.config.eval_sample_images_randomly)
+                                          self.config.eval_sample_images_randomly, prefetch=False)
 
     def iter_train(self) -> None:
         self.train_count = 0

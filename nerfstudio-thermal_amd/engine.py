@@ -862,6 +862,9 @@ class RenderEngine:
             lo, hi = a.group_range[g]
             ranges.append((lo, hi, group_steps[g], lr0, lr_final, max_steps, gidx[g]))
         self._set_grad_zero(True)  # (train_step made sure the arena's gradients are zero; shared mode: one scatter per table)
+        # (the library refuses what it can before its first launch; a refusal or launch error further in leaves gradients behind that no optimiser
+        # launch consumed: the buffer only counts as clean again once the call has returned)
+        a.grads_clean = False
         try:
             call.run(origins, directions, cam, image, is_thermal, nears, fars, self.anneal, jitters, bool(updated), flat, acc, ranges, self.adam_step_count,
                      fwd_buf=fwd_buf, next_plan=next_plan)

@@ -403,9 +403,16 @@ class Optimizers:
         mine_idx = [index[n] for n, _ in live]
         if len(mine_idx) == len(self.optimizers):
             found.zero_()
+        elif mine_idx == list(range(mine_idx[0], mine_idx[-1] + 1)):
+            found[mine_idx[0]:mine_idx[-1] + 1].zero_()
         else:
-            found[mine_idx[0]:mine_idx[-1] + 1].zero_() if mine_idx == list(range(mine_idx[0], mine_idx[-1] + 1)) else found.index_fill_(
-                0, torch.as_tensor(mine_idx, device=device), 0.0)
+            # (the index tensor is built once per group list: torch.as_tensor of a Python list is a pageable host-to-device copy, i.e. a
+            # synchronisation, and this is the optimiser's hot path)
+            cache = self.__dict__.setdefault("_clear_index", {})
+            key = (tuple(mine_idx), str(device))
+            if key not in cache:
+                cache[key] = torch.as_tensor(mine_idx, device=device)
+            found.index_fill_(0, cache[key], 0.0)
         work = []  # (flag, arena, lo, hi, step, lr, (beta1, beta2, eps))
         for n, o in live:
             gi = index[n]

@@ -111,10 +111,64 @@ class ScheduleGuard:
                          "ratio": over / plain if plain > 0 else float("inf"), "threshold": self.ratio, "stalled": stalled}
         return self.decision
 
-    def resync(self, arena, src: int = 0) -> None:
+    def resync(self, arena, src: int = 0, grad_scaler=None) -> None:
+        """Rank `src`'s parameters and Adam moments become everybody's -- and, with a grad scaler (optim.DeviceGradScaler), its loss scale, growth
+        tracker, per-group skip counts and schedule lag too: a rank whose plain leg skipped or backed off would otherwise keep scaling its loss
+        differently from the others for the rest of the run (every rank unscales by its OWN scale behind the all-reduce)."""
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            for t in (arena.params, arena.exp_avg, arena.exp_avg_sq):
+            tensors = [arena.params, arena.exp_avg, arena.exp_avg_sq]
+            if grad_scaler is not None and getattr(grad_scaler, "enabled", True):
+                tensors += [grad_scaler.scale, grad_scaler.growth_tracker, grad_scaler.skipped, grad_scaler.found_inf]
+            for t in tensors:
                 dist.broadcast(t, src=src, group=self.group)
+
+
+class InRunScheduleGuard:
+    """ScheduleGuard for a run that has no iterations to spare for timing legs (what `ns-train thermal-nerfacto-hip` runs on N > 1:
+    trainer.FusedTrainerMixin): the FIRST iterations of the run are the measurement.  `steps_per_leg` iterations run with the overlapped schedule,
+    the next `steps_per_leg` with the simple one -- both exchange the same mean gradient, so every one of them is an ordinary training step: no
+    plain leg, nothing to re-synchronise afterwards --, the caller times each (a synchronise around the step) and hands the time to `record()`;
+    after the second leg the ranks agree on the faster schedule (ScheduleGuard.decide: MAX over the group, overlapped unless the simple one beats
+    it by more than 5 %) and `hook` is that schedule's reducer for the rest of the run.  Never re-execs, never touches the environment.
+    `log(decision, step)` is called once, on every rank, when the decision falls."""
+
+    def __init__(self, world_size: int, overlapped, simple, steps_per_leg: int = 6, skip: int = 2, group=None, log=None):
+        assert steps_per_leg > skip >= 0
+        self.world, self.group = world_size, group
+        self.hooks = {"overlapped": overlapped, "simple": simple}
+        self.steps_per_leg, self.skip, self.log = int(steps_per_leg), int(skip), log
+        self.times = {"overlapped": [], "simple": []}
+        self.decision: Optional[dict] = None
+
+    @property
+    def measuring(self) -> bool:
+        return self.decision is None
+
+    @property
+    def leg(self) -> str:
+        if self.decision is not None:
+            return self.decision["schedule"]
+        return "overlapped" if len(self.times["overlapped"]) < self.steps_per_leg else "simple"
+
+    @property
+    def hook(self):
+        return self.hooks[self.leg]
+
+    def record(self, ms: float, step: int = -1) -> Optional[dict]:
+        """the wall time of the iteration that just ran with `hook`; returns the decision when this call completed the second leg"""
+        if self.decision is not None:
+            return None
+        self.times[self.leg].append(float(ms))
+        if len(self.times["simple"]) < self.steps_per_leg:
+            return None
+        med = lambda v: float(sorted(v[self.skip:])[len(v[self.skip:]) // 2])  # noqa: E731
+        over, simple = med(self.times["overlapped"]), med(self.times["simple"])
+        dec = ScheduleGuard(self.world, group=self.group).decide(simple, over, simple)  # (no plain leg: the simple step stands for it)
+        dec = {**dec, "measured_on": f"iterations 0-{2 * self.steps_per_leg - 1} of the run ({self.steps_per_leg} per schedule, first {self.skip} of each skipped)"}
+        self.decision = dec
+        if self.log is not None:
+            self.log(dec, step)
+        return dec
 
 
 class _StreamWork:
@@ -346,6 +400,11 @@ class ShardedGradReducer(OverlappedGradReducer):
         n = (hi - lo) // self.world
         return lo + self.rank * n, lo + (self.rank + 1) * n
 
+    def _native_scatter(self, group) -> bool:
+        """the backend has reduce_scatter_tensor / all_gather_into_tensor (RCCL); gloo does not (tests/test_parallel_cpu.py drives these branches
+        through stand-ins built on gloo's collectives)"""
+        return dist.get_backend(group) == "nccl"
+
     def begin(self, arena) -> None:
         super().begin(arena)
         self._sharded = {}
@@ -361,7 +420,7 @@ class ShardedGradReducer(OverlappedGradReducer):
         self._sharded[len(self._ranges) - 1] = (lo, hi)
         grads = self._arena.grads
         group = self.side_group() if side else self.group
-        if dist.get_backend(group) == "nccl":
+        if self._native_scatter(group):
             a, b = self._own(lo, hi)
             self._works.append(dist.reduce_scatter_tensor(grads[a:b], grads[lo:hi], op=self._op(), group=group, async_op=True))
         else:  # no reduce-scatter in this backend: the whole slice is reduced, the owned piece is what gets used
@@ -388,7 +447,7 @@ class ShardedGradReducer(OverlappedGradReducer):
         params = self._arena.params
         for lo, hi in self._gather:
             a, b = self._own(lo, hi)
-            if dist.get_backend(self.group) == "nccl":
+            if self._native_scatter(self.group):
                 works.append(dist.all_gather_into_tensor(params[lo:hi], params[a:b], group=self.group, async_op=True))
             else:
                 n = (hi - lo) // self.world

@@ -57,19 +57,42 @@ def _device_scaler(trainer):
     return ds
 
 
-def _grad_hook(trainer):
+def _log_schedule(decision: Dict[str, Any], step: int) -> None:
+    """the guard's decision through the Trainer's writer (utils/writer.py: put_dict goes to every configured writer) and to the console"""
+    scalars = {k: float(v) for k, v in decision.items() if isinstance(v, (int, float)) and v == v}
+    scalars["overlapped_schedule_runs"] = 1.0 if decision.get("schedule") == "overlapped" else 0.0
+    try:
+        from nerfstudio.utils import writer  # type: ignore
+
+        writer.put_dict(name="data-parallel schedule (thermal-nerfacto-hip)", scalar_dict=scalars, step=max(int(step), 0))
+    except Exception:  # noqa: BLE001  (no nerfstudio here, or no writer set up yet: the console line below is the record)
+        pass
+    print("nerfstudio_thermal_amd: data-parallel schedule = %s (overlapped %.3f ms, simple %.3f ms per iteration; %s)" % (
+        decision.get("schedule"), decision.get("overlapped_ms", float("nan")), decision.get("simple_ms") or float("nan"), decision.get("measured_on", "")), flush=True)
+
+
+def _dp_guard(trainer):
     """Data parallel (scripts/train.py:138-151 starts one process per GPU and the pipeline wraps the model in DistributedDataParallel): the fused
-    step has no autograd hooks for DDP's reducer to hang on, so the same mean all-reduce is issued by parallel.OverlappedGradReducer."""
+    step has no autograd hooks for DDP's reducer to hang on, so the same mean all-reduce is issued by this package's reducers -- overlapped with the
+    backward (parallel.OverlappedGradReducer) or after it (parallel.GradAllReducer), whichever the first iterations of THIS run measure as the
+    faster one (parallel.InRunScheduleGuard).  TN_DP_SCHEDULE=overlapped|simple pins the schedule instead.  None on one rank."""
+    import os
+
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return None
-    hook = trainer.__dict__.get("_tn_grad_hook")
-    if hook is None:
-        from .parallel import OverlappedGradReducer
+    guard = trainer.__dict__.get("_tn_dp_guard")
+    if guard is None:
+        from .parallel import GradAllReducer, InRunScheduleGuard, OverlappedGradReducer
 
-        hook = trainer.__dict__["_tn_grad_hook"] = OverlappedGradReducer(dist.get_world_size())
-    return hook
+        world = dist.get_world_size()
+        guard = InRunScheduleGuard(world, OverlappedGradReducer(world), GradAllReducer(world), log=_log_schedule)
+        pinned = os.environ.get("TN_DP_SCHEDULE", "")
+        if pinned in ("overlapped", "simple"):
+            guard.decision = {"schedule": pinned, "pinned_by": "TN_DP_SCHEDULE"}
+        trainer.__dict__["_tn_dp_guard"] = guard
+    return guard
 
 
 def fused_train_iteration(trainer, step: int) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], Dict[str, Any]]:
@@ -78,7 +101,18 @@ def fused_train_iteration(trainer, step: int) -> Tuple[torch.Tensor, Dict[str, t
     m = _model_of(trainer)
     ray_bundle, batch = trainer.pipeline.datamanager.next_train(step)  # pipelines/base_pipeline.py:296-301
     pose_metrics = m.engine.pose_metrics()  # (the reference's metrics hold the pose norms of the forward, i.e. before this iteration's Adam step)
-    loss_dict = m.train_iteration(ray_bundle, batch, step, grad_hook=_grad_hook(trainer), grad_scaler=_device_scaler(trainer), step_callback=False)
+    guard = _dp_guard(trainer)
+    timing = guard is not None and guard.measuring  # (N > 1: the run's first iterations time the two exchange schedules)
+    if timing:
+        import time
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    loss_dict = m.train_iteration(ray_bundle, batch, step, grad_hook=None if guard is None else guard.hook, grad_scaler=_device_scaler(trainer),
+                                  step_callback=False)
+    if timing:
+        torch.cuda.synchronize()
+        guard.record((time.perf_counter() - t0) * 1e3, step)
     metrics_dict = m.engine.train_metrics(pose_metrics)  # + PSNR per spectrum, distortion: one small launch behind the step, no synchronisation
     loss = functools.reduce(torch.add, loss_dict.values())
     return loss, loss_dict, metrics_dict

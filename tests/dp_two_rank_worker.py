@@ -58,7 +58,8 @@ def main_ddp(rank, world, port, golden_dir, out_path):
 
 def main_fused_trainer(rank, world, port, golden_dir, out_path):
     """trainer.FusedTrainerMixin with two ranks: the Trainer's iteration on the fused step, the gradient exchange issued by the mixin
-    (parallel.OverlappedGradReducer over the default process group) instead of DistributedDataParallel's autograd hooks."""
+    (parallel.OverlappedGradReducer / GradAllReducer over the default process group, picked by parallel.InRunScheduleGuard from the run's first
+    twelve iterations) instead of DistributedDataParallel's autograd hooks."""
     from nerfstudio_thermal_amd.parallel import broadcast_params
     from nerfstudio_thermal_amd.rays import RayBundle
     from nerfstudio_thermal_amd.trainer import FusedTrainerMixin
@@ -83,7 +84,8 @@ def main_fused_trainer(rank, world, port, golden_dir, out_path):
     dist.broadcast(theirs, src=0)
     res = {"rank": rank, "params_equal_rank0": bool(torch.equal(mine, theirs)), "params_finite": bool(torch.isfinite(mine).all()),
            "moved": float((model.arena.params - init).double().norm()), "seen_idle": True, "scale": 65536.0,
-           "reference_iterations": trainer.ref_iterations, "exchanges": type(trainer.__dict__.get("_tn_grad_hook")).__name__,
+           "reference_iterations": trainer.ref_iterations, "exchanges": type(trainer.__dict__["_tn_dp_guard"].hooks["overlapped"]).__name__,
+           "guard": {"schedule": trainer.__dict__["_tn_dp_guard"].decision["schedule"], "legs": [len(v) for v in trainer.__dict__["_tn_dp_guard"].times.values()]},
            "losses": {k: float(v) for k, v in loss_dict.items()}}
     with open(out_path, "w") as f:
         json.dump(res, f)

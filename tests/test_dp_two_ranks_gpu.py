@@ -75,3 +75,5 @@ def test_two_ranks_under_the_fused_trainer(golden_dir, tmp_path):
     for r in res:
         assert r["params_equal_rank0"] and r["params_finite"] and r["moved"] > 0, r
         assert r["reference_iterations"] == 0 and r["exchanges"] == "OverlappedGradReducer", r
+        # the run's first twelve iterations timed the two exchange schedules (six each); both ranks took the same decision
+        assert r["guard"]["legs"] == [6, 6] and r["guard"]["schedule"] in ("overlapped", "simple"), r

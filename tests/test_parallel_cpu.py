@@ -238,6 +238,97 @@ def test_two_rank_sharded_optimizer_equals_allreduce_path():
     assert res[0][4] == res[1][4]  # the gathered table is bit-identical on both ranks
 
 
+def _sharded_native_worker(rank, world, port, q):
+    """The branches ShardedGradReducer takes on RCCL -- reduce_scatter_tensor into the owned piece IN PLACE, all_gather_into_tensor of the updated
+    parameters -- driven on two gloo ranks through stand-ins with the collectives' semantics: the reduce-scatter writes ONLY the owned piece (the
+    mean) and leaves NaN in every piece this rank does not own, the all-gather fills the whole slice from the ranks' pieces.  Same parameters as the
+    all-reduce path, and nothing non-finite may reach them."""
+    from nerfstudio_thermal_amd import parallel as P
+    from nerfstudio_thermal_amd.parallel import ShardedGradReducer
+
+    class _Done:
+        def wait(self):
+            pass
+
+    calls = {"reduce_scatter_tensor": 0, "all_gather_into_tensor": 0}
+
+    def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):  # noqa: A002
+        calls["reduce_scatter_tensor"] += 1
+        w = dist.get_world_size(group)
+        n = input.numel() // w
+        assert output.numel() == n and output.data_ptr() == input[rank * n:(rank + 1) * n].data_ptr()  # in place, as the product path issues it
+        full = input.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        if op == dist.ReduceOp.AVG:
+            full /= w
+        input.fill_(float("nan"))  # what this rank does not own is not its to read afterwards
+        output.copy_(full[rank * n:(rank + 1) * n])
+        return _Done()
+
+    def all_gather_into_tensor(output, input, group=None, async_op=False):  # noqa: A002
+        calls["all_gather_into_tensor"] += 1
+        w = dist.get_world_size(group)
+        n = output.numel() // w
+        assert input.numel() == n
+        parts = [torch.empty_like(input) for _ in range(w)]
+        dist.all_gather(parts, input.clone(), group=group)
+        for r, part in enumerate(parts):
+            output[r * n:(r + 1) * n].copy_(part)
+        return _Done()
+
+    class _Native(ShardedGradReducer):
+        def _native_scatter(self, group):
+            return True
+
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    init_distributed("gloo")
+    P.dist.reduce_scatter_tensor, P.dist.all_gather_into_tensor = reduce_scatter_tensor, all_gather_into_tensor
+    arena = ParamArena(_tiny_cfg("shared"), 8, "cpu")
+    base_p = torch.from_numpy(synth.uniform("p", (arena.total,), seed=5))
+    base_g = torch.from_numpy(synth.uniform("g", (arena.total,), seed=3))
+    t0, tshape = arena.layout["field.mlp_base.model.0.hash_table"]
+    tn = int(np.prod(tshape))
+    half = tn // 2
+
+    def run(hook):
+        arena.params.copy_(base_p)
+        arena.grads.copy_(base_g * (rank + 1))
+        hook.begin(arena)
+        hook.reduce_range(t0, t0 + half)
+        hook.reduce_range(t0 + half, t0 + tn)
+        pieces = list(hook.finish_iter())
+        for lo, hi in pieces:
+            arena.params[lo:hi] -= 0.1 * arena.grads[lo:hi]
+        if getattr(hook, "sharded", False):
+            hook.gather_params()
+        return pieces, arena.params.clone()
+
+    _, params_a = run(OverlappedGradReducer(world, side_group=None))
+    hook = _Native(world, rank, min_shard=1024, side_group=None)
+    pieces_b, params_b = run(hook)
+    own = hook._own(t0, t0 + half)
+    q.put((rank, bool(torch.isfinite(params_b).all()), bool(torch.allclose(params_a, params_b, rtol=1e-6, atol=1e-7)), own in pieces_b and (t0, t0 + half) not in pieces_b,
+           calls["reduce_scatter_tensor"] >= 2 and calls["all_gather_into_tensor"] >= 2, params_b.double().sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_reducer_native_collective_branches():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_native_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, finite, same, owned, called, _ in res:
+        assert finite and same and owned and called, res
+    assert res[0][5] == res[1][5]  # the gathered parameters are bit-identical on both ranks
+
+
 def _sharded_leftover_worker(rank, world, port, q):
     """A slice that only finish_iter's LEFTOVER pass issues can be sharded too (separate mode: a whole proposal group as one leftover).  gloo has
     no reduce-scatter and all-reduces the slice, which hides a missed ownership; so the collective is followed by what reduce-scatter would leave
