@@ -3,5 +3,5 @@ sys.path.insert(0, "/root/repo")
 import torch
 import bench
 dev = torch.device("cuda:0")
-r = bench.eval_render_leg(dev, reps=3, profile_path="gpurun_out/r6g/eval_profile.txt")
+r = bench.eval_render_leg(dev, reps=3, profile_path="gpurun_out/eval_profile.txt")
 print(json.dumps(r, indent=1))

@@ -1,7 +1,7 @@
 # Everything under profiles/<round>_* in one gpurun call (tests, PMC passes, bench lines, kernel stats, timelines):
 #   gpurun --timeout 1200 -- 'bash scripts/refresh_profiles.sh > gpurun_out/refresh.log 2>&1'
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${R:-r05}
+R=${R:-r06}
 mkdir -p gpurun_out/$R
 PART=${PART:-all}   # 3: kernel traces / timelines only; 1: tests, PMC passes, hardware-queue sweep, forward ablation, microbenchmark; 2: bench lines, kernel stats, timelines (two gpurun calls: each stays under the 20-minute limit)
 if [ "$PART" != "2" ] && [ "$PART" != "3" ]; then
@@ -36,6 +36,10 @@ b n1_1024rays --rays 1024 --no-cpu-baseline
 b n1_96samples --nerf-samples 96 --no-cpu-baseline
 b n1_splat_1080p --workload splat
 python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1rank_latency.json
+# round 6: the next iteration's sampling front inside the optimiser launch -- same-box A/B of the launch modes (0 = in line, 1 = co-work (default), 2 = serial, 3 = companion stream)
+for m in 0 1 2 3; do TN_NEXT_SAMPLING=$m python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > gpurun_out/$R/bench_n1_next_sampling_mode$m.json; done
+python scripts/eval_probe.py > gpurun_out/$R/eval_render.json 2>/dev/null
+python scripts/sampler_ulps.py gpurun_out/$R/sampler_ulps.md > /dev/null 2>&1
 fi
 rm -rf gpurun_out/prof_a gpurun_out/prof_dp gpurun_out/prof_sep
 # (the last 20 steps of a fused / separate run are the in-step measurement, which issues the backward phase by phase: the timelines show steps of the timed region)
