@@ -35,5 +35,12 @@ def test_default_line_has_every_object_and_no_failed_leg():
     assert 0 < p["density_err_over_1ulp_response"] <= 6.0 and 0 <= p["bins_beyond_64ulp_share"] <= 0.02, p
     for name, leg in d["extra"].items():
         assert "error" not in leg, (name, leg)
+        if name == "eval_render":  # the reference's TEST_RAYS_PER_SEC: full images through the Model API and through tn_render_rays_eval
+            for k in ("get_outputs_for_camera", "tn_render_rays_eval"):
+                assert leg[k]["ms"] > 0 and leg[k]["rays_per_s"] > 1e6 and 0 < leg[k]["frac_of_hbm_roofline"] < 1.0, (name, leg)
+            assert leg["rays"] == 640 * 480 + 160 * 120
+            continue
         assert leg["ms_per_step"] > 0 and leg["rays_per_s"] > 0, (name, leg)
-    assert set(d["extra"]) == {"separate_8192", "nerf_samples_96", "model_api_amp", "fused_trainer"}
+    assert set(d["extra"]) == {"separate_8192", "nerf_samples_96", "model_api_amp", "fused_trainer", "eval_render"}
+    ak = rf["all_kernels"]
+    assert all(v["bound"] == ("l2" if k.startswith("k_prop_fwd") else "hbm") and 0 < v["frac"] < 1.0 for k, v in ak.items()), ak
