@@ -218,23 +218,23 @@ __device__ __forceinline__ void tn_level_corners(float px, float py, float pz, f
   lc.idx[6] = ((fx ^ hfy ^ hfz) & mask) + level_off;  // (f,f,f)
   lc.idx[7] = ((fx ^ hcy ^ hfz) & mask) + level_off;  // (f,c,f)
 }
+// The two features of a level are interpolated TOGETHER, as 2-vectors: the same multiplies and adds per component in the same order (IEEE, no
+// contraction: bit-identical to the scalar form), issued as packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: two floats per lane and
+// instruction) -- the interpolation is ~210 of the ~930 instructions a proposal sample costs, and those kernels are bound by instruction issue.
+typedef float tn_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 tn_level_interp(const float2 f[8], float ox, float oy, float oz) {
-  float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
-  float2 r;
-#define TN_LERP3(C)                                      \
-  {                                                      \
-    float f03 = f[0].C * ox + f[3].C * ux;               \
-    float f12 = f[1].C * ox + f[2].C * ux;               \
-    float f56 = f[5].C * ox + f[6].C * ux;               \
-    float f47 = f[4].C * ox + f[7].C * ux;               \
-    float f0312 = f03 * oy + f12 * uy;                   \
-    float f4756 = f47 * oy + f56 * uy;                   \
-    r.C = f0312 * oz + f4756 * uz;                       \
-  }
-  TN_LERP3(x)
-  TN_LERP3(y)
-#undef TN_LERP3
-  return r;
+  const float ux = 1.0f - ox, uy = 1.0f - oy, uz = 1.0f - oz;
+  tn_v2f v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i].x = f[i].x; v[i].y = f[i].y; }
+  const tn_v2f f03 = v[0] * ox + v[3] * ux;
+  const tn_v2f f12 = v[1] * ox + v[2] * ux;
+  const tn_v2f f56 = v[5] * ox + v[6] * ux;
+  const tn_v2f f47 = v[4] * ox + v[7] * ux;
+  const tn_v2f f0312 = f03 * oy + f12 * uy;
+  const tn_v2f f4756 = f47 * oy + f56 * uy;
+  const tn_v2f r = f0312 * oz + f4756 * uz;
+  return make_float2(r.x, r.y);
 }
 // Trilinear value AND its derivatives wrt the in-cell offset (o = scaled - floor(scaled); d o / d position = res), feature by feature:
 // what autograd derives from tn_level_interp's operation sequence (field_components/encodings.py:449-459 with offset = scaled - scaled_f).
@@ -261,13 +261,18 @@ __device__ __forceinline__ float2 tn_level_interp_jac(const float2 f[8], float o
 #undef TN_LERP3J
   return r;
 }
+// (a table has at most 16 levels x 2^24 entries of 8 bytes: the byte offset of an entry fits 32 bits, and a 32-bit offset on a wave-uniform base is
+// ONE address instruction per gather instead of a 64-bit shift-and-add)
+__device__ __forceinline__ float2 tn_table_entry(const float2* __restrict__ table, uint32_t idx) {
+  return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(table) + (uint32_t)(idx * 8u));
+}
 __device__ __forceinline__ float2 tn_encode_level_jac(const float2* __restrict__ table, float px, float py, float pz, float res, uint32_t mask,
                                                       uint32_t level_off, float jac[6]) {
   LevelCorners lc;
   tn_level_corners(px, py, pz, res, mask, level_off, lc);
   float2 f[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
+  for (int i = 0; i < 8; ++i) f[i] = tn_table_entry(table, lc.idx[i]);
   return tn_level_interp_jac(f, lc.ox, lc.oy, lc.oz, res, jac);
 }
 __device__ __forceinline__ float2 tn_encode_level(const float2* __restrict__ table, float px, float py, float pz, float res, uint32_t mask,
@@ -276,7 +281,7 @@ __device__ __forceinline__ float2 tn_encode_level(const float2* __restrict__ tab
   tn_level_corners(px, py, pz, res, mask, level_off, lc);
   float2 f[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f[i] = table[lc.idx[i]];
+  for (int i = 0; i < 8; ++i) f[i] = tn_table_entry(table, lc.idx[i]);
   return tn_level_interp(f, lc.ox, lc.oy, lc.oz);
 }
 

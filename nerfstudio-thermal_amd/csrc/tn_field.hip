@@ -318,10 +318,10 @@ __global__ void __launch_bounds__(256) k_field_encode_xcd(GridK g, EncSched sc, 
     const uint32_t hcy = (uint32_t)(int)ceilf(sy) * TN_PRIME_Y, hfy = (uint32_t)(int)fyf * TN_PRIME_Y;
     const uint32_t hcz = (uint32_t)(int)ceilf(sz) * TN_PRIME_Z, hfz = (uint32_t)(int)fzf * TN_PRIME_Z;
     ox[u] = sx - fxf; oy[u] = sy - fyf; oz[u] = sz - fzf;
-    fv[u][0] = g.table[((xi ^ hcy ^ hcz) & g.mask) + off];
-    fv[u][1] = g.table[((xi ^ hfy ^ hcz) & g.mask) + off];
-    fv[u][2] = g.table[((xi ^ hcy ^ hfz) & g.mask) + off];
-    fv[u][3] = g.table[((xi ^ hfy ^ hfz) & g.mask) + off];
+    fv[u][0] = tn_table_entry(g.table, ((xi ^ hcy ^ hcz) & g.mask) + off);
+    fv[u][1] = tn_table_entry(g.table, ((xi ^ hfy ^ hcz) & g.mask) + off);
+    fv[u][2] = tn_table_entry(g.table, ((xi ^ hcy ^ hfz) & g.mask) + off);
+    fv[u][3] = tn_table_entry(g.table, ((xi ^ hfy ^ hfz) & g.mask) + off);
   }
 #pragma unroll
   for (int u = 0; u < ENC_PER; ++u) {

@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restri
   adam_block_done(su, found_inf, r.num_flags, skipped, r.lag_index);
 }
 // (the chain alone, for register accounting and A/B timing: TN_NEXT_SAMPLING=2 launches it behind the optimiser launch instead of inside it)
-__global__ void __launch_bounds__(256) k_next_sampling(NextSamplingArgs ns) {
+__global__ void __launch_bounds__(256, 4) k_next_sampling(NextSamplingArgs ns) {
   __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
   next_sampling_body(ns, blockIdx.x, gridDim.x, ns_lds);
 }

@@ -131,12 +131,8 @@ __device__ __forceinline__ void next_sampling_body(const NextSamplingArgs& c, un
   float* s_w0 = lds;
   float* s_w1 = lds + NS_WEIGHT_FLOATS;
   float* s_ray = lds + 2 * NS_WEIGHT_FLOATS;
-  for (int t = threadIdx.x; t < PH * PROP_WROW; t += blockDim.x) {
-    const int j = t / PROP_WROW, k = t - j * PROP_WROW;
-    s_w0[t] = k < PF ? c.p0.w0[j * PF + k] : (k == PF ? c.p0.b0[j] : c.p0.w1[j]);
-    s_w1[t] = k < PF ? c.p1.w0[j * PF + k] : (k == PF ? c.p1.b0[j] : c.p1.w1[j]);
-  }
-  if (threadIdx.x == 0) { s_w0[PH * PROP_WROW] = c.p0.b1[0]; s_w1[PH * PROP_WROW] = c.p1.b1[0]; }
+  prop_stage_weights_into(c.p0.w0, c.p0.b0, c.p0.w1, c.p0.b1, s_w0);
+  prop_stage_weights_into(c.p1.w0, c.p1.b0, c.p1.w1, c.p1.b1, s_w1);
   // (wave-uniform by construction; said so, the ray index and everything addressed by it live in scalar registers)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
   float* lw = lds + 2 * NS_WEIGHT_FLOATS + NS_RAY_FLOATS + wv * NS_WAVE_FLOATS;

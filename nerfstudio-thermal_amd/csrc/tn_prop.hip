@@ -32,24 +32,7 @@ __global__ void __launch_bounds__(256, 2) k_prop_fwd(PropK net, const float* __r
       enc[2 * l + 1] = v.y;
       if (SAVE_ENC) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;  // level-major [PL][P] float2: 512 contiguous bytes per wave and level
     }
-    float out = s_w[PH * PROP_WROW];
-#pragma unroll 4
-    for (int j = 0; j < PH; ++j) {
-      const float4 wa = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW), wb = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW + 4),
-                   wc = *reinterpret_cast<const float4*>(s_w + j * PROP_WROW + 8);
-      float a = wc.z;
-      a = fmaf(wa.x, enc[0], a);
-      a = fmaf(wa.y, enc[1], a);
-      a = fmaf(wa.z, enc[2], a);
-      a = fmaf(wa.w, enc[3], a);
-      a = fmaf(wb.x, enc[4], a);
-      a = fmaf(wb.y, enc[5], a);
-      a = fmaf(wb.z, enc[6], a);
-      a = fmaf(wb.w, enc[7], a);
-      a = fmaf(wc.x, enc[8], a);
-      a = fmaf(wc.y, enc[9], a);
-      out = fmaf(wc.w, fmaxf(a, 0.0f), out);
-    }
+    const float out = prop_mlp(s_w, enc);
     density[i] = c.sel ? expf(out) : 0.0f * expf(out);  // exp(x) * selector (0*inf = nan kept as torch would)
   }
 }
