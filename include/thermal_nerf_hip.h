@@ -38,10 +38,13 @@
  *                                 the first blocks of the main grid's fold launch on iterations without a proposal update
  *      TN_FUSE_RENDER=1           (read per call) tn_train_step with tn_render_fwd / tn_train_losses / tn_render_bwd as ONE launch,
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
+ *      TN_NEXT_SAMPLING=0|2|3     (read per call) tn_train_step's next_sampling: 0 = never taken (every iteration samples in line); 2 = the chain as a launch
+ *                                 of its own behind the optimiser launch; 3 = on a companion stream beside it (A/B timing aids: same results)
  *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
  *                                 half of the output features; a measured experiment that is correct and slower (profiles/r05_experiments.md)
  *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid), TN_DM_PREFETCH=0 (the
- *    device data manager launches every batch itself instead of handing the next one to tn_train_step: A/B timing) and writes
+ *    device data manager launches every batch itself instead of handing the next one to tn_train_step: A/B timing), TN_NEXT_SAMPLING=0 (the engine
+ *    plans no next_sampling), TN_DP_SCHEDULE=overlapped|simple (pins the data-parallel exchange schedule of trainer.FusedTrainerMixin) and writes
  *    nothing into the environment (rounds 2-4 set GPU_MAX_HW_QUEUES=8 at import: the schedules now fit the runtime's default of four).
  */
 #ifndef THERMAL_NERF_HIP_H
