@@ -80,13 +80,15 @@ def _ssim(pred: Tensor, gt: Tensor, kernel_size: int = 11, sigma: float = 1.5, k
     ax = torch.arange(kernel_size, dtype=pred.dtype, device=pred.device) - (kernel_size - 1) / 2.0
     g1 = torch.exp(-(ax / sigma) ** 2 / 2.0)
     g1 = g1 / g1.sum()
-    win = (g1[:, None] * g1[None, :]).expand(C, 1, kernel_size, kernel_size).contiguous()
     rng = torch.maximum(pred.max() - pred.min(), gt.max() - gt.min())
     c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
     pad = (kernel_size - 1) // 2
     p = torch.nn.functional.pad(pred, (pad, pad, pad, pad), mode="reflect")
     t = torch.nn.functional.pad(gt, (pad, pad, pad, pad), mode="reflect")
-    f = lambda x: torch.nn.functional.conv2d(x, win, groups=C)  # noqa: E731
+    # the window is separable (outer product of g1 with itself): two 1-D passes over unfolded views -- plain element-wise kernels.  (A grouped
+    # conv2d goes through MIOpen, whose first call per image shape searches / compiles kernels for seconds: most of an evaluation pass of a few
+    # images was that.)
+    f = lambda x: (((x.unfold(2, kernel_size, 1) * g1).sum(-1)).unfold(3, kernel_size, 1) * g1).sum(-1)  # noqa: E731
     mu_p, mu_t = f(p), f(t)
     s_pp, s_tt, s_pt = f(p * p) - mu_p * mu_p, f(t * t) - mu_t * mu_t, f(p * t) - mu_p * mu_t
     ssim = ((2 * mu_p * mu_t + c1) * (2 * s_pt + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2))

@@ -22,7 +22,7 @@ from .rays import RayBundle
 
 class ThermalPipeline:
     def __init__(self, data: str, model_config: Optional[ThermalNerfactoModelConfig] = None, device="cuda", num_rays_per_batch: int = 4096,
-                 patch_size: int = 2, parser_config: Optional[ThermalNerfDataParserConfig] = None, seed: int = 0):
+                 patch_size: int = 2, parser_config: Optional[ThermalNerfDataParserConfig] = None, seed: int = 0, mixed_precision: bool = True):
         from .model import SceneBox
 
         self.device = torch.device(device)
@@ -39,6 +39,12 @@ class ThermalPipeline:
         self.cam_t = {k: tr.cameras[k].to(self.device).contiguous() for k in ("c2w", "fx", "fy", "cx", "cy", "distortion")}
         self.datamanager = DeviceDataManager(self.cache, self.cam_t, num_rays_per_batch, patch_size)
         self.step = 0
+        # mixed_precision=True in thermal-nerfacto's method config (configs/method_configs.py:260): the Trainer runs every iteration under a
+        # GradScaler (engine/trainer.py:470-495).  Its device-side equivalent also selects the ONE-call iteration (tn_train_step), which samples the
+        # next batch and runs the next iteration's sampling front inside its optimiser launches.
+        from .optim import DeviceGradScaler
+
+        self.grad_scaler = DeviceGradScaler(self.device, num_groups=len(self.model.arena.optimised_groups)) if mixed_precision else None
 
     def train(self, num_steps: int) -> Dict[str, float]:
         """num_steps fused training iterations (callbacks + forward + losses + backward + Adam); returns the last loss dict."""
@@ -55,7 +61,7 @@ class ThermalPipeline:
         for _ in range(num_steps):
             o, d, cam, img, is_th = self.datamanager.next_train(self.step)
             rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones_like(o[:, :1]), camera_indices=cam[:, None])
-            losses = self.model.train_iteration(rb, {"image": img, "is_thermal": is_th}, self.step)
+            losses = self.model.train_iteration(rb, {"image": img, "is_thermal": is_th}, self.step, grad_scaler=self.grad_scaler)
             self.step += 1
         return {k: float(v) for k, v in losses.items()}
 

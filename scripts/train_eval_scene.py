@@ -56,12 +56,16 @@ def main():
         torch.cuda.synchronize()
         curve.append({"step": done, "seconds": time.perf_counter() - t0, **losses})
     train_s = time.perf_counter() - t0
+    pipe.get_average_eval_image_metrics()  # (first pass: allocations, workspaces -- the second one is timed, as TEST_RAYS_PER_SEC is a steady-state figure)
+    torch.cuda.synchronize()
     t1 = time.perf_counter()
     metrics = pipe.get_average_eval_image_metrics()
     torch.cuda.synchronize()
+    eval_rays = int(sum(int(w) * int(h) for w, h in zip(pipe.eval_outputs.cameras["width"], pipe.eval_outputs.cameras["height"])))
     print(json.dumps({"dataset": "synthetic cube scene on disk (transforms.json, RGB frames first, per-frame intrinsics, is_thermal)" if tmp else data,
                       "train_images": len(pipe.train_outputs.image_filenames), "eval_images": len(pipe.eval_outputs.image_filenames), "steps": args.steps,
-                      "train_seconds": train_s, "train_rays_per_s": args.steps * 4096 / train_s, "eval_seconds": time.perf_counter() - t1,
+                      "train_seconds": train_s, "train_rays_per_s": args.steps * 4096 / train_s, "eval_seconds": time.perf_counter() - t1, "eval_rays": eval_rays,
+                      "eval_rays_per_s_incl_image_loading_and_metrics": eval_rays / (time.perf_counter() - t1),
                       "eval_metrics": metrics, "curve": curve}))
 
 
