@@ -276,7 +276,7 @@ def kernel_roofline(eng, cam_t, idx, image=None, is_thermal=None):
         # shared mode: the step's optimiser launch leaves the gradients zero and every table sees one scatter per iteration, so the fold stores
         # instead of adding (TnGrid.table_grad_is_zero) -- timed that way here
         dpos = (d_o, d_d) if net.num_levels == 5 else (None, None)
-        if net.num_levels != 5 and image is not None:
+        if net.num_levels != 5 and image is not None and not eng.separate:  # (shared density: one RGBT composite, the step bench.py's `value` times)
             c = eng.cfg
             d_comp, dw2 = torch.zeros((N, 4), device=o.device), torch.zeros((N, L.S), device=o.device)
             lines = torch.zeros((ops.LOSS_LINES, 16), device=o.device)

@@ -22,8 +22,9 @@
  *    per process too.  There is no other hidden state: no context object, no caches, no allocations -- workspaces are the caller's.
  *    (SURVEY.md 8b proposed tn_create / tn_destroy around an opaque context; with the state reduced to this map a context would own nothing
  *    else, so the teardown is the one call.)
- *  - The data-parallel gradient exchange is NOT part of this ABI (no tn_allreduce_grads): it is torch.distributed over RCCL on slices of the
- *    caller's gradient arena (nerfstudio_thermal_amd/parallel.py), exactly where the reference has torch DDP.
+ *  - The data-parallel gradient exchange: the Python package uses torch.distributed over RCCL on slices of the caller's gradient arena
+ *    (nerfstudio_thermal_amd/parallel.py), exactly where the reference has torch DDP; tn_comm_* / tn_allreduce_grads offer the same exchange to a
+ *    host that binds only this ABI (RCCL resolved at run time, no link-time dependency).
  *  - Environment switches, read once per process, all tuning / diagnostic aids whose defaults are the product path:
  *      TN_NO_FORK=1               no companion streams (everything on the caller's stream)
  *      TN_SCATTER_MODE=2|1|0      table-gradient scatter: 2 = segmented (default: block-private record regions, no global atomics), 1 = binned
@@ -597,6 +598,22 @@ typedef struct TnTrainStep {
   int32_t sampling_done;
 } TnTrainStep;
 TN_API int tn_train_step(const TnTrainStep* step, tn_stream_t stream);
+/* ---- 8e  the data-parallel gradient exchange for a host that binds only this ABI: what torch DDP does for the reference
+ * (pipelines/base_pipeline.py:281-283: mean all-reduce of the gradients over NCCL; scripts/train.py:138-151 starts one process per GPU).
+ * RCCL is resolved at the first call -- from the RCCL the process has loaded already (PyTorch's own), else librccl.so on the loader path -- and is
+ * not a link-time dependency of the library; without one these calls return TN_ELAUNCH.  (The Python package exchanges through torch.distributed,
+ * nerfstudio_thermal_amd/parallel.py: the same library underneath.)
+ *   tn_comm_unique_id(out)            rank 0: 128 bytes (HOST) to hand to every rank (ncclGetUniqueId)
+ *   tn_comm_create(id, world, rank, &comm)   every rank, collectively, on its CURRENT device (ncclCommInitRank)
+ *   tn_allreduce_grads(comm, grads, count, average, stream)   in place over `count` floats of the caller's gradient arena, enqueued on `stream`:
+ *                                     average != 0 -> the mean over the ranks (ncclAvg), else the sum.  Any slice of the arena, as often as the
+ *                                     caller's schedule wants (the whole live range behind the backward, or level ranges behind their folds).
+ *   tn_comm_destroy(comm) */
+TN_API int tn_comm_unique_id(void* unique_id_out);
+TN_API int tn_comm_create(const void* unique_id, int32_t world_size, int32_t rank, void** comm_out);
+TN_API int tn_comm_destroy(void* comm);
+TN_API int tn_allreduce_grads(void* comm, float* grads, int64_t count, int32_t average, tn_stream_t stream);
+
 /* waits for and destroys the library's companion streams (see "State and environment" at the top); 0 or TN_ELAUNCH */
 TN_API int tn_shutdown(void);
 

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TN_LIB names another build of the same library (A/B timing of kernel variants); there is still no fallback if it cannot be loaded
 LIB_PATH = os.path.abspath(os.environ["TN_LIB"]) if os.environ.get("TN_LIB") else os.path.join(_HERE, "libthermal_nerf_hip.so")
-ABI_VERSION = 306  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
+ABI_VERSION = 307  # include/thermal_nerf_hip.h as this binding was written for (tn_version() of the library must match)
 TN_MAX_LEVELS = 16
 TN_MAX_SAMPLES = 256
 TN_RENDER_SCRATCH_FLOATS = 4096
@@ -167,6 +167,10 @@ SIGNATURES = {
     "tn_fill_zero": (C.c_int, [_p, _i64, _p]),
     "tn_train_step": (C.c_int, [C.POINTER(TnTrainStep), _p]),
     "tn_shutdown": (C.c_int, []),
+    "tn_comm_unique_id": (C.c_int, [_p]),
+    "tn_comm_create": (C.c_int, [_p, _i32, _i32, C.POINTER(_p)]),
+    "tn_comm_destroy": (C.c_int, [_p]),
+    "tn_allreduce_grads": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "tn_render_rays_train_bwd_tmp_floats": (_i64, [_i64, _i32, _i32, _i32, _i32]),
     "tn_render_rays_train_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32] + [_p] * 7 + [_i64, _p, _i64, _p, _i64] + [_p] * 3 + [_i32, _p]),
     "tn_splat_workspace_bytes": (_i64, [_i64, _i64, _i32]),

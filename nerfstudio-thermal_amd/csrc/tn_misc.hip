@@ -105,7 +105,7 @@ extern "C" int tn_shutdown(void) {
   return rc;
 }
 
-extern "C" int tn_version(void) { return 306; }  // 306 (round 6): TnNextSampling, TnTrainStep::next_sampling / sampling_done; 305 (round 5): TnSampleRays, TnTrainStep::next_sample; 304: tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
+extern "C" int tn_version(void) { return 307; }  // 307: tn_comm_* / tn_allreduce_grads; 306 (round 6): TnNextSampling, TnTrainStep::next_sampling / sampling_done; 305 (round 5): TnSampleRays, TnTrainStep::next_sample; 304: tn_render_losses_bwd; 303: tn_train_step (one call per training iteration), TN_FIELD_MAX_IMAGES; 302 (round 4): workspace_bytes behind every workspace pointer (a short buffer is TN_EINVAL, not an out-of-bounds write), tn_field_encode_plan; 301: TN_BWD_COUNTERS_CLEAN, proposal workspaces hand d enc over level-major; 300 (round 3): signatures of tn_hash_scatter_workspace_bytes / tn_field_density_fwd changed in round 2, AMP Adam + train-step entry points added
 
 extern "C" int tn_fill_zero(void* ptr, int64_t bytes, tn_stream_t stream) {
   TN_REQUIRE(ptr != nullptr && bytes >= 0, "tn_fill_zero: bad argument");

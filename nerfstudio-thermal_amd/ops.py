@@ -1296,3 +1296,36 @@ def grad_scaler_update(scale: Tensor, growth_tracker: Tensor, found_inf: Tensor,
     check(_lib.load().tn_grad_scaler_update(_f32(scale, "scale", (1,)), C.c_void_p(growth_tracker.data_ptr()), _f32(found_inf, "found_inf"),
                                             int(found_inf.numel()), C.c_void_p(lag.data_ptr()) if lag is not None else None, float(growth_factor),
                                             float(backoff_factor), int(growth_interval), 1 if clear else 0, _stream()), "tn_grad_scaler_update")
+
+
+# ------------------------------------------------------------------------------------------------ 8e: the exchange through the C ABI alone
+class RcclComm:
+    """An RCCL communicator created through the C ABI (tn_comm_*): what a compiled trainer that binds only include/thermal_nerf_hip.h would use
+    for the reference's DistributedDataParallel exchange (pipelines/base_pipeline.py:281-283).  `unique_id` = RcclComm.unique_id() of rank 0,
+    handed to every rank by the caller (a file, a socket, torch.distributed's store); creation is collective over the ranks and binds the
+    current device.  The package's own training paths exchange through torch.distributed (parallel.py): the same library underneath."""
+
+    def __init__(self, unique_id: bytes, world_size: int, rank: int):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id is the 128 bytes of RcclComm.unique_id()")
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, 128)
+        check(_lib.load().tn_comm_create(buf, int(world_size), int(rank), C.byref(self._h)), "tn_comm_create")
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.load().tn_comm_unique_id(buf), "tn_comm_unique_id")
+        return buf.raw
+
+    def allreduce_grads(self, grads: Tensor, average: bool = True) -> None:
+        """in place over the (contiguous fp32) slice `grads` of the gradient arena, on the current stream"""
+        if grads.dtype != torch.float32 or not grads.is_contiguous() or not grads.is_cuda:
+            raise ValueError("allreduce_grads takes a contiguous fp32 device tensor (no CPU fallback)")
+        check(_lib.load().tn_allreduce_grads(self._h, C.c_void_p(grads.data_ptr()), grads.numel(), 1 if average else 0, _stream()), "tn_allreduce_grads")
+
+    def destroy(self) -> None:
+        if self._h:
+            check(_lib.load().tn_comm_destroy(self._h), "tn_comm_destroy")
+            self._h = C.c_void_p()

@@ -233,3 +233,17 @@ def test_sample_rays_block_is_validated_on_the_host(lib):
     assert lib.tn_sample_rays_args(C.byref(a), None) == -22
     assert b"null pointer" in lib.tn_last_error()
 
+
+
+def test_comm_entry_points_validate_on_the_host(lib):
+    """tn_comm_* / tn_allreduce_grads (the exchange for a host that binds only the C ABI): argument validation needs neither a GPU nor RCCL."""
+    import ctypes as C
+
+    assert lib.tn_allreduce_grads(None, None, 16, 1, None) == -22
+    assert b"bad argument" in lib.tn_last_error()
+    assert lib.tn_comm_unique_id(None) == -22
+    h = C.c_void_p()
+    buf = C.create_string_buffer(128)
+    assert lib.tn_comm_create(buf, 2, 5, C.byref(h)) == -22  # rank outside the world
+    assert lib.tn_comm_create(None, 1, 0, C.byref(h)) == -22
+    assert lib.tn_comm_destroy(None) == 0  # nothing to destroy

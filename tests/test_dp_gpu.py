@@ -158,3 +158,24 @@ def test_sharded_reducer_and_bf16_transport_on_one_rank(golden_dir, rccl_group):
     assert torch.equal(g0 == 0, g2 == 0)
     # (the tiny test tables are below the 1 M-gradient bar of the conversion: nothing was rounded, the schedule itself must be unchanged)
     assert float((g0 - g2).abs().max()) <= max(4.0 * noise, 1e-6 * scale)
+
+
+def test_allreduce_grads_through_the_c_abi_on_a_one_rank_communicator():
+    """tn_comm_unique_id / tn_comm_create / tn_allreduce_grads / tn_comm_destroy: an RCCL communicator and the gradient exchange without
+    torch.distributed -- the reference's DDP mean all-reduce (pipelines/base_pipeline.py:281-283) for a host that binds only the C ABI.  One rank
+    is what a one-GPU box offers (RCCL refuses two ranks on one device): the mean over one rank and the sum are the identity, on the caller's
+    stream, in place, on a slice of a gradient arena."""
+    from nerfstudio_thermal_amd import ops
+
+    comm = ops.RcclComm(ops.RcclComm.unique_id(), 1, 0)
+    try:
+        g = torch.randn(3_000_001, device="cuda")
+        want = g.clone()
+        comm.allreduce_grads(g[1:2_000_001])                 # a slice (a level range of the table), mean
+        comm.allreduce_grads(g[2_000_001:], average=False)   # another one, sum
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        with pytest.raises(ValueError):
+            comm.allreduce_grads(g.cpu())
+    finally:
+        comm.destroy()
