@@ -830,7 +830,7 @@ def main():
     if not args.no_grad_scaler:
         if api:
             scaler = torch.amp.GradScaler("cuda")
-        elif hook is None or not getattr(hook, "adam_per_range", False):
+        else:  # (also with Adam per exchanged range / the sharded optimiser: their found_inf flags are agreed on behind the last exchange)
             from nerfstudio_thermal_amd.optim import DeviceGradScaler
 
             scaler = DeviceGradScaler(device, num_groups=len(arena.optimised_groups))

@@ -661,7 +661,7 @@ class RenderEngine:
 
     # ---------------------------------------------------------------- optimiser
     def optimizer_step(self, lr_overrides: Optional[Dict[str, float]] = None, scheduled: bool = True, skip_groups=(), ranges=None,
-                       grad_scaler=None, skipped_have_no_grads: bool = False) -> None:
+                       grad_scaler=None, skipped_have_no_grads: bool = False, flag_reduce=None) -> None:
         """One Adam step per optimiser group over its contiguous arena range (engine/optimizers.py; configs/method_configs.py:274-307).
 
         torch.optim.Adam skips parameters whose .grad is None and advances its per-parameter step count (bias correction) only when it
@@ -737,7 +737,36 @@ class RenderEngine:
                 if scaler is not None and not fuse:
                     scaler.update()
             return
-        assert grad_scaler is None or not grad_scaler.enabled, "the per-range Adam launches of the data-parallel schedule do not take a grad scaler"
+        if grad_scaler is not None and grad_scaler.enabled:
+            # GradScaler semantics with per-range pieces (the sharded-optimiser schedule: this rank's pieces of the reduce-scattered slices + the
+            # replicated small ones).  GradScaler decides per optimiser over the WHOLE gradient, and a non-finite value in a reduce-scattered
+            # slice reaches its owner only: every rank checks what it is about to apply, the flags are MAX-reduced over the ranks (flag_reduce:
+            # ShardedGradReducer.reduce_flags, one collective of num_groups floats), then ONE Adam launch over all pieces decides on the device.
+            gidx = {g: i for i, g in enumerate(a.optimised_groups)}
+            pieces = []
+            for lo, hi in ranges:  # (the generator waits for every exchange on the stream as it yields)
+                gname = next(g for g in a.optimised_groups if a.group_range[g][0] <= lo and hi <= a.group_range[g][1])
+                if gname in hyper and hi > lo:
+                    pieces.append((lo, hi, gname))
+            if len(pieces) > 8:
+                raise NotImplementedError("GradScaler semantics for more than 8 Adam pieces per iteration (coarser level ranges keep it below)")
+            if pieces:
+                grad_scaler.check_ranges(a.grads, [(lo, hi) for lo, hi, _ in pieces], [gidx[g] for _, _, g in pieces])
+            if flag_reduce is not None:
+                flag_reduce(grad_scaler.found_inf)
+            if pieces:
+                on_device_lr = scheduled and not lr_overrides
+                if on_device_lr:
+                    rng = [(lo, hi, hyper[g][0], OPTIMIZERS[g][0]) for lo, hi, g in pieces]
+                    sched = [(OPTIMIZERS[g][1], OPTIMIZERS[g][2]) for _, _, g in pieces]
+                else:
+                    rng, sched = [(lo, hi) + hyper[g] for lo, hi, g in pieces], None
+                ops.adam_step_ranges_amp(a.params, a.grads, a.exp_avg, a.exp_avg_sq, rng, eps=1e-15, found_inf=grad_scaler.found_inf,
+                                         flags=[gidx[g] for _, _, g in pieces], skipped=grad_scaler.skipped, lag_index=grad_scaler.lag_index, count_skip=True,
+                                         schedule=sched, sched_step=self.adam_step_count - 1, zero_grads=False, scaler_update=grad_scaler.fused_update_args())
+            else:
+                grad_scaler.update()
+            return
         for lo, hi in ranges:  # each range lies inside one optimiser group (Adam is element-wise: any partition of a group is the same update)
             gname = next(g for g in a.optimised_groups if a.group_range[g][0] <= lo and hi <= a.group_range[g][1])
             if gname not in hyper:
@@ -965,7 +994,8 @@ class RenderEngine:
             if getattr(grad_hook, "adam_per_range", False):
                 # Adam range by range, each as soon as its exchange has landed: the update of the first table levels runs while the last
                 # ones are still on the wire (one more launch per range on the host)
-                self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle))
+                self.optimizer_step(scheduled=scheduled, skip_groups=skip, ranges=grad_hook.finish_iter(skip=idle), grad_scaler=grad_scaler,
+                                    flag_reduce=getattr(grad_hook, "reduce_flags", None))
                 if getattr(grad_hook, "sharded", False):
                     # optimiser state sharded over the ranks (parallel.ShardedGradReducer): the ranges above were this rank's pieces; now the
                     # updated parameters of every sharded slice are all-gathered

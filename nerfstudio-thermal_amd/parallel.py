@@ -383,7 +383,8 @@ class ShardedGradReducer(OverlappedGradReducer):
     RenderEngine.train_step drives it (`sharded = True`): begin -> backward with reduce_range() -> finish_iter() yields the ranges THIS rank
     runs Adam on -> gather_params().  Backends without reduce-scatter (gloo: the CPU tests) all-reduce the slice instead; everything behind
     the collective -- ownership, Adam on the owned piece, the parameter all-gather -- is the same code.
-    GradScaler semantics (found_inf decided over the whole gradient) would need one more tiny collective; this variant runs without a scaler."""
+    GradScaler semantics: `reduce_flags` (the per-group found_inf flags of what every rank is about to apply, MAX-reduced: one tiny collective);
+    with a scaler the Adam launches follow that collective instead of riding behind each exchange (RenderEngine.optimizer_step(ranges=...))."""
 
     sharded = True
     adam_per_range = True
@@ -439,6 +440,14 @@ class ShardedGradReducer(OverlappedGradReducer):
                 yield self._own(*piece)
             else:
                 yield piece
+
+    def reduce_flags(self, found_inf: torch.Tensor) -> None:
+        """GradScaler semantics for the sharded schedule: a non-finite value in a reduce-scattered slice reaches its OWNER only (the other ranks
+        never see the reduced piece), while torch.amp.GradScaler decides over the whole gradient of an optimiser
+        (torch/amp/grad_scaler.py: found_inf per optimiser).  Every rank checks what it is about to apply -- the pieces it owns, the replicated
+        small slices -- and the per-group flags are MAX-reduced over the ranks: one collective of num_groups floats behind the last exchange."""
+        if self.world > 1:
+            dist.all_reduce(found_inf, op=dist.ReduceOp.MAX, group=self.group)
 
     def gather_params(self) -> None:
         """All-gather of the parameters of every sharded slice (each rank contributes the piece its Adam launch just updated); the current

@@ -195,6 +195,32 @@ def main():
                           "dist_to_allreduce": float((arena2.params - arena.params).double().norm()),
                           "moved": float((arena.params - init).double().norm()),
                           "sharded_slices": sh.slices}
+        # GradScaler semantics on the sharded schedule (ShardedGradReducer.reduce_flags): iteration 3 sees an inf in ONE rank's ground truth only.
+        # The non-finite gradient reaches the owners of the affected pieces -- and every rank must skip the affected groups all the same: parameters
+        # and moments untouched there, bit-identical across the ranks, the scale halved and the skip counted on both; iteration 4 steps again.
+        from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+        sc = DeviceGradScaler("cuda", num_groups=len(arena2.optimised_groups))
+        eng2.train_step(bo, bd, bc, bi, bt, 3, jitters=jit, jitters_thermal=jit_t, grad_hook=sh, grad_scaler=sc)  # a clean scaled iteration first
+        torch.cuda.synchronize()
+        before = (arena2.params.clone(), arena2.exp_avg.clone(), arena2.exp_avg_sq.clone())
+        bad = bi.clone()
+        if rank == 1:
+            bad[:8] = float("inf")
+        eng2.train_step(bo, bd, bc, bad, bt, 4, jitters=jit, jitters_thermal=jit_t, grad_hook=sh, grad_scaler=sc)
+        torch.cuda.synchronize()
+        lo, hi = arena2.group_range["fields"]
+        untouched = all(bool(torch.equal(x[lo:hi], y[lo:hi])) for x, y in zip(before, (arena2.params, arena2.exp_avg, arena2.exp_avg_sq)))
+        skipped = [sc.num_skipped(i) for i in range(len(arena2.optimised_groups))]
+        scale_after = sc.get_scale()
+        eng2.train_step(bo, bd, bc, bi, bt, 5, jitters=jit, jitters_thermal=jit_t, grad_hook=sh, grad_scaler=sc)
+        torch.cuda.synchronize()
+        mine3 = arena2.params.detach().cpu()
+        theirs3 = mine3.clone()
+        dist.broadcast(theirs3, src=0)
+        res["sharded_scaler"] = {"fields_untouched_on_inf": untouched, "skipped": skipped, "scale_after_inf": scale_after,
+                                 "params_equal_rank0": bool(torch.equal(mine3, theirs3)), "params_finite": bool(torch.isfinite(mine3).all()),
+                                 "moved_after": float((arena2.params - before[0]).double().norm())}
     with open(out_path, "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -52,6 +52,10 @@ def test_two_ranks_exchange_the_mean_and_stay_identical(golden_dir, tmp_path, mo
             assert sh["params_equal_rank0"] and sh["params_finite"], sh
             assert sh["dist_to_allreduce"] <= 0.02 * sh["moved"], sh
             assert sh["sharded_slices"] >= 3, sh  # the table's level ranges at least, in every one of the three steps
+            ss = r["sharded_scaler"]  # an inf on ONE rank: both ranks skip the field's group, count it, halve the scale, stay identical and go on
+            fields = 1  # (arena.optimised_groups: proposal_networks, fields, camera_opt)
+            assert ss["fields_untouched_on_inf"] and ss["skipped"][fields] == 1 and ss["scale_after_inf"] == 32768.0, ss
+            assert ss["params_equal_rank0"] and ss["params_finite"] and ss["moved_after"] > 0, ss
     for k in res[0]["losses"]:  # each rank reports the loss of ITS batch: different batches, same order of magnitude, all finite
         assert all(abs(r["losses"][k]) < 1e6 for r in res)
 
