@@ -47,8 +47,10 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/prof_a -o a -- python3 bench.py -
 rocprofv3 --kernel-trace -d gpurun_out/prof_dp -o dp -- python3 bench.py --force-dp --no-dp-guard --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_dp.log 2>&1
 rocprofv3 --kernel-trace -d gpurun_out/prof_sep -o sep -- python3 bench.py --mode separate --rays 8192 --no-cpu-baseline --steps 20 --warmup 10 --long-steps 0 > gpurun_out/$R/prof_sep.log 2>&1
 python scripts/rocpd_stats.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/bench_n1_kernel_stats.csv --split-grid --tail 10 > gpurun_out/$R/bench_n1_kernel_stats_tail.txt 2>&1
-python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --step-from-end 26 > /dev/null 2> gpurun_out/$R/timeline.err
-python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline_update_step.md --step-from-end 25 > /dev/null 2>> gpurun_out/$R/timeline.err
+# (round 6: an iteration of the one-call path starts at k_field_prep -- its sampling front ran in the previous iteration's optimiser launch; iterations
+# 0-9 are the warm-up, 10-59 the timed region, then the phased and stand-alone launches: two consecutive timed iterations are picked by index)
+python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline.md --mark k_field_prep --step-index 30 > /dev/null 2> gpurun_out/$R/timeline.err
+python scripts/rocpd_timeline.py $(find gpurun_out/prof_a -name '*.db' | head -1) gpurun_out/$R/fused_timeline_update_step.md --mark k_field_prep --step-index 31 > /dev/null 2>> gpurun_out/$R/timeline.err
 # (which of two consecutive steps updates the proposal networks depends on the run: the one with fewer launches is the step without an update)
 na=$(head -1 gpurun_out/$R/fused_timeline.md | sed 's/step of \([0-9]*\) kernels.*/\1/'); nb=$(head -1 gpurun_out/$R/fused_timeline_update_step.md | sed 's/step of \([0-9]*\) kernels.*/\1/')
 if [ "$na" -gt "$nb" ]; then mv gpurun_out/$R/fused_timeline.md gpurun_out/$R/tmp.md; mv gpurun_out/$R/fused_timeline_update_step.md gpurun_out/$R/fused_timeline.md; mv gpurun_out/$R/tmp.md gpurun_out/$R/fused_timeline_update_step.md; fi

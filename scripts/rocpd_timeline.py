@@ -3,7 +3,7 @@
 started relative to the step's first kernel and how long it took.  Used to show the order of the RCCL all-reduce kernels relative to the
 scatter launches of the data-parallel schedule (bench.py --force-dp).
 
-    python scripts/rocpd_timeline.py gpurun_out/prof_dp/x_results.db [out.md] [--step-from-end 3]
+    python scripts/rocpd_timeline.py gpurun_out/prof_dp/x_results.db [out.md] [--step-from-end 3] [--mark k_field_prep --step-index 30]
 
 A step is delimited by consecutive launches of k_sample_pixels / k_sample_rays (the first kernel of every bench step), or of k_pose_spaced_bins
 when the pixel sampling rides in the previous step's optimiser launch, or of k_field_prep when the whole sampling front does.
@@ -14,14 +14,25 @@ import sys
 
 
 def main():
-    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--step-from-end"]
+    opts = ("--step-from-end", "--mark", "--step-index")
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] not in opts]
     back = int(sys.argv[sys.argv.index("--step-from-end") + 1]) if "--step-from-end" in sys.argv else 3
+    mark = sys.argv[sys.argv.index("--mark") + 1] if "--mark" in sys.argv else None            # kernel-name substring that opens an iteration
+    index = int(sys.argv[sys.argv.index("--step-index") + 1]) if "--step-index" in sys.argv else None  # iteration counted from the FIRST mark
     con = sqlite3.connect(args[0])
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     lane = [c for c in ("stream_id", "queue_id", "stream", "queue", "tid") if c in cols]
     sel = ", ".join(["name", "start", "end"] + lane)
     rows = con.execute(f"select {sel} from kernels order by start").fetchall()
-    marks = [i for i, r in enumerate(rows) if r[0].startswith(("k_sample_pixels", "k_sample_rays"))]
+    if mark is not None:
+        marks = [i for i, r in enumerate(rows) if mark in r[0]]
+        if index is not None:
+            if len(marks) < index + 2:
+                print("not enough steps in the trace", len(marks))
+                return
+            back = len(marks) - 1 - index
+    else:
+        marks = [i for i, r in enumerate(rows) if r[0].startswith(("k_sample_pixels", "k_sample_rays"))]
     if len(marks) < back + 1:
         # the data manager hands the next batch to the training step (TnTrainStep.next_sample: sampled inside the optimiser launch): the first
         # kernel of an iteration is then the pose correction + level-0 bins
