@@ -577,6 +577,84 @@ def extra_leg(device, mode, rays, nerf_samples, path, steps, warmup):
             "dominant_kernel": name, "dominant_kernel_ms": ms, "dominant_kernel_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def head_bf16x3_leg(device, steps=40, warmup=10):
+    """OPT-IN EXPERIMENT, never part of `value` and never the default: TN_HEAD_BF16X3=1 runs the colour head's two 64-wide layers
+    (fields/thermal_nerfacto_field.py:91-99, field_components/mlp.py:159-178) -- forward, backward chain and weight gradients -- on split-bf16
+    matrix instructions (x = hi + lo, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulators); the density path and every other kernel stay
+    fp32.  The leg times the headline's fused step with and without the switch (fresh engines, same seeds) and carries its own parity block:
+    the eval render of the reference golden under the switch, and the gradients of one training step on one batch against the fp32 path's."""
+    from nerfstudio_thermal_amd.optim import DeviceGradScaler
+
+    prev = os.environ.get("TN_HEAD_BF16X3")
+    res = {"dtype": "bf16x3 (hi + lo split bf16, fp32 accumulate) in the colour head's 64-wide layers; f32 everywhere else",
+           "switch": "TN_HEAD_BF16X3=1 (read per call by tn_field_fwd / tn_field_bwd*)"}
+    try:
+        cam_t, idx, _, _ = make_batch(device, RAYS_PER_GPU, seed=42)
+        cache = make_image_cache(device)
+        grads, timing = {}, {}
+        for flag in ("0", "1"):
+            os.environ["TN_HEAD_BF16X3"] = flag
+            torch.manual_seed(20261)  # (the pixel sampler's and the ray samplers' uniforms: the same batch and jitter for both paths)
+            cfg, arena, eng = build_engine(device)
+            scaler = DeviceGradScaler(device, num_groups=len(arena.optimised_groups))
+            if flag == "1":
+                par = parity_vs_reference(eng, device)
+                res["parity"] = {k: par[k] for k in ("against", "psnr_rgb_db", "psnr_thermal_db", "max_abs_rgb", "max_abs_thermal", "max_abs_density")}
+            # one training step on one batch, gradients read behind the backward (a plain hook: the five-call sequence, same kernels)
+            keep = {}
+
+            def hook(a, keep=keep):
+                for name in a.names():
+                    keep[name] = a.grad_view(name).detach().clone()
+
+            if hasattr(eng, "_bench_dm"):
+                del eng._bench_dm
+            one_step(eng, cam_t, cache, RAYS_PER_GPU, 0, hook, scaler)
+            torch.cuda.synchronize()
+            grads[flag] = keep
+            del eng, arena
+            torch.manual_seed(20262)
+            cfg, arena, eng = build_engine(device)
+            scaler = DeviceGradScaler(device, num_groups=len(arena.optimised_groups))
+            step = 0
+            for _ in range(warmup):
+                one_step(eng, cam_t, cache, RAYS_PER_GPU, step, None, scaler)
+                step += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            upd = 0
+            for _ in range(steps):
+                one_step(eng, cam_t, cache, RAYS_PER_GPU, step, None, scaler)
+                upd += int(eng.steps_since_update == 1)
+                step += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            timing[flag] = {"ms_per_step": dt / steps * 1e3, "rays_per_s": RAYS_PER_GPU * steps / dt, "proposal_update_fraction": upd / steps}
+            del eng, arena
+            torch.cuda.empty_cache()
+        res.update({"steps": steps, "warmup": warmup, "ms_per_step": timing["1"]["ms_per_step"], "rays_per_s": timing["1"]["rays_per_s"],
+                    "proposal_update_fraction": timing["1"]["proposal_update_fraction"], "f32_same_run": timing["0"],
+                    "speedup_over_f32_same_run": timing["0"]["ms_per_step"] / timing["1"]["ms_per_step"]})
+        worst = {}
+        for name, ref in grads["0"].items():
+            scale = float(ref.abs().max())
+            if scale == 0.0:
+                continue
+            worst[name] = float((grads["1"][name] - ref).abs().max()) / scale
+        head = {k: v for k, v in worst.items() if ".mlp_head." in k or "embedding_appearance" in k}
+        res["gradients_vs_f32_path"] = {
+            "what": "max |g_bf16x3 - g_f32| / max |g_f32| per parameter, one training step of 4096 rays on identical weights and batch",
+            "head_max": max(head.values()) if head else None, "all_max": max(worst.values()), "worst_parameter": max(worst, key=worst.get),
+            "note": "the backward's own arithmetic agrees to ~5e-6 on identical saved activations (tests/test_head_bf16x3_gpu.py); what is left here is "
+                    "the forward's ~1e-5 moving a few pre-activations across zero -- a ReLU mask flip changes a gradient by one sample's contribution"}
+    finally:
+        if prev is None:
+            os.environ.pop("TN_HEAD_BF16X3", None)
+        else:
+            os.environ["TN_HEAD_BF16X3"] = prev
+    return res
+
+
 def eval_render_leg(device, reps=3, profile_path=None):
     """TEST_RAYS_PER_SEC of the reference (utils/writer.py:55-56, engine/trainer.py:519-527): one full RGB image (640x480) + one full thermal image
     (160x120) of the synthetic scene's cameras through `Model.get_outputs_for_camera` (models/base_model.py:165-205: chunks of
@@ -1065,6 +1143,11 @@ def main():
                 except Exception as e:  # noqa: BLE001
                     result["extra"][key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            try:  # opt-in experiment (TN_HEAD_BF16X3=1): its own timing and parity block, never the headline
+                result["extra"]["head_bf16x3"] = head_bf16x3_leg(device)
+            except Exception as e:  # noqa: BLE001
+                result["extra"]["head_bf16x3"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             try:  # the eval / render side of the metric: full images through get_outputs_for_camera and through tn_render_rays_eval
                 result["extra"]["eval_render"] = eval_render_leg(device, profile_path=os.environ.get("TN_EVAL_PROFILE"))
             except Exception as e:  # noqa: BLE001

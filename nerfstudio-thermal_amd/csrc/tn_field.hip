@@ -61,8 +61,20 @@ static_assert(PACK_FWD_TOTAL <= PACK_BWD_OFF, "pack layout");
 // the 32 embedding slots of every sample through the matrix cores (32 of the layer's 64 MFMAs per tile).  Rebuilt with the fragments.
 #define FIELD_MAX_IMAGES 4096  // cameras the per-camera tables are sized for (camhead here, the backward's per-camera sums: 1 MB each)
 #define PACK_CAMHEAD_OFF PACK_TOTAL_FLOATS
-#define PACK_REGION_FLOATS (PACK_TOTAL_FLOATS + FIELD_MAX_IMAGES * 64)
-static_assert(PACK_CAMHEAD_OFF % 64 == 0, "pack layout");
+// Behind camhead: the colour head's two 64-wide layers (2 = head0, 3 = head1) as SPLIT-bf16 fragments for v_mfma_f32_32x32x16_bf16 (the opt-in
+// TN_HEAD_BF16X3=1 path: w = hi + lo with hi = bf16(w), lo = bf16(w - hi); a product is hi*hi + hi*lo + lo*hi in fp32 accumulators, ~2^-16
+// relative).  A word = two bf16; a fragment = 64 lanes x 4 words (one ds_read_b128 per lane):
+//   forward  Bf[layer-2][m][t][s][part][lane][q] = part(W[32m + (lane&31)][32t + R(8s + q, lane>>5)])      q = 0..7, part 0 = hi, 1 = lo
+//   backward Bb[layer-2][t][m][s][part][lane][q] = part(W[32m + R(8s + q, lane>>5)][32t + (lane&31)])
+// -- k-step s of a 32-feature tile covers the D-layout registers 8s..8s+7 of both lane halves (k = 8h + q <-> row R(8s + q, h)), so an fp32
+// accumulator tile, split on the vector ALU, is the next layer's B operand exactly as on the fp32 path.
+#define PACK_BF_OFF (PACK_TOTAL_FLOATS + FIELD_MAX_IMAGES * 64)
+#define PACK_BF_LAYER_WORDS (2 * 2 * 2 * 2 * 256)  // [m][t][s][part] fragments of 256 words
+#define PACK_BF_FWD_WORDS (2 * PACK_BF_LAYER_WORDS)
+#define PACK_BF_BWD_OFF (PACK_BF_OFF + PACK_BF_FWD_WORDS)
+#define PACK_BF_WORDS (2 * PACK_BF_FWD_WORDS)
+#define PACK_REGION_FLOATS (PACK_BF_OFF + PACK_BF_WORDS)
+static_assert(PACK_CAMHEAD_OFF % 64 == 0 && PACK_BF_OFF % 64 == 0, "pack layout");
 
 // slot space of the colour head's first layer: [0,16) SH, [16,32) base-MLP output rows 0..15 (row 0 = density logit, weight 0),
 // [32,64) appearance embedding.  nn.Linear column for a slot (or -1):
@@ -127,11 +139,29 @@ __device__ __forceinline__ void field_pack_body(const FieldK& f, float* __restri
       for (int k = 0; k < 32; ++k) s = fmaf(w[k], e[k], s);
       pack[PACK_CAMHEAD_OFF + q] = s;
     }
+    const int w = q - ((ncam * 64 + 255) / 256) * 256;  // split-bf16 fragments of the colour head: one thread per word (two weights)
+    if (w >= 0 && w < PACK_BF_WORDS) {
+      const bool bwd = w >= PACK_BF_FWD_WORDS;
+      const int rel = bwd ? w - PACK_BF_FWD_WORDS : w;
+      const int v = rel & 3, lane = (rel >> 2) & 63, part = (rel >> 8) & 1, s8 = (rel >> 9) & 1, i1 = (rel >> 10) & 1, i0 = (rel >> 11) & 1;
+      const int layer = 2 + (rel >> 12);
+      uint32_t word = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kk = RROW(8 * s8 + 2 * v + e, lane >> 5);
+        // forward [m = i0][t = i1]: W[32m + lane][32t + kk]; backward [t = i0][m = i1]: W[32m + kk][32t + lane]
+        const float x = bwd ? weight_at(f, layer, 32 * i1 + kk, 32 * i0 + (lane & 31)) : weight_at(f, layer, 32 * i0 + (lane & 31), 32 * i1 + kk);
+        const __bf16 hi = (__bf16)x;
+        const __bf16 val = part ? (__bf16)(x - (float)hi) : hi;
+        word |= (uint32_t)__builtin_bit_cast(unsigned short, val) << (16 * e);
+      }
+      reinterpret_cast<uint32_t*>(pack)[PACK_BF_OFF + w] = word;
+    }
   }
 }
 __global__ void k_field_pack(FieldK f, float* __restrict__ pack) { field_pack_body(f, pack, blockIdx.x * blockDim.x + threadIdx.x); }
-static inline int pack_blocks(int num_images) {  // fragment blocks + one thread per (camera, hidden unit) of camhead
-  return PACK_BLOCKS + ((num_images < FIELD_MAX_IMAGES ? num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256;
+static inline int pack_blocks(int num_images) {  // fragment blocks + one thread per (camera, hidden unit) of camhead + the split-bf16 words
+  return PACK_BLOCKS + ((num_images < FIELD_MAX_IMAGES ? num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256 + PACK_BF_WORDS / 256;
 }
 
 // ---- workspace layout (byte offsets; every region 256-B aligned) ------------------------------------------------------
@@ -210,7 +240,7 @@ __global__ void __launch_bounds__(256) k_field_prep(FieldK f, float* __restrict_
                                                     float4* __restrict__ zero, int64_t zero_n4, float4* __restrict__ cam_bias, int cam_bias_n4) {
   int bid = blockIdx.x, nblk = gridDim.x;
   if (PACK) {
-    const int pkb = PACK_BLOCKS + ((f.num_images < FIELD_MAX_IMAGES ? f.num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256;  // = pack_blocks()
+    const int pkb = PACK_BLOCKS + ((f.num_images < FIELD_MAX_IMAGES ? f.num_images : FIELD_MAX_IMAGES) * 64 + 255) / 256 + PACK_BF_WORDS / 256;  // = pack_blocks()
     if (bid < pkb) { field_pack_body(f, pack, bid * 256 + threadIdx.x); return; }
     bid -= pkb; nblk -= pkb;
   }
@@ -391,6 +421,40 @@ __device__ __forceinline__ void sh16(float dx, float dy, float dz, float* c) {
 
 // ---- MFMA helpers ------------------------------------------------------------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// ---- split-bf16 products (TN_HEAD_BF16X3=1, the colour head only; see PACK_BF_OFF) ----------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMAB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// registers 8s..8s+7 of a D-layout tile as the B (or A) operand of k-step s: x = hi + lo (+ ~2^-17 |x|)
+template <int S8>
+__device__ __forceinline__ void bf_split8(const f32x16& v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float x = v[8 * S8 + q];
+    const __bf16 hq = (__bf16)x;
+    hi[q] = hq;
+    lo[q] = (__bf16)(x - (float)hq);
+  }
+}
+// o0 / o1 += W[0..31 / 32..63][32 T .. 32 T + 31] . x  for one 32-feature input tile x (D-layout), fragments of layer LAYER at `frags`
+// ([m][t][s][part][lane] of 4 words); three products per k-step, the small ones first
+template <int T>
+__device__ __forceinline__ void bf3_tile_fwd(const float* __restrict__ frags, int lane, const f32x16& x, f32x16& o0, f32x16& o1) {
+  bf16x8 bh, bl;
+#define BF_FRAG(m, s, part) (*reinterpret_cast<const bf16x8*>(frags + ((((((m) * 2 + T) * 2 + (s)) * 2 + (part))) << 8) + (lane << 2)))
+#define BF_KSTEP(s)                                                                       \
+  {                                                                                       \
+    const bf16x8 a0h = BF_FRAG(0, s, 0), a0l = BF_FRAG(0, s, 1), a1h = BF_FRAG(1, s, 0), a1l = BF_FRAG(1, s, 1); \
+    o0 = MFMAB(a0l, bh, o0); o1 = MFMAB(a1l, bh, o1);                                     \
+    o0 = MFMAB(a0h, bl, o0); o1 = MFMAB(a1h, bl, o1);                                     \
+    o0 = MFMAB(a0h, bh, o0); o1 = MFMAB(a1h, bh, o1);                                     \
+  }
+  bf_split8<0>(x, bh, bl);
+  BF_KSTEP(0)
+  bf_split8<1>(x, bh, bl);
+  BF_KSTEP(1)
+#undef BF_KSTEP
+#undef BF_FRAG
+}
 
 __device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ lds_bias, int layer, int m, int h) {
   f32x16 v;
@@ -490,7 +554,7 @@ __device__ __forceinline__ f32x16 load_enc_lm(const float* __restrict__ enc, int
 #ifndef FWD_EMB_MFMA
 #define FWD_EMB_MFMA 0
 #endif
-template <bool TRAIN>
+template <bool TRAIN, bool BF3>
 __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fwd(const float* __restrict__ pack, const float* __restrict__ encs, int L,
                                                             int64_t PT, const float* __restrict__ sels, const float* __restrict__ shtab,
                                                             const int64_t* __restrict__ cam_idx, const float* __restrict__ emb, int num_images,
@@ -509,8 +573,11 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     const int64_t p0 = wave * TILE + j;
     nin = (FWD_ABLATE & 4) ? f32x16{0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f, 0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f} : load_enc_lm(encs, PT, p0 < P ? p0 : P - 1, h, L);
   }
-  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(pack + i);
+  for (int i = threadIdx.x * 4; i < PACK_FWD_TOTAL; i += blockDim.x * 4) {
+    // (split-bf16 head: the two 64-wide head layers' fragments -- the same 8192 words -- come from the bf16 region instead)
+    const float* src = (BF3 && i >= fwd_off(2) && i < fwd_off(4)) ? pack + PACK_BF_OFF + (i - fwd_off(2)) : pack + i;
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src);
+  }
   __syncthreads();
   const float* lbias = lds + PACK_BIAS_OFF;
 #define AF(layer, m, t, r) lds[fwd_off(layer) + ((((m) * layer_ti(layer) + (t)) * 16 + (r)) << 6) + lane]
@@ -586,21 +653,31 @@ __global__ void __launch_bounds__(FWD_THREADS, FWD_THREADS / 128) k_field_mlp_fw
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- head layer 0
+    if (BF3) {
+      bf3_tile_fwd<0>(lds + fwd_off(2), lane, hi0, c0, c1);
+      if (!CAMHEAD && !(FWD_ABLATE & 2)) bf3_tile_fwd<1>(lds + fwd_off(2), lane, hi1, c0, c1);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 0, r), hi0[r], c0); c1 = MFMA(AF(2, 1, 0, r), hi0[r], c1); }
-    if (!CAMHEAD && !(FWD_ABLATE & 2)) {  // (inference: the mean embedding goes through the matrix cores as before)
+      for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 0, r), hi0[r], c0); c1 = MFMA(AF(2, 1, 0, r), hi0[r], c1); }
+      if (!CAMHEAD && !(FWD_ABLATE & 2)) {  // (inference: the mean embedding goes through the matrix cores as before)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
+        for (int r = 0; r < 16; ++r) { c0 = MFMA(AF(2, 0, 1, r), hi1[r], c0); c1 = MFMA(AF(2, 1, 1, r), hi1[r], c1); }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
     if (TRAIN && !(FWD_ABLATE & 1)) { store_frag(hh1s, tile, 2, 0, lane, c0); store_frag(hh1s, tile, 2, 1, lane, c1); }
     // ---------------- head layer 1
     f32x16 d0 = bias_tile(lbias, 3, 0, h), d1 = bias_tile(lbias, 3, 1, h);
+    if (BF3) {
+      bf3_tile_fwd<0>(lds + fwd_off(2) + PACK_BF_LAYER_WORDS, lane, c0, d0, d1);
+      bf3_tile_fwd<1>(lds + fwd_off(2) + PACK_BF_LAYER_WORDS, lane, c1, d0, d1);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 0, r), c0[r], d0); d1 = MFMA(AF(3, 1, 0, r), c0[r], d1); }
+      for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 0, r), c0[r], d0); d1 = MFMA(AF(3, 1, 0, r), c0[r], d1); }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
+      for (int r = 0; r < 16; ++r) { d0 = MFMA(AF(3, 0, 1, r), c1[r], d0); d1 = MFMA(AF(3, 1, 1, r), c1[r], d1); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
     if (TRAIN && !(FWD_ABLATE & 1)) { store_frag(hh2s, tile, 2, 0, lane, d0); store_frag(hh2s, tile, 2, 1, lane, d1); }
@@ -765,6 +842,58 @@ __device__ __forceinline__ void wgrad_tile16(const float* __restrict__ bufY, int
   }
 }
 
+// ---- split-bf16 forms of the colour head's backward products (TN_HEAD_BF16X3=1) ------------------------------------------------------------
+// o += W[rows of output tile 0][32 M .. 32 M + 31] . x for one 32-feature tile x (fragments [t][m][s][part], t = 0)
+template <int M>
+__device__ __forceinline__ void bf3_tile_one(const float* __restrict__ frags, int lane, const f32x16& x, f32x16& o) {
+  bf16x8 bh, bl;
+#define BF_FRAG(s, part) (*reinterpret_cast<const bf16x8*>(frags + ((((M * 2 + (s)) * 2 + (part))) << 8) + (lane << 2)))
+  bf_split8<0>(x, bh, bl);
+  { const bf16x8 ah = BF_FRAG(0, 0), al = BF_FRAG(0, 1); o = MFMAB(al, bh, o); o = MFMAB(ah, bl, o); o = MFMAB(ah, bh, o); }
+  bf_split8<1>(x, bh, bl);
+  { const bf16x8 ah = BF_FRAG(1, 0), al = BF_FRAG(1, 1); o = MFMAB(al, bh, o); o = MFMAB(ah, bl, o); o = MFMAB(ah, bh, o); }
+#undef BF_FRAG
+}
+// wgrad_tile32 on split bf16: the tile's 32 samples are TWO k-steps of 16; lane (j, h) reads samples 16 s + 8 h + q (q = 0..7) of its column
+// from the same sample-major tiles, splits them, and every (output tile, input tile) pair takes three products per k-step
+template <int MO, int MI>
+__device__ __forceinline__ void wgrad_tile32_bf3(const float* __restrict__ bufY, const float* __restrict__ bufX, int j, int h, f32x16 (&acc)[MO][MI],
+                                                 float (&bsum)[MO]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 ah[MO], al[MO], bh[MI], bl[MI];
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float x = bufY[(16 * s + 8 * h + q) * TSTR + 32 * a + j];
+        bsum[a] += x;
+        const __bf16 hq = (__bf16)x;
+        ah[a][q] = hq;
+        al[a][q] = (__bf16)(x - (float)hq);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float x = bufX[(16 * s + 8 * h + q) * TSTR + 32 * b + j];
+        const __bf16 hq = (__bf16)x;
+        bh[b][q] = hq;
+        bl[b][q] = (__bf16)(x - (float)hq);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < MO; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) {
+        acc[a][b] = MFMAB(al[a], bh[b], acc[a][b]);
+        acc[a][b] = MFMAB(ah[a], bl[b], acc[a][b]);
+        acc[a][b] = MFMAB(ah[a], bh[b], acc[a][b]);
+      }
+  }
+}
+
 struct FusedGrads {
   float *gw0, *gb0, *gw1, *gb1, *ghw0, *ghb0, *ghw1, *ghb1, *ghw2, *ghb2, *gemb;
 };
@@ -819,7 +948,7 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int64_t tile_addr
 #define FB_TOUCH 0  // L2 warm-up loads of the next tile (compile-time experiment, see the kernel): 127 -> 132 us, off
 #endif
 #define FB_SB() do { if (!FB_NO_SB) __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool DENS_ONLY>
+template <bool DENS_ONLY, bool BF3>
 __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
                                                             const float* __restrict__ d_rgb, const float* __restrict__ d_density,
                                                             const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
@@ -832,8 +961,11 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   extern __shared__ __attribute__((aligned(16))) float lds[];  // FB_LDS_FLOATS
   tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the table scatter that follows on this stream
   const float* src = pack + PACK_BWD_OFF;
-  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
+  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4) {
+    // (split-bf16 head: the two 64-wide head layers' backward fragments -- the same 8192 words -- come from the bf16 region)
+    const float* sp = (BF3 && i >= fwd_off(2) && i < fwd_off(4)) ? pack + PACK_BF_BWD_OFF + (i - fwd_off(2)) : src + i;
+    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(sp);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   float* bufY = lds + PACK_BWD_FLOATS + wv * FB_WAVE_FLOATS;
@@ -925,10 +1057,15 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       FB_SB();
       // ---- d hh1 = hw1^T . d hh2
       f32x16 dc0 = zero16, dc1 = zero16;
+      if (BF3) {
+        bf3_tile_fwd<0>(lds + fwd_off(2) + PACK_BF_LAYER_WORDS, lane, dd0, dc0, dc1);
+        bf3_tile_fwd<1>(lds + fwd_off(2) + PACK_BF_LAYER_WORDS, lane, dd1, dc0, dc1);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
+        for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 0, r), dd0[r], dc0); dc1 = MFMA(AB(3, 1, 0, r), dd0[r], dc1); }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
+        for (int r = 0; r < 16; ++r) { dc0 = MFMA(AB(3, 0, 1, r), dd1[r], dc0); dc1 = MFMA(AB(3, 1, 1, r), dd1[r], dc1); }
+      }
       FB_SB();
       WAVE_LDS_SYNC();  // the reads of bufX (hh2) are done
 #pragma unroll
@@ -941,7 +1078,9 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       const v4f_t* bp = reinterpret_cast<const v4f_t*>(hins) + tile * 128 + lane;
       const v4f_t hb0 = FRAG_NT ? __builtin_nontemporal_load(bp) : bp[0], hb1 = FRAG_NT ? __builtin_nontemporal_load(bp + 64) : bp[64];
       WAVE_LDS_SYNC();
-      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);  // d hw1 += gy_hh2^T hh1
+      if (!(FB_ABLATE & 2)) {  // d hw1 += gy_hh2^T hh1
+        if (BF3) wgrad_tile32_bf3<2, 2>(bufY, bufX, j, h, acc3, bs3); else wgrad_tile32<2, 2>(bufY, bufX, j, h, acc3, bs3);
+      }
       FB_SB();
       WAVE_LDS_SYNC();
       {
@@ -955,7 +1094,9 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       s0 = load_frag(h1s, tile, 2, 0, lane); s1 = load_frag(h1s, tile, 2, 1, lane);   // used two blocks further down
       WAVE_LDS_SYNC();
       float tb[2] = {0.0f, 0.0f};  // this tile's share of the layer's bias gradient (lane (j, h): k-parity h of output 32a + j)
-      if (!(FB_ABLATE & 2)) wgrad_tile32<2, 1>(bufY, bufX, j, h, acc2, tb);  // d hw0 (slots 0..31) += gy_hh1^T hin
+      if (!(FB_ABLATE & 2)) {  // d hw0 (slots 0..31) += gy_hh1^T hin
+        if (BF3) wgrad_tile32_bf3<2, 1>(bufY, bufX, j, h, acc2, tb); else wgrad_tile32<2, 1>(bufY, bufX, j, h, acc2, tb);
+      }
       bs2[0] += tb[0]; bs2[1] += tb[1];
       FB_SB();
       // ---- appearance-embedding rows (see emb_cam above): the tile's bias sums go to the running sums of its camera
@@ -988,10 +1129,15 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
       FB_SB();
       // ---- d head-input slots 0..31 = Wslot^T . d hh1 (sh | base outputs: only the base outputs' rows are used below; slots 32..63, the
       // embedding, take their gradient through cam_bias)
+      if (BF3) {
+        bf3_tile_one<0>(lds + fwd_off(2), lane, dc0, di0);
+        bf3_tile_one<1>(lds + fwd_off(2), lane, dc1, di0);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0);
+        for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 0, r), dc0[r], di0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0);
+        for (int r = 0; r < 16; ++r) di0 = MFMA(AB(2, 0, 1, r), dc1[r], di0);
+      }
       FB_SB();
     } else {
       s0 = nx0; s1 = nx1;
@@ -1567,6 +1713,12 @@ static FieldK make_fieldk(const TnField* f) {
   FieldK k{f->w0, f->b0, f->w1, f->b1, f->hw0, f->hb0, f->hw1, f->hb1, f->hw2, f->hb2, f->emb, f->num_channels, f->num_images};
   return k;
 }
+// TN_HEAD_BF16X3=1 (opt-in, never the default): the colour head's two 64-wide layers on split-bf16 matrix instructions.  Read per call, so a
+// process can compare both paths.
+static bool tn_head_bf16x3() {
+  const char* e = getenv("TN_HEAD_BF16X3");
+  return e != nullptr && e[0] == '1';
+}
 static int mlp_grid(int64_t P) {
   int64_t tiles = tn_cdiv(P, TILE);
   return (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tiles, 4), 512));
@@ -1655,15 +1807,19 @@ int tn_field_fwd_ex(const TnField* field, const float* origins, const float* dir
   const size_t shmem = PACK_FWD_TOTAL * sizeof(float);
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(tn_cdiv(tn_cdiv(P, TILE), FWD_THREADS / 64), 512));
   const int L = field->grid.num_levels;
-  if (training) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_mlp_fwd<true>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), ws.pack, ws.enc, L, ws.PT, ws.sel, ws.sh, camera_indices,
-                       field->emb, field->num_images, 1, N, S, field->num_channels, density, rgb, density_pre, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y);
-  } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(k_field_mlp_fwd<false>, dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), ws.pack, ws.enc, L, ws.PT, ws.sel, ws.sh, camera_indices,
-                       field->emb, field->num_images, 0, N, S, field->num_channels, density, rgb, density_pre, nullptr, nullptr, nullptr, nullptr, nullptr);
+#define FWD_LAUNCH(TRAIN_, BF3_, ...)                                                                                                          \
+  {                                                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_mlp_fwd<TRAIN_, BF3_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    hipLaunchKernelGGL((k_field_mlp_fwd<TRAIN_, BF3_>), dim3(grid), dim3(FWD_THREADS), shmem, tn_s(stream), ws.pack, ws.enc, L, ws.PT, ws.sel, ws.sh, \
+                       camera_indices, field->emb, field->num_images, TRAIN_ ? 1 : 0, N, S, field->num_channels, density, rgb, density_pre, __VA_ARGS__); \
   }
+  const bool bf3 = tn_head_bf16x3();
+  if (training) {
+    if (bf3) FWD_LAUNCH(true, true, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y) else FWD_LAUNCH(true, false, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.y)
+  } else {
+    if (bf3) FWD_LAUNCH(false, true, nullptr, nullptr, nullptr, nullptr, nullptr) else FWD_LAUNCH(false, false, nullptr, nullptr, nullptr, nullptr, nullptr)
+  }
+#undef FWD_LAUNCH
   TN_CHECK_LAUNCH("tn_field_fwd");
   return TN_OK;
 }
@@ -1765,12 +1921,16 @@ int tn_field_bwd_phase_ex(const TnField* field, const float* origins, const floa
       hipLaunchKernelGGL(k_field_bwd_pair<false>, dim3(grid), dim3(512), shmem_p, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
                          S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     } else if (dens_only) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL(k_field_bwd_fused<true>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((k_field_bwd_fused<true, false>), dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
                          C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
+    } else if (tn_head_bf16x3()) {  // (opt-in: the colour head's products on split bf16; the density path inside the same kernel stays fp32)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((k_field_bwd_fused<false, true>), dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
+                         S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-      hipLaunchKernelGGL(k_field_bwd_fused<false>, dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      hipLaunchKernelGGL((k_field_bwd_fused<false, false>), dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
                          S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
     }
     // the appearance-embedding rows from the per-camera sums the launch above left in the workspace: at the head of k_field_dpos when that

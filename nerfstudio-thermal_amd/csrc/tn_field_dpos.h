@@ -136,7 +136,9 @@ __device__ __forceinline__ void field_dpos_body(const DposArgs& a, unsigned bid,
         if (lane - o2 >= start) v[k] += t;
       }
     }
-    if (live && h == 0 && tail) {
+    // (no `live` test: in a last, partial tile the lanes beyond the last sample belong to the last ray's segment -- pc = P - 1 -- and carry zeros,
+    // so that segment's tail IS such a lane; testing `live` here dropped the partial tile's share of the last ray: any N * S % 32 != 0)
+    if (h == 0 && tail) {
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         if (v[k] != 0.0f) atomicAdd((k < 3 ? a.d_origins : a.d_directions) + ray * 3 + (k % 3), v[k]);

@@ -226,7 +226,7 @@ def test_hash_scatter_accumulates_at_least_as_accurately_as_fp32():
 @pytest.mark.parametrize("mode,training", [("shared", False), ("shared", True), ("separate", True)])
 def test_field_fwd_bwd(mode, training):
     ocfg, params, cfg, arena = setup_pair(mode)
-    N, S = 100, 48  # 4800 points: not a multiple of the 32-sample MFMA tile
+    N, S = 101, 48  # 4848 points = 151.5 of the 32-sample MFMA tiles: the last ray ends in a half-empty tile
     r = rays(N)
     nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
     s, e = sample_level(N, S, nears, fars)
@@ -269,7 +269,7 @@ def test_field_density_only_fwd_bwd(mode):
     """get_density alone with its own backward (density2 / density2_thermal of separate mode, models/thermal_nerfacto.py:447-458): every
     gradient of the density path vs oracle autograd, and nothing of the colour head is touched."""
     ocfg, params, cfg, arena = setup_pair(mode)
-    N, S = 100, 48
+    N, S = 101, 48  # (151.5 tiles)
     r = rays(N)
     nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
     s, e = sample_level(N, S, nears, fars)
