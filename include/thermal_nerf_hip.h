@@ -41,8 +41,10 @@
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
  *      TN_NEXT_SAMPLING=0|2|3     (read per call) tn_train_step's next_sampling: 0 = never taken (every iteration samples in line); 2 = the chain as a launch
  *                                 of its own behind the optimiser launch; 3 = on a companion stream beside it (A/B timing aids: same results)
- *      TN_FIELD_BWD_PAIR=1        (read per call) tn_field_bwd's MLP phase as k_field_bwd_pair -- two waves per SIMD, each wave of a pair owning
- *                                 half of the output features; a measured experiment that is correct and slower (profiles/r05_experiments.md)
+ *      TN_HEAD_BF16X3=1           (read per call; opt-in experiment, never the default) the colour head's two 64-wide layers in tn_field_fwd /
+ *                                 tn_field_bwd* on split-bf16 matrix instructions: x = hi + lo in bf16, three v_mfma_f32_32x32x16_bf16 per
+ *                                 product, fp32 accumulators (~2^-16 relative).  The density path stays fp32 bit for bit.  RGB / thermal agree
+ *                                 with the fp32 path to ~1e-5; tests/test_head_bf16x3_gpu.py, bench.py extra.head_bf16x3
  *    The Python package reads TN_FUSE_SMALL=0 (one launch per reference seam instead of the fused small kernels: test aid), TN_DM_PREFETCH=0 (the
  *    device data manager launches every batch itself instead of handing the next one to tn_train_step: A/B timing), TN_NEXT_SAMPLING=0 (the engine
  *    plans no next_sampling), TN_DP_SCHEDULE=overlapped|simple (pins the data-parallel exchange schedule of trainer.FusedTrainerMixin) and writes

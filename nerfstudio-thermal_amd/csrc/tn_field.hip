@@ -915,7 +915,7 @@ __device__ __forceinline__ FbSmall fb_load_small(int64_t tile, int64_t tile_addr
                                                  const float* __restrict__ hins, const float* __restrict__ d_density, const float* __restrict__ sel,
                                                  const float* __restrict__ ys, const float* __restrict__ d_rgb, const int64_t* __restrict__ cam_idx) {
   // tile: the tile whose samples these are (beyond the last tile: no valid sample, every gradient zero); tile_addr <= the last tile: where the
-  // per-tile array is read (k_field_bwd_pair's virtual tiles; k_field_bwd_fused passes the same index twice)
+  // per-tile array is read (k_field_bwd_fused passes the same index twice)
   FbSmall q;
   const int64_t p = tile * TILE + j;
   const bool valid = p < P;
@@ -1287,413 +1287,8 @@ __global__ void __launch_bounds__(256, 1) k_field_bwd_fused(const float* __restr
   }
 }
 
-// ======================================================================================================================================
-// k_field_bwd_pair: the same backward (chain + every weight gradient) with TWO waves per SIMD.
-//
-// k_field_bwd_fused runs ONE wave per SIMD: the 192 weight-gradient accumulators plus the chain's temporaries take ~450 of the 512 registers,
-// and the wave is one in-order instruction stream whose matrix phases (chain steps, weight-gradient products: 46 % of its cycles) and vector /
-// LDS phases (ReLU masks, the sample-major transposition tiles, accumulator moves: the other half) follow each other -- nothing runs beside a
-// phase but the wave's own next instruction (profiles/r04_pmc.json: MFMA busy 0.46, waves parked 42 % = waiting for the matrix pipe, active or
-// waiting for LDS / memory the rest).  Splitting the ROLES over two waves (chain wave + weight-gradient wave) was tried in round 4 and lost:
-// a kernel has one register allocation, the weight-gradient role's 192 accumulators left the chain role no registers either.
-//
-// Here the two waves of a PAIR split the OUTPUT FEATURES instead: wave q owns features 32 q .. 32 q + 31 of every 64-wide layer -- its half
-// of every chain step's result and its half of every weight gradient (80 accumulators instead of 192) -- and both run the same code, so one
-// register allocation (<= 256) fits both and two pairs' waves share each SIMD: one wave's matrix phase runs beside the other's vector phase.
-//   * a chain step dIN^T = W^T . dOUT^T needs ALL of dOUT as its B operand: a wave has its own half in registers (the accumulator tile it
-//     just produced) and reads the partner's half back from the pair's dY tile in LDS, where the partner put it for the weight-gradient
-//     product anyway (four ds_read_b128);
-//   * the two chain steps with ONE 32-feature output tile (d head input, d enc) are split along K instead: each wave multiplies its own half
-//     of dOUT and the partial sums are exchanged through 2 KB of LDS;
-//   * the transposition tiles (dY, X) exist once per pair: each wave writes its half of the columns;
-//   * synchronisation is the block barrier (8 waves = 4 pairs in lockstep; gfx950 has no named barriers): 10 per tile.
-// Same inputs, outputs and workspace layout as k_field_bwd_fused; sums are formed in a different order (two 16-term partial sums instead of
-// one 32-term chain in the K-split steps; eight waves instead of four in the block sum), so results agree to rounding, not bit for bit.
-// MEASURED (MI355X, 4096 x 48 samples, stand-alone): k_field_bwd_fused 126-128 us; this kernel with block barriers 136 us; with the pair-level
-// synchronisation below 151 us.  It is correct (the field tests pass on it) and slower, for a reason the register file dictates: at 256
-// registers per wave (two waves per SIMD) the 80 accumulators leave no room to request an activation tile a phase ahead, so every tile is
-// loaded right where it is used and five HBM round trips per tile lie open (the one-wave kernel hides them behind the previous phase's
-// matrix work with 64 registers of prefetched tiles); the compiler still spills 15-24 registers.  Staging the tiles in LDS instead
-// (buffer_load ... lds) would need ~30 KB per pair on top of the 57 KB of packed weights and the transposition tiles: more than the CU has.
-// Kept as TN_FIELD_BWD_PAIR=1 (default off).
-#define FP_EXCH_FLOATS 1024                                              // two exchange areas of [2 float4][64 lanes]
-#define FP_PAIR_FLOATS (2 * FB_TILE_FLOATS + 128 + 32 + FP_EXCH_FLOATS + 32)  // dY tile, X tile, g3 [32][4], camera of each sample [32], exchange, the pair's phase flags
-#define FP_LDS_FLOATS (PACK_BWD_FLOATS + 4 * FP_PAIR_FLOATS)
-static_assert(FB_RED_TOTAL + 4 * 64 + 8 <= 4 * FP_PAIR_FLOATS, "block-sum area (+ the embedding merge) must fit in the per-pair buffers");
-static_assert(FP_LDS_FLOATS * 4 <= 160 * 1024, "LDS of one CU");
-
-__device__ __forceinline__ f32x16 lds_get_tile(const float* __restrict__ buf, int j, int h, int m) {
-  f32x16 v;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 t = *reinterpret_cast<const float4*>(buf + j * TSTR + 32 * m + 8 * g + 4 * h);
-    v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
-  }
-  return v;
-}
-// rows 32 q .. 32 q + 31 of dW[64][MI x 32] += dY^T X over the tile's 32 samples; bsum += this lane's share of sum_p dY[p][32 q + j]
-template <int MI>
-__device__ __forceinline__ void wgrad_half32(const float* __restrict__ bufY, const float* __restrict__ bufX, int j, int h, int q, f32x16 (&acc)[MI], float& bsum) {
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const float av = bufY[(2 * t + h) * TSTR + 32 * q + j];
-    float bv[MI];
-#pragma unroll
-    for (int b = 0; b < MI; ++b) bv[b] = bufX[(2 * t + h) * TSTR + 32 * b + j];
-    bsum += av;
-#pragma unroll
-    for (int b = 0; b < MI; ++b) acc[b] = MFMA(av, bv[b], acc[b]);
-  }
-}
-// columns 32 q .. 32 q + 31 of dW[16][64] += dY^T X (see wgrad_tile16); the bias sum is taken by wave 0 only
-__device__ __forceinline__ void wgrad_half16(const float* __restrict__ bufY, int ldy, int ncols, const float* __restrict__ bufX, int lane, int q,
-                                             f32x4v (&acc)[2], float& bsum) {
-  const int c = lane & 15, ks = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const float av = c < ncols ? bufY[(4 * t + ks) * ldy + c] : 0.0f;
-    if (q == 0) bsum += av;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[b] = MFMA16(av, bufX[(4 * t + ks) * TSTR + 16 * (2 * q + b) + c], acc[b]);
-  }
-}
-
-template <bool DENS_ONLY>
-__global__ void __launch_bounds__(512, 2) k_field_bwd_pair(const float* __restrict__ pack, const float* __restrict__ sel, const float* __restrict__ ys,
-                                                           const float* __restrict__ d_rgb, const float* __restrict__ d_density,
-                                                           const int64_t* __restrict__ cam_idx, int num_images, int64_t P, int S, int C,
-                                                           const float* __restrict__ shtab, const float* __restrict__ emb,
-                                                           float* __restrict__ cam_bias, int L, int64_t PT,
-                                                           const float* __restrict__ encs, const float* __restrict__ h1s,
-                                                           const float* __restrict__ hins, const float* __restrict__ hh1s,
-                                                           const float* __restrict__ hh2s, float* __restrict__ g_enc, FusedGrads G,
-                                                           uint32_t* __restrict__ zero_ptr, int zero_words) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // FP_LDS_FLOATS
-  tn_zero_words(zero_ptr, zero_words);  // the bucket counters of the table scatter that follows on this stream
-  const float* src = pack + PACK_BWD_OFF;
-  for (int i = threadIdx.x * 4; i < PACK_BWD_FLOATS; i += blockDim.x * 4)
-    *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-  const int q = wv & 1, pr = wv >> 1;  // half of the output features, pair of the block
-  float* bufY = lds + PACK_BWD_FLOATS + pr * FP_PAIR_FLOATS;
-  float* bufX = bufY + FB_TILE_FLOATS;
-  float* bufG = bufX + FB_TILE_FLOATS;             // g3 [32][4]
-  int* bufC = reinterpret_cast<int*>(bufG + 128);  // camera of each sample of the tile
-  float* exch = bufG + 160;                        // [2 waves][2][64 lanes] float4
-  // Synchronisation of the PAIR, not of the block: a block barrier would march all eight waves through the same phase at the same time -- the
-  // two waves of a SIMD would both want the matrix pipe, then both the vector ALU, and nothing would overlap (measured: 136 us against the
-  // one-wave kernel's 126).  Each wave publishes the number of the phase it has finished in LDS and waits for its partner's; the pairs of a
-  // block drift apart freely.  (LDS operations of a wave execute in order and the release fence drains them before the flag is written.)
-  volatile int* flag = reinterpret_cast<volatile int*>(exch + FP_EXCH_FLOATS);  // [2]
-  int epoch = 0;
-  if (lane == 0) flag[q] = 0;
-  __syncthreads();
-#define PAIR_SYNC()                                              \
-  do {                                                           \
-    ++epoch;                                                     \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       \
-    if (lane == 0) flag[q] = epoch;                              \
-    while (flag[1 - q] < epoch) __builtin_amdgcn_s_sleep(1);     \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       \
-  } while (0)
-  const int64_t ntiles = tn_cdiv(P, TILE);
-  const int64_t pair = (int64_t)blockIdx.x * 4 + pr;
-  const int64_t npairs = (int64_t)gridDim.x * 4;
-#define AB(layer, t, m, r) lds[fwd_off(layer) + ((((t) * layer_mo(layer) + (m)) * 16 + (r)) << 6) + lane]
-  const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const f32x4v zero4 = {0, 0, 0, 0};
-  // this wave's half of the weight-gradient accumulators: rows 32 q.. of d hw1 [64][64], d hw0 [64][32 slots], d w0 [64][32]; columns 32 q.. of
-  // d hw2 [16][64], d w1 [16][64]
-  f32x16 acc3[2] = {zero16, zero16}, acc2[1] = {zero16}, acc0[1] = {zero16};
-  f32x4v acc4[2] = {zero4, zero4}, acc1[2] = {zero4, zero4};
-  float bs3 = 0.f, bs2 = 0.f, bs0 = 0.f, bs4 = 0.f, bs1 = 0.f;
-  int emb_cam = -1;      // running per-camera sum of head layer 0's bias gradient, features 32 q + j (see k_field_bwd_fused); both waves of a pair
-  float emb_sum = 0.0f;  // see the same cameras, lanes j and 32 + j hold the same sum, the lower half flushes
-  const int64_t tpw = tn_cdiv(ntiles, npairs);  // a pair walks a contiguous slab of tiles; every pair of the block runs tpw iterations (barriers)
-  const int64_t tile_begin = pair * tpw;
-  const int64_t tile_end = (pair + 1) * tpw < ntiles ? (pair + 1) * tpw : ntiles;
-  // Every pair of the block runs tpw iterations (the block barriers must match).  A tile index beyond the last tile is a VIRTUAL tile: its loads
-  // are clamped to the last real tile and its upstream gradients are zero (fb_load_small: no valid sample), so every dY of the tile is an exact
-  // zero -- the weight-gradient products add 0 * X, the per-camera sums add 0 to camera -1, nothing is stored.
-  const int64_t last_tile = ntiles - 1;
-  FbSmall nsm;
-  f32x16 nx;  // next tile's first activation tile, this wave's half (hh2, or h1 for the density-only backward)
-  {
-    const int64_t tl = tile_begin < last_tile ? tile_begin : last_tile;
-    nsm = fb_load_small<DENS_ONLY>(tile_begin, tl, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
-    nx = load_frag(DENS_ONLY ? h1s : hh2s, tl, 2, q, lane);
-  }
-  for (int64_t it = 0; it < tpw; ++it) {
-    const int64_t tile = tile_begin + it;
-    const int64_t tl = tile < last_tile ? tile : last_tile;  // where the tile's activations are read from
-    const int64_t p = tile * TILE + j;
-    const bool valid = p < P;
-    const int64_t pc = valid ? p : P - 1;
-    const FbSmall sm = nsm;
-    f32x16 sq;  // h1 tile q (ReLU mask of the base MLP)
-    float dbo[8];
-    if (!DENS_ONLY) {
-      f32x16 dc = zero16;  // d hh1, this wave's half
-      {
-        if (q == 0 && h == 0) {
-          *reinterpret_cast<float4*>(bufG + j * 4) = make_float4(sm.g3[0], sm.g3[1], sm.g3[2], sm.g3[3]);
-          bufC[j] = sm.cam;
-        }
-        // ---- d hh2 (features 32 q ..) = hw2^T . g3
-        f32x16 dd = zero16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dd = MFMA(AB(4, q, 0, r), sm.g3[r], dd);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dd[r] = nx[r] > 0.0f ? dd[r] : 0.0f;
-        lds_put_tile(bufX, j, h, q, nx);  // X of head layer 2: hh2
-        lds_put_tile(bufY, j, h, q, dd);  // dY of head layer 1: gy_hh2
-        PAIR_SYNC();  // 1
-        if (!(FB_ABLATE & 4)) wgrad_half16(bufG, 4, C, bufX, lane, q, acc4, bs4);  // d hw2 (columns 32 q ..) += g3^T hh2
-        // ---- d hh1 (features 32 q ..) = hw1^T . d hh2: own half first (in registers), then the partner's
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dc = MFMA(AB(3, q, q, r), dd[r], dc);
-        const f32x16 ddp = lds_get_tile(bufY, j, h, 1 - q);  // the partner's half of d hh2
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dc = MFMA(AB(3, q, 1 - q, r), ddp[r], dc);
-      }
-      {
-        // (requested behind the matrix work, not a phase ahead as in the one-wave kernel: the other pairs' waves on this SIMD cover the latency,
-        // and at 256 registers per wave every tile that is prefetched across a chain step is a spill)
-        const f32x16 tq = load_frag(hh1s, tl, 2, q, lane);
-        PAIR_SYNC();  // 2: the reads of bufX (hh2) are done; bufY keeps gy_hh2 for the weight gradient below
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dc[r] = tq[r] > 0.0f ? dc[r] : 0.0f;
-        lds_put_tile(bufX, j, h, q, tq);  // X of head layer 1: hh1
-      }
-      PAIR_SYNC();  // 3
-      if (!(FB_ABLATE & 2)) wgrad_half32<2>(bufY, bufX, j, h, q, acc3, bs3);  // d hw1 (rows 32 q ..) += gy_hh2^T hh1
-      PAIR_SYNC();  // 4
-      lds_put_tile(bufY, j, h, q, dc);  // dY of head layer 0: gy_hh1
-      if (q == 1) {
-        // head-input slots 0..31 (X of head layer 0), rebuilt as the forward built them: sh | the 16 saved base outputs of the tile
-        const v4f_t* bp = reinterpret_cast<const v4f_t*>(hins) + tl * 128 + lane;
-        const v4f_t hb0 = FRAG_NT ? __builtin_nontemporal_load(bp) : bp[0], hb1 = FRAG_NT ? __builtin_nontemporal_load(bp + 64) : bp[64];
-        const float* shp = shtab + (int64_t)sm.ray * 16 + h * 8;
-        const float4 sa = *reinterpret_cast<const float4*>(shp), sb = *reinterpret_cast<const float4*>(shp + 4);
-        f32x16 t0;
-        t0[0] = sa.x; t0[1] = sa.y; t0[2] = sa.z; t0[3] = sa.w; t0[4] = sb.x; t0[5] = sb.y; t0[6] = sb.z; t0[7] = sb.w;
-        t0[8] = hb0.x; t0[9] = hb0.y; t0[10] = hb0.z; t0[11] = hb0.w; t0[12] = hb1.x; t0[13] = hb1.y; t0[14] = hb1.z; t0[15] = hb1.w;
-        lds_put_tile(bufX, j, h, 0, t0);
-      }
-      PAIR_SYNC();  // 5
-      {
-        float tb = 0.0f;  // this tile's share of the layer's bias gradient (lane (j, h): k-parity h of output 32 q + j)
-        if (!(FB_ABLATE & 2)) wgrad_half32<1>(bufY, bufX, j, h, q, acc2, tb);  // d hw0 (rows 32 q .., slots 0..31) += gy_hh1^T hin
-        bs2 += tb;
-        if (!(FB_ABLATE & 1)) {  // appearance-embedding rows: the tile's bias sums go to the running sums of its camera
-          const float tt = tb + __shfl_xor(tb, 32, 64);  // all 32 samples of output 32 q + j
-          const int cam0 = __builtin_amdgcn_readfirstlane(sm.cam);
-          if (__ballot(sm.cam >= 0 && sm.cam != cam0) == 0) {
-            if (cam0 != emb_cam) {
-              if (emb_cam >= 0 && emb_sum != 0.0f && h == 0) atomicAdd(cam_bias + (int64_t)emb_cam * 64 + 32 * q + j, emb_sum);
-              emb_cam = cam0;
-              emb_sum = 0.0f;
-            }
-            emb_sum += tt;
-          } else {
-            // a camera boundary inside the tile: the tile's rows sample by sample (bufY holds gy_hh1 [32 samples][64], bufC the cameras)
-            for (int qq = 0; qq < 32; ++qq) {
-              const int c = bufC[qq];
-              if (c >= 0) {
-                if (c != emb_cam) {
-                  if (emb_cam >= 0 && emb_sum != 0.0f && h == 0) atomicAdd(cam_bias + (int64_t)emb_cam * 64 + 32 * q + j, emb_sum);
-                  emb_cam = c;
-                  emb_sum = 0.0f;
-                }
-                emb_sum += bufY[qq * TSTR + 32 * q + j];
-              }
-            }
-          }
-        }
-        // ---- d head-input slots 0..31 = Wslot^T . d hh1, K split over the pair: this wave's half of d hh1
-        f32x16 dip = zero16;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dip = MFMA(AB(2, 0, q, r), dc[r], dip);
-        // rows 16..31 (registers 8..15: the base outputs' slots) go to the partner
-        float4* ex = reinterpret_cast<float4*>(exch + q * 512);
-        ex[lane] = make_float4(dip[8], dip[9], dip[10], dip[11]);
-        ex[64 + lane] = make_float4(dip[12], dip[13], dip[14], dip[15]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) dbo[r] = dip[8 + r];
-      }
-      sq = load_frag(h1s, tl, 2, q, lane);
-      PAIR_SYNC();  // 6
-      {
-        const float4* ex = reinterpret_cast<const float4*>(exch + (1 - q) * 512);
-        const float4 a = ex[lane], b = ex[64 + lane];
-        dbo[0] += a.x; dbo[1] += a.y; dbo[2] += a.z; dbo[3] += a.w; dbo[4] += b.x; dbo[5] += b.y; dbo[6] += b.z; dbo[7] += b.w;  // (a + b == b + a: both waves agree)
-      }
-    } else {
-      sq = nx;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) dbo[r] = 0.0f;
-      PAIR_SYNC();  // (the previous tile's readers of bufX / bufY are done)
-    }
-    {
-      // ---- d base_out: row 0 (half 0, register 0) takes the trunc_exp gradient instead
-      const float g = sm.g_dens * expf(fminf(fmaxf(sm.pre_logit, -15.0f), 15.0f)) * sm.sel_p;
-      if (h == 0) dbo[0] = valid ? g : 0.0f;
-      if (q == 0) {  // dY of base layer 1: gy_bo [32][16] in the first 16 columns of bufY
-        *reinterpret_cast<float4*>(bufY + j * TSTR + 4 * h) = make_float4(dbo[0], dbo[1], dbo[2], dbo[3]);
-        *reinterpret_cast<float4*>(bufY + j * TSTR + 8 + 4 * h) = make_float4(dbo[4], dbo[5], dbo[6], dbo[7]);
-      }
-      lds_put_tile(bufX, j, h, q, sq);  // X of base layer 1: h1
-    }
-    PAIR_SYNC();  // 7
-    f32x16 dh = zero16;
-    if (!(FB_ABLATE & 4)) wgrad_half16(bufY, TSTR, 16, bufX, lane, q, acc1, bs1);  // d w1 (columns 32 q ..) += gy_bo^T h1
-    // ---- d h1 (features 32 q ..) = w1^T . d base_out   (k-steps r < 8: rows < 16)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) dh = MFMA(AB(1, q, 0, r), dbo[r], dh);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dh[r] = sq[r] > 0.0f ? dh[r] : 0.0f;
-    PAIR_SYNC();  // 8
-    lds_put_tile(bufY, j, h, q, dh);  // dY of base layer 0: gy_h1
-    if (q == 1) {
-      const f32x16 e0 = load_enc_lm(encs, PT, pc, h, L);
-      lds_put_tile(bufX, j, h, 0, e0);  // X of base layer 0: enc
-    }
-    PAIR_SYNC();  // 9
-    f32x16 dep = zero16;
-    if (!(FB_ABLATE & 2)) wgrad_half32<1>(bufY, bufX, j, h, q, acc0, bs0);  // d w0 (rows 32 q ..) += gy_h1^T enc
-    // ---- d enc = w0^T . d h1, K split over the pair; wave q finishes register groups 2 q, 2 q + 1 (levels 8 q + 2 h ..) and hands the other two
-    // groups of its partial sum to the partner
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dep = MFMA(AB(0, 0, q, r), dh[r], dep);
-    {
-      float4* ex = reinterpret_cast<float4*>(exch + q * 512);
-      if (q == 0) {  // (static register indices in both branches: a runtime index into the accumulator tile would go through scratch)
-        ex[lane] = make_float4(dep[8], dep[9], dep[10], dep[11]);
-        ex[64 + lane] = make_float4(dep[12], dep[13], dep[14], dep[15]);
-      } else {
-        ex[lane] = make_float4(dep[0], dep[1], dep[2], dep[3]);
-        ex[64 + lane] = make_float4(dep[4], dep[5], dep[6], dep[7]);
-      }
-    }
-    {  // the next tile's first loads, behind the last matrix work of this one
-      const int64_t tn = tile + 1, tnl = tn < last_tile ? tn : last_tile;
-      nsm = fb_load_small<DENS_ONLY>(tn, tnl, j, h, P, S, C, num_images, hins, d_density, sel, ys, d_rgb, cam_idx);
-      nx = load_frag(DENS_ONLY ? h1s : hh2s, tnl, 2, q, lane);
-    }
-    PAIR_SYNC();  // 10
-    if (valid) {  // d enc, level-major [16][P] float2: registers 4g..4g+3 = levels 4g + 2h (f0, f1), 4g + 2h + 1 (f0, f1)
-      const float4* ex = reinterpret_cast<const float4*>(exch + (1 - q) * 512);
-      const float4 a = ex[lane], b = ex[64 + lane];
-      float mine[8];
-      if (q == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) mine[i] = dep[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) mine[i] = dep[8 + i];
-      }
-      // (a + b == b + a exactly: the sum of the pair's two partial sums does not depend on which wave forms it)
-      const float v[8] = {mine[0] + a.x, mine[1] + a.y, mine[2] + a.z, mine[3] + a.w, mine[4] + b.x, mine[5] + b.y, mine[6] + b.z, mine[7] + b.w};
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int g = 2 * q + gg;
-        *reinterpret_cast<float2*>(g_enc + (int64_t)(4 * g + 2 * h) * 2 * P + 2 * p) = make_float2(v[4 * gg], v[4 * gg + 1]);
-        *reinterpret_cast<float2*>(g_enc + (int64_t)(4 * g + 2 * h + 1) * 2 * P + 2 * p) = make_float2(v[4 * gg + 2], v[4 * gg + 3]);
-      }
-    }
-  }
-#undef AB
-#undef PAIR_SYNC
-  if (FB_ABLATE & 8) return;
-  // ---- block sum of the accumulators (plain LDS read-modify-write, one PAIR per turn: its two waves hold disjoint halves), then one burst of
-  // global float atomics per block; exact zeros stay exact zeros (v != 0 guard)
-  __syncthreads();  // every pair is done with its tile buffers: the sums go there
-  float* red = lds + PACK_BWD_FLOATS;
-  if (!DENS_ONLY) {
-    float* esum = red + FB_RED_TOTAL;                  // [4 pairs][64 sums]
-    int* ecam = reinterpret_cast<int*>(esum + 4 * 64);  // [4]
-    if (h == 0) esum[pr * 64 + 32 * q + j] = emb_sum;
-    if (lane == 0 && q == 0) ecam[pr] = emb_cam;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      for (int e = 0; e < 4; ++e) {
-        const int cam = ecam[e];
-        if (cam < 0) continue;
-        bool first = true;
-        for (int f = 0; f < e; ++f) first = first && (ecam[f] != cam);
-        if (!first) continue;
-        float tot = 0.0f;
-        for (int f = e; f < 4; ++f)
-          if (ecam[f] == cam) tot += esum[f * 64 + threadIdx.x];
-        if (tot != 0.0f) atomicAdd(cam_bias + (int64_t)cam * 64 + threadIdx.x, tot);
-      }
-    }
-    __syncthreads();  // (esum / ecam lie behind FB_RED_TOTAL: not touched by the turns below, but keep the phases apart)
-  }
-  const int c16 = lane & 15, k16 = lane >> 4;
-  for (int w = 0; w < 4; ++w) {
-    if (pr == w) {
-#define RED_PUT(idx, v) { float* d_ = &red[idx]; *d_ = (w == 0) ? (v) : *d_ + (v); }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = 32 * q + RROW(r, h);
-        if (!DENS_ONLY) {
-#pragma unroll
-          for (int b = 0; b < 2; ++b) RED_PUT(FB_RED_W3 + o * 64 + 32 * b + j, acc3[b][r]);
-          RED_PUT(FB_RED_W2 + o * 32 + j, acc2[0][r]);  // [64 out][32 slots]
-        }
-        RED_PUT(FB_RED_W0 + o * 32 + j, acc0[0][r]);
-      }
-      {
-        // bias sums: lane (j, h) holds its k-parity share of output 32 q + j
-        const float s3 = bs3 + __shfl_xor(bs3, 32, 64), s2 = bs2 + __shfl_xor(bs2, 32, 64), s0_ = bs0 + __shfl_xor(bs0, 32, 64);
-        if (h == 0) {
-          if (!DENS_ONLY) { RED_PUT(FB_RED_B3 + 32 * q + j, s3); RED_PUT(FB_RED_B2 + 32 * q + j, s2); }
-          RED_PUT(FB_RED_B0 + 32 * q + j, s0_);
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (!DENS_ONLY) RED_PUT(FB_RED_W4 + (4 * k16 + r) * 64 + 16 * (2 * q + b) + c16, acc4[b][r]);
-          RED_PUT(FB_RED_W1 + (4 * k16 + r) * 64 + 16 * (2 * q + b) + c16, acc1[b][r]);
-        }
-      if (q == 0) {
-        float s4 = bs4 + __shfl_xor(bs4, 16, 64); s4 += __shfl_xor(s4, 32, 64);
-        float s1_ = bs1 + __shfl_xor(bs1, 16, 64); s1_ += __shfl_xor(s1_, 32, 64);
-        if (lane < 16) {
-          if (!DENS_ONLY) RED_PUT(FB_RED_B4 + lane, s4);
-          RED_PUT(FB_RED_B1 + lane, s1_);
-        }
-      }
-#undef RED_PUT
-    }
-    __syncthreads();
-  }
-  for (int t = threadIdx.x; t < FB_RED_TOTAL; t += blockDim.x) {
-    const float v = red[t];
-    if (v == 0.0f) continue;
-    float* dst = nullptr;
-    if (t < FB_RED_W2) { if (!DENS_ONLY) dst = G.ghw1 + t; }
-    else if (t < FB_RED_W0) {  // d hw0, slots 0..31 (sh | base outputs): [64 out][32 slots] at the head of the region, the rest unused
-      const int qq = t - FB_RED_W2;
-      if (qq >= 64 * 32) continue;
-      const int col = slot_to_col(qq & 31);
-      if (!DENS_ONLY && col >= 0) dst = G.ghw0 + (qq >> 5) * 63 + col;
-    }
-    else if (t < FB_RED_W4) dst = G.gw0 + (t - FB_RED_W0);
-    else if (t < FB_RED_W1) { const int qq = t - FB_RED_W4; if (!DENS_ONLY && (qq >> 6) < C) dst = G.ghw2 + qq; }
-    else if (t < FB_RED_B3) dst = G.gw1 + (t - FB_RED_W1);
-    else if (t < FB_RED_B2) { if (!DENS_ONLY) dst = G.ghb1 + (t - FB_RED_B3); }
-    else if (t < FB_RED_B0) { if (!DENS_ONLY) dst = G.ghb0 + (t - FB_RED_B2); }
-    else if (t < FB_RED_B4) dst = G.gb0 + (t - FB_RED_B0);
-    else if (t < FB_RED_B1) { if (!DENS_ONLY && (t - FB_RED_B4) < C) dst = G.ghb2 + (t - FB_RED_B4); }
-    else dst = G.gb1 + (t - FB_RED_B1);
-    if (dst) atomicAdd(dst, v);
-  }
-}
+// (k_field_bwd_pair -- the same backward with TWO waves per SIMD, each wave of a pair owning half of the output features -- was measured at
+// 136-151 us against this kernel's 126 and removed in round 6; what it taught is in profiles/r05_experiments.md.)
 
 // ---- host entry points -----------------------------------------------------------------------------------------------------
 static int check_field(const TnField* f, const char* who, bool need_grad) {
@@ -1906,21 +1501,7 @@ int tn_field_bwd_phase_ex(const TnField* field, const float* origins, const floa
     uint32_t* zp;
     int zw;
     tn_grid_scatter_counters(field->grid, P, ws.scatter, &zp, &zw);  // the bin pass then starts without a memset launch of its own
-    // TN_FIELD_BWD_PAIR=1: k_field_bwd_pair (two waves per SIMD, each wave of a pair owning half of the output features) -- an experiment that is
-    // kept, tested (tests/test_hip_ops_gpu.py::test_field_bwd_pair_variant) and OFF: 151 us against this kernel's 127 (profiles/r05_experiments.md).
-    // Read per call, so that a test can switch it inside one process.
-    const char* pair_env = getenv("TN_FIELD_BWD_PAIR");
-    const bool use_pair = pair_env != nullptr && atoi(pair_env) != 0;
-    const size_t shmem_p = FP_LDS_FLOATS * sizeof(float);
-    if (use_pair && dens_only) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_p);
-      hipLaunchKernelGGL(k_field_bwd_pair<true>, dim3(grid), dim3(512), shmem_p, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
-                         C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
-    } else if (use_pair) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_pair<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_p);
-      hipLaunchKernelGGL(k_field_bwd_pair<false>, dim3(grid), dim3(512), shmem_p, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P,
-                         S, C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);
-    } else if (dens_only) {
+    if (dens_only) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       hipLaunchKernelGGL((k_field_bwd_fused<true, false>), dim3(grid), dim3(256), shmem, st, ws.pack, ws.sel, ws.y, d_rgb, d_density, camera_indices, field->num_images, P, S,
                          C, ws.sh, field->emb, ws.cam_bias, field->grid.num_levels, ws.PT, ws.enc, ws.h1, ws.hin, ws.hh1, ws.hh2, ws.g_enc, G, zp, zw);

@@ -41,6 +41,10 @@ def test_default_line_has_every_object_and_no_failed_leg():
             assert leg["rays"] == 640 * 480 + 160 * 120
             continue
         assert leg["ms_per_step"] > 0 and leg["rays_per_s"] > 0, (name, leg)
-    assert set(d["extra"]) == {"separate_8192", "nerf_samples_96", "model_api_amp", "fused_trainer", "eval_render"}
+        if name == "head_bf16x3":  # the opt-in split-bf16 colour head: its own dtype, its own parity block, the fp32 step of the same run beside it
+            assert "bf16x3" in leg["dtype"] and leg["f32_same_run"]["ms_per_step"] > 0
+            assert leg["parity"]["max_abs_rgb"] <= 1e-3 and leg["parity"]["max_abs_thermal"] <= 1e-3, leg
+            assert 0 < leg["gradients_vs_f32_path"]["head_max"] <= 3e-3, leg  # (3e-4 without a flipped ReLU mask; measured 3e-5)
+    assert set(d["extra"]) == {"separate_8192", "nerf_samples_96", "model_api_amp", "fused_trainer", "eval_render", "head_bf16x3"}
     ak = rf["all_kernels"]
     assert all(v["bound"] == ("l2" if k.startswith("k_prop_fwd") else "hbm") and 0 < v["frac"] < 1.0 for k, v in ak.items()), ak

@@ -1104,46 +1104,6 @@ def test_hash_scatter_store_variant_equals_the_adding_one():
     assert float((a - b).abs().max()) <= 1e-5 * scale  # (float atomics of the overflow / replica paths, order of the fold's double atomics)
 
 
-def test_field_bwd_pair_variant(monkeypatch):
-    """TN_FIELD_BWD_PAIR=1 (k_field_bwd_pair: two waves per SIMD, each wave of a pair owning half of the output features; kept as a measured
-    experiment, default off) computes what k_field_bwd_fused computes: every gradient of the main field within rounding of the default kernel's,
-    colour + density backward and the density-only backward, tiles that do not divide the pairs evenly."""
-    ocfg, params, cfg, arena = setup_pair("shared")
-    N, S = 301, 48  # 452 tiles, 113 blocks of 4 pairs: the last block holds virtual tiles
-    r = rays(N)
-    cam = torch.arange(N) % ocfg.num_images
-    nears, fars = torch.ones(N, 1) * 0.05, torch.ones(N, 1) * 1000.0
-    _, e = sample_level(N, S, nears, fars)
-    fld = field_params(arena, "field", cfg, with_grads=True)
-    C = fld.num_channels
-    gd = torch.from_numpy(synth.uniform("gpd", (N, S), seed=SEED))
-    gc = torch.from_numpy(synth.uniform("gpc", (N, S, C), seed=SEED))
-    k = orc.field_keys("field")
-    for dens_only in (False, True):
-        res = {}
-        for pair in ("0", "1"):
-            monkeypatch.setenv("TN_FIELD_BWD_PAIR", pair)
-            arena.zero_grad()
-            d_o, d_d = torch.zeros((N, 3), device=DEV), torch.zeros((N, 3), device=DEV)
-            if dens_only:
-                ops.field_density_fwd(fld, g(r["origins"]), g(r["directions"]), g(e), training=True, tag="cross")
-                ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), g(gd), None, d_o, d_d, tag="cross")
-            else:
-                ops.field_fwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), True)
-                ops.field_bwd(fld, g(r["origins"]), g(r["directions"]), g(cam), g(e), g(gd), g(gc), d_o, d_d)
-            torch.cuda.synchronize()
-            res[pair] = {s: arena.grad_view(k[s]).detach().clone() for s in ("table", "w0", "b0", "w1", "b1", "hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb")}
-            res[pair]["d_o"], res[pair]["d_d"] = d_o, d_d
-        for name, ref in res["0"].items():
-            scale = float(ref.abs().max())
-            if dens_only and name in ("hw0", "hb0", "hw1", "hb1", "hw2", "hb2", "emb"):
-                assert scale == 0.0 and float(res["1"][name].abs().max()) == 0.0, name
-                continue
-            assert scale > 0, name
-            assert md(res["1"][name], ref) <= 2e-5 * scale, (dens_only, name, md(res["1"][name], ref), scale)
-            assert bool(((res["1"][name] == 0) == (ref == 0)).all()) or name in ("d_o", "d_d"), (name, "zero pattern")
-
-
 @pytest.mark.parametrize("scatter_mode", ["2", "1"])
 def test_field_bwd_d_position_as_co_work_of_the_bin_launch(monkeypatch, scatter_mode):
     """The main field's d position pass runs in extra blocks of the table scatter's bin launch (tn_field_dpos.h; segmented path) or as a launch of
