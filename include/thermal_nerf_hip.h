@@ -39,8 +39,11 @@
  *                                 the first blocks of the main grid's fold launch on iterations without a proposal update
  *      TN_FUSE_RENDER=1           (read per call) tn_train_step with tn_render_fwd / tn_train_losses / tn_render_bwd as ONE launch,
  *                                 tn_render_losses_bwd -- a measured experiment that is correct and not faster (profiles/r05_experiments.md)
- *      TN_NEXT_SAMPLING=0|2|3     (read per call) tn_train_step's next_sampling: 0 = never taken (every iteration samples in line); 2 = the chain as a launch
- *                                 of its own behind the optimiser launch; 3 = on a companion stream beside it (A/B timing aids: same results)
+ *      TN_NEXT_SAMPLING=0|2|3|4   (read per call) tn_train_step's next_sampling: 0 = never taken (every iteration samples in line); 2 = the chain as a launch
+ *                                 of its own behind the optimiser launch; 3 = on a companion stream beside it (A/B timing aids: same results);
+ *                                 4 = (opt-in experiment) the chain's waves also step most of the field's optimiser range themselves, between
+ *                                 their stages, through LDS-staged asynchronous loads: same forward buffer bit for bit, the same Adam
+ *                                 arithmetic; the launch 141 -> 132 us (profiles/r06_next_sampling.md).  TN_FUSED_SITES=<n> sizes its share
  *      TN_HEAD_BF16X3=1           (read per call; opt-in experiment, never the default) the colour head's two 64-wide layers in tn_field_fwd /
  *                                 tn_field_bwd* on split-bf16 matrix instructions: x = hi + lo in bf16, three v_mfma_f32_32x32x16_bf16 per
  *                                 product, fp32 accumulators (~2^-16 relative).  The density path stays fp32 bit for bit.  RGB / thermal agree

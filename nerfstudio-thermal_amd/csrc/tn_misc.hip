@@ -1118,13 +1118,18 @@ __global__ void k_adam_ranges_amp(float* __restrict__ p, const float* __restrict
 // waves per SIMD with persistent Adam blocks (1 or 2 per CU, 4 x the loads in flight per lane) interleaved 1 : 4 / 2 : 4 with the chain blocks --
 // were built and measured SLOWER (177 / 196 us): the chain spills 26 / 47 registers there and HBM wants ~100 KB in flight per CU, which one or two
 // Adam waves per SIMD do not provide.
+// FUSED (TN_NEXT_SAMPLING=4, an experiment): the chain's waves step the first fa.batches batches of the launch's one range themselves, between
+// their stages (tn_next_sampling.h: FusedAdam); the range row takes the rest.
+template <bool FUSED>
 __global__ void __launch_bounds__(256, 4) k_adam_ranges_amp_next(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                                  AdamRangesAmp r, double beta1, double beta2, float eps, const float* __restrict__ inv_scale,
                                                                  float* __restrict__ found_inf, int32_t* __restrict__ skipped, int count_skip, int zero_g,
-                                                                 ScalerUpdate su, NextSamplingArgs ns) {
+                                                                 ScalerUpdate su, NextSamplingArgs ns, FusedAdam fa) {
   __shared__ __attribute__((aligned(16))) float ns_lds[NS_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float fa_stage[FUSED ? 4 * FA_STAGE_FLOATS : 4];
+  __shared__ float fa_scal[4];
   if (blockIdx.y == 0) {
-    if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body(ns, blockIdx.x, (unsigned)ns.blocks, ns_lds);
+    if (blockIdx.x < (unsigned)ns.blocks) next_sampling_body<FUSED>(ns, blockIdx.x, (unsigned)ns.blocks, ns_lds, &fa, fa_stage, fa_scal);
   } else {
     adam_range_body(p, g, m, v, r, beta1, beta2, eps, inv_scale, found_inf, skipped, count_skip, zero_g, (int)blockIdx.y - 1, (int)blockIdx.x, (int)gridDim.x);
   }
@@ -1237,8 +1242,29 @@ static int adam_ranges_amp_impl(float* params, const float* grads, float* exp_av
       TN_CHECK_LAUNCH("tn_next_sampling");
       return TN_OK;
     }
-    hipLaunchKernelGGL(k_adam_ranges_amp_next, dim3(grid, n + 1), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps,
-                       inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, ns);
+    FusedAdam fa{};
+    if (mode && mode[0] == '4' && n == 1 && inv_scale == nullptr) {
+      // the chain's waves step the head of the (one) range: as many 256-float batches as their service points can take; the range row the rest
+      const int64_t nb = r.cnt[0] / 256, W = (int64_t)ns.blocks * 4, trips = tn_cdiv(chain->N, W);
+      const char* fs = getenv("TN_FUSED_SITES");  // (tuning aid: batches per ray the host hands to the chain's waves; default = what their stages take)
+      const int64_t per_ray = fs ? std::max(1, atoi(fs)) : FA_SITES_PER_RAY;
+      const int64_t take = std::min<int64_t>(nb - 1, per_ray * trips * W);
+      if (take >= W) {
+        fa.p = params + r.off[0]; fa.g = grads + r.off[0]; fa.m = exp_avg + r.off[0]; fa.v = exp_avg_sq + r.off[0];
+        fa.batches = (uint32_t)take;
+        fa.flag = r.flag[0]; fa.step = r.step[0]; fa.max_steps = r.max_steps[0]; fa.sched_step = r.sched_step; fa.lag_index = r.lag_index;
+        fa.zero_g = (int)zero_grads;
+        fa.beta1 = beta1; fa.beta2 = beta2; fa.lr = r.lr[0]; fa.lr_final = r.lr_final[0]; fa.eps = (float)eps;
+        fa.found_inf = found_inf; fa.skipped = skipped;
+        r.off[0] += take * 256; r.cnt[0] -= take * 256;
+      }
+    }
+    if (fa.batches > 0)
+      hipLaunchKernelGGL(k_adam_ranges_amp_next<true>, dim3(grid, n + 1), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps,
+                         inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, ns, fa);
+    else
+      hipLaunchKernelGGL(k_adam_ranges_amp_next<false>, dim3(grid, n + 1), dim3(256), 0, tn_s(stream), params, grads, exp_avg, exp_avg_sq, r, beta1, beta2, (float)eps,
+                         inv_scale, const_cast<float*>(found_inf), skipped, (int)count_skip, (int)zero_grads, su, ns, fa);
     TN_CHECK_LAUNCH("tn_adam_step_ranges_amp(next_sampling)");
     return TN_OK;
   }

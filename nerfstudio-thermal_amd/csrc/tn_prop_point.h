@@ -63,8 +63,12 @@ __device__ __forceinline__ float prop_mlp(const float* s_w, const float (&enc)[P
 // rows of prop_stage_weights.  enc_out (SAVE_ENC): level-major [PL][P] float2, entry i.
 // LEVEL_FENCE: nothing is scheduled across the boundary between two levels (8 gathers in flight, not 40) -- measured: no fewer registers, more latency; unused.
 // OPTIONAL_ENC: enc_out may be NULL at run time (wave-uniform): one instantiation for both kinds of iteration.
-template <bool SAVE_ENC, bool LEVEL_FENCE = false, bool OPTIONAL_ENC = false>
-__device__ __forceinline__ float prop_density_sample(const PropK& net, const float* s_w, float px, float py, float pz, bool sel, int64_t i, int64_t P, float* enc_out) {
+// hook: called between the gathers and the MLP, once the encoding has arrived (tn_next_sampling.h requests a batch of the optimiser's data there:
+// in flight while the MLP runs from registers and LDS, landed before the next sample's table loads are waited for)
+struct PropNoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool SAVE_ENC, bool LEVEL_FENCE = false, bool OPTIONAL_ENC = false, class Hook = PropNoHook>
+__device__ __forceinline__ float prop_density_sample(const PropK& net, const float* s_w, float px, float py, float pz, bool sel, int64_t i, int64_t P, float* enc_out,
+                                                     Hook hook = Hook()) {
   float enc[PF];
 #pragma unroll
   for (int l = 0; l < PL; ++l) {
@@ -72,7 +76,17 @@ __device__ __forceinline__ float prop_density_sample(const PropK& net, const flo
     float2 v = tn_encode_level(net.g.table, px, py, pz, net.g.res[l], net.g.mask, (uint32_t)l * net.g.tsize);
     enc[2 * l] = v.x;
     enc[2 * l + 1] = v.y;
-    if (SAVE_ENC && (!OPTIONAL_ENC || enc_out != nullptr)) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;  // level-major [PL][P] float2: 512 contiguous bytes per wave and level
+    // level-major [PL][P] float2: 512 contiguous bytes per wave and level.  (With a hook the stores follow it: the hook waits for the wave's
+    // outstanding memory operations, and five fresh stores would be among them)
+    if (__is_same(Hook, PropNoHook) && SAVE_ENC && (!OPTIONAL_ENC || enc_out != nullptr)) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = v;
+  }
+  if (!__is_same(Hook, PropNoHook)) {
+    asm volatile("" :: "v"(enc[0]), "v"(enc[1]), "v"(enc[2]), "v"(enc[3]), "v"(enc[4]), "v"(enc[5]), "v"(enc[6]), "v"(enc[7]), "v"(enc[8]), "v"(enc[9]));
+    hook();
+    if (SAVE_ENC && (!OPTIONAL_ENC || enc_out != nullptr)) {
+#pragma unroll
+      for (int l = 0; l < PL; ++l) *reinterpret_cast<float2*>(enc_out + ((int64_t)l * P + i) * 2) = make_float2(enc[2 * l], enc[2 * l + 1]);
+    }
   }
   const float out = prop_mlp(s_w, enc);
   return sel ? expf(out) : 0.0f * expf(out);  // exp(x) * selector (0*inf = nan kept as torch would)

@@ -171,7 +171,7 @@ def test_next_batch_is_sampled_inside_the_training_step(scene):
 
 
 
-@pytest.mark.parametrize("mode", ["cowork", "serial", "fork"])
+@pytest.mark.parametrize("mode", ["cowork", "serial", "fork", "fused"])
 def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
     """TnTrainStep.next_sampling: the sampling front of iteration k + 1 (pose correction, level-0 bins, both proposal levels' density -> weights ->
     PDF resampling) runs in co-work blocks of iteration k's optimiser launch, behind a launch that steps the groups it reads.  Against the same run
@@ -189,7 +189,8 @@ def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
 
     N = 256
     if mode != "cowork":  # (A/B timing aids: the chain as a launch of its own behind the optimiser launch / on a companion stream beside it)
-        monkeypatch.setenv("TN_NEXT_SAMPLING", "2" if mode == "serial" else "3")
+        # ("fused", TN_NEXT_SAMPLING=4: the chain's waves also step most of the field's optimiser range between their stages)
+        monkeypatch.setenv("TN_NEXT_SAMPLING", {"serial": "2", "fork": "3", "fused": "4"}[mode])
 
     def run(chain: bool, states=None):
         random.seed(5)
@@ -218,7 +219,7 @@ def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
             call = eng._step_call
             used += int(planned and call.st.sampling_done == 1)
             torch.cuda.synchronize()
-            rec.append({"before": before, "buf": call._keep[3].clone(), "off": list(call.off), "losses": {k: float(v) for k, v in losses.items()},
+            rec.append({"before": before, "after": (ar.params.clone(), ar.exp_avg.clone(), ar.exp_avg_sq.clone()), "buf": call._keep[3].clone(), "off": list(call.off), "losses": {k: float(v) for k, v in losses.items()},
                         "updated": eng.last_updated, "since": eng.steps_since_update, "scale": scaler.get_scale(),
                         "skipped": [scaler.num_skipped(i) for i in range(3)], "lag": scaler.schedule_lag(), "counts": call.counts})
             assert ops._PENDING_SAMPLE is None, step
@@ -248,4 +249,12 @@ def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
         if step != 6:
             for k, v in a["losses"].items():
                 assert abs(v - b["losses"][k]) <= 1e-5 * abs(b["losses"][k]) + 1e-12, (step, k)
+        # the optimiser step itself, whichever launch layout carried it: from the same state and (up to the order of float atomics) the same
+        # gradients -- parameters within a thousandth of the largest learning rate (1e-2: a batch stepped twice or not at all is off by a whole
+        # step), moments to 1e-4, and the entries that never saw a gradient untouched in both
+        for which, (x, y) in enumerate(zip(a["after"], b["after"])):
+            tol = 1e-5 if which == 0 else 1e-4 * float(y.abs().max()) + 1e-12
+            assert float((x - y).abs().max()) <= tol, (step, which, float((x - y).abs().max()), tol)
+            if which > 0:
+                assert float(((x == 0) != (y == 0)).float().mean()) <= 1e-4, (step, which)  # (an exact cancellation may differ in one of the runs)
     assert saw_plain and saw_update and A[-1]["skipped"][1] == 1
