@@ -36,8 +36,8 @@ b n1_1024rays --rays 1024 --no-cpu-baseline
 b n1_96samples --nerf-samples 96 --no-cpu-baseline
 b n1_splat_1080p --workload splat
 python scripts/rccl_latency.py 2>/dev/null | grep '^{' > gpurun_out/$R/rccl_1rank_latency.json
-# round 6: the next iteration's sampling front inside the optimiser launch -- same-box A/B of the launch modes (0 = in line, 1 = co-work (default), 2 = serial, 3 = companion stream)
-for m in 0 1 2 3; do TN_NEXT_SAMPLING=$m python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > gpurun_out/$R/bench_n1_next_sampling_mode$m.json; done
+# round 6: the next iteration's sampling front inside the optimiser launch -- same-box A/B of the launch modes (0 = in line, 1 = co-work (default), 2 = serial, 3 = companion stream, 4 = opt-in: Adam inside the chain's waves)
+for m in 0 1 2 3 4; do TN_NEXT_SAMPLING=$m python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > gpurun_out/$R/bench_n1_next_sampling_mode$m.json; done
 python scripts/eval_probe.py > gpurun_out/$R/eval_render.json 2>/dev/null
 python scripts/sampler_ulps.py gpurun_out/$R/sampler_ulps.md > /dev/null 2>&1
 fi
