@@ -171,8 +171,9 @@ def test_next_batch_is_sampled_inside_the_training_step(scene):
 
 
 
-@pytest.mark.parametrize("mode", ["cowork", "serial", "fork", "fused"])
-def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
+@pytest.mark.parametrize("mode,counts", [("cowork", None), ("serial", None), ("fork", None), ("fused", None),
+                                         ("cowork", ((200, 80), 50)), ("fused", ((200, 80), 50))])  # (last trips of a level with 8 / 16 lanes; 50 x N field samples: partial tiles)
+def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode, counts):
     """TnTrainStep.next_sampling: the sampling front of iteration k + 1 (pose correction, level-0 bins, both proposal levels' density -> weights ->
     PDF resampling) runs in co-work blocks of iteration k's optimiser launch, behind a launch that steps the groups it reads.  Against the same run
     with every iteration sampling in line (engine.next_sampling = False), from re-synchronised states as the other comparisons here: the forward's
@@ -196,7 +197,8 @@ def test_next_sampling_inside_the_training_step(scene, monkeypatch, mode):
         random.seed(5)
         torch.manual_seed(29)
         dm = HipDataManagerConfig(data=scene, dataparser=ThermalNerfDataParserConfig(train_split_fraction=0.9), train_num_rays_per_batch=N).setup(device="cuda:0")
-        cfg = ThermalNerfactoModelConfig(density_mode="shared", log2_hashmap_size=12)
+        extra = {} if counts is None else {"num_proposal_samples_per_ray": counts[0], "num_nerf_samples_per_ray": counts[1]}
+        cfg = ThermalNerfactoModelConfig(density_mode="shared", log2_hashmap_size=12, **extra)
         for a in cfg.proposal_net_args_list:
             a["log2_hashmap_size"] = 10
         model = cfg.setup(scene_box=dm.train_dataset.scene_box, num_train_data=len(dm.train_dataset), metadata=dm.train_dataset.metadata, device="cuda:0")
